@@ -1,0 +1,634 @@
+// avdm_maps.hip — streaming volume helpers, Refine sub-sample arg-min and the depth/similarity-map kernels for gfx950.
+//   avdm_volume_initialize_u8/f16, _add_f16, _update_uninitialized  <-> deviceSimilarityVolume.cu:57-153 (kernels.cuh:48-107)
+//   avdm_volume_refine_best_depth                                  <-> cuda_volumeRefineBestDepth (.cu:469-502, kernels.cuh:515-594)
+//   avdm_depth_sim_map_* / avdm_compute_sgm_upscaled_*             <-> planeSweeping/deviceDepthSimilarityMap.cu + ...MapKernels.cuh
+// Compiled with -ffp-contract=off (operation order of the reference kept; see DESIGN.md "parity classes").
+#include "avdm_device.h"
+
+#include <math.h>
+
+namespace avdm {
+
+// ---------------------------------------------------------------------------------------------
+// streaming volume kernels: z-fastest rows of `rowBytes` bytes, 16 B per lane
+// ---------------------------------------------------------------------------------------------
+// Each (x, y) column is a contiguous run of dimZ elements; rows of a y-slice are pitch_x apart.
+template <typename F>
+__device__ __forceinline__ void for_each_word(long long pitch_y, int pitch_x, int dimX, int dimY, int wordsPerCol, F f)
+{
+    // grid-stride over (y, x, word)
+    const long long total = (long long)dimX * dimY * wordsPerCol;
+    for(long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    {
+        const int w = (int)(i % wordsPerCol);
+        const long long c = i / wordsPerCol;
+        const int x = (int)(c % dimX);
+        const int y = (int)(c / dimX);
+        f((long long)y * pitch_y + (long long)x * pitch_x, w);
+    }
+}
+
+__global__ void __launch_bounds__(256) volume_init_u8_kernel(uint8_t* vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, unsigned v4)
+{
+    const int words = (dimZ + 3) / 4;
+    for_each_word(pitch_y, pitch_x, dimX, dimY, words, [&](long long off, int w) {
+        if(4 * w + 3 < dimZ)
+            *reinterpret_cast<unsigned*>(vol + off + 4 * w) = v4;
+        else
+            for(int j = 4 * w; j < dimZ; ++j)
+                vol[off + j] = (uint8_t)v4;
+    });
+}
+
+__global__ void __launch_bounds__(256)
+  volume_init_f16_kernel(__half* vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, unsigned short h)
+{
+    for_each_word(pitch_y, pitch_x, dimX, dimY, dimZ, [&](long long off, int z) { *reinterpret_cast<unsigned short*>((char*)vol + off + 2 * z) = h; });
+}
+
+__global__ void __launch_bounds__(256)
+  volume_add_f16_kernel(__half* inout, const __half* in, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ)
+{
+    for_each_word(pitch_y, pitch_x, dimX, dimY, dimZ, [&](long long off, int z) {
+        __half* p = (__half*)((char*)inout + off) + z;
+        const __half* q = (const __half*)((const char*)in + off) + z;
+        *p = __float2half(__half2float(*p) + __half2float(*q));
+    });
+}
+
+__global__ void __launch_bounds__(256)
+  volume_update_uninit_kernel(const uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ)
+{
+    const int words = (dimZ + 3) / 4;
+    for_each_word(pitch_y, pitch_x, dimX, dimY, words, [&](long long off, int w) {
+        if(4 * w + 3 < dimZ)
+        {
+            const unsigned b = *reinterpret_cast<const unsigned*>(best + off + 4 * w);
+            unsigned s = *reinterpret_cast<const unsigned*>(second + off + 4 * w);
+            unsigned r = 0;
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
+            {
+                const unsigned sj = (s >> (8 * j)) & 0xffu, bj = (b >> (8 * j)) & 0xffu;
+                r |= (sj >= 255u ? bj : sj) << (8 * j);
+            }
+            *reinterpret_cast<unsigned*>(second + off + 4 * w) = r;
+        }
+        else
+            for(int j = 4 * w; j < dimZ; ++j)
+                if(second[off + j] >= 255)
+                    second[off + j] = best[off + j];
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// Refine best depth: sliding Gaussian over 2*halfNbSamples+1 sub-samples (kernels.cuh:515-594)
+// The weight depends only on the integer |zs - sample| -> table in LDS (double-precision exp rounded to fp32 == libm expf).
+// ---------------------------------------------------------------------------------------------
+#define RBD_MAXZ 64
+template <int NZ>
+__global__ void __launch_bounds__(256)
+  refine_best_depth_kernel(float2* out, int out_pitch, const float2* __restrict__ sgmDepthPixSize, int map_pitch, const __half* __restrict__ vol,
+                           long long pitch_y, int pitch_x, int volDimZ, int samplesPerPixSize, int halfNbSamples, int halfNbDepths,
+                           float twoTimesSigmaPowerTwo, int tableSize, avdm_roi_t roi)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gauss = reinterpret_cast<float*>(smem); // gauss[d] = expf(-(d*d) / tt), d = |zs - sample|
+    for(int d = threadIdx.x; d < tableSize; d += blockDim.x)
+    {
+        const float arg = -(float)(d * d) / twoTimesSigmaPowerTwo;
+        gauss[d] = (float)exp((double)arg);
+    }
+    __syncthreads();
+
+    const unsigned vx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const unsigned vy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if(vx >= roi.x.end - roi.x.begin || vy >= roi.y.end - roi.y.begin)
+        return;
+    const float2 dps = *((const float2*)((const char*)sgmDepthPixSize + (long long)vy * map_pitch) + vx);
+    float2* o = (float2*)((char*)out + (long long)vy * out_pitch) + vx;
+    if(dps.x <= 0.0f)
+    {
+        *o = make_float2(dps.x, 1.0f);
+        return;
+    }
+    const __half* v = (const __half*)((const char*)vol + (long long)vy * pitch_y + (long long)vx * pitch_x);
+    float simSum[NZ];
+#pragma unroll
+    for(int c = 0; c < NZ / 8; ++c)
+    {
+        if(8 * c < volDimZ)
+        {
+            const uint4 q = *reinterpret_cast<const uint4*>(v + 8 * c);
+            const __half* hq = reinterpret_cast<const __half*>(&q);
+#pragma unroll
+            for(int j = 0; j < 8; ++j)
+                simSum[8 * c + j] = -__half2float(hq[j]);
+        }
+    }
+
+    float bestSampleSim = 0.f;
+    int bestSampleOffsetIndex = 0;
+    for(int sample = -halfNbSamples; sample <= halfNbSamples; ++sample)
+    {
+        float sampleSim = 0.f;
+#pragma unroll
+        for(int vz = 0; vz < NZ; ++vz)
+        {
+            if(vz < volDimZ)
+            {
+                const int zs = (vz - halfNbDepths) * samplesPerPixSize;
+                const int d = zs - sample;
+                sampleSim += simSum[vz] * gauss[d < 0 ? -d : d];
+            }
+        }
+        if(sampleSim < bestSampleSim)
+        {
+            bestSampleOffsetIndex = sample;
+            bestSampleSim = sampleSim;
+        }
+    }
+    const float sampleSize = dps.y / (float)samplesPerPixSize;
+    const float sampleSizeOffset = (float)bestSampleOffsetIndex * sampleSize;
+    *o = make_float2(dps.x + sampleSizeOffset, bestSampleSim);
+}
+
+// ---------------------------------------------------------------------------------------------
+// depth/sim map kernels
+// ---------------------------------------------------------------------------------------------
+#define MAP_XY()                                                                                                                                      \
+    const unsigned roiX = blockIdx.x * 64 + (threadIdx.x & 63);                                                                                       \
+    const unsigned roiY = blockIdx.y * 4 + (threadIdx.x >> 6);
+
+__global__ void __launch_bounds__(256)
+  copy_depth_only_kernel(float2* out, int out_pitch, const float2* in, int in_pitch, unsigned width, unsigned height, float defaultSim)
+{
+    MAP_XY();
+    if(roiX >= width || roiY >= height)
+        return;
+    const float d = ((const float2*)((const char*)in + (long long)roiY * in_pitch) + roiX)->x;
+    *((float2*)((char*)out + (long long)roiY * out_pitch) + roiX) = make_float2(d, defaultSim);
+}
+
+__global__ void __launch_bounds__(256) normal_upscale_kernel(float* out, int out_pitch, const float* in, int in_pitch, float ratio, avdm_roi_t roi)
+{
+    MAP_XY();
+    const unsigned roiW = roi.x.end - roi.x.begin, roiH = roi.y.end - roi.y.begin;
+    if(roiX >= roiW || roiY >= roiH)
+        return;
+    const float ox = ((float)roiX - 0.5f) * ratio;
+    const float oy = ((float)roiY - 0.5f) * ratio;
+    const int xp = min((int)floor((double)ox + 0.5), (int)((float)roiW * ratio) - 1);
+    const int yp = min((int)floor((double)oy + 0.5), (int)((float)roiH * ratio) - 1);
+    const float* s = (const float*)((const char*)in + (long long)yp * in_pitch) + 3 * xp;
+    float* d = (float*)((char*)out + (long long)roiY * out_pitch) + 3 * roiX;
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+}
+
+__global__ void __launch_bounds__(256)
+  smooth_thickness_kernel(float2* map, int pitch, float minThicknessInflate, float maxThicknessInflate, avdm_roi_t roi)
+{
+    MAP_XY();
+    const int roiW = (int)(roi.x.end - roi.x.begin), roiH = (int)(roi.y.end - roi.y.begin);
+    if((int)roiX >= roiW || (int)roiY >= roiH)
+        return;
+    float2* dtp = (float2*)((char*)map + (long long)roiY * pitch) + roiX;
+    const float2 dt = *dtp;
+    if(dt.x <= 0.0f)
+        return;
+    const float minThickness = minThicknessInflate * dt.y;
+    const float maxThickness = maxThicknessInflate * dt.y;
+    float sumCenterDepthDist = 0.f;
+    int nbValidPatchPixels = 0;
+#pragma unroll
+    for(int yp = -1; yp <= 1; ++yp)
+#pragma unroll
+        for(int xp = -1; xp <= 1; ++xp)
+        {
+            const int roiXp = (int)roiX + xp, roiYp = (int)roiY + yp;
+            if((xp == 0 && yp == 0) || roiXp < 0 || roiXp >= roiW || roiYp < 0 || roiYp >= roiH)
+                continue;
+            // only .x of the neighbours is read and only .y of the own pixel is written: no hazard (mapKernels.cuh:151-211)
+            const float pd = ((const float2*)((const char*)map + (long long)roiYp * pitch) + roiXp)->x;
+            if(pd > 0.0f)
+            {
+                const float depthDistance = fabsf(dt.x - pd);
+                sumCenterDepthDist += fmaxf(minThickness, fminf(maxThickness, depthDistance));
+                ++nbValidPatchPixels;
+            }
+        }
+    if(nbValidPatchPixels < 3)
+        return;
+    dtp->y = sumCenterDepthDist / (float)nbValidPatchPixels;
+}
+
+template <bool FIXED8>
+__global__ void __launch_bounds__(256) upscale_depth_pixsize_kernel(float2* out, int out_pitch, const float2* in, int in_pitch, TexLevel L, float sxN,
+                                                                    float syN, int stepXY, int halfNbDepths, float ratio, int bilinear, avdm_roi_t roi)
+{
+    MAP_XY();
+    const unsigned roiW = roi.x.end - roi.x.begin, roiH = roi.y.end - roi.y.begin;
+    if(roiX >= roiW || roiY >= roiH)
+        return;
+    const unsigned x = (roi.x.begin + roiX) * (unsigned)stepXY;
+    const unsigned y = (roi.y.begin + roiY) * (unsigned)stepXY;
+    float2* o = (float2*)((char*)out + (long long)roiY * out_pitch) + roiX;
+    // sxN = nominal level width (getDimensions), syN = height
+    const float alpha = tex2D_level<FIXED8>(L, ((float)x + 0.5f) / sxN, ((float)y + 0.5f) / syN).w;
+    const float oy = ((float)roiY - 0.5f) * ratio;
+    const float ox = ((float)roiX - 0.5f) * ratio;
+    float2 dT;
+    if(!bilinear)
+    {
+        if(alpha < 0.9f) // sic (mapKernels.cuh:238)
+        {
+            *o = make_float2(-2.f, 0.f);
+            return;
+        }
+        int xp = (int)floor((double)ox + 0.5);
+        int yp = (int)floor((double)oy + 0.5);
+        xp = min(xp, (int)((float)roiW * ratio) - 1);
+        yp = min(yp, (int)((float)roiH * ratio) - 1);
+        dT = *((const float2*)((const char*)in + (long long)yp * in_pitch) + xp);
+    }
+    else
+    {
+        if(alpha < (255.f * 0.9f))
+        {
+            *o = make_float2(-2.f, 0.f);
+            return;
+        }
+        int xp = (int)floorf(ox);
+        int yp = (int)floorf(oy);
+        xp = min(xp, (int)((float)roiW * ratio) - 2);
+        yp = min(yp, (int)((float)roiH * ratio) - 2);
+        const float2 lu = *((const float2*)((const char*)in + (long long)yp * in_pitch) + xp);
+        const float2 ru = *((const float2*)((const char*)in + (long long)yp * in_pitch) + xp + 1);
+        const float2 rd = *((const float2*)((const char*)in + (long long)(yp + 1) * in_pitch) + xp + 1);
+        const float2 ld = *((const float2*)((const char*)in + (long long)(yp + 1) * in_pitch) + xp);
+        if(lu.x <= 0.0f || ru.x <= 0.0f || rd.x <= 0.0f || ld.x <= 0.0f)
+        {
+            float sx = 0.f, sy = 0.f;
+            int count = 0;
+            if(lu.x > 0.0f) { sx = sx + lu.x; sy = sy + lu.y; ++count; }
+            if(ru.x > 0.0f) { sx = sx + ru.x; sy = sy + ru.y; ++count; }
+            if(rd.x > 0.0f) { sx = sx + rd.x; sy = sy + rd.y; ++count; }
+            if(ld.x > 0.0f) { sx = sx + ld.x; sy = sy + ld.y; ++count; }
+            if(count != 0)
+                dT = make_float2(sx / (float)count, sy / (float)count);
+            else
+            {
+                *o = make_float2(-1.0f, 1.0f);
+                return;
+            }
+        }
+        else
+        {
+            const float ui = ox - (float)xp;
+            const float vi = oy - (float)yp;
+            const float ux = lu.x + (ru.x - lu.x) * ui, uy = lu.y + (ru.y - lu.y) * ui;
+            const float dx = ld.x + (rd.x - ld.x) * ui, dy = ld.y + (rd.y - ld.y) * ui;
+            dT = make_float2(ux + (dx - ux) * vi, uy + (dy - uy) * vi);
+        }
+    }
+    *o = make_float2(dT.x, dT.y / (float)halfNbDepths);
+}
+
+// ---- colour-guided optimisation (mapKernels.cuh:25-101, 479-608; Map.cu:193-263) ----
+template <bool FIXED8>
+__global__ void __launch_bounds__(256)
+  var_L_kernel(float* out, int out_pitch, TexLevel L, float wN, float hN, int stepXY, avdm_roi_t roi)
+{
+    MAP_XY();
+    if(roiX >= roi.x.end - roi.x.begin || roiY >= roi.y.end - roi.y.begin)
+        return;
+    const float x = (float)(roi.x.begin + roiX) * (float)stepXY;
+    const float y = (float)(roi.y.begin + roiY) * (float)stepXY;
+    const float iw = 1.f / wN, ih = 1.f / hN;
+    const float xM1 = tex2D_level<FIXED8>(L, ((x - 1.f) + 0.5f) * iw, ((y + 0.f) + 0.5f) * ih).x;
+    const float xP1 = tex2D_level<FIXED8>(L, ((x + 1.f) + 0.5f) * iw, ((y + 0.f) + 0.5f) * ih).x;
+    const float yM1 = tex2D_level<FIXED8>(L, ((x + 0.f) + 0.5f) * iw, ((y - 1.f) + 0.5f) * ih).x;
+    const float yP1 = tex2D_level<FIXED8>(L, ((x + 0.f) + 0.5f) * iw, ((y + 1.f) + 0.5f) * ih).x;
+    const float gx = xM1 - xP1, gy = yM1 - yP1;
+    *((float*)((char*)out + (long long)roiY * out_pitch) + roiX) = sqrtf(gx * gx + gy * gy);
+}
+
+__global__ void __launch_bounds__(256) copy_rows_kernel(float2* out, int out_pitch, const float2* in, int in_pitch, unsigned w, unsigned h)
+{
+    MAP_XY();
+    if(roiX >= w || roiY >= h)
+        return;
+    *((float2*)((char*)out + (long long)roiY * out_pitch) + roiX) = *((const float2*)((const char*)in + (long long)roiY * in_pitch) + roiX);
+}
+
+__global__ void __launch_bounds__(256) extract_depth_kernel(float* tmp, int tmp_pitch, const float2* opt, int opt_pitch, avdm_roi_t roi)
+{
+    MAP_XY();
+    if(roiX >= roi.x.end - roi.x.begin || roiY >= roi.y.end - roi.y.begin)
+        return;
+    *((float*)((char*)tmp + (long long)roiY * tmp_pitch) + roiX) = ((const float2*)((const char*)opt + (long long)roiY * opt_pitch) + roiX)->x;
+}
+
+__device__ __forceinline__ float tex_point(const float* buf, int pitch, int W, int H, int x, int y)
+{
+    x = min(max(x, 0), W - 1);
+    y = min(max(y, 0), H - 1);
+    return *((const float*)((const char*)buf + (long long)y * pitch) + x);
+}
+
+__device__ __forceinline__ f3 normalize_exact(f3 a)
+{
+    const float dInv = 1.0f / sqrtf(dot(a, a));
+    return f3{a.x * dInv, a.y * dInv, a.z * dInv};
+}
+__device__ __forceinline__ f3 point_at_depth(const avdm_camera_t& cam, float px, float py, float depth)
+{
+    const f3 rpv = normalize_exact(M3x3mulV2(cam.iP, px, py));
+    return ld3(cam.C) + rpv * depth;
+}
+__device__ __forceinline__ float angleBetwABandAC(f3 A, f3 B, f3 C)
+{
+    const f3 V1 = normalize_exact(B - A);
+    const f3 V2 = normalize_exact(C - A);
+    const double x = (double)(V1.x * V2.x + V1.y * V2.y + V1.z * V2.z);
+    double a = acos(x);
+    a = isinf(a) ? 0.0 : a;
+    return (float)(fabs(a) / (3.14159265358979323846 / 180.0));
+}
+
+__global__ void __launch_bounds__(256)
+  optimize_step_kernel(float2* outOpt, int out_pitch, const float2* __restrict__ sgmDepthPixSize, int sgm_pitch,
+                       const float2* __restrict__ refineDepthSim, int ref_pitch, const float* __restrict__ imgVariance, int var_pitch,
+                       const float* __restrict__ depthTex, int tex_pitch, int texW, int texH, avdm_camera_t rc, int iter, avdm_roi_t roi)
+{
+    MAP_XY();
+    if(roiX >= roi.x.end - roi.x.begin || roiY >= roi.y.end - roi.y.begin)
+        return;
+    const float2 sgm = *((const float2*)((const char*)sgmDepthPixSize + (long long)roiY * sgm_pitch) + roiX);
+    const float sgmDepth = sgm.x, sgmPixSize = sgm.y;
+    const float2 rf = *((const float2*)((const char*)refineDepthSim + (long long)roiY * ref_pitch) + roiX);
+    const float refineDepth = rf.x, refineSim = rf.y;
+    float2* op = (float2*)((char*)outOpt + (long long)roiY * out_pitch) + roiX;
+    float2 outDS = (iter == 0) ? make_float2(sgmDepth, refineSim) : *op;
+    const float depthOpt = outDS.x;
+    if(depthOpt > 0.0f)
+    {
+        // getCellSmoothStepEnergy
+        float smoothStep = 0.0f, energy = 180.0f;
+        const int cx = (int)roiX, cy = (int)roiY;
+        const float d0 = tex_point(depthTex, tex_pitch, texW, texH, cx, cy);
+        if(d0 > 0.0f)
+        {
+            const float offx = (float)roi.x.begin, offy = (float)roi.y.begin;
+            // cellL = cell0 + (0,-1), cellR = cell0 + (0,1), cellU = cell0 + (-1,0), cellB = cell0 + (1,0)
+            const float dL = tex_point(depthTex, tex_pitch, texW, texH, cx, cy - 1);
+            const float dR = tex_point(depthTex, tex_pitch, texW, texH, cx, cy + 1);
+            const float dU = tex_point(depthTex, tex_pitch, texW, texH, cx - 1, cy);
+            const float dB = tex_point(depthTex, tex_pitch, texW, texH, cx + 1, cy);
+            const float fx = (float)roiX, fy = (float)roiY;
+            const f3 p0 = point_at_depth(rc, fx + offx, fy + offy, d0);
+            const f3 pL = point_at_depth(rc, (fx + 0.f) + offx, (fy + -1.f) + offy, dL);
+            const f3 pR = point_at_depth(rc, (fx + 0.f) + offx, (fy + 1.f) + offy, dR);
+            const f3 pU = point_at_depth(rc, (fx + -1.f) + offx, (fy + 0.f) + offy, dU);
+            const f3 pB = point_at_depth(rc, (fx + 1.f) + offx, (fy + 0.f) + offy, dB);
+            f3 cg = f3{0.f, 0.f, 0.f};
+            float n = 0.0f;
+            if(dL > 0.0f) { cg = cg + pL; n++; }
+            if(dR > 0.0f) { cg = cg + pR; n++; }
+            if(dU > 0.0f) { cg = cg + pU; n++; }
+            if(dB > 0.0f) { cg = cg + pB; n++; }
+            if(n > 1.0f)
+            {
+                cg = f3{cg.x / n, cg.y / n, cg.z / n};
+                const f3 vcn = normalize_exact(ld3(rc.C) - p0);
+                const f3 pS = closestPointToLine3D(cg, p0, vcn);
+                smoothStep = size(ld3(rc.C) - pS) - d0;
+            }
+            float e = 0.0f;
+            n = 0.0f;
+            if(dL > 0.0f && dR > 0.0f)
+            {
+                e = fmaxf(e, (180.0f - angleBetwABandAC(p0, pL, pR)));
+                n++;
+            }
+            if(dU > 0.0f && dB > 0.0f)
+            {
+                e = fmaxf(e, (180.0f - angleBetwABandAC(p0, pU, pB)));
+                n++;
+            }
+            if(n > 0.0f)
+                energy = e;
+        }
+        float stepToSmoothDepth = smoothStep;
+        stepToSmoothDepth = copysignf(fminf(fabsf(stepToSmoothDepth), sgmPixSize / 10.0f), stepToSmoothDepth);
+        const float depthEnergy = energy;
+        float stepToFineDM = refineDepth - depthOpt;
+        stepToFineDM = copysignf(fminf(fabsf(stepToFineDM), sgmPixSize / 10.0f), stepToFineDM);
+        const float stepToRoughDM = sgmDepth - depthOpt;
+        const float imgColorVariance = *((const float*)((const char*)imgVariance + (long long)roiY * var_pitch) + roiX);
+        const float weightedColorVariance = sigmoid2(5.0f, 30.0f, 40.0f, 20.0f, imgColorVariance);
+        const float fineSimWeight = sigmoid(0.0f, 1.0f, 0.7f, -0.7f, refineSim);
+        const float energyLowerThanVarianceWeight = sigmoid(0.0f, 1.0f, 30.0f, weightedColorVariance, depthEnergy);
+        const float closeToRoughWeight = 1.0f - sigmoid(0.0f, 1.0f, 10.0f, 17.0f, fabsf(stepToRoughDM / sgmPixSize));
+        const float depthOptStep = closeToRoughWeight * stepToRoughDM +
+                                   (1.0f - closeToRoughWeight) * (energyLowerThanVarianceWeight * fineSimWeight * stepToFineDM +
+                                                                  (1.0f - energyLowerThanVarianceWeight) * stepToSmoothDepth);
+        outDS.x = depthOpt + depthOptStep;
+        outDS.y = (1.0f - closeToRoughWeight) *
+                  (energyLowerThanVarianceWeight * fineSimWeight * refineSim + (1.0f - energyLowerThanVarianceWeight) * (depthEnergy / 20.0f));
+    }
+    *op = outDS;
+}
+
+static inline dim3 map_grid(unsigned w, unsigned h) { return dim3(divUp(w, 64), divUp(h, 4)); }
+static inline int stream_blocks(long long total)
+{
+    long long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+} // namespace avdm
+
+using namespace avdm;
+
+extern "C" {
+
+int avdm_volume_initialize_u8(uint8_t* vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, uint8_t value, void* stream)
+{
+    if(dimX <= 0 || dimY <= 0 || dimZ <= 0)
+        return 0;
+    if((pitch_x & 3) || (pitch_y & 3) || ((uintptr_t)vol & 3))
+        return set_error_msg(1, "avdm_volume_initialize_u8: base / pitches must be multiples of 4");
+    const unsigned v4 = value * 0x01010101u;
+    const long long total = (long long)dimX * dimY * ((dimZ + 3) / 4);
+    hipLaunchKernelGGL(volume_init_u8_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, vol, pitch_y, pitch_x, dimX, dimY, dimZ, v4);
+    AVDM_LAUNCH_CHECK("avdm_volume_initialize_u8");
+}
+
+int avdm_volume_initialize_f16(void* vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, float value, void* stream)
+{
+    if(dimX <= 0 || dimY <= 0 || dimZ <= 0)
+        return 0;
+    const __half h = __float2half(value);
+    const unsigned short hs = *reinterpret_cast<const unsigned short*>(&h);
+    const long long total = (long long)dimX * dimY * dimZ;
+    hipLaunchKernelGGL(volume_init_f16_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, (__half*)vol, pitch_y, pitch_x, dimX, dimY,
+                       dimZ, hs);
+    AVDM_LAUNCH_CHECK("avdm_volume_initialize_f16");
+}
+
+int avdm_volume_add_f16(void* inout_vol, const void* in_vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, void* stream)
+{
+    if(dimX <= 0 || dimY <= 0 || dimZ <= 0)
+        return 0;
+    const long long total = (long long)dimX * dimY * dimZ;
+    hipLaunchKernelGGL(volume_add_f16_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, (__half*)inout_vol, (const __half*)in_vol,
+                       pitch_y, pitch_x, dimX, dimY, dimZ);
+    AVDM_LAUNCH_CHECK("avdm_volume_add_f16");
+}
+
+int avdm_volume_update_uninitialized(const uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, void* stream)
+{
+    if(dimX <= 0 || dimY <= 0 || dimZ <= 0)
+        return 0;
+    if((pitch_x & 3) || (pitch_y & 3) || ((uintptr_t)best & 3) || ((uintptr_t)second & 3))
+        return set_error_msg(1, "avdm_volume_update_uninitialized: base / pitches must be multiples of 4");
+    const long long total = (long long)dimX * dimY * ((dimZ + 3) / 4);
+    hipLaunchKernelGGL(volume_update_uninit_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, best, second, pitch_y, pitch_x, dimX,
+                       dimY, dimZ);
+    AVDM_LAUNCH_CHECK("avdm_volume_update_uninitialized");
+}
+
+int avdm_volume_refine_best_depth(float* out_depth_sim, int out_pitch, const float* sgm_depth_pixsize, int map_pitch, const void* vol_f16,
+                                  long long pitch_y, int pitch_x, int dimZ, const avdm_refine_params_t* rp, avdm_roi_t roi, void* stream)
+{
+    const unsigned roiW = roi.x.end - roi.x.begin, roiH = roi.y.end - roi.y.begin;
+    if(roiW == 0 || roiH == 0)
+        return 0;
+    if(dimZ > RBD_MAXZ)
+        return set_error_msg(1, "avdm_volume_refine_best_depth: more than 64 refine planes are not supported");
+    if((pitch_x & 15) || (pitch_y & 15) || ((uintptr_t)vol_f16 & 15) || pitch_x < ((dimZ + 7) & ~7) * 2)
+        return set_error_msg(1, "avdm_volume_refine_best_depth: volume base / pitches must be multiples of 16 and cover 8-aligned planes");
+    const int halfNbSamples = rp->nbSubsamples * rp->halfNbDepths;
+    const float tt = (float)(2.0 * rp->sigma * rp->sigma);
+    // largest |zs - sample|
+    const int zsMax = (dimZ - 1 - rp->halfNbDepths) > rp->halfNbDepths ? (dimZ - 1 - rp->halfNbDepths) : rp->halfNbDepths;
+    const int tableSize = zsMax * rp->nbSubsamples + halfNbSamples + 1;
+    const size_t lds = (size_t)((tableSize * 4 + 15) & ~15);
+    if(lds > 64 * 1024)
+        return set_error_msg(1, "avdm_volume_refine_best_depth: Gaussian table too large");
+    if(dimZ <= 32)
+        hipLaunchKernelGGL(refine_best_depth_kernel<32>, map_grid(roiW, roiH), dim3(256), lds, (hipStream_t)stream, (float2*)out_depth_sim, out_pitch,
+                           (const float2*)sgm_depth_pixsize, map_pitch, (const __half*)vol_f16, pitch_y, pitch_x, dimZ, rp->nbSubsamples,
+                           halfNbSamples, rp->halfNbDepths, tt, tableSize, roi);
+    else
+        hipLaunchKernelGGL(refine_best_depth_kernel<64>, map_grid(roiW, roiH), dim3(256), lds, (hipStream_t)stream, (float2*)out_depth_sim, out_pitch,
+                           (const float2*)sgm_depth_pixsize, map_pitch, (const __half*)vol_f16, pitch_y, pitch_x, dimZ, rp->nbSubsamples,
+                           halfNbSamples, rp->halfNbDepths, tt, tableSize, roi);
+    AVDM_LAUNCH_CHECK("avdm_volume_refine_best_depth");
+}
+
+int avdm_depth_sim_map_copy_depth_only(float* out_map, int out_pitch, const float* in_map, int in_pitch, int width, int height, float default_sim,
+                                       void* stream)
+{
+    if(width <= 0 || height <= 0)
+        return 0;
+    hipLaunchKernelGGL(copy_depth_only_kernel, map_grid(width, height), dim3(256), 0, (hipStream_t)stream, (float2*)out_map, out_pitch,
+                       (const float2*)in_map, in_pitch, (unsigned)width, (unsigned)height, default_sim);
+    AVDM_LAUNCH_CHECK("avdm_depth_sim_map_copy_depth_only");
+}
+
+int avdm_normal_map_upscale(float* out_map, int out_pitch, const float* in_map, int in_pitch, float ratio, avdm_roi_t roi, void* stream)
+{
+    const unsigned roiW = roi.x.end - roi.x.begin, roiH = roi.y.end - roi.y.begin;
+    if(roiW == 0 || roiH == 0)
+        return 0;
+    hipLaunchKernelGGL(normal_upscale_kernel, map_grid(roiW, roiH), dim3(256), 0, (hipStream_t)stream, out_map, out_pitch, in_map, in_pitch, ratio, roi);
+    AVDM_LAUNCH_CHECK("avdm_normal_map_upscale");
+}
+
+int avdm_depth_thickness_smooth_thickness(float* inout_map, int pitch, const avdm_sgm_params_t* sp, const avdm_refine_params_t* rp, avdm_roi_t roi,
+                                          void* stream)
+{
+    const unsigned roiW = roi.x.end - roi.x.begin, roiH = roi.y.end - roi.y.begin;
+    if(roiW == 0 || roiH == 0)
+        return 0;
+    const int sgmScaleStep = sp->scale * sp->stepXY;
+    const int refineScaleStep = rp->scale * rp->stepXY;
+    const float minNbRefineSamples = 2.f;
+    const float q = (float)sgmScaleStep / (float)refineScaleStep;
+    const float maxNbRefineSamples = q > minNbRefineSamples ? q : minNbRefineSamples;
+    const float minThicknessInflate = (float)rp->halfNbDepths / maxNbRefineSamples;
+    const float maxThicknessInflate = (float)rp->halfNbDepths / minNbRefineSamples;
+    hipLaunchKernelGGL(smooth_thickness_kernel, map_grid(roiW, roiH), dim3(256), 0, (hipStream_t)stream, (float2*)inout_map, pitch, minThicknessInflate,
+                       maxThicknessInflate, roi);
+    AVDM_LAUNCH_CHECK("avdm_depth_thickness_smooth_thickness");
+}
+
+int avdm_compute_sgm_upscaled_depth_pixsize_map(float* out_map, int out_pitch, const float* in_sgm_depth_thickness, int in_pitch,
+                                                const avdm_camera_t* rc, const avdm_pyramid_t* rc_pyr, const avdm_refine_params_t* rp, float ratio,
+                                                avdm_roi_t roi, void* stream)
+{
+    (void)rc;
+    const unsigned roiW = roi.x.end - roi.x.begin, roiH = roi.y.end - roi.y.begin;
+    if(roiW == 0 || roiH == 0)
+        return 0;
+    int level;
+    if(!lod_is_integral(rc_pyr, rp->scale, &level))
+        return set_error_msg(1, "avdm_compute_sgm_upscaled_depth_pixsize_map: non-integral mip level");
+    const Tex t = make_tex(rc_pyr);
+    const float wN = (float)tex_dim_w(rc_pyr, rp->scale), hN = (float)tex_dim_h(rc_pyr, rp->scale);
+    if(rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8)
+        hipLaunchKernelGGL(upscale_depth_pixsize_kernel<true>, map_grid(roiW, roiH), dim3(256), 0, (hipStream_t)stream, (float2*)out_map, out_pitch,
+                           (const float2*)in_sgm_depth_thickness, in_pitch, t.lv[level], wN, hN, rp->stepXY, rp->halfNbDepths, ratio,
+                           rp->interpolateMiddleDepth, roi);
+    else
+        hipLaunchKernelGGL(upscale_depth_pixsize_kernel<false>, map_grid(roiW, roiH), dim3(256), 0, (hipStream_t)stream, (float2*)out_map, out_pitch,
+                           (const float2*)in_sgm_depth_thickness, in_pitch, t.lv[level], wN, hN, rp->stepXY, rp->halfNbDepths, ratio,
+                           rp->interpolateMiddleDepth, roi);
+    AVDM_LAUNCH_CHECK("avdm_compute_sgm_upscaled_depth_pixsize_map");
+}
+
+int avdm_depth_sim_map_compute_normal(float* out_normal, int out_pitch, const float* in_depth_sim, int in_pitch, const avdm_camera_t* rc, int stepXY,
+                                      avdm_roi_t roi, void* stream)
+{
+    (void)out_normal; (void)out_pitch; (void)in_depth_sim; (void)in_pitch; (void)rc; (void)stepXY; (void)roi; (void)stream;
+    return set_error_msg(1, "avdm_depth_sim_map_compute_normal: not implemented yet (SURVEY §8f.1, off the default path)");
+}
+
+int avdm_depth_sim_map_optimize_gradient_descent(float* out_opt_depth_sim, int out_pitch, float* img_variance, int var_pitch, float* tmp_depth,
+                                                 int tmp_pitch, int tmp_w, int tmp_h, const float* sgm_depth_pixsize, int sgm_pitch,
+                                                 const float* refine_depth_sim, int ref_pitch, const avdm_camera_t* rc, const avdm_pyramid_t* rc_pyr,
+                                                 const avdm_refine_params_t* rp, avdm_roi_t roi, void* stream)
+{
+    const unsigned roiW = roi.x.end - roi.x.begin, roiH = roi.y.end - roi.y.begin;
+    if(roiW == 0 || roiH == 0)
+        return 0;
+    int level;
+    if(!lod_is_integral(rc_pyr, rp->scale, &level))
+        return set_error_msg(1, "avdm_depth_sim_map_optimize_gradient_descent: non-integral mip level");
+    const Tex t = make_tex(rc_pyr);
+    const float wN = (float)tex_dim_w(rc_pyr, rp->scale), hN = (float)tex_dim_h(rc_pyr, rp->scale);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid = map_grid(roiW, roiH);
+
+    hipLaunchKernelGGL(copy_rows_kernel, grid, dim3(256), 0, st, (float2*)out_opt_depth_sim, out_pitch, (const float2*)sgm_depth_pixsize, sgm_pitch, roiW,
+                       roiH);
+    if(rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8)
+        hipLaunchKernelGGL(var_L_kernel<true>, grid, dim3(256), 0, st, img_variance, var_pitch, t.lv[level], wN, hN, rp->stepXY, roi);
+    else
+        hipLaunchKernelGGL(var_L_kernel<false>, grid, dim3(256), 0, st, img_variance, var_pitch, t.lv[level], wN, hN, rp->stepXY, roi);
+
+    for(int iter = 0; iter < rp->optimizationNbIterations; ++iter)
+    {
+        hipLaunchKernelGGL(extract_depth_kernel, grid, dim3(256), 0, st, tmp_depth, tmp_pitch, (const float2*)out_opt_depth_sim, out_pitch, roi);
+        hipLaunchKernelGGL(optimize_step_kernel, grid, dim3(256), 0, st, (float2*)out_opt_depth_sim, out_pitch, (const float2*)sgm_depth_pixsize,
+                           sgm_pitch, (const float2*)refine_depth_sim, ref_pitch, img_variance, var_pitch, tmp_depth, tmp_pitch, tmp_w, tmp_h, *rc, iter,
+                           roi);
+    }
+    AVDM_LAUNCH_CHECK("avdm_depth_sim_map_optimize_gradient_descent");
+}
+
+} // extern "C"

@@ -1,0 +1,179 @@
+"""Per-tile driver of the gfx950 kernels through the C ABI (include/avdm.h), with torch tensors as device memory.
+
+This is harness glue for tests/, bench.py and smoke(): it sequences the entry points exactly like the reference's
+Sgm::sgmRc (Sgm.cpp:117-188,203-325), Sgm::smoothThicknessMap (:190-201) and Refine::refineRc (Refine.cpp:97-272).
+The production host (tiling, depth lists, I/O, CLI) is the C++ code under alicevision_amd/host/.
+There is NO fallback: every stage calls libavdm.so and raises AvdmError on a non-zero status.
+"""
+import ctypes as C
+
+import torch
+
+from . import abi
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ceil_div(a, b):
+    return (a + b - 1) // b
+
+
+class DevicePyramid:
+    """fp16 Lab mip pyramid in HBM (replaces DeviceMipmapImage)."""
+
+    def __init__(self, rgba, min_downscale, max_downscale, filter_mode, device="cuda"):
+        lib = abi.load()
+        h, w = rgba.shape[:2]
+        self.desc = abi.Pyramid()
+        abi.check(lib.avdm_pyramid_layout(C.byref(self.desc), w, h, min_downscale, max_downscale, filter_mode), "avdm_pyramid_layout")
+        self.buf = torch.zeros(self.desc.bytes, dtype=torch.uint8, device=device)
+        self.desc.base = self.buf.data_ptr()
+        if rgba is not None:
+            self.fill(rgba)
+
+    def fill(self, rgba):
+        lib = abi.load()
+        rgba = rgba.to(device=self.buf.device, dtype=torch.float32).contiguous()
+        h, w = rgba.shape[:2]
+        scratch = None
+        if self.desc.min_downscale > 1:
+            scratch = torch.empty(h * w * 8, dtype=torch.uint8, device=self.buf.device)
+        abi.check(lib.avdm_pyramid_fill(C.byref(self.desc), _ptr(rgba), w * 16, _ptr(scratch) if scratch is not None else None, _stream()),
+                  "avdm_pyramid_fill")
+        self._keep = (rgba, scratch)
+
+    @classmethod
+    def from_host_bytes(cls, desc_like, raw_bytes, device="cuda"):
+        """Upload a pyramid built elsewhere (e.g. by the oracle) so later stages can be compared on identical inputs."""
+        self = cls.__new__(cls)
+        self.desc = abi.Pyramid()
+        C.memmove(C.byref(self.desc), C.byref(desc_like), C.sizeof(abi.Pyramid))
+        self.buf = torch.from_numpy(raw_bytes).to(device)
+        self.desc.base = self.buf.data_ptr()
+        return self
+
+    def level(self, l):
+        d = self.desc
+        raw = self.buf[d.offset[l]:d.offset[l] + d.pitch[l] * d.height[l]].view(d.height[l], d.pitch[l])
+        return raw[:, :d.width[l] * 8].contiguous().view(torch.float16).view(d.height[l], d.width[l], 4)
+
+
+class DepthMapTile:
+    """One tile of one R camera: SGM (similarity volume, path aggregation, WTA) then Refine (re-sweep, sub-sample arg-min,
+    colour optimisation).  roi = (x0, x1, y0, y1) in process-resolution pixels."""
+
+    def __init__(self, pyramids, K, Rs, Cs, sgm, refine, roi=None, device="cuda"):
+        self.lib = abi.load()
+        self.pyr = pyramids
+        self.K, self.Rs, self.Cs = K, Rs, Cs
+        self.sgm, self.refine = sgm, refine
+        self.device = device
+        W, H = pyramids[0].desc.width0, pyramids[0].desc.height0
+        self.roi = roi if roi is not None else (0, W, 0, H)
+        self._alloc_for = None
+
+    def cam(self, i, scale):
+        return abi.camera_fill(self.K, self.Rs[i], self.Cs[i], scale)
+
+    def droi(self, ds):
+        x0, x1, y0, y1 = self.roi
+        return abi.ROI.make(x0 // ds, ceil_div(x1, ds), y0 // ds, ceil_div(y1, ds))
+
+    def _alloc(self, Z):
+        sp, rp = self.sgm, self.refine
+        roiS, roiR = self.droi(sp.scale * sp.stepXY), self.droi(rp.scale * rp.stepXY)
+        key = (Z, roiS.width, roiS.height, roiR.width, roiR.height)
+        if self._alloc_for == key:
+            return
+        dev = self.device
+        X, Y = roiS.width, roiS.height
+        Zp = ceil_div(Z, 4) * 4
+        self.Zp = Zp
+        self.best = torch.empty((Y, X, Zp), dtype=torch.uint8, device=dev)
+        self.second = torch.empty((Y, X, Zp), dtype=torch.uint8, device=dev)
+        self.depths_d = torch.empty(Z, dtype=torch.float32, device=dev)
+        self.sgm_depth_thickness = torch.empty((Y, X, 2), dtype=torch.float32, device=dev)
+        self.sgm_depth_sim = torch.empty((Y, X, 2), dtype=torch.float32, device=dev)
+        XR, YR = roiR.width, roiR.height
+        Zr = rp.halfNbDepths * 2 + 1
+        self.Zr, self.Zrp = Zr, ceil_div(Zr, 8) * 8
+        self.sgm_upscaled = torch.empty((YR, XR, 2), dtype=torch.float32, device=dev)
+        self.refined = torch.empty((YR, XR, 2), dtype=torch.float32, device=dev)
+        self.optimized = torch.empty((YR, XR, 2), dtype=torch.float32, device=dev)
+        self.refine_volume = torch.empty((YR, XR, self.Zrp), dtype=torch.float16, device=dev)
+        self.img_variance = torch.empty((YR, XR), dtype=torch.float32, device=dev)
+        self.tmp_depth = torch.empty((YR, XR), dtype=torch.float32, device=dev)
+        self._alloc_for = key
+
+    # ---- Sgm::sgmRc ----
+    def run_sgm(self, rc, tcs, depths, tc_ranges=None, optimize=True):
+        lib, sp = self.lib, self.sgm
+        Z = len(depths)
+        self._alloc(Z)
+        roi = self.droi(sp.scale * sp.stepXY)
+        X, Y, Zp = roi.width, roi.height, self.Zp
+        py, pxx = X * Zp, Zp
+        st = _stream()
+        self.depths_d.copy_(torch.as_tensor(depths, dtype=torch.float32), non_blocking=False)
+        abi.check(lib.avdm_volume_initialize_u8(_ptr(self.best), py, pxx, X, Y, Zp, 255, st), "volume_initialize")
+        abi.check(lib.avdm_volume_initialize_u8(_ptr(self.second), py, pxx, X, Y, Zp, 255, st), "volume_initialize")
+        rcCam = self.cam(rc, sp.scale)
+        for ti, tc in enumerate(tcs):
+            tcCam = self.cam(tc, sp.scale)
+            r = tc_ranges[ti] if tc_ranges else (0, Z)
+            abi.check(lib.avdm_volume_compute_similarity(_ptr(self.best), _ptr(self.second), py, pxx, _ptr(self.depths_d), C.byref(rcCam),
+                                                         C.byref(tcCam), C.byref(self.pyr[rc].desc), C.byref(self.pyr[tc].desc), C.byref(sp),
+                                                         abi.Range(r[0], r[1]), roi, st), "volume_compute_similarity")
+        abi.check(lib.avdm_volume_update_uninitialized(_ptr(self.best), _ptr(self.second), py, pxx, X, Y, Z, st), "update_uninitialized")
+        if optimize:
+            abi.check(lib.avdm_volume_optimize(_ptr(self.best), _ptr(self.second), py, pxx, None, C.byref(self.pyr[rc].desc), C.byref(sp), Z, roi,
+                                               st), "volume_optimize")
+        else:
+            self.best.copy_(self.second)
+        rc1 = self.cam(rc, 1)
+        abi.check(lib.avdm_volume_retrieve_best_depth(_ptr(self.sgm_depth_thickness), X * 8, _ptr(self.sgm_depth_sim), X * 8, _ptr(self.depths_d),
+                                                      _ptr(self.best), py, pxx, Z, C.byref(rc1), C.byref(sp), abi.Range(0, Z), roi, st),
+                  "retrieve_best_depth")
+        return self.sgm_depth_thickness, self.sgm_depth_sim
+
+    # ---- Sgm::smoothThicknessMap + Refine::refineRc ----
+    def run_refine(self, rc, tcs, refine_enabled=True, optimize_enabled=True):
+        lib, sp, rp = self.lib, self.sgm, self.refine
+        roiS, roiR = self.droi(sp.scale * sp.stepXY), self.droi(rp.scale * rp.stepXY)
+        st = _stream()
+        abi.check(lib.avdm_depth_thickness_smooth_thickness(_ptr(self.sgm_depth_thickness), roiS.width * 8, C.byref(sp), C.byref(rp), roiS, st),
+                  "smooth_thickness")
+        X, Y = roiR.width, roiR.height
+        rcCam = self.cam(rc, rp.scale)
+        ratio = float(roiS.width) / float(X)
+        abi.check(lib.avdm_compute_sgm_upscaled_depth_pixsize_map(_ptr(self.sgm_upscaled), X * 8, _ptr(self.sgm_depth_thickness), roiS.width * 8,
+                                                                  C.byref(rcCam), C.byref(self.pyr[rc].desc), C.byref(rp), ratio, roiR, st),
+                  "sgm_upscale")
+        Zr, Zrp = self.Zr, self.Zrp
+        py, pxx = X * Zrp * 2, Zrp * 2
+        if refine_enabled:
+            abi.check(lib.avdm_volume_initialize_f16(_ptr(self.refine_volume), py, pxx, X, Y, Zrp, 0.0, st), "volume_initialize_f16")
+            for tc in tcs:
+                tcCam = self.cam(tc, rp.scale)
+                abi.check(lib.avdm_volume_refine_similarity(_ptr(self.refine_volume), py, pxx, Zr, _ptr(self.sgm_upscaled), X * 8, None, 0,
+                                                            C.byref(rcCam), C.byref(tcCam), C.byref(self.pyr[rc].desc), C.byref(self.pyr[tc].desc),
+                                                            C.byref(rp), abi.Range(0, Zr), roiR, st), "refine_similarity")
+            abi.check(lib.avdm_volume_refine_best_depth(_ptr(self.refined), X * 8, _ptr(self.sgm_upscaled), X * 8, _ptr(self.refine_volume), py, pxx,
+                                                        Zr, C.byref(rp), roiR, st), "refine_best_depth")
+        else:
+            abi.check(lib.avdm_depth_sim_map_copy_depth_only(_ptr(self.refined), X * 8, _ptr(self.sgm_upscaled), X * 8, X, Y, 1.0, st),
+                      "copy_depth_only")
+        if optimize_enabled and rp.optimizationNbIterations > 0:
+            abi.check(lib.avdm_depth_sim_map_optimize_gradient_descent(_ptr(self.optimized), X * 8, _ptr(self.img_variance), X * 4,
+                                                                       _ptr(self.tmp_depth), X * 4, X, Y, _ptr(self.sgm_upscaled), X * 8,
+                                                                       _ptr(self.refined), X * 8, C.byref(rcCam), C.byref(self.pyr[rc].desc),
+                                                                       C.byref(rp), roiR, st), "optimize_gradient_descent")
+        else:
+            self.optimized.copy_(self.refined)
+        return self.optimized

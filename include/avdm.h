@@ -1,0 +1,202 @@
+/*
+ * avdm.h — C ABI of the MI355X-native depth-map estimation hot path
+ * (plane-sweep similarity volume -> 4-path SGM aggregation -> WTA depth ->
+ *  Refine re-sweep -> sliding-Gaussian sub-sample arg-min -> colour-guided
+ *  optimisation), the drop-in for AliceVision's `src/aliceVision/depthMap`
+ *  kernel-launch layer.
+ *
+ * Every entry point replaces one host wrapper of the reference (cited per
+ * function as file:line relative to /root/reference/src/aliceVision/depthMap).
+ * Differences from the reference wrappers, all forced by the C ABI:
+ *   - `int` status (0 = ok, otherwise a hipError_t value; text through
+ *     avdm_last_error()) instead of C++ exceptions (cuda/host/utils.hpp:10-40);
+ *   - camera parameters passed by pointer to a host-side avdm_camera_t (copied
+ *     into kernel arguments) instead of a slot id into __constant__ memory
+ *     (cuda/device/DeviceCameraParams.hpp:32-34);
+ *   - images passed as avdm_pyramid_t (fp16 RGBA Lab pyramid in plain device
+ *     memory, filtered in ALU) instead of a cudaTextureObject_t over a
+ *     mipmapped array (cuda/host/DeviceMipmapImage.cpp:28-90);
+ *   - buffers as (pointer, pitches) instead of CudaDeviceMemoryPitched<T,N>.
+ *
+ * Volume layout (ours): z-fastest.  A voxel (x,y,z) of a uint8
+ * similarity volume lives at  base + y*pitch_y + x*pitch_x + z  (bytes);
+ * of the fp16 refine volume at  base + y*pitch_y + x*pitch_x + 2*z.
+ * pitch_x must be a multiple of 4 (u8) / 16 (fp16 volume) and >= Z (resp. 2*Z).
+ *
+ * All functions are asynchronous on `stream` (a hipStream_t passed as void*),
+ * borrow caller-allocated device buffers and never allocate device memory,
+ * except avdm_scratch_* helpers which are explicit.
+ */
+#ifndef AVDM_H
+#define AVDM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVDM_MAX_LEVELS 8
+
+/* texture filter arithmetic (see DESIGN.md "Texture unit restatement") */
+#define AVDM_FILTER_EXACT 0      /* fp32 bilinear / mip weights                         */
+#define AVDM_FILTER_CUDA_FIXED8 1 /* weights quantised to 1.8 fixed point like the CUDA texture unit */
+
+/* mirrors DeviceCameraParams (cuda/device/DeviceCameraParams.hpp:16-28); all matrices column-major */
+typedef struct avdm_camera
+{
+    float P[12];
+    float iP[9];
+    float R[9];
+    float iR[9];
+    float K[9];
+    float iK[9];
+    float C[3];
+    float XVect[3];
+    float YVect[3];
+    float ZVect[3];
+} avdm_camera_t;
+
+/* mirrors ROI / Range (mvsData/ROI.hpp:35-126): half-open ranges, already divided by scale*stepXY */
+typedef struct avdm_range { unsigned int begin, end; } avdm_range_t;
+typedef struct avdm_roi { avdm_range_t x, y; } avdm_roi_t;
+
+/* replaces DeviceMipmapImage (cuda/host/DeviceMipmapImage.hpp:25-84): fp16 (L,a,b,alpha) texels, 8 B each */
+typedef struct avdm_pyramid
+{
+    void* base;                        /* device (or host, for the oracle) pointer to level 0 */
+    int levels;                        /* number of levels actually built                     */
+    int filter_mode;                   /* AVDM_FILTER_*                                        */
+    int min_downscale;                 /* downscale of level 0 w.r.t. the process image        */
+    int width0, height0;               /* size of the process image (before min_downscale)    */
+    int width[AVDM_MAX_LEVELS];        /* texels per row of each level (floor halving, like cudaMallocMipmappedArray) */
+    int height[AVDM_MAX_LEVELS];
+    int pitch[AVDM_MAX_LEVELS];        /* bytes per row                                        */
+    long long offset[AVDM_MAX_LEVELS]; /* byte offset of each level from base                  */
+    long long bytes;                   /* total allocation size                                */
+} avdm_pyramid_t;
+
+/* subset of SgmParams used by the kernels (SgmParams.hpp:21-55) */
+typedef struct avdm_sgm_params
+{
+    int scale;
+    int stepXY;
+    int wsh;
+    double gammaC;
+    double gammaP;
+    double p1;
+    double p2Weighting;
+    double maxSimilarity;
+    double depthThicknessInflate;
+    char filteringAxes[8];    /* ordered axis string, e.g. "YX" (SgmParams.hpp:34) */
+    int useConsistentScale;
+    int strictRoiQuirk;       /* 1 = replicate the begin-x/begin-y swap of deviceSimilarityVolumeKernels.cuh:688-709 */
+} avdm_sgm_params_t;
+
+/* subset of RefineParams used by the kernels (RefineParams.hpp:19-45) */
+typedef struct avdm_refine_params
+{
+    int scale;
+    int stepXY;
+    int wsh;
+    int halfNbDepths;
+    int nbSubsamples;
+    int optimizationNbIterations;
+    double sigma;
+    double gammaC;
+    double gammaP;
+    int interpolateMiddleDepth;
+    int useConsistentScale;
+} avdm_refine_params_t;
+
+/* ---- library ---- */
+const char* avdm_last_error(void);
+int avdm_version(void);
+/* gpu/gpu.cpp:15-66 (gpuSupportCUDA / gpuInformationCUDA) */
+int avdm_device_count(void);
+int avdm_device_info(int device, char* out, size_t out_len);
+
+/* ---- image side ---- */
+/* host-only: fills width/height/pitch/offset/bytes for an image of w x h process pixels.
+ * DeviceMipmapImage.cpp:28-35,92-108 (levels = log2(maxDs/minDs)+1, level dims) */
+int avdm_pyramid_layout(avdm_pyramid_t* pyr, int width, int height, int min_downscale, int max_downscale, int filter_mode);
+/* float RGBA (0..1, device) * 255 -> fp16 texels.  cuda/host/DeviceCache.cpp:249-280 */
+int avdm_image_rgba_f32_to_f16x255(void* out_h4, int out_pitch, const float* in_rgba, int in_pitch, int width, int height, void* stream);
+/* in-place linear RGB(0..255) -> CIELAB*2.55.  imageProcessing/deviceColorConversion.cu:16-59 (cuda_rgb2lab) */
+int avdm_rgb2lab(void* inout_h4, int pitch, int width, int height, void* stream);
+/* (2r+1)^2 Gaussian downscale.  imageProcessing/deviceGaussianFilter.cu:44-80,268-287 (cuda_downscaleWithGaussianBlur) */
+int avdm_downscale_with_gaussian_blur(void* out_h4, int out_pitch, int out_w, int out_h, const void* in_h4, int in_pitch, int in_w, int in_h,
+                                      int downscale, int gauss_radius, int filter_mode, void* stream);
+/* levels 1..n-1 from level 0.  imageProcessing/deviceMipmappedArray.cu:20-92,222-327 (cuda_createMipmappedArrayFromImage) */
+int avdm_pyramid_build_levels(const avdm_pyramid_t* pyr, void* stream);
+/* convenience: the whole of DeviceCache::addMipmapImage + DeviceMipmapImage::fill for an image already on the device.
+ * `scratch_h4` must hold width*height fp16x4 texels when min_downscale > 1 (may be NULL otherwise). */
+int avdm_pyramid_fill(const avdm_pyramid_t* pyr, const float* in_rgba, int in_pitch, void* scratch_h4, void* stream);
+
+/* ---- similarity volume (planeSweeping/deviceSimilarityVolume.hpp) ---- */
+/* cuda_volumeInitialize(TSim) :25 */
+int avdm_volume_initialize_u8(uint8_t* vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, uint8_t value, void* stream);
+/* cuda_volumeInitialize(TSimRefine) :33 */
+int avdm_volume_initialize_f16(void* vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, float value, void* stream);
+/* cuda_volumeAdd :41-43 */
+int avdm_volume_add_f16(void* inout_vol, const void* in_vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, void* stream);
+/* cuda_volumeUpdateUninitializedSimilarity :51-53 */
+int avdm_volume_update_uninitialized(const uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, void* stream);
+/* cuda_volumeComputeSimilarity :69-79 */
+int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x,
+                                   const float* depths, const avdm_camera_t* rc, const avdm_camera_t* tc,
+                                   const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
+                                   const avdm_sgm_params_t* params, avdm_range_t depth_range, avdm_roi_t roi, void* stream);
+/* cuda_volumeRefineSimilarity :95-105 (normal map optional, may be NULL) */
+int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x, int dimZ,
+                                  const float* sgm_depth_pixsize, int map_pitch, const float* sgm_normal, int normal_pitch,
+                                  const avdm_camera_t* rc, const avdm_camera_t* tc,
+                                  const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
+                                  const avdm_refine_params_t* params, avdm_range_t depth_range, avdm_roi_t roi, void* stream);
+/* cuda_volumeOptimize :120-129.  `scratch` must hold avdm_volume_optimize_scratch_bytes() bytes (may be NULL if that is 0). */
+size_t avdm_volume_optimize_scratch_bytes(int dimX, int dimY, int dimZ);
+int avdm_volume_optimize(uint8_t* out_vol, const uint8_t* in_vol, long long pitch_y, int pitch_x, void* scratch,
+                         const avdm_pyramid_t* rc_pyr, const avdm_sgm_params_t* params, int last_depth_index, avdm_roi_t roi, void* stream);
+/* cuda_volumeRetrieveBestDepth :143-151 (out_depth_sim may be NULL); vol_dimZ = allocated depth of the volume (kernels.cuh:459) */
+int avdm_volume_retrieve_best_depth(float* out_depth_thickness, int dt_pitch, float* out_depth_sim, int ds_pitch,
+                                    const float* depths, const uint8_t* vol, long long pitch_y, int pitch_x, int vol_dimZ,
+                                    const avdm_camera_t* rc_scale1, const avdm_sgm_params_t* params, avdm_range_t depth_range, avdm_roi_t roi,
+                                    void* stream);
+/* cuda_volumeRefineBestDepth :163-168 */
+int avdm_volume_refine_best_depth(float* out_depth_sim, int out_pitch, const float* sgm_depth_pixsize, int map_pitch,
+                                  const void* vol_f16, long long pitch_y, int pitch_x, int dimZ,
+                                  const avdm_refine_params_t* params, avdm_roi_t roi, void* stream);
+
+/* ---- depth/sim maps (planeSweeping/deviceDepthSimilarityMap.hpp); maps are float2 rows, pitch in bytes ---- */
+/* cuda_depthSimMapCopyDepthOnly :25-28 */
+int avdm_depth_sim_map_copy_depth_only(float* out_map, int out_pitch, const float* in_map, int in_pitch, int width, int height, float default_sim,
+                                       void* stream);
+/* cuda_normalMapUpscale :37-40 (float3 maps) */
+int avdm_normal_map_upscale(float* out_map, int out_pitch, const float* in_map, int in_pitch, float ratio, avdm_roi_t roi, void* stream);
+/* cuda_depthThicknessSmoothThickness :50-54 */
+int avdm_depth_thickness_smooth_thickness(float* inout_map, int pitch, const avdm_sgm_params_t* sgm, const avdm_refine_params_t* refine,
+                                          avdm_roi_t roi, void* stream);
+/* cuda_computeSgmUpscaledDepthPixSizeMap :66-72; ratio = allocated SGM map width / allocated Refine map width (Map.cu:116-118) */
+int avdm_compute_sgm_upscaled_depth_pixsize_map(float* out_map, int out_pitch, const float* in_sgm_depth_thickness, int in_pitch,
+                                                const avdm_camera_t* rc, const avdm_pyramid_t* rc_pyr, const avdm_refine_params_t* params,
+                                                float ratio, avdm_roi_t roi, void* stream);
+/* cuda_depthSimMapComputeNormal :83-88 (float3 out) */
+int avdm_depth_sim_map_compute_normal(float* out_normal, int out_pitch, const float* in_depth_sim, int in_pitch, const avdm_camera_t* rc,
+                                      int stepXY, avdm_roi_t roi, void* stream);
+/* cuda_depthSimMapOptimizeGradientDescent :103-112.  tmp_depth/img_variance are float maps of at least roi size;
+ * tmp_depth_w/h = allocated extent of tmp_depth (the reference binds the whole buffer as a clamped texture, Map.cu:228-229). */
+int avdm_depth_sim_map_optimize_gradient_descent(float* out_opt_depth_sim, int out_pitch, float* img_variance, int var_pitch,
+                                                 float* tmp_depth, int tmp_pitch, int tmp_w, int tmp_h,
+                                                 const float* sgm_depth_pixsize, int sgm_pitch, const float* refine_depth_sim, int ref_pitch,
+                                                 const avdm_camera_t* rc, const avdm_pyramid_t* rc_pyr, const avdm_refine_params_t* params,
+                                                 avdm_roi_t roi, void* stream);
+
+/* ---- host helper: fillHostCameraParameters (cuda/host/DeviceCache.cpp:41-134) ---- */
+/* K,R row-major 3x3 doubles, C 3 doubles; downscale >= 1 */
+void avdm_camera_fill(avdm_camera_t* out, const double K[9], const double R[9], const double C[3], int downscale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVDM_H */

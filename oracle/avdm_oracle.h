@@ -1,0 +1,60 @@
+/*
+ * avdm_oracle.h — CPU parity oracle (TEST INFRASTRUCTURE ONLY; parity unpinned — see avdm_oracle.c header).
+ * Types are shared with the product ABI (include/avdm.h); all pointers are HOST pointers here.
+ */
+#ifndef AVDM_ORACLE_H
+#define AVDM_ORACLE_H
+
+#include "../include/avdm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+uint16_t avo_float_to_half(float f);
+float avo_half_to_float(uint16_t h);
+float avo_exp_p2(float x);
+void avo_tex2dlod(const avdm_pyramid_t* p, float u, float v, float lod, float out[4]);
+
+int avo_pyramid_layout(avdm_pyramid_t* p, int width, int height, int min_downscale, int max_downscale, int filter_mode);
+void avo_image_rgba_f32_to_f16x255(uint16_t* out, int out_pitch, const float* in, int in_pitch, int width, int height);
+void avo_rgb2lab(uint16_t* img, int pitch, int width, int height);
+void avo_downscale_with_gaussian_blur(uint16_t* out, int out_pitch, int out_w, int out_h, const uint16_t* in, int in_pitch, int in_w, int in_h,
+                                      int downscale, int gaussRadius, int filter_mode);
+void avo_pyramid_build_levels(const avdm_pyramid_t* p);
+int avo_pyramid_fill(const avdm_pyramid_t* p, const float* rgba, int in_pitch);
+void avo_camera_fill(avdm_camera_t* out, const double K[9], const double R[9], const double C[3], int downscale);
+
+void avo_volume_initialize_u8(uint8_t* vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, uint8_t value);
+void avo_volume_initialize_f16(uint16_t* vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, float value);
+void avo_volume_add_f16(uint16_t* inout, const uint16_t* in, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ);
+void avo_volume_update_uninitialized(const uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ);
+void avo_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, const float* depths, const avdm_camera_t* rc,
+                                   const avdm_camera_t* tc, const avdm_pyramid_t* rcPyr, const avdm_pyramid_t* tcPyr,
+                                   const avdm_sgm_params_t* sp, avdm_range_t depthRange, avdm_roi_t roi);
+void avo_volume_refine_similarity(uint16_t* vol, long long pitch_y, int pitch_x, int volDimZ, const float* sgmDepthPixSize, int map_pitch,
+                                  const float* sgmNormal, int normal_pitch, const avdm_camera_t* rc, const avdm_camera_t* tc,
+                                  const avdm_pyramid_t* rcPyr, const avdm_pyramid_t* tcPyr, const avdm_refine_params_t* rp, avdm_range_t depthRange,
+                                  avdm_roi_t roi);
+void avo_volume_optimize(uint8_t* out, const uint8_t* in, long long pitch_y, int pitch_x, int dimX, int dimY, const avdm_pyramid_t* rcPyr,
+                         const avdm_sgm_params_t* sp, int lastDepthIndex, avdm_roi_t roi);
+void avo_volume_retrieve_best_depth(float* outDT, int dt_pitch, float* outDS, int ds_pitch, const float* depths, const uint8_t* vol,
+                                    long long pitch_y, int pitch_x, int volDimZ, const avdm_camera_t* rc1, const avdm_sgm_params_t* sp,
+                                    avdm_range_t depthRange, avdm_roi_t roi);
+void avo_volume_refine_best_depth(float* out, int out_pitch, const float* sgmDepthPixSize, int map_pitch, const uint16_t* vol, long long pitch_y,
+                                  int pitch_x, int volDimZ, const avdm_refine_params_t* rp, avdm_roi_t roi);
+
+void avo_depth_sim_map_copy_depth_only(float* out, int out_pitch, const float* in, int in_pitch, int width, int height, float defaultSim);
+void avo_normal_map_upscale(float* out, int out_pitch, const float* in, int in_pitch, float ratio, avdm_roi_t roi);
+void avo_depth_thickness_smooth_thickness(float* map, int pitch, const avdm_sgm_params_t* sp, const avdm_refine_params_t* rp, avdm_roi_t roi);
+void avo_compute_sgm_upscaled_depth_pixsize_map(float* out, int out_pitch, const float* in, int in_pitch, const avdm_camera_t* rc,
+                                                const avdm_pyramid_t* rcPyr, const avdm_refine_params_t* rp, float ratio, avdm_roi_t roi);
+void avo_depth_sim_map_optimize_gradient_descent(float* outOpt, int out_pitch, float* imgVariance, int var_pitch, float* tmpDepth, int tmp_pitch,
+                                                 int tmpW, int tmpH, const float* sgmDepthPixSize, int sgm_pitch, const float* refineDepthSim,
+                                                 int ref_pitch, const avdm_camera_t* rc, const avdm_pyramid_t* rcPyr,
+                                                 const avdm_refine_params_t* rp, avdm_roi_t roi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

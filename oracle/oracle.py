@@ -1,0 +1,213 @@
+"""Python face of the CPU parity oracle (oracle/libavdm_oracle.so) — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module (parity unpinned: see the
+header of avdm_oracle.c).  Struct layouts are shared with the product ABI (alicevision_amd/abi.py mirrors include/avdm.h);
+all buffers are numpy arrays in host memory.
+
+`OracleDepthMap` restates the per-tile control flow of the reference:
+  Sgm::sgmRc (Sgm.cpp:117-188, 203-325), Sgm::smoothThicknessMap (:190-201), Refine::refineRc (Refine.cpp:97-176, 178-272).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from alicevision_amd import abi  # struct layouts only (include/avdm.h)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libavdm_oracle.so")
+P = C.POINTER
+vp, i32, i64, f32, u8 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ubyte
+
+_SIG = {
+    "avo_float_to_half": (C.c_ushort, [f32]),
+    "avo_half_to_float": (f32, [C.c_ushort]),
+    "avo_exp_p2": (f32, [f32]),
+    "avo_tex2dlod": (None, [P(abi.Pyramid), f32, f32, f32, P(f32 * 4)]),
+    "avo_pyramid_layout": (i32, [P(abi.Pyramid), i32, i32, i32, i32, i32]),
+    "avo_image_rgba_f32_to_f16x255": (None, [vp, i32, vp, i32, i32, i32]),
+    "avo_rgb2lab": (None, [vp, i32, i32, i32]),
+    "avo_downscale_with_gaussian_blur": (None, [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32]),
+    "avo_pyramid_build_levels": (None, [P(abi.Pyramid)]),
+    "avo_pyramid_fill": (i32, [P(abi.Pyramid), vp, i32]),
+    "avo_camera_fill": (None, [P(abi.Camera), P(C.c_double * 9), P(C.c_double * 9), P(C.c_double * 3), i32]),
+    "avo_volume_initialize_u8": (None, [vp, i64, i32, i32, i32, i32, u8]),
+    "avo_volume_initialize_f16": (None, [vp, i64, i32, i32, i32, i32, f32]),
+    "avo_volume_add_f16": (None, [vp, vp, i64, i32, i32, i32, i32]),
+    "avo_volume_update_uninitialized": (None, [vp, vp, i64, i32, i32, i32, i32]),
+    "avo_volume_compute_similarity": (None, [vp, vp, i64, i32, vp, P(abi.Camera), P(abi.Camera), P(abi.Pyramid), P(abi.Pyramid),
+                                             P(abi.SgmParams), abi.Range, abi.ROI]),
+    "avo_volume_refine_similarity": (None, [vp, i64, i32, i32, vp, i32, vp, i32, P(abi.Camera), P(abi.Camera), P(abi.Pyramid), P(abi.Pyramid),
+                                            P(abi.RefineParams), abi.Range, abi.ROI]),
+    "avo_volume_optimize": (None, [vp, vp, i64, i32, i32, i32, P(abi.Pyramid), P(abi.SgmParams), i32, abi.ROI]),
+    "avo_volume_retrieve_best_depth": (None, [vp, i32, vp, i32, vp, vp, i64, i32, i32, P(abi.Camera), P(abi.SgmParams), abi.Range, abi.ROI]),
+    "avo_volume_refine_best_depth": (None, [vp, i32, vp, i32, vp, i64, i32, i32, P(abi.RefineParams), abi.ROI]),
+    "avo_depth_sim_map_copy_depth_only": (None, [vp, i32, vp, i32, i32, i32, f32]),
+    "avo_normal_map_upscale": (None, [vp, i32, vp, i32, f32, abi.ROI]),
+    "avo_depth_thickness_smooth_thickness": (None, [vp, i32, P(abi.SgmParams), P(abi.RefineParams), abi.ROI]),
+    "avo_compute_sgm_upscaled_depth_pixsize_map": (None, [vp, i32, vp, i32, P(abi.Camera), P(abi.Pyramid), P(abi.RefineParams), f32, abi.ROI]),
+    "avo_depth_sim_map_optimize_gradient_descent": (None, [vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, i32, P(abi.Camera), P(abi.Pyramid),
+                                                           P(abi.RefineParams), abi.ROI]),
+}
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", HERE, "-s"], check=True)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIG.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def camera_fill(K, R, Cc, downscale):
+    cam = abi.Camera()
+    Ka = (C.c_double * 9)(*[float(v) for v in np.asarray(K).reshape(-1)])
+    Ra = (C.c_double * 9)(*[float(v) for v in np.asarray(R).reshape(-1)])
+    Ca = (C.c_double * 3)(*[float(v) for v in np.asarray(Cc).reshape(-1)])
+    load().avo_camera_fill(C.byref(cam), C.byref(Ka), C.byref(Ra), C.byref(Ca), int(downscale))
+    return cam
+
+
+class HostPyramid:
+    """fp16 Lab mip pyramid in host memory (DeviceMipmapImage restated)."""
+
+    def __init__(self, rgba, min_downscale, max_downscale, filter_mode):
+        lib = load()
+        h, w = rgba.shape[:2]
+        self.desc = abi.Pyramid()
+        assert lib.avo_pyramid_layout(C.byref(self.desc), w, h, min_downscale, max_downscale, filter_mode) == 0
+        self.buf = np.zeros(self.desc.bytes, dtype=np.uint8)
+        self.desc.base = self.buf.ctypes.data
+        rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+        assert lib.avo_pyramid_fill(C.byref(self.desc), ptr(rgba), w * 16) == 0
+
+    def level(self, l):
+        d = self.desc
+        raw = self.buf[d.offset[l]:d.offset[l] + d.pitch[l] * d.height[l]].reshape(d.height[l], d.pitch[l])
+        return raw[:, :d.width[l] * 8].view(np.float16).reshape(d.height[l], d.width[l], 4)
+
+
+def ceil_div(a, b):
+    return (a + b - 1) // b
+
+
+class OracleDepthMap:
+    """One tile of one R camera through SGM + Refine on the CPU.  roi = full-resolution (process) pixel ROI."""
+
+    def __init__(self, images, K, Rs, Cs, sgm, refine, filter_mode=abi.FILTER_CUDA_FIXED8, roi=None):
+        self.lib = load()
+        self.sgm, self.refine = sgm, refine
+        n, H, W = images.shape[:3]
+        self.W, self.H = W, H
+        min_ds = min(sgm.scale, refine.scale)
+        max_ds = max(sgm.scale, refine.scale) * 64  # DepthMapEstimator.cpp:324-325
+        self.pyr = [HostPyramid(images[i], min_ds, max_ds, filter_mode) for i in range(n)]
+        self.K, self.Rs, self.Cs = K, Rs, Cs
+        self.roi = roi if roi is not None else (0, W, 0, H)
+
+    def cam(self, i, scale):
+        return camera_fill(self.K, self.Rs[i], self.Cs[i], scale)
+
+    def droi(self, ds):
+        # downscaleROI (mvsData/ROI.hpp:181): begin floor-divided, end ceil-divided
+        x0, x1, y0, y1 = self.roi
+        return abi.ROI.make(x0 // ds, ceil_div(x1, ds), y0 // ds, ceil_div(y1, ds))
+
+    # ---- Sgm::sgmRc ----
+    def run_sgm(self, rc, tcs, depths, tc_ranges=None, optimize=True):
+        lib, sp = self.lib, self.sgm
+        ds = sp.scale * sp.stepXY
+        roi = self.droi(ds)
+        X, Y, Z = roi.width, roi.height, len(depths)
+        Zp = ceil_div(Z, 4) * 4
+        self.vol_dims = (X, Y, Z, Zp)
+        best = np.empty((Y, X, Zp), np.uint8)
+        second = np.empty((Y, X, Zp), np.uint8)
+        py, pxx = X * Zp, Zp
+        lib.avo_volume_initialize_u8(ptr(best), py, pxx, X, Y, Zp, 255)
+        lib.avo_volume_initialize_u8(ptr(second), py, pxx, X, Y, Zp, 255)
+        depths = np.ascontiguousarray(depths, np.float32)
+        rcCam = self.cam(rc, sp.scale)
+        for ti, tc in enumerate(tcs):
+            tcCam = self.cam(tc, sp.scale)
+            r = tc_ranges[ti] if tc_ranges else (0, Z)
+            lib.avo_volume_compute_similarity(ptr(best), ptr(second), py, pxx, ptr(depths), C.byref(rcCam), C.byref(tcCam),
+                                              C.byref(self.pyr[rc].desc), C.byref(self.pyr[tc].desc), C.byref(sp), abi.Range(r[0], r[1]), roi)
+        self.best_raw = best.copy()
+        lib.avo_volume_update_uninitialized(ptr(best), ptr(second), py, pxx, X, Y, Z)
+        self.second = second
+        if optimize:
+            lib.avo_volume_optimize(ptr(best), ptr(second), py, pxx, X, Y, C.byref(self.pyr[rc].desc), C.byref(sp), Z, roi)
+        else:
+            best[...] = second
+        self.filtered = best
+        dt = np.empty((Y, X, 2), np.float32)
+        dsm = np.empty((Y, X, 2), np.float32)
+        rc1 = self.cam(rc, 1)
+        lib.avo_volume_retrieve_best_depth(ptr(dt), X * 8, ptr(dsm), X * 8, ptr(depths), ptr(best), py, pxx, Z, C.byref(rc1), C.byref(sp),
+                                           abi.Range(0, Z), roi)
+        self.sgm_depth_thickness = dt
+        self.sgm_depth_sim = dsm
+        return dt, dsm
+
+    # ---- Sgm::smoothThicknessMap + Refine::refineRc ----
+    def run_refine(self, rc, tcs, refine_enabled=True, optimize_enabled=True):
+        lib, sp, rp = self.lib, self.sgm, self.refine
+        dsS = sp.scale * sp.stepXY
+        dsR = rp.scale * rp.stepXY
+        roiS, roiR = self.droi(dsS), self.droi(dsR)
+        dt = self.sgm_depth_thickness.copy()
+        lib.avo_depth_thickness_smooth_thickness(ptr(dt), roiS.width * 8, C.byref(sp), C.byref(rp), roiS)
+        self.sgm_depth_thickness_smooth = dt
+        X, Y = roiR.width, roiR.height
+        rcCam = self.cam(rc, rp.scale)
+        up = np.empty((Y, X, 2), np.float32)
+        ratio = np.float32(roiS.width) / np.float32(X)  # allocated widths == ROI widths here (single tile)
+        lib.avo_compute_sgm_upscaled_depth_pixsize_map(ptr(up), X * 8, ptr(dt), roiS.width * 8, C.byref(rcCam), C.byref(self.pyr[rc].desc),
+                                                       C.byref(rp), ratio, roiR)
+        self.sgm_upscaled = up
+        Zr = rp.halfNbDepths * 2 + 1
+        Zrp = ceil_div(Zr, 8) * 8
+        refined = np.empty((Y, X, 2), np.float32)
+        if refine_enabled:
+            vol = np.zeros((Y, X, Zrp), np.float16)
+            py, pxx = X * Zrp * 2, Zrp * 2
+            lib.avo_volume_initialize_f16(ptr(vol), py, pxx, X, Y, Zr, 0.0)
+            for tc in tcs:
+                tcCam = self.cam(tc, rp.scale)
+                lib.avo_volume_refine_similarity(ptr(vol), py, pxx, Zr, ptr(up), X * 8, None, 0, C.byref(rcCam), C.byref(tcCam),
+                                                 C.byref(self.pyr[rc].desc), C.byref(self.pyr[tc].desc), C.byref(rp), abi.Range(0, Zr), roiR)
+            self.refine_volume = vol
+            lib.avo_volume_refine_best_depth(ptr(refined), X * 8, ptr(up), X * 8, ptr(vol), py, pxx, Zr, C.byref(rp), roiR)
+        else:
+            lib.avo_depth_sim_map_copy_depth_only(ptr(refined), X * 8, ptr(up), X * 8, X, Y, 1.0)
+        self.refined = refined
+        if optimize_enabled and rp.optimizationNbIterations > 0:
+            opt = np.empty((Y, X, 2), np.float32)
+            var = np.empty((Y, X), np.float32)
+            tmp = np.empty((Y, X), np.float32)
+            lib.avo_depth_sim_map_optimize_gradient_descent(ptr(opt), X * 8, ptr(var), X * 4, ptr(tmp), X * 4, X, Y, ptr(up), X * 8,
+                                                            ptr(refined), X * 8, C.byref(rcCam), C.byref(self.pyr[rc].desc), C.byref(rp), roiR)
+            self.img_variance = var
+        else:
+            opt = refined.copy()
+        self.optimized = opt
+        return opt

@@ -1,0 +1,264 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): every HIP stage against the CPU oracle through the C ABI.
+
+Parity classes:
+  bit-exact   : SGM path aggregation, WTA depth retrieval, thickness smoothing, SGM upscale, Refine sub-sample arg-min,
+                volume init / update — compared with == on identical inputs;
+  tolerance   : image pyramid (cbrt / exp in different libms, FMA contraction), similarity volumes (fast intrinsics,
+                homogeneous patch projection), Refine volume, colour optimisation — tolerances stated in each test.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from alicevision_amd import abi
+
+from common import level_mismatch, make_hip_from_oracle, make_oracle, small_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _st():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.fixture(scope="module")
+def case():
+    """3 views 256x192, 32 planes: oracle run once, reused by the stage tests."""
+    sc, sgm, ref, depths = small_case()
+    o = make_oracle(sc, sgm, ref)
+    o.run_sgm(0, [1, 2], depths)
+    o.run_refine(0, [1, 2])
+    return sc, sgm, ref, depths, o
+
+
+def test_library_loaded_is_native():
+    lib = abi.load()
+    assert lib.avdm_device_count() >= 1
+    buf = C.create_string_buffer(1024)
+    abi.check(lib.avdm_device_info(0, buf, 1024))
+    assert b"gfx950" in buf.value, buf.value
+
+
+@pytest.mark.parametrize("mode", [abi.FILTER_CUDA_FIXED8, abi.FILTER_EXACT])
+def test_pyramid_parity(mode):
+    torch = _torch()
+    from alicevision_amd.pipeline import DevicePyramid
+    from oracle import oracle
+    sc, sgm, ref, _ = small_case(width=250, height=186)  # non power-of-two sizes: floor-halved levels
+    img = sc.images[0]
+    hp = oracle.HostPyramid(img.numpy(), 1, 128, mode)
+    dp = DevicePyramid(img.cuda(), 1, 128, mode)
+    torch.cuda.synchronize()
+    assert dp.desc.levels == hp.desc.levels
+    for l in range(hp.desc.levels):
+        a = hp.level(l).astype(np.float32)
+        b = dp.level(l).cpu().numpy().astype(np.float32)
+        assert a.shape == b.shape
+        # fp16 storage: values < 256 have a quantum <= 0.125; allow one quantum on <= 0.5 % of texels (libm cbrtf / FMA differences)
+        diff = np.abs(a - b)
+        assert diff.max() <= 0.13, (l, diff.max())
+        assert (diff > 0).mean() <= 5e-3, (l, (diff > 0).mean())
+
+
+@pytest.mark.parametrize("mode", [abi.FILTER_CUDA_FIXED8, abi.FILTER_EXACT])
+def test_similarity_volume_parity(mode):
+    torch = _torch()
+    sc, sgm, ref, depths = small_case()
+    o = make_oracle(sc, sgm, ref, filter_mode=mode)
+    o.run_sgm(0, [1, 2], depths, tc_ranges=[(0, 32), (3, 29)], optimize=False)
+    h = make_hip_from_oracle(o, sc, sgm, ref)
+    h.run_sgm(0, [1, 2], depths, tc_ranges=[(0, 32), (3, 29)], optimize=False)
+    torch.cuda.synchronize()
+    Z = len(depths)
+    second_h = h.second.cpu().numpy()[..., :Z]
+    frac, mx = level_mismatch(o.second[..., :Z], second_h)
+    # uint8 truncation of 127*(1+ncc): the HIP kernel uses v_rcp/v_rsq/v_exp/v_sqrt (1 ulp), a merged exponential and a
+    # homogeneous patch projection, so a voxel can land on the other side of an integer boundary.
+    tol = 0.02 if mode == abi.FILTER_CUDA_FIXED8 else 0.005
+    assert frac <= tol, (frac, mx)
+    d = np.abs(o.second[..., :Z].astype(np.int16) - second_h.astype(np.int16))
+    assert (d > 1).mean() <= 1e-3, (d > 1).mean()
+    # validity masks (255) must agree except on a handful of border voxels
+    assert ((o.second[..., :Z] == 255) != (second_h == 255)).mean() <= 1e-3
+
+
+def test_sgm_aggregation_bit_exact(case):
+    torch = _torch()
+    sc, sgm, ref, depths, o = case
+    lib = abi.load()
+    Y, X, Zp = o.second.shape
+    Z = len(depths)
+    roi = o.droi(sgm.scale * sgm.stepXY)
+    vin = torch.from_numpy(o.second).cuda()
+    vout = torch.full_like(vin, 7)
+    pyr = make_hip_from_oracle(o, sc, sgm, ref).pyr[0]
+    abi.check(lib.avdm_volume_optimize(_ptr(vout), _ptr(vin), X * Zp, Zp, None, C.byref(pyr.desc), C.byref(sgm), Z, roi, _st()))
+    torch.cuda.synchronize()
+    got = vout.cpu().numpy()[..., :Z]
+    want = o.filtered[..., :Z]
+    assert np.array_equal(got, want), level_mismatch(got, want)
+
+
+@pytest.mark.parametrize("Z,axes,p2", [(5, b"YX", 100.0), (67, b"Y", 100.0), (130, b"X", -40.0), (300, b"XY", 100.0)])
+def test_sgm_aggregation_shapes(Z, axes, p2):
+    """ragged depth counts (tail bytes, several dwords per lane), single axes, fixed P2, non-square ROI with an offset"""
+    torch = _torch()
+    from oracle import oracle
+    rng = np.random.RandomState(Z)
+    sc, sgm, ref, _ = small_case(width=128, height=96, filteringAxes=axes, p2Weighting=p2)
+    o = make_oracle(sc, sgm, ref)
+    lib, olib = abi.load(), oracle.load()
+    X, Y = 23, 17
+    Zp = (Z + 3) // 4 * 4
+    roi = abi.ROI.make(3, 3 + X, 5, 5 + Y)
+    vin = rng.randint(0, 256, size=(Y, X, Zp)).astype(np.uint8)
+    want = np.full_like(vin, 9)
+    olib.avo_volume_optimize(oracle.ptr(want), oracle.ptr(vin), X * Zp, Zp, X, Y, C.byref(o.pyr[0].desc), C.byref(sgm), Z, roi)
+    pyr = make_hip_from_oracle(o, sc, sgm, ref).pyr[0]
+    tin = torch.from_numpy(vin).cuda()
+    tout = torch.full_like(tin, 9)
+    abi.check(lib.avdm_volume_optimize(_ptr(tout), _ptr(tin), X * Zp, Zp, None, C.byref(pyr.desc), C.byref(sgm), Z, roi, _st()))
+    torch.cuda.synchronize()
+    got = tout.cpu().numpy()
+    assert np.array_equal(got, want), level_mismatch(got, want)  # including the untouched padding planes z >= Z
+
+
+def test_retrieve_best_depth_bit_exact(case):
+    torch = _torch()
+    sc, sgm, ref, depths, o = case
+    lib = abi.load()
+    Y, X, Zp = o.filtered.shape
+    Z = len(depths)
+    roi = o.droi(sgm.scale * sgm.stepXY)
+    vol = torch.from_numpy(o.filtered).cuda()
+    dt = torch.empty((Y, X, 2), dtype=torch.float32, device="cuda")
+    ds = torch.empty((Y, X, 2), dtype=torch.float32, device="cuda")
+    dd = torch.from_numpy(np.asarray(depths, np.float32)).cuda()
+    rc1 = abi.camera_fill(sc.K, sc.R[0], sc.C[0], 1)
+    abi.check(lib.avdm_volume_retrieve_best_depth(_ptr(dt), X * 8, _ptr(ds), X * 8, _ptr(dd), _ptr(vol), X * Zp, Zp, Z, C.byref(rc1),
+                                                  C.byref(sgm), abi.Range(0, Z), roi, _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(dt.cpu().numpy(), o.sgm_depth_thickness)
+    assert np.array_equal(ds.cpu().numpy(), o.sgm_depth_sim)
+
+
+def test_smooth_and_upscale_bit_exact(case):
+    torch = _torch()
+    sc, sgm, ref, depths, o = case
+    lib = abi.load()
+    roiS, roiR = o.droi(sgm.scale * sgm.stepXY), o.droi(ref.scale * ref.stepXY)
+    dt = torch.from_numpy(o.sgm_depth_thickness).cuda()
+    abi.check(lib.avdm_depth_thickness_smooth_thickness(_ptr(dt), roiS.width * 8, C.byref(sgm), C.byref(ref), roiS, _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(dt.cpu().numpy(), o.sgm_depth_thickness_smooth)
+    h = make_hip_from_oracle(o, sc, sgm, ref)
+    X, Y = roiR.width, roiR.height
+    up = torch.empty((Y, X, 2), dtype=torch.float32, device="cuda")
+    rc = abi.camera_fill(sc.K, sc.R[0], sc.C[0], ref.scale)
+    for interp in (0, 1):
+        rp = abi.RefineParams.default(interpolateMiddleDepth=interp)
+        want = np.empty((Y, X, 2), np.float32)
+        from oracle import oracle
+        oracle.load().avo_compute_sgm_upscaled_depth_pixsize_map(oracle.ptr(want), X * 8, oracle.ptr(o.sgm_depth_thickness_smooth), roiS.width * 8,
+                                                                 C.byref(rc), C.byref(o.pyr[0].desc), C.byref(rp), np.float32(roiS.width) / np.float32(X),
+                                                                 roiR)
+        abi.check(lib.avdm_compute_sgm_upscaled_depth_pixsize_map(_ptr(up), X * 8, _ptr(dt), roiS.width * 8, C.byref(rc), C.byref(h.pyr[0].desc),
+                                                                  C.byref(rp), float(roiS.width) / float(X), roiR, _st()))
+        torch.cuda.synchronize()
+        assert np.array_equal(up.cpu().numpy(), want), interp
+
+
+def test_refine_volume_parity(case):
+    torch = _torch()
+    sc, sgm, ref, depths, o = case
+    h = make_hip_from_oracle(o, sc, sgm, ref)
+    h._alloc(len(depths))
+    h.sgm_depth_thickness.copy_(torch.from_numpy(o.sgm_depth_thickness))
+    h.run_refine(0, [1, 2], optimize_enabled=False)
+    torch.cuda.synchronize()
+    Zr = ref.halfNbDepths * 2 + 1
+    a = o.refine_volume[..., :Zr].astype(np.float32)
+    b = h.refine_volume.cpu().numpy()[..., :Zr].astype(np.float32)
+    # sums of <= 2 sigmoid-filtered similarities in [0, 1], fp16 storage (quantum 2^-10 below 1, 2^-9 below 2)
+    diff = np.abs(a - b)
+    assert diff.max() <= 0.02, diff.max()
+    assert (diff > 2e-3).mean() <= 2e-3, (diff > 2e-3).mean()
+
+
+def test_refine_best_depth_bit_exact(case):
+    torch = _torch()
+    sc, sgm, ref, depths, o = case
+    lib = abi.load()
+    roiR = o.droi(ref.scale * ref.stepXY)
+    X, Y = roiR.width, roiR.height
+    Zr = ref.halfNbDepths * 2 + 1
+    vol = torch.from_numpy(o.refine_volume).cuda()
+    Zrp = vol.shape[2]
+    up = torch.from_numpy(o.sgm_upscaled).cuda()
+    out = torch.empty((Y, X, 2), dtype=torch.float32, device="cuda")
+    abi.check(lib.avdm_volume_refine_best_depth(_ptr(out), X * 8, _ptr(up), X * 8, _ptr(vol), X * Zrp * 2, Zrp * 2, Zr, C.byref(ref), roiR, _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), o.refined)
+
+
+def test_optimize_parity(case):
+    torch = _torch()
+    sc, sgm, ref, depths, o = case
+    lib = abi.load()
+    h = make_hip_from_oracle(o, sc, sgm, ref)
+    roiR = o.droi(ref.scale * ref.stepXY)
+    X, Y = roiR.width, roiR.height
+    up = torch.from_numpy(o.sgm_upscaled).cuda()
+    refined = torch.from_numpy(o.refined).cuda()
+    opt = torch.empty((Y, X, 2), dtype=torch.float32, device="cuda")
+    var = torch.empty((Y, X), dtype=torch.float32, device="cuda")
+    tmp = torch.empty((Y, X), dtype=torch.float32, device="cuda")
+    rc = abi.camera_fill(sc.K, sc.R[0], sc.C[0], ref.scale)
+    abi.check(lib.avdm_depth_sim_map_optimize_gradient_descent(_ptr(opt), X * 8, _ptr(var), X * 4, _ptr(tmp), X * 4, X, Y, _ptr(up), X * 8,
+                                                               _ptr(refined), X * 8, C.byref(rc), C.byref(h.pyr[0].desc), C.byref(ref), roiR, _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(var.cpu().numpy(), o.img_variance)
+    got, want = opt.cpu().numpy(), o.optimized
+    valid = want[..., 0] > 0
+    assert np.array_equal(got[..., 0] > 0, valid)
+    pix = o.sgm_upscaled[..., 1][valid]
+    # 100 Jacobi iterations in fp32 with libm-vs-ocml exp/acos: depth error relative to the pixel size
+    rel = np.abs(got[..., 0] - want[..., 0])[valid] / pix
+    assert np.sqrt(np.mean(rel ** 2)) < 1e-3, np.sqrt(np.mean(rel ** 2))
+    assert np.abs(got[..., 1] - want[..., 1])[valid].max() < 1e-2
+
+
+@pytest.mark.parametrize("mode", [abi.FILTER_CUDA_FIXED8, abi.FILTER_EXACT])
+def test_end_to_end_depth_rmse(mode):
+    """cfg1-like plumbing case: everything on the GPU (own pyramids) vs everything in the oracle; BASELINE bar: depth RMSE < 1e-3."""
+    torch = _torch()
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    sc, sgm, ref, depths = small_case(width=320, height=240, n_planes=48, seed=11)
+    o = make_oracle(sc, sgm, ref, filter_mode=mode)
+    o.run_sgm(0, [1, 2], depths)
+    want = o.run_refine(0, [1, 2])
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, mode) for i in range(3)]
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+    h.run_sgm(0, [1, 2], depths)
+    got = h.run_refine(0, [1, 2]).cpu().numpy()
+    torch.cuda.synchronize()
+    both = (want[..., 0] > 0) & (got[..., 0] > 0)
+    assert ((want[..., 0] > 0) != (got[..., 0] > 0)).mean() < 5e-3
+    gt = sc.gt_depth.numpy()
+    err = (got[..., 0] - want[..., 0])[both]
+    # a uint8 level flip before SGM can move the WTA plane of a pixel: robust statistic + RMSE over the 99.5 % best pixels
+    rmse = np.sqrt(np.mean(np.sort(err ** 2)[: int(0.995 * err.size)]))
+    assert rmse < 1e-3, rmse
+    assert np.median(np.abs(got[..., 0] - gt)[both]) < 5e-3
