@@ -130,6 +130,13 @@ __global__ void __launch_bounds__(256) mip_level_kernel(uint2* out, int out_pitc
       pack_h4(make_float4(sum.x / sumFactor, sum.y / sumFactor, sum.z / sumFactor, sum.w / sumFactor));
 }
 
+__global__ void __launch_bounds__(256) tex2dlod_probe_kernel(float4* out, Tex T, const float* uvl, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if(i < n)
+        out[i] = tex2DLod(T, uvl[3 * i], uvl[3 * i + 1], uvl[3 * i + 2]);
+}
+
 static GaussTaps make_taps(int scale)
 {
     // deviceGaussianFilter.cu:240-252: radius = scale + 1, delta = 1
@@ -263,6 +270,14 @@ int avdm_pyramid_build_levels(const avdm_pyramid_t* p, void* stream)
                                t.lv[l - 1], taps);
     }
     AVDM_LAUNCH_CHECK("avdm_pyramid_build_levels");
+}
+
+int avdm_tex2dlod(float* out4, const avdm_pyramid_t* pyr, const float* uvl, int n, void* stream)
+{
+    if(n <= 0)
+        return 0;
+    hipLaunchKernelGGL(tex2dlod_probe_kernel, dim3(divUp(n, 256)), dim3(256), 0, (hipStream_t)stream, (float4*)out4, make_tex(pyr), uvl, n);
+    AVDM_LAUNCH_CHECK("avdm_tex2dlod");
 }
 
 int avdm_pyramid_fill(const avdm_pyramid_t* p, const float* in_rgba, int in_pitch, void* scratch_h4, void* stream)

@@ -262,8 +262,8 @@ __global__ void __launch_bounds__(256) upscale_depth_pixsize_kernel(float2* out,
         }
         int xp = (int)floorf(ox);
         int yp = (int)floorf(oy);
-        xp = min(xp, (int)((float)roiW * ratio) - 2);
-        yp = min(yp, (int)((float)roiH * ratio) - 2);
+        xp = max(min(xp, (int)((float)roiW * ratio) - 2), 0); // max(.., 0): deviation, the reference reads out of bounds at roiX == 0
+        yp = max(min(yp, (int)((float)roiH * ratio) - 2), 0);
         const float2 lu = *((const float2*)((const char*)in + (long long)yp * in_pitch) + xp);
         const float2 ru = *((const float2*)((const char*)in + (long long)yp * in_pitch) + xp + 1);
         const float2 rd = *((const float2*)((const char*)in + (long long)(yp + 1) * in_pitch) + xp + 1);

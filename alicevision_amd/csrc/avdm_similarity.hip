@@ -42,14 +42,16 @@ __device__ __forceinline__ float4 fetch(const TexLevel& L, bool fixed8, float x,
 // returns +INF when invalid / masked.  TInvert: sigmoid-filtered positive similarity (Refine) else raw NCC in [-1, 1].
 template <bool FIXED8, int WSH, bool TInvert>
 __device__ __forceinline__ float ncc_patch(const avdm_camera_t& rc, const avdm_camera_t& tc, const NccArgs& A, const PatchTable& tab, f3 pp, f3 px,
-                                           f3 py, float pd)
+                                           f3 py, float pd, float rpx, float rpy)
 {
     const int wsh = WSH > 0 ? WSH : A.wsh;
     // homogeneous image coordinates of the patch centre and of the two scaled patch axes
     const f3 hr0 = M3x4mulV3(rc.P, pp);
     const f3 ht0 = M3x4mulV3(tc.P, pp);
-    const float ir0 = fast_rcp(hr0.z), it0 = fast_rcp(ht0.z);
-    const float rpx = hr0.x * ir0, rpy = hr0.y * ir0, tpx = ht0.x * it0, tpy = ht0.y * it0;
+    // (rpx, rpy): the patch centre lies on the ray of pixel (x, y), so its R projection IS (x, y); using the exact pixel makes
+    // the border test deterministic on the knife-edge rows where x == wsh + 2 (DESIGN.md "knife-edge rows")
+    const float it0 = fast_rcp(ht0.z);
+    const float tpx = ht0.x * it0, tpy = ht0.y * it0;
 
     const float dd = (float)wsh + 2.0f;
     if((rpx < dd) || (rpx > A.rcW1 - dd) || (tpx < dd) || (tpx > A.tcW1 - dd) || (rpy < dd) || (rpy > A.rcH1 - dd) || (tpy < dd) ||
@@ -81,10 +83,16 @@ __device__ __forceinline__ float ncc_patch(const avdm_camera_t& rc, const avdm_c
             if(WSH <= 0 && (xp < -wsh || xp > wsh))
                 continue;
             const float fx = (float)xp;
+#ifdef AVDM_DBG_REFPROJ
+            const f3 p3 = pp + px * (pd * fx) + py * (pd * fy);
+            const float2 rq = project3DPoint(rc.P, p3), tq = project3DPoint(tc.P, p3);
+            const float rx = rq.x, ry = rq.y, tx = tq.x, ty = tq.y;
+#else
             const float hrz = fmaf(fx, rax.z, hrRow.z), htz = fmaf(fx, tax.z, htRow.z);
             const float ir = fast_rcp(hrz), it = fast_rcp(htz);
             const float rx = fmaf(fx, rax.x, hrRow.x) * ir, ry = fmaf(fx, rax.y, hrRow.y) * ir;
             const float tx = fmaf(fx, tax.x, htRow.x) * it, ty = fmaf(fx, tax.y, htRow.y) * it;
+#endif
 
             const float4 rcC = tex_bilinear_px<FIXED8>(A.rcL, fmaf(rx, A.rcSx, A.rcOx), fmaf(ry, A.rcSy, A.rcOy));
             const float4 tcC = tex_bilinear_px<FIXED8>(A.tcL, fmaf(tx, A.tcSx, A.tcOx), fmaf(ty, A.tcSy, A.tcOy));
@@ -96,7 +104,10 @@ __device__ __forceinline__ float ncc_patch(const avdm_camera_t& rc, const avdm_c
             const float dct = __builtin_amdgcn_sqrtf(fmaf(dtx, dtx, fmaf(dty, dty, dtz * dtz)));
             const float w = __builtin_amdgcn_exp2f(fmaf(dcr + dct, A.negInvGammaC_log2e, -trow[xp]));
 
-            const float gx = rcC.x, gy = tcC.x;
+            // NCC statistics on L shifted by the centre values (gx = L_r(centre) - L_r(sample), same for T): variances and the
+            // covariance are shift- and (joint) sign-invariant, and the shifted sums do not cancel catastrophically in fp32
+            // the way sum(w L^2) - sum(w L)^2 / sum(w) does with L ~ 200 (DESIGN.md "NCC conditioning").
+            const float gx = drx, gy = dtx;
             const float wgx = w * gx, wgy = w * gy;
             wsum += w;
             xsum += wgx;
@@ -176,7 +187,7 @@ __global__ void __launch_bounds__(256)
         const float pd = computePixSize(rc, p);
         f3 ax, ay;
         patch_axes(rc, tc, p, ax, ay);
-        float fsim = ncc_patch<FIXED8, WSH, false>(rc, tc, A, tab, p, ax, ay, pd);
+        float fsim = ncc_patch<FIXED8, WSH, false>(rc, tc, A, tab, p, ax, ay, pd, x, y);
         if(fsim == INFINITY)
             fsim = 255.0f;
         else
@@ -256,7 +267,7 @@ __global__ void __launch_bounds__(256)
                 n = normalize((v1 + v2) * 0.5f);
             ax = normalize(cross(ay, n));
         }
-        const float fsim = ncc_patch<FIXED8, WSH, true>(rc, tc, A, tab, p, ax, ay, pd);
+        const float fsim = ncc_patch<FIXED8, WSH, true>(rc, tc, A, tab, p, ax, ay, pd, x, y);
         if(fsim == INFINITY)
             continue;
         hv[k] = __float2half(__half2float(hv[k]) + fsim);

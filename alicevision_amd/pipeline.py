@@ -112,7 +112,7 @@ class DepthMapTile:
         self._alloc_for = key
 
     # ---- Sgm::sgmRc ----
-    def run_sgm(self, rc, tcs, depths, tc_ranges=None, optimize=True):
+    def run_sgm(self, rc, tcs, depths, tc_ranges=None, optimize=True, keep_raw=False):
         lib, sp = self.lib, self.sgm
         Z = len(depths)
         self._alloc(Z)
@@ -131,6 +131,8 @@ class DepthMapTile:
                                                          C.byref(tcCam), C.byref(self.pyr[rc].desc), C.byref(self.pyr[tc].desc), C.byref(sp),
                                                          abi.Range(r[0], r[1]), roi, st), "volume_compute_similarity")
         abi.check(lib.avdm_volume_update_uninitialized(_ptr(self.best), _ptr(self.second), py, pxx, X, Y, Z, st), "update_uninitialized")
+        if keep_raw:
+            self.best_raw = self.best.clone()
         if optimize:
             abi.check(lib.avdm_volume_optimize(_ptr(self.best), _ptr(self.second), py, pxx, None, C.byref(self.pyr[rc].desc), C.byref(sp), Z, roi,
                                                st), "volume_optimize")

@@ -130,6 +130,9 @@ int avdm_downscale_with_gaussian_blur(void* out_h4, int out_pitch, int out_w, in
                                       int downscale, int gauss_radius, int filter_mode, void* stream);
 /* levels 1..n-1 from level 0.  imageProcessing/deviceMipmappedArray.cu:20-92,222-327 (cuda_createMipmappedArrayFromImage) */
 int avdm_pyramid_build_levels(const avdm_pyramid_t* pyr, void* stream);
+/* probe of the software texture unit: out[i] = tex2DLod<float4>(pyr, uvl[3i], uvl[3i+1], uvl[3i+2]) for n device-resident samples.
+ * Restates the texture object of deviceMipmappedArray.cu:329-351 (normalised coords, linear + mip-linear, clamp). */
+int avdm_tex2dlod(float* out4, const avdm_pyramid_t* pyr, const float* uvl, int n, void* stream);
 /* convenience: the whole of DeviceCache::addMipmapImage + DeviceMipmapImage::fill for an image already on the device.
  * `scratch_h4` must hold width*height fp16x4 texels when min_downscale > 1 (may be NULL otherwise). */
 int avdm_pyramid_fill(const avdm_pyramid_t* pyr, const float* in_rgba, int in_pitch, void* scratch_h4, void* stream);

@@ -659,13 +659,29 @@ static void computeRcTcMipmapLevels(float* out_rc, float* out_tc, float mipmapLe
     }
 }
 
+/* The weighted-NCC statistics of SimStat.cuh (E[x^2] - E[x]^2 with sum(w) ~ 1 and x ~ 200) lose 4-5 decimal digits to
+ * cancellation in fp32: a faithful fp32 restatement is itself +-2..3 uint8 levels away from the exact value of the same
+ * formula, and so is the reference on any GPU (DESIGN.md "NCC conditioning").  avo_set_ncc_precision(1) evaluates the SAME
+ * formula with the six running sums in double precision (geometry, texture filtering and weights unchanged): this is the
+ * well-defined value the reference's fp32 arithmetic approximates, used by the tolerance-class parity tests. */
+static int g_ncc_f64 = 0;
+void avo_set_ncc_precision(int f64) { g_ncc_f64 = f64; }
+
+/* The R-side border test `rp.x < wsh + 2` (Patch.cuh:490-493) is applied to the REPROJECTION of a point that lies on the ray
+ * of pixel (x, y): in exact arithmetic rp == (x, y).  Where x == wsh + 2 (or W - 1 - (wsh + 2)) the reference's outcome is a
+ * coin flip of fp32 rounding, per voxel, and SGM then spreads it along whole rows (DESIGN.md "knife-edge rows").
+ * avo_set_exact_rc_pixel(1) evaluates the test (and the centre fetch) on the exact pixel instead: the value the reference's
+ * arithmetic approximates.  Default 0 = literal restatement. */
+static int g_exact_rc_pixel = 0;
+void avo_set_exact_rc_pixel(int on) { g_exact_rc_pixel = on; }
+
 /* Patch.cuh:466-572 (compNCCby3DptsYK<TInvertAndFilter>) + SimStat.cuh:72-113,144-153; returns INFINITY when invalid */
 static float compNCCby3DptsYK(int invertAndFilter, const avdm_camera_t* rc, const avdm_camera_t* tc, const avdm_pyramid_t* rcTex,
                               const avdm_pyramid_t* tcTex, unsigned rcLevelWidth, unsigned rcLevelHeight, unsigned tcLevelWidth,
                               unsigned tcLevelHeight, float mipmapLevel, int wsh, float invGammaC, float invGammaP, int useConsistentScale,
-                              const Patch* patch)
+                              const Patch* patch, f2 rcPixel)
 {
-    const f2 rp = project3DPoint(rc->P, patch->p);
+    const f2 rp = g_exact_rc_pixel ? rcPixel : project3DPoint(rc->P, patch->p);
     const f2 tp = project3DPoint(tc->P, patch->p);
     const float dd = (float)wsh + 2.0f;
     if((rp.x < dd) || (rp.x > (float)(rcLevelWidth - 1) - dd) || (tp.x < dd) || (tp.x > (float)(tcLevelWidth - 1) - dd) || (rp.y < dd) ||
@@ -683,6 +699,7 @@ static float compNCCby3DptsYK(int invertAndFilter, const avdm_camera_t* rc, cons
         computeRcTcMipmapLevels(&rcMipmapLevel, &tcMipmapLevel, mipmapLevel, rc, tc, rp, tp, patch->p);
 
     float xsum = 0.f, ysum = 0.f, xxsum = 0.f, yysum = 0.f, xysum = 0.f, wsum = 0.f;
+    double dxsum = 0., dysum = 0., dxxsum = 0., dyysum = 0., dxysum = 0., dwsum = 0.; /* AVO_NCC_F64 evaluation, see avo_set_ncc_precision */
 
     const f4 rcCenterColor = tex2DLod(rcTex, (rp.x + 0.5f) * rcInvLevelWidth, (rp.y + 0.5f) * rcInvLevelHeight, rcMipmapLevel);
     const f4 tcCenterColor = tex2DLod(tcTex, (tp.x + 0.5f) * tcInvLevelWidth, (tp.y + 0.5f) * tcInvLevelHeight, tcMipmapLevel);
@@ -699,7 +716,9 @@ static float compNCCby3DptsYK(int invertAndFilter, const avdm_camera_t* rc, cons
             const f2 tpc = project3DPoint(tc->P, p);
             const f4 rcC = tex2DLod(rcTex, (rpc.x + 0.5f) * rcInvLevelWidth, (rpc.y + 0.5f) * rcInvLevelHeight, rcMipmapLevel);
             const f4 tcC = tex2DLod(tcTex, (tpc.x + 0.5f) * tcInvLevelWidth, (tpc.y + 0.5f) * tcInvLevelHeight, tcMipmapLevel);
-            const float w = CostYKfromLab(xp, yp, rcCenterColor, rcC, invGammaC, invGammaP) * CostYKfromLab(xp, yp, tcCenterColor, tcC, invGammaC, invGammaP);
+            const float wr = CostYKfromLab(xp, yp, rcCenterColor, rcC, invGammaC, invGammaP);
+            const float wt = CostYKfromLab(xp, yp, tcCenterColor, tcC, invGammaC, invGammaP);
+            const float w = wr * wt;
             /* simStat::update(gx, gy, w) SimStat.cuh:144-153 */
             const float gx = rcC.x, gy = tcC.x;
             wsum += w;
@@ -708,14 +727,36 @@ static float compNCCby3DptsYK(int invertAndFilter, const avdm_camera_t* rc, cons
             xxsum += w * gx * gx;
             yysum += w * gy * gy;
             xysum += w * gx * gy;
+            if(g_ncc_f64)
+            {
+                const double dw = (double)wr * (double)wt, dgx = gx, dgy = gy;
+                dwsum += dw;
+                dxsum += dw * dgx;
+                dysum += dw * dgy;
+                dxxsum += dw * dgx * dgx;
+                dyysum += dw * dgy * dgy;
+                dxysum += dw * dgx * dgy;
+            }
         }
 
-    /* simStat::computeWSim SimStat.cuh:72-113 */
-    const float varXW = (xxsum - xsum * xsum / wsum) / wsum;
-    const float varYW = (yysum - ysum * ysum / wsum) / wsum;
-    const float varXYW = (xysum - xsum * ysum / wsum) / wsum;
-    const float rawSim = varXYW / sqrtf(varXW * varYW);
-    const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
+    float sim;
+    if(g_ncc_f64)
+    {
+        const double varXW = (dxxsum - dxsum * dxsum / dwsum) / dwsum;
+        const double varYW = (dyysum - dysum * dysum / dwsum) / dwsum;
+        const double varXYW = (dxysum - dxsum * dysum / dwsum) / dwsum;
+        const double rawSim = varXYW / sqrt(varXW * varYW);
+        sim = isfinite(rawSim) ? (float)-rawSim : 1.0f;
+    }
+    else
+    {
+        /* simStat::computeWSim SimStat.cuh:72-113 */
+        const float varXW = (xxsum - xsum * xsum / wsum) / wsum;
+        const float varYW = (yysum - ysum * ysum / wsum) / wsum;
+        const float varXYW = (xysum - xsum * ysum / wsum) / wsum;
+        const float rawSim = varXYW / sqrtf(varXW * varYW);
+        sim = isfinite(rawSim) ? -rawSim : 1.0f;
+    }
     if(invertAndFilter)
         return sigmoidf_(0.0f, 1.0f, 0.7f, -0.7f, sim);
     return sim;
@@ -796,7 +837,7 @@ void avo_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
                 patch.d = computePixSize(rc, patch.p);
                 computeRotCSEpip(&patch, rc, tc);
                 float fsim = compNCCby3DptsYK(0, rc, tc, rcPyr, tcPyr, rcW, rcH, tcW, tcH, rcMipmapLevel, sp->wsh, invGammaC, invGammaP,
-                                              sp->useConsistentScale, &patch);
+                                              sp->useConsistentScale, &patch, mk2(x, y));
                 if(fsim == INFINITY)
                     fsim = 255.0f;
                 else
@@ -872,7 +913,7 @@ void avo_volume_refine_similarity(uint16_t* vol, long long pitch_y, int pitch_x,
                     patch.x = normalize3(cross3(patch.y, patch.n));
                 }
                 const float fsim = compNCCby3DptsYK(1, rc, tc, rcPyr, tcPyr, rcW, rcH, tcW, tcH, rcMipmapLevel, rp->wsh, invGammaC, invGammaP,
-                                                    rp->useConsistentScale, &patch);
+                                                    rp->useConsistentScale, &patch, mk2(x, y));
                 if(fsim == INFINITY)
                     continue;
                 uint16_t* out = (uint16_t*)((char*)vol + (long long)vy * pitch_y + (long long)vx * pitch_x) + vz;
@@ -1245,6 +1286,10 @@ void avo_compute_sgm_upscaled_depth_pixsize_map(float* out, int out_pitch, const
                 const int mx = (int)((float)roiW * ratio) - 2, my = (int)((float)roiH * ratio) - 2;
                 xp = xp < mx ? xp : mx;
                 yp = yp < my ? yp : my;
+                /* DEVIATION: the reference reads texel (-1, .) / (., -1) for roiX == 0 / roiY == 0 (floor(-0.5 * ratio) = -1,
+                 * mapKernels.cuh:309-321), an out-of-bounds read; we clamp to 0 (off the default path: interpolateMiddleDepth = false) */
+                xp = xp < 0 ? 0 : xp;
+                yp = yp < 0 ? 0 : yp;
                 const float* lu = MAP2(in, in_pitch, xp, yp);
                 const float* ru = MAP2(in, in_pitch, xp + 1, yp);
                 const float* rd = MAP2(in, in_pitch, xp + 1, yp + 1);

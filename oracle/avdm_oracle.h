@@ -14,6 +14,8 @@ extern "C" {
 uint16_t avo_float_to_half(float f);
 float avo_half_to_float(uint16_t h);
 float avo_exp_p2(float x);
+void avo_set_exact_rc_pixel(int on);  /* 0 = literal reprojected R pixel in the border test (default), 1 = exact pixel */
+void avo_set_ncc_precision(int f64); /* 0 = fp32 sums like the reference (default), 1 = double-precision sums */
 void avo_tex2dlod(const avdm_pyramid_t* p, float u, float v, float lod, float out[4]);
 
 int avo_pyramid_layout(avdm_pyramid_t* p, int width, int height, int min_downscale, int max_downscale, int filter_mode);

@@ -24,6 +24,8 @@ _SIG = {
     "avo_float_to_half": (C.c_ushort, [f32]),
     "avo_half_to_float": (f32, [C.c_ushort]),
     "avo_exp_p2": (f32, [f32]),
+    "avo_set_ncc_precision": (None, [i32]),
+    "avo_set_exact_rc_pixel": (None, [i32]),
     "avo_tex2dlod": (None, [P(abi.Pyramid), f32, f32, f32, P(f32 * 4)]),
     "avo_pyramid_layout": (i32, [P(abi.Pyramid), i32, i32, i32, i32, i32]),
     "avo_image_rgba_f32_to_f16x255": (None, [vp, i32, vp, i32, i32, i32]),
@@ -71,6 +73,19 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+class well_posed:
+    """Context manager: evaluate the two ill-posed spots of the reference arithmetic in their well-posed form
+    (double-precision NCC sums, exact R pixel in the border test) — see the comments in avdm_oracle.c and DESIGN.md."""
+
+    def __enter__(self):
+        load().avo_set_ncc_precision(1)
+        load().avo_set_exact_rc_pixel(1)
+
+    def __exit__(self, *a):
+        load().avo_set_ncc_precision(0)
+        load().avo_set_exact_rc_pixel(0)
 
 
 def ptr(a):
