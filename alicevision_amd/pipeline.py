@@ -24,6 +24,43 @@ def ceil_div(a, b):
     return (a + b - 1) // b
 
 
+class StageTimers:
+    """HIP-event timing of stage ranges on the current stream (torch events wrap hipEvent on the same stream)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+
+    class _Range:
+        def __init__(self, owner, name):
+            self.o, self.name = owner, name
+
+        def __enter__(self):
+            if self.o.enabled:
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.b = torch.cuda.Event(enable_timing=True)
+                self.a.record()
+
+        def __exit__(self, *exc):
+            if self.o.enabled:
+                self.b.record()
+                self.o.events.setdefault(self.name, []).append((self.a, self.b))
+
+    def range(self, name):
+        return StageTimers._Range(self, name)
+
+    def reset(self):
+        self.events = {}
+
+    def mean_ms(self, per=None):
+        """mean ms per occurrence (or per `per` steps) of every stage; call after a device synchronize"""
+        out = {}
+        for k, lst in self.events.items():
+            tot = sum(a.elapsed_time(b) for a, b in lst)
+            out[k] = tot / (per if per else len(lst))
+        return out
+
+
 class DevicePyramid:
     """fp16 Lab mip pyramid in HBM (replaces DeviceMipmapImage)."""
 
@@ -36,6 +73,17 @@ class DevicePyramid:
         self.desc.base = self.buf.data_ptr()
         if rgba is not None:
             self.fill(rgba)
+
+    @classmethod
+    def allocate(cls, width, height, min_downscale, max_downscale, filter_mode, device="cuda"):
+        """pyramid storage without content (to be filled later or received from another rank)"""
+        self = cls.__new__(cls)
+        lib = abi.load()
+        self.desc = abi.Pyramid()
+        abi.check(lib.avdm_pyramid_layout(C.byref(self.desc), width, height, min_downscale, max_downscale, filter_mode), "avdm_pyramid_layout")
+        self.buf = torch.zeros(self.desc.bytes, dtype=torch.uint8, device=device)
+        self.desc.base = self.buf.data_ptr()
+        return self
 
     def fill(self, rgba):
         lib = abi.load()
@@ -77,6 +125,16 @@ class DepthMapTile:
         W, H = pyramids[0].desc.width0, pyramids[0].desc.height0
         self.roi = roi if roi is not None else (0, W, 0, H)
         self._alloc_for = None
+        self.timers = StageTimers()
+
+    def enable_timers(self, on=True):
+        self.timers.enabled = on
+
+    def reset_timers(self):
+        self.timers.reset()
+
+    def stage_ms(self):
+        return self.timers.mean_ms()
 
     def cam(self, i, scale):
         return abi.camera_fill(self.K, self.Rs[i], self.Cs[i], scale)
@@ -121,27 +179,33 @@ class DepthMapTile:
         py, pxx = X * Zp, Zp
         st = _stream()
         self.depths_d.copy_(torch.as_tensor(depths, dtype=torch.float32), non_blocking=False)
-        abi.check(lib.avdm_volume_initialize_u8(_ptr(self.best), py, pxx, X, Y, Zp, 255, st), "volume_initialize")
-        abi.check(lib.avdm_volume_initialize_u8(_ptr(self.second), py, pxx, X, Y, Zp, 255, st), "volume_initialize")
+        T = self.timers
+        with T.range("sgm_volume_init"):
+            abi.check(lib.avdm_volume_initialize_u8(_ptr(self.best), py, pxx, X, Y, Zp, 255, st), "volume_initialize")
+            abi.check(lib.avdm_volume_initialize_u8(_ptr(self.second), py, pxx, X, Y, Zp, 255, st), "volume_initialize")
         rcCam = self.cam(rc, sp.scale)
-        for ti, tc in enumerate(tcs):
-            tcCam = self.cam(tc, sp.scale)
-            r = tc_ranges[ti] if tc_ranges else (0, Z)
-            abi.check(lib.avdm_volume_compute_similarity(_ptr(self.best), _ptr(self.second), py, pxx, _ptr(self.depths_d), C.byref(rcCam),
-                                                         C.byref(tcCam), C.byref(self.pyr[rc].desc), C.byref(self.pyr[tc].desc), C.byref(sp),
-                                                         abi.Range(r[0], r[1]), roi, st), "volume_compute_similarity")
-        abi.check(lib.avdm_volume_update_uninitialized(_ptr(self.best), _ptr(self.second), py, pxx, X, Y, Z, st), "update_uninitialized")
+        with T.range("sgm_similarity"):
+            for ti, tc in enumerate(tcs):
+                tcCam = self.cam(tc, sp.scale)
+                r = tc_ranges[ti] if tc_ranges else (0, Z)
+                abi.check(lib.avdm_volume_compute_similarity(_ptr(self.best), _ptr(self.second), py, pxx, _ptr(self.depths_d), C.byref(rcCam),
+                                                             C.byref(tcCam), C.byref(self.pyr[rc].desc), C.byref(self.pyr[tc].desc), C.byref(sp),
+                                                             abi.Range(r[0], r[1]), roi, st), "volume_compute_similarity")
+        with T.range("sgm_update_uninit"):
+            abi.check(lib.avdm_volume_update_uninitialized(_ptr(self.best), _ptr(self.second), py, pxx, X, Y, Z, st), "update_uninitialized")
         if keep_raw:
             self.best_raw = self.best.clone()
         if optimize:
-            abi.check(lib.avdm_volume_optimize(_ptr(self.best), _ptr(self.second), py, pxx, None, C.byref(self.pyr[rc].desc), C.byref(sp), Z, roi,
-                                               st), "volume_optimize")
+            with T.range("sgm_optimize"):
+                abi.check(lib.avdm_volume_optimize(_ptr(self.best), _ptr(self.second), py, pxx, None, C.byref(self.pyr[rc].desc), C.byref(sp), Z,
+                                                   roi, st), "volume_optimize")
         else:
             self.best.copy_(self.second)
         rc1 = self.cam(rc, 1)
-        abi.check(lib.avdm_volume_retrieve_best_depth(_ptr(self.sgm_depth_thickness), X * 8, _ptr(self.sgm_depth_sim), X * 8, _ptr(self.depths_d),
-                                                      _ptr(self.best), py, pxx, Z, C.byref(rc1), C.byref(sp), abi.Range(0, Z), roi, st),
-                  "retrieve_best_depth")
+        with T.range("sgm_retrieve_best_depth"):
+            abi.check(lib.avdm_volume_retrieve_best_depth(_ptr(self.sgm_depth_thickness), X * 8, _ptr(self.sgm_depth_sim), X * 8,
+                                                          _ptr(self.depths_d), _ptr(self.best), py, pxx, Z, C.byref(rc1), C.byref(sp),
+                                                          abi.Range(0, Z), roi, st), "retrieve_best_depth")
         return self.sgm_depth_thickness, self.sgm_depth_sim
 
     # ---- Sgm::smoothThicknessMap + Refine::refineRc ----
@@ -149,33 +213,40 @@ class DepthMapTile:
         lib, sp, rp = self.lib, self.sgm, self.refine
         roiS, roiR = self.droi(sp.scale * sp.stepXY), self.droi(rp.scale * rp.stepXY)
         st = _stream()
-        abi.check(lib.avdm_depth_thickness_smooth_thickness(_ptr(self.sgm_depth_thickness), roiS.width * 8, C.byref(sp), C.byref(rp), roiS, st),
-                  "smooth_thickness")
+        T = self.timers
         X, Y = roiR.width, roiR.height
         rcCam = self.cam(rc, rp.scale)
         ratio = float(roiS.width) / float(X)
-        abi.check(lib.avdm_compute_sgm_upscaled_depth_pixsize_map(_ptr(self.sgm_upscaled), X * 8, _ptr(self.sgm_depth_thickness), roiS.width * 8,
-                                                                  C.byref(rcCam), C.byref(self.pyr[rc].desc), C.byref(rp), ratio, roiR, st),
-                  "sgm_upscale")
+        with T.range("smooth_and_upscale"):
+            abi.check(lib.avdm_depth_thickness_smooth_thickness(_ptr(self.sgm_depth_thickness), roiS.width * 8, C.byref(sp), C.byref(rp), roiS, st),
+                      "smooth_thickness")
+            abi.check(lib.avdm_compute_sgm_upscaled_depth_pixsize_map(_ptr(self.sgm_upscaled), X * 8, _ptr(self.sgm_depth_thickness),
+                                                                      roiS.width * 8, C.byref(rcCam), C.byref(self.pyr[rc].desc), C.byref(rp), ratio,
+                                                                      roiR, st), "sgm_upscale")
         Zr, Zrp = self.Zr, self.Zrp
         py, pxx = X * Zrp * 2, Zrp * 2
         if refine_enabled:
-            abi.check(lib.avdm_volume_initialize_f16(_ptr(self.refine_volume), py, pxx, X, Y, Zrp, 0.0, st), "volume_initialize_f16")
-            for tc in tcs:
-                tcCam = self.cam(tc, rp.scale)
-                abi.check(lib.avdm_volume_refine_similarity(_ptr(self.refine_volume), py, pxx, Zr, _ptr(self.sgm_upscaled), X * 8, None, 0,
-                                                            C.byref(rcCam), C.byref(tcCam), C.byref(self.pyr[rc].desc), C.byref(self.pyr[tc].desc),
-                                                            C.byref(rp), abi.Range(0, Zr), roiR, st), "refine_similarity")
-            abi.check(lib.avdm_volume_refine_best_depth(_ptr(self.refined), X * 8, _ptr(self.sgm_upscaled), X * 8, _ptr(self.refine_volume), py, pxx,
-                                                        Zr, C.byref(rp), roiR, st), "refine_best_depth")
+            with T.range("refine_volume_init"):
+                abi.check(lib.avdm_volume_initialize_f16(_ptr(self.refine_volume), py, pxx, X, Y, Zrp, 0.0, st), "volume_initialize_f16")
+            with T.range("refine_similarity"):
+                for tc in tcs:
+                    tcCam = self.cam(tc, rp.scale)
+                    abi.check(lib.avdm_volume_refine_similarity(_ptr(self.refine_volume), py, pxx, Zr, _ptr(self.sgm_upscaled), X * 8, None, 0,
+                                                                C.byref(rcCam), C.byref(tcCam), C.byref(self.pyr[rc].desc),
+                                                                C.byref(self.pyr[tc].desc), C.byref(rp), abi.Range(0, Zr), roiR, st),
+                              "refine_similarity")
+            with T.range("refine_best_depth"):
+                abi.check(lib.avdm_volume_refine_best_depth(_ptr(self.refined), X * 8, _ptr(self.sgm_upscaled), X * 8, _ptr(self.refine_volume), py,
+                                                            pxx, Zr, C.byref(rp), roiR, st), "refine_best_depth")
         else:
             abi.check(lib.avdm_depth_sim_map_copy_depth_only(_ptr(self.refined), X * 8, _ptr(self.sgm_upscaled), X * 8, X, Y, 1.0, st),
                       "copy_depth_only")
         if optimize_enabled and rp.optimizationNbIterations > 0:
-            abi.check(lib.avdm_depth_sim_map_optimize_gradient_descent(_ptr(self.optimized), X * 8, _ptr(self.img_variance), X * 4,
-                                                                       _ptr(self.tmp_depth), X * 4, X, Y, _ptr(self.sgm_upscaled), X * 8,
-                                                                       _ptr(self.refined), X * 8, C.byref(rcCam), C.byref(self.pyr[rc].desc),
-                                                                       C.byref(rp), roiR, st), "optimize_gradient_descent")
+            with T.range("color_optimize"):
+                abi.check(lib.avdm_depth_sim_map_optimize_gradient_descent(_ptr(self.optimized), X * 8, _ptr(self.img_variance), X * 4,
+                                                                           _ptr(self.tmp_depth), X * 4, X, Y, _ptr(self.sgm_upscaled), X * 8,
+                                                                           _ptr(self.refined), X * 8, C.byref(rcCam), C.byref(self.pyr[rc].desc),
+                                                                           C.byref(rp), roiR, st), "optimize_gradient_descent")
         else:
             self.optimized.copy_(self.refined)
         return self.optimized
