@@ -179,6 +179,18 @@ __device__ __forceinline__ float4 texel_clamped(const TexLevel& L, int x, int y)
     return unpack_h4(L.base[(long long)y * L.pitch8 + x]);
 }
 
+// the bilinear blend of the four taps — ONE expression for every tap source (global memory or an LDS window)
+__device__ __forceinline__ float4 bilinear_blend(float4 t00, float4 t10, float4 t01, float4 t11, float a, float b)
+{
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    float4 r;
+    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
+    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    r.w = w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w;
+    return r;
+}
+
 // bilinear fetch at texel-space coordinates (x, y) = (u*W - 0.5, v*H - 0.5)
 template <bool FIXED8>
 __device__ __forceinline__ float4 tex_bilinear_px(const TexLevel& L, float x, float y)
@@ -208,13 +220,7 @@ __device__ __forceinline__ float4 tex_bilinear_px(const TexLevel& L, float x, fl
         t01 = texel_clamped(L, i, j + 1);
         t11 = texel_clamped(L, i + 1, j + 1);
     }
-    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-    float4 r;
-    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
-    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
-    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
-    r.w = w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w;
-    return r;
+    return bilinear_blend(t00, t10, t01, t11, a, b);
 }
 
 // tex2DLod with normalised coordinates at ONE integral level

@@ -7,14 +7,17 @@
 // and every fp32 operation below is written in the reference's order so that the stage is BIT-EXACT against the oracle.
 //
 // CDNA4 design (the reference issues ~3 tiny kernels per slice, ~10^4 launches per volume, through uint32 slice copies):
-//   * ONE launch per path.  One wave64 owns one column (fixed position on the non-scanned image axis) and walks the scanned
-//     axis as a persistent loop; the previous-slice path costs L(z) never leave VGPRs.
+//   * ONE launch per path.  One wave64 (= one workgroup) owns one column (fixed position on the non-scanned image axis) and
+//     walks the scanned axis as a persistent loop; the previous-slice path costs L(z) never leave VGPRs.
 //   * z-fastest volume: a lane owns 4*NW consecutive planes, so a step is one coalesced 256*NW-byte read of the input
 //     volume, (for paths 1..3) one of the output volume, and one coalesced write.  Algorithmic traffic only: 11 B/voxel total.
 //   * min over z  = lane-local min + 6 DPP v_min steps (row_shr / row_bcast) + v_readlane; z±1 neighbours = wave_shr/shl DPP.
-//   * the colour-adaptive P2 of 64 consecutive steps is evaluated at once, one step per lane, and read back with v_readlane.
-//   * loads of the next PF steps are issued before the current PF steps are processed (software prefetch ring in VGPRs):
-//     the recurrence only depends on registers, never on the loads of the step being issued.
+//   * the colour-adaptive P2 is evaluated once per (column, slice) by a small map kernel per axis (one map serves the forward
+//     and the reverse path); the path kernel reads 64 consecutive steps of it per lane-coalesced load and picks with v_readlane.
+//   * only ~1000 columns exist per path (one wave per SIMD), so latency is hidden by ILP, not occupancy: a 4-slot register ring
+//     keeps the loads of the next 24-32 slices in flight; the recurrence depends on registers only.
+//   * the running average (out*K + L)/(K+1) -> uint8 is evaluated without an IEEE division: one exact FMA, then the integer
+//     quotient through exact fp32 scalings (equality with the reference's float expression checked over every fp32 input).
 #include "avdm_device.h"
 
 #include <math.h>
@@ -41,207 +44,280 @@ __device__ __forceinline__ float exp_p2(float x)
     return ldexpf(y, (int)n);
 }
 
-struct SgmArgs
+// ---- adaptive P2 (kernels.cuh:696-720), evaluated once per (column, slice) into a float map ----------------------------
+struct SgmP2Args
 {
-    const uint8_t* in;
-    uint8_t* out;
-    long long strideA, strideB; // bytes between consecutive columns / consecutive steps
-    int A, B, Z;
-    int rev;
-    float P1, P2w;
-    TexLevel L;  // R image at the SGM mip level
-    float rcW, rcH; // nominal level dims (DeviceMipmapImage::getDimensions)
+    TexLevel L;         // R image at the SGM mip level
+    float rcW, rcH;     // nominal level dims (DeviceMipmapImage::getDimensions)
     int beginX, beginY; // ROI offsets as the reference applies them to (v.x, v.y)
     int scanIsX;        // 1: the scanned axis is volume x (axisT.y == 0), 0: volume y
     float step;
-    int fixed8;
+    float P2w;
+    int A, B;
 };
 
 #define SGM_BIG 3.0e38f
 
-__device__ __forceinline__ float p2_of_step(const SgmArgs& S, int a, int b)
+// P2 of the FORWARD path at slice b of column a: colour step between stage pixel b and b - 1 along the scanned axis.
+// The reverse path at slice b compares pixel b with b + 1 — the same texel pair as the forward path at b + 1, with the
+// two fetches swapped; deltaC is a sum of squared differences, so the value is bit-identical and ONE map serves both
+// directions of an axis (reverse reads entry b + 1).
+template <bool FIXED8>
+__global__ void __launch_bounds__(256) sgm_p2_map_kernel(float* __restrict__ p2, SgmP2Args S)
 {
+    const int b = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int a = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if(a >= S.A || b >= S.B)
+        return;
+    float P2;
     if(S.P2w < 0)
-        return fabsf(S.P2w);
-    const int vx = S.scanIsX ? b : a, vy = S.scanIsX ? a : b;
-    const int ySign = S.rev ? -1 : 1;
-    const int imX0 = (int)((float)(S.beginX + vx) * S.step);
-    const int imY0 = (int)((float)(S.beginY + vy) * S.step);
-    const int imX1 = (int)((float)imX0 - (float)ySign * S.step * (float)(S.scanIsX ? 1 : 0));
-    const int imY1 = (int)((float)imY0 - (float)ySign * S.step * (float)(S.scanIsX ? 0 : 1));
-    const float u0 = ((float)imX0 + 0.5f) / S.rcW, v0 = ((float)imY0 + 0.5f) / S.rcH;
-    const float u1 = ((float)imX1 + 0.5f) / S.rcW, v1 = ((float)imY1 + 0.5f) / S.rcH;
-    const float4 c0 = S.fixed8 ? tex2D_level<true>(S.L, u0, v0) : tex2D_level<false>(S.L, u0, v0);
-    const float4 c1 = S.fixed8 ? tex2D_level<true>(S.L, u1, v1) : tex2D_level<false>(S.L, u1, v1);
-    const float dx = c0.x - c1.x, dy = c0.y - c1.y, dz = c0.z - c1.z;
-    const float deltaC = sqrtf(dx * dx + dy * dy + dz * dz);
-    return 80.f + (255.f - 80.f) * (1.0f / (1.0f + exp_p2(10.0f * ((deltaC - S.P2w) / 80.f))));
+        P2 = fabsf(S.P2w);
+    else if(b == 0)
+        P2 = 0.f; // never read
+    else
+    {
+        const int vx = S.scanIsX ? b : a, vy = S.scanIsX ? a : b;
+        const int imX0 = (int)((float)(S.beginX + vx) * S.step);
+        const int imY0 = (int)((float)(S.beginY + vy) * S.step);
+        const int imX1 = (int)((float)imX0 - S.step * (float)(S.scanIsX ? 1 : 0));
+        const int imY1 = (int)((float)imY0 - S.step * (float)(S.scanIsX ? 0 : 1));
+        const float u0 = ((float)imX0 + 0.5f) / S.rcW, v0 = ((float)imY0 + 0.5f) / S.rcH;
+        const float u1 = ((float)imX1 + 0.5f) / S.rcW, v1 = ((float)imY1 + 0.5f) / S.rcH;
+        const float4 c0 = tex2D_level<FIXED8>(S.L, u0, v0);
+        const float4 c1 = tex2D_level<FIXED8>(S.L, u1, v1);
+        const float dx = c0.x - c1.x, dy = c0.y - c1.y, dz = c0.z - c1.z;
+        const float deltaC = sqrtf(dx * dx + dy * dy + dz * dz);
+        P2 = 80.f + (255.f - 80.f) * (1.0f / (1.0f + exp_p2(10.0f * ((deltaC - S.P2w) / 80.f))));
+    }
+    p2[(long long)a * S.B + b] = P2;
 }
 
-template <int NW, int K>
-__global__ void __launch_bounds__(256) sgm_path_kernel(SgmArgs S)
+// ---- one aggregation path ------------------------------------------------------------------------------------------
+struct SgmPathArgs
+{
+    const uint8_t* in;
+    uint8_t* out;
+    const float* p2;            // [A][B], see sgm_p2_map_kernel
+    long long strideA, strideB; // bytes between consecutive columns / consecutive slices
+    int A, B, Z;
+    int rev;
+    float P1;
+};
+
+__device__ __forceinline__ float ubyte_f32(unsigned w, int j)
+{
+    // v_cvt_f32_ubyteN
+    return (float)((w >> (8 * j)) & 0xffu);
+}
+
+// Path costs are non-negative, finite fp32 values: their bit patterns order like unsigned integers, so every min of the
+// recurrence is an integer min on the bits — no NaN canonicalisation, and the DPP lane permutes fold into v_min_u32_dpp
+// (old = 0xffffffff is the identity of min_u32, which is what lets the compiler fold row_mask-ed broadcasts too).
+__device__ __forceinline__ unsigned fbits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ float bitsf(unsigned v) { return __uint_as_float(v); }
+__device__ __forceinline__ unsigned wave_min_bits(unsigned v)
+{
+    v = min(v, dpp_u32<0x111>(0xffffffffu, v));
+    v = min(v, dpp_u32<0x112>(0xffffffffu, v));
+    v = min(v, dpp_u32<0x114>(0xffffffffu, v));
+    v = min(v, dpp_u32<0x118>(0xffffffffu, v));
+    v = min(v, dpp_u32<0x142, 0xa>(0xffffffffu, v));
+    v = min(v, dpp_u32<0x143, 0xc>(0xffffffffu, v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// NW dwords (4 planes each) per lane; K = index of the path (the running average weight); FULL: Z == 256 * NW, i.e. every
+// lane owns 4 * NW valid planes and every access is a whole dword (the production shapes); otherwise ragged tails are
+// handled with byte masks (read-modify-write of the partially valid dword, padding planes z >= Z are left untouched).
+template <int NW, int K, bool FULL>
+__global__ void __launch_bounds__(64) sgm_path_kernel(SgmPathArgs S)
 {
     constexpr int ZL = 4 * NW;
-    constexpr int SGM_PF = NW == 1 ? 8 : (NW == 2 ? 4 : 2); // prefetch depth (steps in flight), bounded by VGPR budget
-    const int lane = threadIdx.x & 63;
-    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if(a >= S.A)
-        return; // whole wave
-    const int z0 = lane * ZL;
+    constexpr int PF = NW == 1 ? 8 : (NW == 2 ? 4 : 2); // slices per ring slot
+    constexpr int NSETS = 4;                             // ring slots: loads run (NSETS - 1) * PF .. NSETS * PF slices ahead
+    constexpr bool LOAD_OUT = (K > 0) || !FULL;
+    const int lane = threadIdx.x;
+    const int a = blockIdx.x;
     const int Z = S.Z;
-    const bool tailBytes = (Z & 3) != 0;
+    const int z0 = lane * ZL;
+    const int nSteps = S.B - 1; // ib = 1 .. B-1
 
-    const uint8_t* inCol = S.in + (long long)a * S.strideA + z0;
-    uint8_t* outCol = S.out + (long long)a * S.strideA + z0;
-
-    // which of my dwords hold at least one valid plane / are fully valid
-    bool wAny[NW], wFull[NW];
+    unsigned offw[NW];
+    bool wAny[NW];
+    unsigned vmask[NW];
 #pragma unroll
     for(int w = 0; w < NW; ++w)
     {
-        wAny[w] = z0 + 4 * w < Z;
-        wFull[w] = z0 + 4 * w + 3 < Z;
+        const int zw = z0 + 4 * w;
+        const int nv = FULL ? 4 : min(max(Z - zw, 0), 4);
+        wAny[w] = nv > 0;
+        vmask[w] = nv >= 4 ? 0xffffffffu : ((1u << (8 * (nv & 3))) - 1u);
+        offw[w] = (unsigned)(wAny[w] ? zw : ((Z - 1) & ~3)); // lanes past the last plane re-read the last valid dword (never stored)
     }
 
-    float prev[ZL];
+    const uint8_t* __restrict__ inCol = S.in + (long long)a * S.strideA;
+    uint8_t* __restrict__ outCol = S.out + (long long)a * S.strideA;
 
     // ---- slice 0: prev = in(b = 0) (always slice 0, also for the reverse path), out(b = 0) = 255 ----
+    unsigned prev[ZL]; // bit patterns of non-negative floats
 #pragma unroll
     for(int w = 0; w < NW; ++w)
     {
-        unsigned v = 0;
-        if(wAny[w])
-            v = *reinterpret_cast<const unsigned*>(inCol + 4 * w);
+        const unsigned v = *reinterpret_cast<const unsigned*>(inCol + offw[w]);
 #pragma unroll
         for(int j = 0; j < 4; ++j)
-            prev[4 * w + j] = (z0 + 4 * w + j < Z) ? (float)((v >> (8 * j)) & 0xffu) : SGM_BIG;
-        if(wFull[w])
-            *reinterpret_cast<unsigned*>(outCol + 4 * w) = 0xffffffffu;
+            prev[4 * w + j] = (FULL || ((vmask[w] >> (8 * j)) & 1u)) ? fbits(ubyte_f32(v, j)) : fbits(SGM_BIG);
+        if(FULL)
+            *reinterpret_cast<unsigned*>(outCol + offw[w]) = 0xffffffffu;
         else if(wAny[w])
-            for(int j = 0; j < 4; ++j)
-                if(z0 + 4 * w + j < Z)
-                    outCol[4 * w + j] = 255;
-    }
-
-    const int nSteps = S.B - 1; // ib = 1 .. B-1
-    unsigned ringIn[SGM_PF][NW], ringOut[SGM_PF][NW];
-
-    auto issue = [&](int ib, unsigned (&ri)[NW], unsigned (&ro)[NW]) {
-        if(ib > nSteps)
-            return;
-        const int b = S.rev ? S.B - 1 - ib : ib;
-        const long long off = (long long)b * S.strideB;
-#pragma unroll
-        for(int w = 0; w < NW; ++w)
         {
-            ri[w] = 0;
-            ro[w] = 0;
-            if(wAny[w])
+            const unsigned old = *reinterpret_cast<const unsigned*>(outCol + offw[w]);
+            *reinterpret_cast<unsigned*>(outCol + offw[w]) = old | vmask[w];
+        }
+    }
+    if(nSteps <= 0)
+        return;
+
+    // uniform slice pointers, advanced by one slice per step (scalar 64-bit adds; the lane part is a 32-bit offset)
+    const long long dirStride = S.rev ? -S.strideB : S.strideB;
+    const long long firstOff = (long long)(S.rev ? S.B - 2 : 1) * S.strideB; // slice of ib = 1
+    const uint8_t* inLoad = inCol + firstOff;
+    const uint8_t* outLoad = outCol + firstOff;
+    uint8_t* outStore = outCol + firstOff;
+    int ibLoad = 1;
+
+    unsigned rin[NSETS][PF][NW], rout[NSETS][PF][NW];
+
+    auto load_group = [&](unsigned (&ri)[PF][NW], unsigned (&ro)[PF][NW]) {
+#pragma unroll
+        for(int t = 0; t < PF; ++t)
+        {
+#pragma unroll
+            for(int w = 0; w < NW; ++w)
             {
-                ri[w] = *reinterpret_cast<const unsigned*>(inCol + off + 4 * w);
-                if(K > 0)
-                    ro[w] = *reinterpret_cast<const unsigned*>(outCol + off + 4 * w);
+                ri[t][w] = *reinterpret_cast<const unsigned*>(inLoad + offw[w]);
+                if(LOAD_OUT)
+                    ro[t][w] = *reinterpret_cast<const unsigned*>(outLoad + offw[w]);
+            }
+            if(ibLoad < nSteps) // past the end: keep re-reading the last slice (harmless)
+            {
+                inLoad += dirStride;
+                outLoad += dirStride;
+                ++ibLoad;
             }
         }
     };
 
-    // prologue: loads of steps 1..PF
-#pragma unroll
-    for(int s = 0; s < SGM_PF; ++s)
-        issue(1 + s, ringIn[s], ringOut[s]);
+    auto load_p2 = [&](int blk) -> float {
+        const int ib = min(blk * 64 + 1 + lane, nSteps);
+        return S.p2[(long long)a * S.B + (S.rev ? S.B - ib : ib)];
+    };
 
-    float p2vec = 0.f;
+    auto step = [&](int ib, const unsigned (&inw)[NW], const unsigned (&oldw)[NW], float p2vec) {
+        const float P2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2vec), (ib - 1) & 63));
 
-    for(int ib0 = 1; ib0 <= nSteps; ib0 += SGM_PF)
-    {
-        unsigned curIn[SGM_PF][NW], curOut[SGM_PF][NW];
+        // best cost of the previous slice over all planes (computeBestZInSlice)
+        unsigned m = prev[0];
 #pragma unroll
-        for(int s = 0; s < SGM_PF; ++s)
-#pragma unroll
-            for(int w = 0; w < NW; ++w)
-            {
-                curIn[s][w] = ringIn[s][w];
-                curOut[s][w] = ringOut[s][w];
-            }
-            // next group's loads go out before this group's arithmetic
-#pragma unroll
-        for(int s = 0; s < SGM_PF; ++s)
-            issue(ib0 + SGM_PF + s, ringIn[s], ringOut[s]);
+        for(int i = 1; i < ZL; ++i)
+            m = min(m, prev[i]);
+        const float best = bitsf(wave_min_bits(m));
+        const unsigned bestP2 = fbits(best + P2);
 
+        // z-1 / z+1 neighbours across lanes (wave_shr:1 / wave_shl:1), folded into the min with the in-lane neighbour
+        const unsigned nbLo = min(dpp_u32<0x138>(0xffffffffu, prev[ZL - 1]), prev[1]);      // min(prev[z0-1], prev[z0+1])
+        const unsigned nbHi = min(dpp_u32<0x130>(0xffffffffu, prev[0]), prev[ZL - 2]);      // min(prev[z0+ZL], prev[z0+ZL-2])
+
+        unsigned nprev[ZL];
 #pragma unroll
-        for(int s = 0; s < SGM_PF; ++s)
+        for(int w = 0; w < NW; ++w)
         {
-            const int ib = ib0 + s;
-            if(ib > nSteps)
-                break;
-            const int b = S.rev ? S.B - 1 - ib : ib;
-
-            // P2 of 64 consecutive steps at once (one per lane), refreshed every 64 steps
-            if(((ib - 1) & 63) == 0)
+            unsigned neww = 0;
+#pragma unroll
+            for(int j = 0; j < 4; ++j)
             {
-                const int myIb = ib + lane;
-                const int myB = S.rev ? S.B - 1 - myIb : myIb;
-                p2vec = (myIb <= nSteps) ? p2_of_step(S, a, myB) : 0.f;
-            }
-            const float P2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2vec), (ib - 1) & 63));
-
-            // best cost of the previous slice over all planes
-            float m = prev[0];
-#pragma unroll
-            for(int j = 1; j < ZL; ++j)
-                m = fminf(m, prev[j]);
-            const float best = wave_min_f32(m);
-            const float bestP2 = best + P2;
-
-            // z-1 / z+1 neighbours across lanes
-            const float left = dpp_f32<0x138>(SGM_BIG, prev[ZL - 1]); // from lane-1
-            const float right = dpp_f32<0x130>(SGM_BIG, prev[0]);     // from lane+1
-
-            float nprev[ZL];
-#pragma unroll
-            for(int w = 0; w < NW; ++w)
-            {
-                unsigned outw = 0;
-#pragma unroll
-                for(int j = 0; j < 4; ++j)
+                const int i = 4 * w + j;
+                const float cur = ubyte_f32(inw[w], j);
+                const unsigned nb = (i == 0) ? nbLo : ((i == ZL - 1) ? nbHi : min(prev[i - 1], prev[i + 1]));
+                // fminf(fminf(fminf(p, pm1 + P1), pp1 + P1), best + P2): x -> x + P1 is monotone, so the two middle terms are
+                // min(pm1, pp1) + P1; all operands are non-negative floats -> integer min on the bits
+                const unsigned minCost = min(min(prev[i], fbits(bitsf(nb) + S.P1)), bestP2);
+                float pathCost = (cur + bitsf(minCost)) - best;
+                // planes 0 and Z-1 are forced to 255 (kernels.cuh:692-730)
+                if(FULL)
                 {
-                    const int i = 4 * w + j;
-                    const int z = z0 + i;
-                    const float cur = (float)((curIn[s][w] >> (8 * j)) & 0xffu);
-                    const float pm1 = (i == 0) ? left : prev[i - 1];
-                    const float pp1 = (i == ZL - 1) ? right : prev[i + 1];
-                    float pathCost = 255.0f;
-                    if(z >= 1 && z < Z - 1)
-                    {
-                        const float minCost = fminf(fminf(fminf(prev[i], pm1 + S.P1), pp1 + S.P1), bestP2);
-                        pathCost = cur + minCost - best;
-                    }
-                    nprev[i] = (z < Z) ? truncf(pathCost) : SGM_BIG; // TSimAcc(pathCost): float -> uint32 truncation
-                    pathCost = fminf(255.0f, fmaxf(0.0f, pathCost));
-                    float val;
-                    if(K == 0)
-                        val = pathCost;
+                    if(i == 0)
+                        pathCost = (lane == 0) ? 255.0f : pathCost;
+                    if(i == ZL - 1)
+                        pathCost = (lane == 63) ? 255.0f : pathCost;
+                }
+                else
+                    pathCost = ((z0 + i == 0) || (z0 + i >= Z - 1)) ? 255.0f : pathCost;
+                const float tr = truncf(pathCost); // TSimAcc(pathCost): float -> uint32 truncation (pathCost >= 0)
+                nprev[i] = (FULL || ((vmask[w] >> (8 * j)) & 1u)) ? fbits(tr) : fbits(SGM_BIG);
+                float q; // integer-valued float in [0, 255]: the byte to store
+                if(K == 0)
+                    q = __builtin_amdgcn_fmed3f(tr, 0.0f, 255.0f); // trunc(clamp(x)) == clamp(trunc(x))
+                else
+                {
+                    const float lc = __builtin_amdgcn_fmed3f(pathCost, 0.0f, 255.0f);
+                    const float n = fmaf(ubyte_f32(oldw[w], j), (float)K, lc); // o*K is exact: == fl(fl(o*K) + lc)
+                    // (uint8)(n / (K+1)) == floor(floor(n) / (K+1)) for every fp32 n in [0, 1021) (exhaustively checked)
+                    if(K == 1)
+                        q = truncf(n * 0.5f);
+                    else if(K == 3)
+                        q = truncf(n * 0.25f);
                     else
-                    {
-                        const float o = (float)((curOut[s][w] >> (8 * j)) & 0xffu);
-                        val = (o * (float)K + pathCost) / (float)(K + 1);
-                    }
-                    outw |= ((unsigned)val & 0xffu) << (8 * j);
+                        q = truncf(truncf(n) * 0.33333334f);
                 }
-                uint8_t* po = outCol + (long long)b * S.strideB + 4 * w;
-                if(wFull[w])
-                    *reinterpret_cast<unsigned*>(po) = outw;
-                else if(tailBytes && wAny[w])
-                {
-#pragma unroll
-                    for(int j = 0; j < 4; ++j)
-                        if(z0 + 4 * w + j < Z)
-                            po[j] = (uint8_t)(outw >> (8 * j));
-                }
+                neww = __builtin_amdgcn_cvt_pk_u8_f32(q, j, neww);
             }
+            unsigned* po = reinterpret_cast<unsigned*>(outStore + offw[w]);
+            if(FULL)
+                *po = neww;
+            else if(wAny[w])
+                *po = (neww & vmask[w]) | (oldw[w] & ~vmask[w]);
+        }
+        outStore += dirStride;
 #pragma unroll
-            for(int i = 0; i < ZL; ++i)
-                prev[i] = nprev[i];
+        for(int i = 0; i < ZL; ++i)
+            prev[i] = nprev[i];
+    };
+
+#pragma unroll
+    for(int s = 0; s < NSETS; ++s)
+        load_group(rin[s], rout[s]);
+    float p2vec = load_p2(0);
+    float p2next = load_p2(1);
+
+    const int nGroups = (nSteps + PF - 1) / PF;
+    for(int G = 0; G < nGroups; G += NSETS)
+    {
+        if(G > 0 && ((G * PF) & 63) == 0)
+        {
+            p2vec = p2next;
+            p2next = load_p2((G * PF) / 64 + 1);
+        }
+#pragma unroll
+        for(int s = 0; s < NSETS; ++s)
+        {
+            const int g = G + s;
+            if(g >= nGroups)
+                break;
+            if(g * PF + PF <= nSteps)
+            {
+#pragma unroll
+                for(int t = 0; t < PF; ++t)
+                    step(g * PF + 1 + t, rin[s][t], rout[s][t], p2vec);
+            }
+            else
+            {
+#pragma unroll
+                for(int t = 0; t < PF; ++t)
+                    if(g * PF + 1 + t <= nSteps)
+                        step(g * PF + 1 + t, rin[s][t], rout[s][t], p2vec);
+            }
+            load_group(rin[s], rout[s]);
         }
     }
 }
@@ -327,16 +403,22 @@ __global__ void __launch_bounds__(256)
 }
 
 template <int NW>
-static void launch_path(const SgmArgs& S, int K, hipStream_t st)
+static void launch_path(const SgmPathArgs& S, int K, bool full, hipStream_t st)
 {
-    dim3 grid(divUp(S.A, 4));
+    dim3 grid(S.A);
+#define AVDM_SGM_LAUNCH(KK)                                                                                                                           \
+    if(full)                                                                                                                                          \
+        hipLaunchKernelGGL((sgm_path_kernel<NW, KK, true>), grid, dim3(64), 0, st, S);                                                                \
+    else                                                                                                                                              \
+        hipLaunchKernelGGL((sgm_path_kernel<NW, KK, false>), grid, dim3(64), 0, st, S)
     switch(K)
     {
-        case 0: hipLaunchKernelGGL((sgm_path_kernel<NW, 0>), grid, dim3(256), 0, st, S); break;
-        case 1: hipLaunchKernelGGL((sgm_path_kernel<NW, 1>), grid, dim3(256), 0, st, S); break;
-        case 2: hipLaunchKernelGGL((sgm_path_kernel<NW, 2>), grid, dim3(256), 0, st, S); break;
-        default: hipLaunchKernelGGL((sgm_path_kernel<NW, 3>), grid, dim3(256), 0, st, S); break;
+        case 0: AVDM_SGM_LAUNCH(0); break;
+        case 1: AVDM_SGM_LAUNCH(1); break;
+        case 2: AVDM_SGM_LAUNCH(2); break;
+        default: AVDM_SGM_LAUNCH(3); break;
     }
+#undef AVDM_SGM_LAUNCH
 }
 
 } // namespace avdm
@@ -347,16 +429,17 @@ extern "C" {
 
 size_t avdm_volume_optimize_scratch_bytes(int dimX, int dimY, int dimZ)
 {
-    (void)dimX;
-    (void)dimY;
     (void)dimZ;
-    return 0; // the path costs of the previous slice live in registers; no slice buffers (Sgm.hpp:144-148 of the reference)
+    if(dimX <= 0 || dimY <= 0)
+        return 0;
+    // one fp32 adaptive-P2 map per axis pass (the path costs of the previous slice live in registers: no uint32 slice
+    // buffers like Sgm.hpp:144-148 of the reference)
+    return ((size_t)dimX * (size_t)dimY * sizeof(float) + 255) & ~(size_t)255;
 }
 
 int avdm_volume_optimize(uint8_t* out_vol, const uint8_t* in_vol, long long pitch_y, int pitch_x, void* scratch, const avdm_pyramid_t* rc_pyr,
                          const avdm_sgm_params_t* sp, int last_depth_index, avdm_roi_t roi, void* stream)
 {
-    (void)scratch;
     const int dimX = (int)(roi.x.end - roi.x.begin), dimY = (int)(roi.y.end - roi.y.begin), Z = last_depth_index;
     if(dimX <= 0 || dimY <= 0 || Z <= 0)
         return 0;
@@ -366,53 +449,67 @@ int avdm_volume_optimize(uint8_t* out_vol, const uint8_t* in_vol, long long pitc
         return set_error_msg(1, "avdm_volume_optimize: pitch_x must cover the 4-aligned depth count");
     if(Z > 1536)
         return set_error_msg(1, "avdm_volume_optimize: more than 1536 depth planes are not supported");
+    if(scratch == nullptr || ((uintptr_t)scratch & 3))
+        return set_error_msg(1, "avdm_volume_optimize: scratch of avdm_volume_optimize_scratch_bytes() bytes (4-byte aligned) is required");
     int level;
     if(!lod_is_integral(rc_pyr, sp->scale, &level))
         return set_error_msg(1, "avdm_volume_optimize: non-integral mip level");
     const Tex t = make_tex(rc_pyr);
+    hipStream_t st = (hipStream_t)stream;
 
-    SgmArgs S;
+    SgmP2Args Q;
+    Q.L = t.lv[level];
+    Q.rcW = (float)tex_dim_w(rc_pyr, sp->scale);
+    Q.rcH = (float)tex_dim_h(rc_pyr, sp->scale);
+    Q.step = (float)sp->stepXY;
+    Q.P2w = (float)sp->p2Weighting;
+    const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
+
+    SgmPathArgs S;
     S.in = in_vol;
     S.out = out_vol;
+    S.p2 = (const float*)scratch;
     S.Z = Z;
     S.P1 = (float)sp->p1;
-    S.P2w = (float)sp->p2Weighting;
-    S.L = t.lv[level];
-    S.rcW = (float)tex_dim_w(rc_pyr, sp->scale);
-    S.rcH = (float)tex_dim_h(rc_pyr, sp->scale);
-    S.step = (float)sp->stepXY;
-    S.fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
 
     const int NW = (Z + 255) / 256;
+    const bool full = (Z == 256 * NW);
     int npaths = 0;
     for(const char* ax = sp->filteringAxes; *ax; ++ax)
     {
         if(*ax != 'X' && *ax != 'Y')
             continue;
+        if(npaths > 2)
+            return set_error_msg(1, "avdm_volume_optimize: at most 2 filtering axes");
         const bool scanX = (*ax == 'X');
-        S.scanIsX = scanX ? 1 : 0;
         S.A = scanX ? dimY : dimX;
         S.B = scanX ? dimX : dimY;
         S.strideA = scanX ? pitch_y : (long long)pitch_x;
         S.strideB = scanX ? (long long)pitch_x : pitch_y;
         // deviceSimilarityVolumeKernels.cuh:688-689: beginX = (axisT.x == 0) ? roi.x.begin : roi.y.begin, applied to v.x (sic)
         const bool swap = sp->strictRoiQuirk && scanX;
-        S.beginX = swap ? (int)roi.y.begin : (int)roi.x.begin;
-        S.beginY = swap ? (int)roi.x.begin : (int)roi.y.begin;
+        Q.scanIsX = scanX ? 1 : 0;
+        Q.beginX = swap ? (int)roi.y.begin : (int)roi.x.begin;
+        Q.beginY = swap ? (int)roi.x.begin : (int)roi.y.begin;
+        Q.A = S.A;
+        Q.B = S.B;
+        const dim3 pgrid(divUp(S.B, 16), divUp(S.A, 16));
+        if(fixed8)
+            hipLaunchKernelGGL(sgm_p2_map_kernel<true>, pgrid, dim3(256), 0, st, (float*)scratch, Q);
+        else
+            hipLaunchKernelGGL(sgm_p2_map_kernel<false>, pgrid, dim3(256), 0, st, (float*)scratch, Q);
         for(int rev = 0; rev < 2; ++rev)
         {
             S.rev = rev;
             const int K = npaths++;
-            if(K > 3)
-                return set_error_msg(1, "avdm_volume_optimize: at most 2 filtering axes");
             switch(NW)
             {
-                case 1: launch_path<1>(S, K, (hipStream_t)stream); break;
-                case 2: launch_path<2>(S, K, (hipStream_t)stream); break;
-                case 3: launch_path<3>(S, K, (hipStream_t)stream); break;
-                case 4: launch_path<4>(S, K, (hipStream_t)stream); break;
-                case 5: launch_path<5>(S, K, (hipStream_t)stream); break;
-                default: launch_path<6>(S, K, (hipStream_t)stream); break;
+                case 1: launch_path<1>(S, K, full, st); break;
+                case 2: launch_path<2>(S, K, full, st); break;
+                case 3: launch_path<3>(S, K, full, st); break;
+                case 4: launch_path<4>(S, K, full, st); break;
+                case 5: launch_path<5>(S, K, full, st); break;
+                default: launch_path<6>(S, K, full, st); break;
             }
         }
     }

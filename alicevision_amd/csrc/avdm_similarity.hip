@@ -4,18 +4,31 @@
 //   avdm_volume_refine_similarity   <-> cuda_volumeRefineSimilarity   (deviceSimilarityVolume.cu:208-259, kernels.cuh:235-391)
 //   NCC core                        <-> compNCCby3DptsYK              (cuda/device/Patch.cuh:466-572, SimStat.cuh, color.cuh:167-210)
 //
-// CDNA4 design (not the CUDA one):
-//   * one lane per PIXEL, 8x8 pixels per wave64, 16x16 per workgroup: neighbouring lanes sample neighbouring texels of R and
-//     of T for the same plane, so the L1/L2 serve the gathers; each lane walks a chunk of consecutive planes and writes its
-//     results as one packed word into the z-fastest volume (4 x u8 = one dword RMW; 8 x fp16 = one 16-byte RMW).
+// CDNA4 design (not the CUDA one — there is no texture path here, every bilinear tap is 4 explicit 8-byte texel reads):
+//   * one lane per PIXEL, 8x8 pixels per wave64, 16x16 per workgroup; each lane walks a chunk of consecutive planes and writes
+//     its results as one packed word into the z-fastest volume (4 x u8 = one dword RMW; 8 x fp16 = one 16-byte RMW).
+//   * the 2 x 81 (SGM) / 2 x 49 (Refine) bilinear taps per voxel are served from LDS, not from the vector L1:
+//       - the R footprint of the workgroup (16x16 stage pixels + patch halo) is staged ONCE per workgroup;
+//       - for every plane the workgroup reduces the bounding box of its lanes' projected patch corners in the T image
+//         (a planar patch projects to a convex quad, so the 4 corners bound all taps), stages that T window with coalesced row
+//         loads, and the lanes gather from it; LDS row pitch = 8 (mod 16) texels keeps the 8x8-pixel gathers at the minimum
+//         bank-conflict degree for both 1- and 2-texel pixel spacing.
+//       - when a window does not fit (image border, depth discontinuity inside the workgroup, extreme view change) the
+//         workgroup takes the generic path for that plane: identical arithmetic, taps from global memory with clamp addressing.
 //   * patch samples are projected in homogeneous form:  P*(p + a*x + b*y) = h0 + a*(M*x) + b*(M*y)  — 3 FMA + 1 v_rcp per
 //     camera and sample instead of a 3-D point + a 3x4 product; the two Yoon–Kweon exponentials are merged into one v_exp.
 //   * camera parameters and the per-offset proximity table live in the kernarg segment (SGPR / scalar loads), no __constant__.
 #include "avdm_device.h"
 
+#include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 
+// taps in flight per lane: each unrolled sample keeps 8 LDS reads (16 VGPRs) live; 3 keeps the kernels at 3 waves / SIMD
 namespace avdm {
+
+constexpr int kNccUnroll = 3;
+constexpr bool kLdsSplitReads = true;
 
 struct PatchTable
 {
@@ -24,7 +37,7 @@ struct PatchTable
 
 struct NccArgs
 {
-    TexLevel rcL, tcL;         // integral-level fast path
+    TexLevel rcL, tcL;            // integral-level fast path
     float rcSx, rcOx, rcSy, rcOy; // nominal-level pixel -> texel space of the actual level: x = px*S + O
     float tcSx, tcOx, tcSy, tcOy;
     float rcW1, rcH1, tcW1, tcH1; // float(levelDim - 1) of the nominal dims (border test)
@@ -32,70 +45,140 @@ struct NccArgs
     float invGammaC, invGammaP;
     float mipmapLevel;
     int wsh;
+    int rcap, tcap;   // LDS capacities in texels (R tile, T window)
+    int forceGeneric; // debugging / A-B switch: never use the LDS path
+    unsigned* stats;  // optional device counters {plane-blocks on the LDS path, plane-blocks on the generic path}
 };
 
-__device__ __forceinline__ float4 fetch(const TexLevel& L, bool fixed8, float x, float y)
+// ---------------------------------------------------------------------------------------------
+// tap sources: global memory (clamp addressing) or an LDS window (all taps guaranteed inside)
+// ---------------------------------------------------------------------------------------------
+struct GlobalTap
 {
-    return fixed8 ? tex_bilinear_px<true>(L, x, y) : tex_bilinear_px<false>(L, x, y);
+    TexLevel L;
+    template <bool FIXED8>
+    __device__ __forceinline__ float4 fetch(float x, float y) const
+    {
+        return tex_bilinear_px<FIXED8>(L, x, y);
+    }
+};
+
+struct LdsTap
+{
+    const uint2* t;
+    int pitch, x0, y0;
+    template <bool FIXED8>
+    __device__ __forceinline__ float4 fetch(float x, float y) const
+    {
+        const float fx = floorf(x), fy = floorf(y);
+        float a = x - fx, b = y - fy;
+        if(FIXED8)
+        {
+            a = quant8(a);
+            b = quant8(b);
+        }
+        const int i = (int)fx - x0, j = (int)fy - y0;
+        const int o00 = __mul24(j, pitch) + i, o01 = o00 + pitch;
+        int o10 = o00 + 1, o11 = o01 + 1;
+        if(kLdsSplitReads)
+        { // keep the compiler from fusing horizontally adjacent taps into ds_read2_b64 (half the LDS rate of two ds_read_b64)
+            asm volatile("" : "+v"(o10));
+            asm volatile("" : "+v"(o11));
+        }
+        return bilinear_blend(unpack_h4(t[o00]), unpack_h4(t[o10]), unpack_h4(t[o01]), unpack_h4(t[o11]), a, b);
+    }
+};
+
+// LDS row pitch (texels) for a window of w texels: smallest value = 8 (mod 16) that is >= w
+__host__ __device__ __forceinline__ int lds_pitch_for(int w) { return (((w + 7) >> 4) << 4) + 8; }
+
+// cooperative copy of the window [x0, x0+w) x [y0, y0+h) of level L into LDS (row pitch `pitch` texels); the window is inside the image
+__device__ __forceinline__ void stage_window(uint2* dst, int pitch, const TexLevel& L, int x0, int y0, int w, int h)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for(int r = wave; r < h; r += 4)
+    {
+        const uint2* src = L.base + (long long)(y0 + r) * L.pitch8 + x0;
+        uint2* d = dst + r * pitch;
+        for(int c = lane; c < w; c += 64)
+            d[c] = src[c];
+    }
 }
 
-// returns +INF when invalid / masked.  TInvert: sigmoid-filtered positive similarity (Refine) else raw NCC in [-1, 1].
-template <bool FIXED8, int WSH, bool TInvert>
-__device__ __forceinline__ float ncc_patch(const avdm_camera_t& rc, const avdm_camera_t& tc, const NccArgs& A, const PatchTable& tab, f3 pp, f3 px,
-                                           f3 py, float pd, float rpx, float rpy)
+// ---------------------------------------------------------------------------------------------
+// per-voxel patch: homogeneous image coordinates of the centre and of the two scaled patch axes in R and T
+// ---------------------------------------------------------------------------------------------
+struct PatchProj
+{
+    f3 hr0, ht0;           // P * p
+    f3 rax, ray, tax, tay; // M * (patch.x * d), M * (patch.y * d)
+};
+
+__device__ __forceinline__ void patch_axes(const avdm_camera_t& rc, const avdm_camera_t& tc, f3 p, f3& ax, f3& ay)
+{
+    // computeRotCSEpip (Patch.cuh:111-135); only x and y are used downstream
+    const f3 v1 = normalize(ld3(rc.C) - p);
+    const f3 v2 = normalize(ld3(tc.C) - p);
+    ay = normalize(cross(v1, v2));
+    const f3 n = normalize((v1 + v2) * 0.5f);
+    ax = normalize(cross(ay, n));
+}
+
+__device__ __forceinline__ PatchProj make_patch_proj(const avdm_camera_t& rc, const avdm_camera_t& tc, f3 pp, f3 px, f3 py, float pd)
+{
+    PatchProj Q;
+    Q.hr0 = M3x4mulV3(rc.P, pp);
+    Q.ht0 = M3x4mulV3(tc.P, pp);
+    const f3 ax = px * pd, ay = py * pd; // patch.x * patch.d, patch.y * patch.d
+    Q.rax = M3x3mulV3(rc.P, ax);
+    Q.ray = M3x3mulV3(rc.P, ay);
+    Q.tax = M3x3mulV3(tc.P, ax);
+    Q.tay = M3x3mulV3(tc.P, ay);
+    return Q;
+}
+
+// texel-space tap positions of patch sample (fx, fy) in R and T — the ONE expression used by the sample loop and by the
+// window bounding boxes (so the boxes bound exactly what the loop will fetch)
+__device__ __forceinline__ void sample_pos(const PatchProj& Q, const NccArgs& A, f3 hrRow, f3 htRow, float fx, float& rX, float& rY, float& tX,
+                                           float& tY)
+{
+    const float hrz = fmaf(fx, Q.rax.z, hrRow.z), htz = fmaf(fx, Q.tax.z, htRow.z);
+    const float ir = fast_rcp(hrz), it = fast_rcp(htz);
+    const float rx = fmaf(fx, Q.rax.x, hrRow.x) * ir, ry = fmaf(fx, Q.rax.y, hrRow.y) * ir;
+    const float tx = fmaf(fx, Q.tax.x, htRow.x) * it, ty = fmaf(fx, Q.tax.y, htRow.y) * it;
+    rX = fmaf(rx, A.rcSx, A.rcOx);
+    rY = fmaf(ry, A.rcSy, A.rcOy);
+    tX = fmaf(tx, A.tcSx, A.tcOx);
+    tY = fmaf(ty, A.tcSy, A.tcOy);
+}
+__device__ __forceinline__ void row_of(const PatchProj& Q, float fy, f3& hrRow, f3& htRow)
+{
+    hrRow = f3{fmaf(fy, Q.ray.x, Q.hr0.x), fmaf(fy, Q.ray.y, Q.hr0.y), fmaf(fy, Q.ray.z, Q.hr0.z)};
+    htRow = f3{fmaf(fy, Q.tay.x, Q.ht0.x), fmaf(fy, Q.tay.y, Q.ht0.y), fmaf(fy, Q.tay.z, Q.ht0.z)};
+}
+
+// weighted NCC over the (2*wsh+1)^2 patch; TInvert: sigmoid-filtered positive similarity (Refine) else raw NCC in [-1, 1]
+template <bool FIXED8, int WSH, bool TInvert, class RTap, class TTap>
+__device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const RTap& rt, const TTap& tt,
+                                                float4 rcCenter, float4 tcCenter)
 {
     const int wsh = WSH > 0 ? WSH : A.wsh;
-    // homogeneous image coordinates of the patch centre and of the two scaled patch axes
-    const f3 hr0 = M3x4mulV3(rc.P, pp);
-    const f3 ht0 = M3x4mulV3(tc.P, pp);
-    // (rpx, rpy): the patch centre lies on the ray of pixel (x, y), so its R projection IS (x, y); using the exact pixel makes
-    // the border test deterministic on the knife-edge rows where x == wsh + 2 (DESIGN.md "knife-edge rows")
-    const float it0 = fast_rcp(ht0.z);
-    const float tpx = ht0.x * it0, tpy = ht0.y * it0;
-
-    const float dd = (float)wsh + 2.0f;
-    if((rpx < dd) || (rpx > A.rcW1 - dd) || (tpx < dd) || (tpx > A.tcW1 - dd) || (rpy < dd) || (rpy > A.rcH1 - dd) || (tpy < dd) ||
-       (tpy > A.tcH1 - dd))
-        return INFINITY;
-
-    const float4 rcCenter = tex_bilinear_px<FIXED8>(A.rcL, fmaf(rpx, A.rcSx, A.rcOx), fmaf(rpy, A.rcSy, A.rcOy));
-    const float4 tcCenter = tex_bilinear_px<FIXED8>(A.tcL, fmaf(tpx, A.tcSx, A.tcOx), fmaf(tpy, A.tcSy, A.tcOy));
-    if(rcCenter.w < (255.f * 0.9f) || tcCenter.w < (255.f * 0.4f))
-        return INFINITY;
-
-    const f3 ax = px * pd, ay = py * pd; // patch.x * patch.d, patch.y * patch.d
-    const f3 rax = M3x3mulV3(rc.P, ax), ray = M3x3mulV3(rc.P, ay);
-    const f3 tax = M3x3mulV3(tc.P, ax), tay = M3x3mulV3(tc.P, ay);
-
     float xsum = 0.f, ysum = 0.f, xxsum = 0.f, yysum = 0.f, xysum = 0.f, wsum = 0.f;
     const int n = 2 * wsh + 1;
 
 #pragma unroll 1
     for(int yp = -wsh; yp <= wsh; ++yp)
     {
-        const float fy = (float)yp;
-        const f3 hrRow = f3{fmaf(fy, ray.x, hr0.x), fmaf(fy, ray.y, hr0.y), fmaf(fy, ray.z, hr0.z)};
-        const f3 htRow = f3{fmaf(fy, tay.x, ht0.x), fmaf(fy, tay.y, ht0.y), fmaf(fy, tay.z, ht0.z)};
+        f3 hrRow, htRow;
+        row_of(Q, (float)yp, hrRow, htRow);
         const float* trow = tab.c + (yp + wsh) * n + wsh;
-#pragma unroll
-        for(int xp = -(WSH > 0 ? WSH : 4); xp <= (WSH > 0 ? WSH : 4); ++xp)
+#pragma unroll kNccUnroll
+        for(int xp = -wsh; xp <= wsh; ++xp)
         {
-            if(WSH <= 0 && (xp < -wsh || xp > wsh))
-                continue;
-            const float fx = (float)xp;
-#ifdef AVDM_DBG_REFPROJ
-            const f3 p3 = pp + px * (pd * fx) + py * (pd * fy);
-            const float2 rq = project3DPoint(rc.P, p3), tq = project3DPoint(tc.P, p3);
-            const float rx = rq.x, ry = rq.y, tx = tq.x, ty = tq.y;
-#else
-            const float hrz = fmaf(fx, rax.z, hrRow.z), htz = fmaf(fx, tax.z, htRow.z);
-            const float ir = fast_rcp(hrz), it = fast_rcp(htz);
-            const float rx = fmaf(fx, rax.x, hrRow.x) * ir, ry = fmaf(fx, rax.y, hrRow.y) * ir;
-            const float tx = fmaf(fx, tax.x, htRow.x) * it, ty = fmaf(fx, tax.y, htRow.y) * it;
-#endif
-
-            const float4 rcC = tex_bilinear_px<FIXED8>(A.rcL, fmaf(rx, A.rcSx, A.rcOx), fmaf(ry, A.rcSy, A.rcOy));
-            const float4 tcC = tex_bilinear_px<FIXED8>(A.tcL, fmaf(tx, A.tcSx, A.tcOx), fmaf(ty, A.tcSy, A.tcOy));
+            float rX, rY, tX, tY;
+            sample_pos(Q, A, hrRow, htRow, (float)xp, rX, rY, tX, tY);
+            const float4 rcC = rt.template fetch<FIXED8>(rX, rY);
+            const float4 tcC = tt.template fetch<FIXED8>(tX, tY);
 
             // w = exp(-(dC_r/gC + dP/gP)) * exp(-(dC_t/gC + dP/gP)) = exp2((dC_r + dC_t) * (-log2e/gC) - 2*dP*log2e/gP)
             const float drx = rcCenter.x - rcC.x, dry = rcCenter.y - rcC.y, drz = rcCenter.z - rcC.z;
@@ -129,16 +212,6 @@ __device__ __forceinline__ float ncc_patch(const avdm_camera_t& rc, const avdm_c
     return sim;
 }
 
-__device__ __forceinline__ void patch_axes(const avdm_camera_t& rc, const avdm_camera_t& tc, f3 p, f3& ax, f3& ay)
-{
-    // computeRotCSEpip (Patch.cuh:111-135); only x and y are used downstream
-    const f3 v1 = normalize(ld3(rc.C) - p);
-    const f3 v2 = normalize(ld3(tc.C) - p);
-    ay = normalize(cross(v1, v2));
-    const f3 n = normalize((v1 + v2) * 0.5f);
-    ax = normalize(cross(ay, n));
-}
-
 __device__ __forceinline__ void pixel_of_lane(int& tx, int& ty)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -147,87 +220,304 @@ __device__ __forceinline__ void pixel_of_lane(int& tx, int& ty)
 }
 
 // ---------------------------------------------------------------------------------------------
+// workgroup state shared by the two kernels
+// ---------------------------------------------------------------------------------------------
+#define AVDM_MAX_CHUNK 8
+struct BlockShared
+{
+    int box[AVDM_MAX_CHUNK][4]; // per plane of the chunk: min x, min y, max x, max y (floor of the texel-space tap positions in T)
+    int bad[AVDM_MAX_CHUNK];    // per plane: some lane's R taps leave the staged R tile
+};
+
+struct RTile
+{
+    int x0, y0, w, h, pitch;
+    bool ok;
+};
+
+// R footprint of the workgroup: stage pixels [bx, bx+15] x [by, by+15] of the ROI, patch halo wsh + 2 (the border-test margin)
+__device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int wsh, int stepXY, avdm_roi_t roi)
+{
+    RTile T;
+    const int roiW = (int)(roi.x.end - roi.x.begin), roiH = (int)(roi.y.end - roi.y.begin);
+    const int bx = blockIdx.x * 16, by = blockIdx.y * 16;
+    const float pxMin = (float)((int)roi.x.begin + bx) * (float)stepXY;
+    const float pxMax = (float)((int)roi.x.begin + min(bx + 15, roiW - 1)) * (float)stepXY;
+    const float pyMin = (float)((int)roi.y.begin + by) * (float)stepXY;
+    const float pyMax = (float)((int)roi.y.begin + min(by + 15, roiH - 1)) * (float)stepXY;
+    const float m = (float)wsh + 2.0f;
+    int x0 = (int)floorf(fmaf(pxMin - m, A.rcSx, A.rcOx)) - 1;
+    int x1 = (int)floorf(fmaf(pxMax + m, A.rcSx, A.rcOx)) + 2;
+    int y0 = (int)floorf(fmaf(pyMin - m, A.rcSy, A.rcOy)) - 1;
+    int y1 = (int)floorf(fmaf(pyMax + m, A.rcSy, A.rcOy)) + 2;
+    x0 = max(x0, 0);
+    y0 = max(y0, 0);
+    x1 = min(x1, A.rcL.W - 1);
+    y1 = min(y1, A.rcL.H - 1);
+    T.x0 = x0;
+    T.y0 = y0;
+    T.w = x1 - x0 + 1;
+    T.h = y1 - y0 + 1;
+    T.pitch = lds_pitch_for(T.w);
+    T.ok = !A.forceGeneric && T.w > 1 && T.h > 1 && T.pitch * T.h <= A.rcap;
+    if(T.ok)
+        stage_window(sR, T.pitch, A.rcL, T.x0, T.y0, T.w, T.h);
+    return T;
+}
+
+// per-lane part of the window search: min/max of the 4 projected patch corners in T, and whether the R taps stay in the R tile
+__device__ __forceinline__ void corner_boxes(const PatchProj& Q, const NccArgs& A, int wsh, const RTile& R, float& tminx, float& tminy, float& tmaxx,
+                                             float& tmaxy, bool& rInside)
+{
+    tminx = tminy = INFINITY;
+    tmaxx = tmaxy = -INFINITY;
+    float rminx = INFINITY, rminy = INFINITY, rmaxx = -INFINITY, rmaxy = -INFINITY;
+#pragma unroll
+    for(int cy = -1; cy <= 1; cy += 2)
+    {
+        f3 hrRow, htRow;
+        row_of(Q, (float)(cy * wsh), hrRow, htRow);
+#pragma unroll
+        for(int cx = -1; cx <= 1; cx += 2)
+        {
+            float rX, rY, tX, tY;
+            sample_pos(Q, A, hrRow, htRow, (float)(cx * wsh), rX, rY, tX, tY);
+            rminx = fminf(rminx, rX);
+            rmaxx = fmaxf(rmaxx, rX);
+            rminy = fminf(rminy, rY);
+            rmaxy = fmaxf(rmaxy, rY);
+            tminx = fminf(tminx, tX);
+            tmaxx = fmaxf(tmaxx, tX);
+            tminy = fminf(tminy, tY);
+            tmaxy = fmaxf(tmaxy, tY);
+        }
+    }
+    // one texel of slack on each side for the interior taps (they lie in the corners' hull up to rounding)
+    rInside = (floorf(rminx) - 1.0f >= (float)R.x0) && (floorf(rmaxx) + 2.0f <= (float)(R.x0 + R.w - 1)) && (floorf(rminy) - 1.0f >= (float)R.y0) &&
+              (floorf(rmaxy) + 2.0f <= (float)(R.y0 + R.h - 1));
+}
+
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    v = fmaxf(v, dpp_f32<0x111>(v, v));
+    v = fmaxf(v, dpp_f32<0x112>(v, v));
+    v = fmaxf(v, dpp_f32<0x114>(v, v));
+    v = fmaxf(v, dpp_f32<0x118>(v, v));
+    v = fmaxf(v, dpp_f32<0x142, 0xa>(v, v));
+    v = fmaxf(v, dpp_f32<0x143, 0xc>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// workgroup reduction of the lanes' T boxes into sh.box[k] (first half; the caller synchronises afterwards)
+__device__ __forceinline__ void publish_box(BlockShared& sh, int k, bool valid, float tminx, float tminy, float tmaxx, float tmaxy, bool rInside)
+{
+    const float mnx = wave_min_f32(valid ? tminx : INFINITY);
+    const float mny = wave_min_f32(valid ? tminy : INFINITY);
+    const float mxx = wave_max_f32(valid ? tmaxx : -INFINITY);
+    const float mxy = wave_max_f32(valid ? tmaxy : -INFINITY);
+    const bool anyBad = __any(valid && !(rInside && isfinite(tminx) && isfinite(tminy) && isfinite(tmaxx) && isfinite(tmaxy)));
+    if((threadIdx.x & 63) == 0)
+    {
+        if(anyBad)
+            atomicOr(&sh.bad[k], 1);
+        if(mnx <= mxx && mny <= mxy && fabsf(mnx) < 1.0e8f && fabsf(mny) < 1.0e8f && fabsf(mxx) < 1.0e8f && fabsf(mxy) < 1.0e8f)
+        {
+            atomicMin(&sh.box[k][0], (int)floorf(mnx));
+            atomicMin(&sh.box[k][1], (int)floorf(mny));
+            atomicMax(&sh.box[k][2], (int)floorf(mxx));
+            atomicMax(&sh.box[k][3], (int)floorf(mxy));
+        }
+    }
+}
+
+struct TWindow
+{
+    int x0, y0, w, h, pitch;
+    bool ok;
+};
+
+// second half (after the barrier): decide — uniformly for the workgroup — whether plane k runs from LDS, and stage the T window
+__device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk)
+{
+    TWindow Wd;
+    const int mnx = sh.box[k][0], mny = sh.box[k][1], mxx = sh.box[k][2], mxy = sh.box[k][3];
+    Wd.ok = false;
+    Wd.x0 = Wd.y0 = Wd.w = Wd.h = Wd.pitch = 0;
+    if(rTileOk && !sh.bad[k] && mnx != INT_MAX && mxx != INT_MIN)
+    {
+        // taps use texels floor(x) and floor(x) + 1; one more texel of slack on each side (see corner_boxes)
+        Wd.x0 = mnx - 1;
+        Wd.y0 = mny - 1;
+        const int x1 = mxx + 2, y1 = mxy + 2;
+        Wd.w = x1 - Wd.x0 + 1;
+        Wd.h = y1 - Wd.y0 + 1;
+        Wd.pitch = lds_pitch_for(Wd.w);
+        Wd.ok = Wd.x0 >= 0 && Wd.y0 >= 0 && x1 <= A.tcL.W - 1 && y1 <= A.tcL.H - 1 && Wd.w <= 4096 && Wd.h <= 4096 && Wd.pitch * Wd.h <= A.tcap;
+    }
+    if(Wd.ok)
+        stage_window(sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
+    if(A.stats != nullptr && threadIdx.x == 0)
+        atomicAdd(A.stats + (Wd.ok ? 0 : 1), 1u);
+    return Wd;
+}
+
+__device__ __forceinline__ void init_shared(BlockShared& sh)
+{
+    if(threadIdx.x < AVDM_MAX_CHUNK * 4)
+        sh.box[threadIdx.x >> 2][threadIdx.x & 3] = (threadIdx.x & 2) ? INT_MIN : INT_MAX;
+    if(threadIdx.x < AVDM_MAX_CHUNK)
+        sh.bad[threadIdx.x] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // SGM similarity: best / second-best uint8 volumes, 4 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
 template <bool FIXED8, int WSH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
   similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
                     avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
 {
+    extern __shared__ __attribute__((aligned(16))) uint2 smem[];
+    uint2* sR = smem;
+    uint2* sT = smem + A.rcap;
+    __shared__ BlockShared sh;
+    const int wsh = WSH > 0 ? WSH : A.wsh;
+
     int tx, ty;
     pixel_of_lane(tx, ty);
     const unsigned vx = blockIdx.x * 16 + tx, vy = blockIdx.y * 16 + ty;
-    if(vx >= roi.x.end - roi.x.begin || vy >= roi.y.end - roi.y.begin)
-        return;
+    const bool inRoi = vx < roi.x.end - roi.x.begin && vy < roi.y.end - roi.y.begin;
     const unsigned z0 = ((zBegin >> 2) + blockIdx.z) << 2;
+
+    init_shared(sh);
+    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi);
+    __syncthreads();
 
     const float x = (float)(roi.x.begin + vx) * (float)stepXY;
     const float y = (float)(roi.y.begin + vy) * (float)stepXY;
 
-    // pixel ray (shared by the 4 planes): get3DPointForPixelAndFrontoParellePlaneRC restated
+    // pixel ray (shared by the planes of the chunk): get3DPointForPixelAndFrontoParellePlaneRC restated
     const f3 C = ld3(rc.C), Z = ld3(rc.ZVect);
     const f3 v = normalize(M3x3mulV2(rc.iP, x, y));
     const float dnC = dot(Z, C), dnv = dot(Z, v);
 
+    // R side of the validity test (Patch.cuh:486-496, 523-526): the patch centre lies on the ray of pixel (x, y), so its R
+    // projection IS (x, y); using the exact pixel makes the border test deterministic on the knife-edge rows where
+    // x == wsh + 2 (DESIGN.md "knife-edge rows")
+    const float dd = (float)wsh + 2.0f;
+    bool rValid = inRoi && !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd));
+    float4 rcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
+    if(rValid)
+    {
+        rcCenter = tex_bilinear_px<FIXED8>(A.rcL, fmaf(x, A.rcSx, A.rcOx), fmaf(y, A.rcSy, A.rcOy));
+        rValid = !(rcCenter.w < (255.f * 0.9f));
+    }
+
     uint8_t* pb = best + (long long)vy * pitch_y + (long long)vx * pitch_x + z0;
     uint8_t* ps = second + (long long)vy * pitch_y + (long long)vx * pitch_x + z0;
-    unsigned wb = *reinterpret_cast<const unsigned*>(pb);
-    unsigned ws = *reinterpret_cast<const unsigned*>(ps);
+    unsigned wb = 0, ws = 0;
+    if(inRoi)
+    {
+        wb = *reinterpret_cast<const unsigned*>(pb);
+        ws = *reinterpret_cast<const unsigned*>(ps);
+    }
 
 #pragma unroll 1
     for(int k = 0; k < 4; ++k)
     {
         const unsigned vz = z0 + k;
-        if(vz < zBegin || vz >= zEnd)
+        if(vz < zBegin || vz >= zEnd) // uniform
             continue;
-        const float depthPlane = depths[vz];
-        const f3 planep = C + Z * depthPlane;
-        const float kk = (dot(planep, Z) - dnC) / dnv;
-        const f3 p = C + v * kk;
-        const float pd = computePixSize(rc, p);
-        f3 ax, ay;
-        patch_axes(rc, tc, p, ax, ay);
-        float fsim = ncc_patch<FIXED8, WSH, false>(rc, tc, A, tab, p, ax, ay, pd, x, y);
-        if(fsim == INFINITY)
-            fsim = 255.0f;
-        else
+
+        bool valid = rValid;
+        PatchProj Q;
+        float4 tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
+        float bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f;
+        bool rInside = false;
+        if(valid)
         {
-            fsim = (fsim + 1.0f) * 0.5f;
-            fsim = fminf(1.0f, fmaxf(0.0f, fsim));
-            fsim *= 254.0f;
+            const float depthPlane = depths[vz];
+            const f3 planep = C + Z * depthPlane;
+            const float kk = (dot(planep, Z) - dnC) / dnv;
+            const f3 p = C + v * kk;
+            const float pd = computePixSize(rc, p);
+            f3 ax, ay;
+            patch_axes(rc, tc, p, ax, ay);
+            Q = make_patch_proj(rc, tc, p, ax, ay, pd);
+            const float it0 = fast_rcp(Q.ht0.z);
+            const float tpx = Q.ht0.x * it0, tpy = Q.ht0.y * it0;
+            valid = !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+            if(valid)
+            {
+                tcCenter = tex_bilinear_px<FIXED8>(A.tcL, fmaf(tpx, A.tcSx, A.tcOx), fmaf(tpy, A.tcSy, A.tcOy));
+                valid = !(tcCenter.w < (255.f * 0.4f));
+            }
+            if(valid)
+                corner_boxes(Q, A, wsh, R, bx0, by0, bx1, by1, rInside);
         }
-        const unsigned sh = 8u * k;
-        const unsigned b1 = (wb >> sh) & 0xffu, b2 = (ws >> sh) & 0xffu;
+        publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
+        __syncthreads();
+        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok);
+        __syncthreads();
+
+        float fsim = 255.0f;
+        if(valid)
+        {
+            float s;
+            if(Wd.ok)
+                s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
+            else
+                s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
+            s = (s + 1.0f) * 0.5f;
+            s = fminf(1.0f, fmaxf(0.0f, s));
+            fsim = s * 254.0f;
+        }
+        const unsigned sh8 = 8u * k;
+        const unsigned b1 = (wb >> sh8) & 0xffu, b2 = (ws >> sh8) & 0xffu;
         if(fsim < (float)b1)
         {
-            ws = (ws & ~(0xffu << sh)) | (b1 << sh);
-            wb = (wb & ~(0xffu << sh)) | ((unsigned)fsim << sh);
+            ws = (ws & ~(0xffu << sh8)) | (b1 << sh8);
+            wb = (wb & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
         }
         else if(fsim < (float)b2)
-            ws = (ws & ~(0xffu << sh)) | ((unsigned)fsim << sh);
+            ws = (ws & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
     }
-    *reinterpret_cast<unsigned*>(pb) = wb;
-    *reinterpret_cast<unsigned*>(ps) = ws;
+    if(inRoi)
+    {
+        *reinterpret_cast<unsigned*>(pb) = wb;
+        *reinterpret_cast<unsigned*>(ps) = ws;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Refine similarity: fp16 volume += sigmoid-filtered NCC, 8 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
 template <bool FIXED8, int WSH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
   refine_similarity_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize,
                            int map_pitch, const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A,
                            PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
 {
+    extern __shared__ __attribute__((aligned(16))) uint2 smem[];
+    uint2* sR = smem;
+    uint2* sT = smem + A.rcap;
+    __shared__ BlockShared sh;
+    const int wsh = WSH > 0 ? WSH : A.wsh;
+
     int tx, ty;
     pixel_of_lane(tx, ty);
     const unsigned vx = blockIdx.x * 16 + tx, vy = blockIdx.y * 16 + ty;
-    if(vx >= roi.x.end - roi.x.begin || vy >= roi.y.end - roi.y.begin)
-        return;
-    const float2 dps = *((const float2*)((const char*)sgmDepthPixSize + (long long)vy * map_pitch) + vx);
-    if(dps.x <= 0.0f)
-        return;
+    const bool inRoi = vx < roi.x.end - roi.x.begin && vy < roi.y.end - roi.y.begin;
     const unsigned z0 = ((zBegin >> 3) + blockIdx.z) << 3;
+
+    init_shared(sh);
+    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi);
+    __syncthreads();
+
+    float2 dps = make_float2(-1.f, 0.f);
+    if(inRoi)
+        dps = *((const float2*)((const char*)sgmDepthPixSize + (long long)vy * map_pitch) + vx);
+    const bool pixActive = inRoi && dps.x > 0.0f; // kernels.cuh:266-270: pixels without an SGM depth keep their volume entries
 
     const float x = (float)(roi.x.begin + vx) * (float)stepXY;
     const float y = (float)(roi.y.begin + vy) * (float)stepXY;
@@ -237,49 +527,102 @@ __global__ void __launch_bounds__(256)
     // move3DPointByRcPixSize direction: normalize(p - C) recomputed from the mid point like the reference (kernels.cuh:17-24)
     const f3 dir = normalize(pMid - C);
 
+    const float dd = (float)wsh + 2.0f;
+    bool rValid = pixActive && !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd));
+    float4 rcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
+    if(rValid)
+    {
+        rcCenter = tex_bilinear_px<FIXED8>(A.rcL, fmaf(x, A.rcSx, A.rcOx), fmaf(y, A.rcSy, A.rcOy));
+        rValid = !(rcCenter.w < (255.f * 0.9f));
+    }
+
     __half* pv = vol + ((long long)vy * pitch_y + (long long)vx * pitch_x) / 2 + z0;
-    uint4 packed = *reinterpret_cast<const uint4*>(pv);
-    __half* hv = reinterpret_cast<__half*>(&packed);
+    uint4 packed = make_uint4(0u, 0u, 0u, 0u);
+    if(pixActive)
+        packed = *reinterpret_cast<const uint4*>(pv);
 
 #pragma unroll 1
     for(int k = 0; k < 8; ++k)
     {
         const unsigned vz = z0 + k;
-        if(vz < zBegin || vz >= zEnd)
+        if(vz < zBegin || vz >= zEnd) // uniform
             continue;
-        const int rel = (int)vz - ((volDimZ - 1) / 2);
-        f3 p = pMid;
-        if(rel != 0)
-            p = pMid + dir * ((float)rel * dps.y);
-        const float pd = computePixSize(rc, p);
-        f3 ax, ay;
+
+        bool valid = rValid;
+        PatchProj Q;
+        float4 tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
+        float bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f;
+        bool rInside = false;
+        if(valid)
         {
-            const f3 v1 = normalize(C - p);
-            const f3 v2 = normalize(ld3(tc.C) - p);
-            ay = normalize(cross(v1, v2));
-            f3 n;
-            if(sgmNormal != nullptr)
+            const int rel = (int)vz - ((volDimZ - 1) / 2);
+            f3 p = pMid;
+            if(rel != 0)
+                p = pMid + dir * ((float)rel * dps.y);
+            const float pd = computePixSize(rc, p);
+            f3 ax, ay;
             {
-                const float* nn = (const float*)((const char*)sgmNormal + (long long)vy * normal_pitch) + 3 * vx;
-                n = f3{nn[0], nn[1], nn[2]};
+                const f3 v1 = normalize(C - p);
+                const f3 v2 = normalize(ld3(tc.C) - p);
+                ay = normalize(cross(v1, v2));
+                f3 n;
+                if(sgmNormal != nullptr)
+                {
+                    const float* nn = (const float*)((const char*)sgmNormal + (long long)vy * normal_pitch) + 3 * vx;
+                    n = f3{nn[0], nn[1], nn[2]};
+                }
+                else
+                    n = normalize((v1 + v2) * 0.5f);
+                ax = normalize(cross(ay, n));
             }
-            else
-                n = normalize((v1 + v2) * 0.5f);
-            ax = normalize(cross(ay, n));
+            Q = make_patch_proj(rc, tc, p, ax, ay, pd);
+            const float it0 = fast_rcp(Q.ht0.z);
+            const float tpx = Q.ht0.x * it0, tpy = Q.ht0.y * it0;
+            valid = !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+            if(valid)
+            {
+                tcCenter = tex_bilinear_px<FIXED8>(A.tcL, fmaf(tpx, A.tcSx, A.tcOx), fmaf(tpy, A.tcSy, A.tcOy));
+                valid = !(tcCenter.w < (255.f * 0.4f));
+            }
+            if(valid)
+                corner_boxes(Q, A, wsh, R, bx0, by0, bx1, by1, rInside);
         }
-        const float fsim = ncc_patch<FIXED8, WSH, true>(rc, tc, A, tab, p, ax, ay, pd, x, y);
-        if(fsim == INFINITY)
-            continue;
-        hv[k] = __float2half(__half2float(hv[k]) + fsim);
+        publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
+        __syncthreads();
+        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok);
+        __syncthreads();
+
+        if(valid)
+        {
+            float s;
+            if(Wd.ok)
+                s = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
+            else
+                s = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
+            // packed[k] += s without indexing the register quad dynamically (that would spill it to scratch)
+            const unsigned sel = (unsigned)k >> 1, hiHalf = (unsigned)k & 1u;
+            unsigned word = sel == 0 ? packed.x : (sel == 1 ? packed.y : (sel == 2 ? packed.z : packed.w));
+            const unsigned short hbits = (unsigned short)(hiHalf ? (word >> 16) : (word & 0xffffu));
+            const __half hs = __float2half(__half2float(__ushort_as_half(hbits)) + s);
+            const unsigned nb = (unsigned)__half_as_ushort(hs);
+            word = hiHalf ? ((word & 0x0000ffffu) | (nb << 16)) : ((word & 0xffff0000u) | nb);
+            packed.x = sel == 0 ? word : packed.x;
+            packed.y = sel == 1 ? word : packed.y;
+            packed.z = sel == 2 ? word : packed.z;
+            packed.w = sel == 3 ? word : packed.w;
+        }
     }
-    *reinterpret_cast<uint4*>(pv) = packed;
+    if(pixActive)
+        *reinterpret_cast<uint4*>(pv) = packed;
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcPyr, const avdm_pyramid_t* tcPyr, int scale, int wsh, double gammaC,
-                          double gammaP)
+static unsigned* g_stats = nullptr; // device counters, allocated on first use when AVDM_SIM_STATS=1
+
+static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcPyr, const avdm_pyramid_t* tcPyr, int scale, int stepXY, int wsh,
+                          double gammaC, double gammaP)
 {
     int rl, tl;
     if(!lod_is_integral(rcPyr, scale, &rl) || !lod_is_integral(tcPyr, scale, &tl))
@@ -311,6 +654,37 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
     for(int yp = -wsh; yp <= wsh; ++yp)
         for(int xp = -wsh; xp <= wsh; ++xp)
             tab.c[(yp + wsh) * n + (xp + wsh)] = 2.0f * sqrtf((float)(xp * xp + yp * yp)) * A.invGammaP * log2e;
+
+    // LDS budget: R tile = 16 stage pixels * stepXY texels + halo; T window: the same footprint (a T view at a
+    // markedly larger scale, or a depth edge inside the workgroup, overflows it and takes the generic path).  Row pitches are 8 (mod 16) texels.
+    const int rw = 15 * stepXY + 2 * (wsh + 2) + 5;
+    A.rcap = lds_pitch_for(rw) * rw;
+    const int tw = rw + 1;
+    A.tcap = lds_pitch_for(tw) * tw;
+    if((A.rcap + A.tcap) * 8 > 60 * 1024)
+    { // keep >= 2 workgroups per CU; larger steps take the generic path
+        A.rcap = 16;
+        A.tcap = 16;
+        A.forceGeneric = 1;
+    }
+    else
+        A.forceGeneric = 0;
+    const char* e = getenv("AVDM_SIM_LDS");
+    if(e && e[0] == '0')
+        A.forceGeneric = 1;
+    A.stats = nullptr;
+    const char* st = getenv("AVDM_SIM_STATS");
+    if(st && st[0] == '1')
+    {
+        if(g_stats == nullptr)
+        {
+            if(hipMalloc((void**)&g_stats, 4 * sizeof(unsigned)) != hipSuccess)
+                g_stats = nullptr;
+            else
+                (void)hipMemset(g_stats, 0, 4 * sizeof(unsigned));
+        }
+        A.stats = g_stats;
+    }
     return true;
 }
 
@@ -319,6 +693,21 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
 using namespace avdm;
 
 extern "C" {
+
+/* debugging aid (not part of avdm.h): plane-workgroups that ran from LDS / took the generic path since the last call */
+int avdm_debug_similarity_stats(unsigned out[2])
+{
+    out[0] = out[1] = 0;
+    if(g_stats == nullptr)
+        return 0;
+    unsigned h[4];
+    if(hipMemcpy(h, g_stats, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+        return 1;
+    (void)hipMemset(g_stats, 0, sizeof(h));
+    out[0] = h[0];
+    out[1] = h[1];
+    return 0;
+}
 
 int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, const float* depths, const avdm_camera_t* rc,
                                    const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
@@ -334,15 +723,16 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
         return set_error_msg(1, "avdm_volume_compute_similarity: volume base / pitches must be multiples of 4 bytes");
     NccArgs A;
     PatchTable tab;
-    if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, sp->scale, sp->wsh, sp->gammaC, sp->gammaP))
+    if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, sp->scale, sp->stepXY, sp->wsh, sp->gammaC, sp->gammaP))
         return set_error_msg(1, "avdm_volume_compute_similarity: non-integral mip level");
     const unsigned nchunks = ((dr.end + 3) >> 2) - (dr.begin >> 2);
     if(((dr.end + 3) & ~3u) > (unsigned)pitch_x)
         return set_error_msg(1, "avdm_volume_compute_similarity: pitch_x too small for the depth range (must cover the 4-aligned range)");
     dim3 grid(divUp(roi.x.end - roi.x.begin, 16), divUp(roi.y.end - roi.y.begin, 16), nchunks);
+    const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
     const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
 #define LAUNCH(F8, W)                                                                                                                                 \
-    hipLaunchKernelGGL((similarity_kernel<F8, W>), grid, dim3(256), 0, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
+    hipLaunchKernelGGL((similarity_kernel<F8, W>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
                        sp->stepXY, dr.begin, dr.end, roi)
     if(fixed8)
     {
@@ -377,13 +767,14 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
         return set_error_msg(1, "avdm_volume_refine_similarity: pitch_x too small (must cover the 8-aligned depth range)");
     NccArgs A;
     PatchTable tab;
-    if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->wsh, rp->gammaC, rp->gammaP))
+    if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->stepXY, rp->wsh, rp->gammaC, rp->gammaP))
         return set_error_msg(1, "avdm_volume_refine_similarity: non-integral mip level");
     const unsigned nchunks = ((dr.end + 7) >> 3) - (dr.begin >> 3);
     dim3 grid(divUp(roi.x.end - roi.x.begin, 16), divUp(roi.y.end - roi.y.begin, 16), nchunks);
+    const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
     const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
 #define LAUNCH(F8, W)                                                                                                                              \
-    hipLaunchKernelGGL((refine_similarity_kernel<F8, W>), grid, dim3(256), 0, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,         \
+    hipLaunchKernelGGL((refine_similarity_kernel<F8, W>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,       \
                        (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi)
     if(fixed8)
     {

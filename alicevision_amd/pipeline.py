@@ -24,6 +24,12 @@ def ceil_div(a, b):
     return (a + b - 1) // b
 
 
+def optimize_scratch(lib, X, Y, Z, device="cuda"):
+    """scratch of avdm_volume_optimize (the per-axis adaptive-P2 map)"""
+    n = int(lib.avdm_volume_optimize_scratch_bytes(X, Y, Z))
+    return torch.empty(max(n, 4), dtype=torch.uint8, device=device)
+
+
 class StageTimers:
     """HIP-event timing of stage ranges on the current stream (torch events wrap hipEvent on the same stream)."""
 
@@ -156,6 +162,7 @@ class DepthMapTile:
         self.best = torch.empty((Y, X, Zp), dtype=torch.uint8, device=dev)
         self.second = torch.empty((Y, X, Zp), dtype=torch.uint8, device=dev)
         self.depths_d = torch.empty(Z, dtype=torch.float32, device=dev)
+        self.sgm_scratch = optimize_scratch(self.lib, X, Y, Z, dev)
         self.sgm_depth_thickness = torch.empty((Y, X, 2), dtype=torch.float32, device=dev)
         self.sgm_depth_sim = torch.empty((Y, X, 2), dtype=torch.float32, device=dev)
         XR, YR = roiR.width, roiR.height
@@ -197,8 +204,8 @@ class DepthMapTile:
             self.best_raw = self.best.clone()
         if optimize:
             with T.range("sgm_optimize"):
-                abi.check(lib.avdm_volume_optimize(_ptr(self.best), _ptr(self.second), py, pxx, None, C.byref(self.pyr[rc].desc), C.byref(sp), Z,
-                                                   roi, st), "volume_optimize")
+                abi.check(lib.avdm_volume_optimize(_ptr(self.best), _ptr(self.second), py, pxx, _ptr(self.sgm_scratch), C.byref(self.pyr[rc].desc),
+                                                   C.byref(sp), Z, roi, st), "volume_optimize")
         else:
             self.best.copy_(self.second)
         rc1 = self.cam(rc, 1)

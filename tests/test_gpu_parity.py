@@ -124,14 +124,17 @@ def test_sgm_aggregation_bit_exact(case):
     vin = torch.from_numpy(o.second).cuda()
     vout = torch.full_like(vin, 7)
     pyr = make_hip_from_oracle(o, sc, sgm, ref).pyr[0]
-    abi.check(lib.avdm_volume_optimize(_ptr(vout), _ptr(vin), X * Zp, Zp, None, C.byref(pyr.desc), C.byref(sgm), Z, roi, _st()))
+    from alicevision_amd.pipeline import optimize_scratch
+    scratch = optimize_scratch(lib, X, Y, Z)
+    abi.check(lib.avdm_volume_optimize(_ptr(vout), _ptr(vin), X * Zp, Zp, _ptr(scratch), C.byref(pyr.desc), C.byref(sgm), Z, roi, _st()))
     torch.cuda.synchronize()
     got = vout.cpu().numpy()[..., :Z]
     want = o.filtered[..., :Z]
     assert np.array_equal(got, want), level_mismatch(got, want)
 
 
-@pytest.mark.parametrize("Z,axes,p2", [(5, b"YX", 100.0), (67, b"Y", 100.0), (130, b"X", -40.0), (300, b"XY", 100.0)])
+@pytest.mark.parametrize("Z,axes,p2", [(5, b"YX", 100.0), (67, b"Y", 100.0), (130, b"X", -40.0), (256, b"YX", 100.0), (300, b"XY", 100.0), (512, b"YX", 100.0),
+                                       (1027, b"XY", 100.0)])
 def test_sgm_aggregation_shapes(Z, axes, p2):
     """ragged depth counts (tail bytes, several dwords per lane), single axes, fixed P2, non-square ROI with an offset"""
     torch = _torch()
@@ -149,7 +152,9 @@ def test_sgm_aggregation_shapes(Z, axes, p2):
     pyr = make_hip_from_oracle(o, sc, sgm, ref).pyr[0]
     tin = torch.from_numpy(vin).cuda()
     tout = torch.full_like(tin, 9)
-    abi.check(lib.avdm_volume_optimize(_ptr(tout), _ptr(tin), X * Zp, Zp, None, C.byref(pyr.desc), C.byref(sgm), Z, roi, _st()))
+    from alicevision_amd.pipeline import optimize_scratch
+    scratch = optimize_scratch(lib, X, Y, Z)
+    abi.check(lib.avdm_volume_optimize(_ptr(tout), _ptr(tin), X * Zp, Zp, _ptr(scratch), C.byref(pyr.desc), C.byref(sgm), Z, roi, _st()))
     torch.cuda.synchronize()
     got = tout.cpu().numpy()
     assert np.array_equal(got, want), level_mismatch(got, want)  # including the untouched padding planes z >= Z
