@@ -47,7 +47,7 @@ struct NccArgs
     int wsh;
     int rcap, tcap;   // LDS capacities in texels (R tile, T window)
     int forceGeneric; // debugging / A-B switch: never use the LDS path
-    unsigned* stats;  // optional device counters {plane-blocks on the LDS path, plane-blocks on the generic path}
+    unsigned* stats;  // optional device counters per plane-workgroup: {LDS path, R tile unusable, T taps leave the image, T window too large}
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -212,6 +212,149 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
     return sim;
 }
 
+// ---------------------------------------------------------------------------------------------
+// FIXED8 fast path from LDS: the same weighted NCC with the R and T sides carried as the two halves of packed fp32 registers
+// (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work per VALU slot — the plain fp32 VALU issues one wave instruction per
+// 4 cycles per SIMD, so packing is what halves the instruction count), and the horizontal half of each bilinear tap done by
+// v_dot2_f32_f16 directly on the fp16 texel pairs:
+//   * FIXED8 weights are k/256, k = 0..256: exactly representable in fp16, products with fp16 texels are exact in the fp32
+//     accumulator of v_dot2 — the horizontal lerp is evaluated with one rounding instead of three;
+//   * weights are kept as integers (k, 256 - k): every interpolated colour carries a factor 2^16, which is folded into the
+//     centre colours and into the gammaC factor (powers of two commute with fp32 rounding; the NCC itself is scale-free).
+// ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2h pk_half_weights(float w0, float w1) { return __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(w0, w1)); }
+// v_dot2_f32_f16 with the inline constant 0 as addend: the builtin selects the accumulate-in-place VOP2 form (v_dot2c) and pays a
+// v_mov 0 per call; a plain VALU instruction in asm needs no wait-count or hazard handling (cdna_hip_programming.md §5.7)
+__device__ __forceinline__ float dot2_h(unsigned pair, v2h w)
+{
+    float r;
+    asm("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(r) : "v"(pair), "v"(w));
+    return r;
+}
+__device__ __forceinline__ v2f floor2(v2f v) { return v2f{floorf(v.x), floorf(v.y)}; }
+#define AVDM_PERM_LO 0x05040100u // {lo16(src1), lo16(src0)}
+#define AVDM_PERM_HI 0x07060302u // {hi16(src1), hi16(src0)}
+
+struct LdsWindows
+{
+    const uint2* lds; // base of the dynamic LDS array (R tile at 0, T window at rcap)
+    int rPitch, tPitch;
+    float rPitchF, tPitchF;
+    float rOff, tOff; // -(y0 * pitch + x0) (+ rcap for T): integer-valued, |.| < 2^24
+};
+
+// horizontal lerp of the three colour channels of one row: taps t0 (left) and t1 (right), weights {256 - A, A} as fp16 pair
+struct Lab3
+{
+    float L, a, b;
+};
+__device__ __forceinline__ Lab3 hlerp3(uint2 t0, uint2 t1, v2h w)
+{
+    Lab3 r;
+    r.L = dot2_h(__builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_LO), w);
+    r.a = dot2_h(__builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_HI), w);
+    r.b = dot2_h(__builtin_amdgcn_perm(t1.y, t0.y, AVDM_PERM_LO), w);
+    return r;
+}
+
+template <int WSH, bool TInvert>
+__device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const LdsWindows& Wn,
+                                                           float4 rcCenter, float4 tcCenter)
+{
+    const int wsh = WSH > 0 ? WSH : A.wsh;
+    const int n = 2 * wsh + 1;
+    const v2f ax = {Q.rax.x, Q.tax.x}, ay = {Q.rax.y, Q.tax.y}, az = {Q.rax.z, Q.tax.z};
+    const v2f bx = {Q.ray.x, Q.tay.x}, by = {Q.ray.y, Q.tay.y}, bz = {Q.ray.z, Q.tay.z};
+    const v2f h0x = {Q.hr0.x, Q.ht0.x}, h0y = {Q.hr0.y, Q.ht0.y}, h0z = {Q.hr0.z, Q.ht0.z};
+    const v2f Sx = {A.rcSx, A.tcSx}, Ox = {A.rcOx, A.tcOx}, Sy = {A.rcSy, A.tcSy}, Oy = {A.rcOy, A.tcOy};
+    const v2f pitch2 = {Wn.rPitchF, Wn.tPitchF}, off2 = {Wn.rOff, Wn.tOff};
+    const float S16 = 65536.0f;
+    const v2f cL = v2f{rcCenter.x, tcCenter.x} * S16, ca = v2f{rcCenter.y, tcCenter.y} * S16, cb = v2f{rcCenter.z, tcCenter.z} * S16;
+    const float kC = A.negInvGammaC_log2e * (1.0f / 65536.0f);
+
+    v2f sum1 = {0.f, 0.f}; // {xsum, ysum}
+    v2f sum2 = {0.f, 0.f}; // {xxsum, yysum}
+    float xysum = 0.f, wsum = 0.f;
+
+#pragma unroll 1
+    for(int yp = -wsh; yp <= wsh; ++yp)
+    {
+        const float fy = (float)yp;
+        const v2f rowx = fy * bx + h0x, rowy = fy * by + h0y, rowz = fy * bz + h0z; // == row_of()
+        const float* trow = tab.c + (yp + wsh) * n + wsh;
+#pragma unroll kNccUnroll
+        for(int xp = -wsh; xp <= wsh; ++xp)
+        {
+            const float fx = (float)xp;
+            // == sample_pos(): homogeneous coordinates, one v_rcp per image, texel-space transform
+            const v2f hz = fx * az + rowz;
+            const v2f inv = {fast_rcp(hz.x), fast_rcp(hz.y)};
+            v2f X = (fx * ax + rowx) * inv;
+            v2f Y = (fx * ay + rowy) * inv;
+            X = X * Sx + Ox;
+            Y = Y * Sy + Oy;
+            const v2f fX = floor2(X), fY = floor2(Y);
+            // quant8(): weights in units of 1/256
+            const v2f wa = floor2((X - fX) * 256.0f + 0.5f), wb = floor2((Y - fY) * 256.0f + 0.5f);
+            const v2f na = 256.0f - wa, nb = 256.0f - wb;
+            // window-relative texel index, in fp32 (exact integers), then one conversion per image
+            const v2f oidx = fY * pitch2 + (fX + off2);
+            const int oR = (int)oidx.x, oT = (int)oidx.y;
+            int oR1 = oR + 1, oT1 = oT + 1;
+            if(kLdsSplitReads)
+            {
+                asm volatile("" : "+v"(oR1));
+                asm volatile("" : "+v"(oT1));
+            }
+            const uint2 r00 = Wn.lds[oR], r10 = Wn.lds[oR1], r01 = Wn.lds[oR + Wn.rPitch], r11 = Wn.lds[oR1 + Wn.rPitch];
+            const uint2 t00 = Wn.lds[oT], t10 = Wn.lds[oT1], t01 = Wn.lds[oT + Wn.tPitch], t11 = Wn.lds[oT1 + Wn.tPitch];
+
+            const v2h wr = pk_half_weights(na.x, wa.x), wt = pk_half_weights(na.y, wa.y);
+            const Lab3 rt = hlerp3(r00, r10, wr), tt = hlerp3(t00, t10, wt), rb = hlerp3(r01, r11, wr), tb = hlerp3(t01, t11, wt);
+            const v2f L2 = v2f{rt.L, tt.L} * nb + v2f{rb.L, tb.L} * wb; // x 2^16
+            const v2f a2 = v2f{rt.a, tt.a} * nb + v2f{rb.a, tb.a} * wb;
+            const v2f b2 = v2f{rt.b, tt.b} * nb + v2f{rb.b, tb.b} * wb;
+
+            const v2f dL = cL - L2, da = ca - a2, db = cb - b2;
+            const v2f sq = dL * dL + (da * da + db * db);
+            const float dcs = __builtin_amdgcn_sqrtf(sq.x) + __builtin_amdgcn_sqrtf(sq.y);
+            const float w = __builtin_amdgcn_exp2f(fmaf(dcs, kC, -trow[xp]));
+
+            const v2f wg = dL * w;
+            wsum += w;
+            sum1 += wg;
+            sum2 = wg * dL + sum2;
+            xysum = fmaf(wg.x, dL.y, xysum);
+        }
+    }
+
+    const float iw = fast_rcp(wsum);
+    const float varXW = (sum2.x - sum1.x * sum1.x * iw) * iw;
+    const float varYW = (sum2.y - sum1.y * sum1.y * iw) * iw;
+    const float varXYW = (xysum - sum1.x * sum1.y * iw) * iw;
+    const float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
+    const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
+    if(TInvert)
+        return sigmoid(0.0f, 1.0f, 0.7f, -0.7f, sim);
+    return sim;
+}
+
+__device__ __forceinline__ LdsWindows make_windows(const uint2* smem, int rcap, int rPitch, int rx0, int ry0, int tPitch, int tx0, int ty0)
+{
+    LdsWindows W;
+    W.lds = smem;
+    W.rPitch = rPitch;
+    W.tPitch = tPitch;
+    W.rPitchF = (float)rPitch;
+    W.tPitchF = (float)tPitch;
+    W.rOff = -(float)(ry0 * rPitch + rx0);
+    W.tOff = (float)(rcap - (ty0 * tPitch + tx0));
+    return W;
+}
+
 __device__ __forceinline__ void pixel_of_lane(int& tx, int& ty)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -292,9 +435,13 @@ __device__ __forceinline__ void corner_boxes(const PatchProj& Q, const NccArgs& 
             tmaxy = fmaxf(tmaxy, tY);
         }
     }
-    // one texel of slack on each side for the interior taps (they lie in the corners' hull up to rounding)
-    rInside = (floorf(rminx) - 1.0f >= (float)R.x0) && (floorf(rmaxx) + 2.0f <= (float)(R.x0 + R.w - 1)) && (floorf(rminy) - 1.0f >= (float)R.y0) &&
-              (floorf(rmaxy) + 2.0f <= (float)(R.y0 + R.h - 1));
+    // the taps themselves (texels floor(x), floor(x) + 1) must be inside the image and inside the staged tile; one more texel
+    // of slack on each side for the interior taps (they lie in the corners' hull up to rounding), clipped at the image edge
+    const float W1 = (float)(A.rcL.W - 1), H1 = (float)(A.rcL.H - 1);
+    const float x0 = floorf(rminx), x1 = floorf(rmaxx) + 1.0f, y0 = floorf(rminy), y1 = floorf(rmaxy) + 1.0f;
+    rInside = x0 >= 0.0f && y0 >= 0.0f && x1 <= W1 && y1 <= H1 && (fmaxf(x0 - 1.0f, 0.0f) >= (float)R.x0) &&
+              (fminf(x1 + 1.0f, W1) <= (float)(R.x0 + R.w - 1)) && (fmaxf(y0 - 1.0f, 0.0f) >= (float)R.y0) &&
+              (fminf(y1 + 1.0f, H1) <= (float)(R.y0 + R.h - 1));
 }
 
 __device__ __forceinline__ float wave_max_f32(float v)
@@ -343,21 +490,26 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
     const int mnx = sh.box[k][0], mny = sh.box[k][1], mxx = sh.box[k][2], mxy = sh.box[k][3];
     Wd.ok = false;
     Wd.x0 = Wd.y0 = Wd.w = Wd.h = Wd.pitch = 0;
+    int reason = 1; // 0 = LDS path, 1 = R tile unusable / nothing valid, 2 = T taps leave the image, 3 = T window exceeds the LDS budget
     if(rTileOk && !sh.bad[k] && mnx != INT_MAX && mxx != INT_MIN)
     {
-        // taps use texels floor(x) and floor(x) + 1; one more texel of slack on each side (see corner_boxes)
-        Wd.x0 = mnx - 1;
-        Wd.y0 = mny - 1;
-        const int x1 = mxx + 2, y1 = mxy + 2;
+        // the taps (texels floor(x), floor(x) + 1) must be inside the T image; the window adds one texel of slack on each side
+        // (see corner_boxes), clipped at the image edge
+        const bool inImage = mnx >= 0 && mny >= 0 && mxx + 1 <= A.tcL.W - 1 && mxy + 1 <= A.tcL.H - 1;
+        Wd.x0 = max(mnx - 1, 0);
+        Wd.y0 = max(mny - 1, 0);
+        const int x1 = min(mxx + 2, A.tcL.W - 1), y1 = min(mxy + 2, A.tcL.H - 1);
         Wd.w = x1 - Wd.x0 + 1;
         Wd.h = y1 - Wd.y0 + 1;
         Wd.pitch = lds_pitch_for(Wd.w);
-        Wd.ok = Wd.x0 >= 0 && Wd.y0 >= 0 && x1 <= A.tcL.W - 1 && y1 <= A.tcL.H - 1 && Wd.w <= 4096 && Wd.h <= 4096 && Wd.pitch * Wd.h <= A.tcap;
+        const bool fits = Wd.w <= 4096 && Wd.h <= 4096 && Wd.pitch * Wd.h <= A.tcap;
+        Wd.ok = inImage && fits;
+        reason = Wd.ok ? 0 : (inImage ? 3 : 2);
     }
     if(Wd.ok)
         stage_window(sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
     if(A.stats != nullptr && threadIdx.x == 0)
-        atomicAdd(A.stats + (Wd.ok ? 0 : 1), 1u);
+        atomicAdd(A.stats + reason, 1u);
     return Wd;
 }
 
@@ -464,7 +616,10 @@ __global__ void __launch_bounds__(256, 3)
         if(valid)
         {
             float s;
-            if(Wd.ok)
+            if(Wd.ok && FIXED8)
+                s = ncc_accumulate_lds_fixed8<WSH, false>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0), rcCenter,
+                                                          tcCenter);
+            else if(Wd.ok)
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
             else
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
@@ -595,7 +750,10 @@ __global__ void __launch_bounds__(256, 3)
         if(valid)
         {
             float s;
-            if(Wd.ok)
+            if(Wd.ok && FIXED8)
+                s = ncc_accumulate_lds_fixed8<WSH, true>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0), rcCenter,
+                                                         tcCenter);
+            else if(Wd.ok)
                 s = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
             else
                 s = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
@@ -694,18 +852,18 @@ using namespace avdm;
 
 extern "C" {
 
-/* debugging aid (not part of avdm.h): plane-workgroups that ran from LDS / took the generic path since the last call */
-int avdm_debug_similarity_stats(unsigned out[2])
+/* debugging aid (not part of avdm.h): plane-workgroups since the last call {LDS path, generic: R tile, generic: T outside, generic: T too large} */
+int avdm_debug_similarity_stats(unsigned out[4])
 {
-    out[0] = out[1] = 0;
+    out[0] = out[1] = out[2] = out[3] = 0;
     if(g_stats == nullptr)
         return 0;
     unsigned h[4];
     if(hipMemcpy(h, g_stats, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
         return 1;
     (void)hipMemset(g_stats, 0, sizeof(h));
-    out[0] = h[0];
-    out[1] = h[1];
+    for(int i = 0; i < 4; ++i)
+        out[i] = h[i];
     return 0;
 }
 

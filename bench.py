@@ -173,9 +173,10 @@ def main():
         }
         if os.environ.get("AVDM_SIM_STATS") == "1":
             import ctypes
-            st = (ctypes.c_uint * 2)()
+            st = (ctypes.c_uint * 4)()
             abi.load().avdm_debug_similarity_stats(st)
-            line["similarity_plane_workgroups"] = {"lds": int(st[0]), "generic": int(st[1])}
+            line["similarity_plane_workgroups"] = {"lds": int(st[0]), "generic_r_tile": int(st[1]), "generic_t_outside": int(st[2]),
+                                                   "generic_t_too_large": int(st[3])}
         if world == 1 and not args.no_cpu_baseline:
             small = make_scene(3, 512, 384, seed=3, device="cpu")
             line["cpu_baseline"] = cpu_baseline(small, sgm, ref, Z, W * H, T)
