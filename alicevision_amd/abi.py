@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libavdm.so")
+LIB_PATH = os.environ.get("AVDM_LIB", os.path.join(HERE, "csrc", "libavdm.so"))  # AVDM_LIB: A/B builds of the SAME sources while tuning
 
 AVDM_MAX_LEVELS = 8
 FILTER_EXACT = 0

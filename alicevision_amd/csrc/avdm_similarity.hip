@@ -27,7 +27,10 @@
 // taps in flight per lane: each unrolled sample keeps 8 LDS reads (16 VGPRs) live; 3 keeps the kernels at 3 waves / SIMD
 namespace avdm {
 
-constexpr int kNccUnroll = 3;
+#ifndef AVDM_NCC_UNROLL
+#define AVDM_NCC_UNROLL 3
+#endif
+constexpr int kNccUnroll = AVDM_NCC_UNROLL;
 constexpr bool kLdsSplitReads = true;
 
 struct PatchTable
@@ -47,6 +50,7 @@ struct NccArgs
     int wsh;
     int rcap, tcap;   // LDS capacities in texels (R tile, T window)
     int forceGeneric; // debugging / A-B switch: never use the LDS path
+    int noPacked;     // debugging / A-B switch: LDS path with the plain fp32 tap arithmetic
     unsigned* stats;  // optional device counters per plane-workgroup: {LDS path, R tile unusable, T taps leave the image, T window too large}
 };
 
@@ -215,42 +219,47 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
 // ---------------------------------------------------------------------------------------------
 // FIXED8 fast path from LDS: the same weighted NCC with the R and T sides carried as the two halves of packed fp32 registers
 // (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work per VALU slot — the plain fp32 VALU issues one wave instruction per
-// 4 cycles per SIMD, so packing is what halves the instruction count), and the horizontal half of each bilinear tap done by
-// v_dot2_f32_f16 directly on the fp16 texel pairs:
-//   * FIXED8 weights are k/256, k = 0..256: exactly representable in fp16, products with fp16 texels are exact in the fp32
-//     accumulator of v_dot2 — the horizontal lerp is evaluated with one rounding instead of three;
-//   * weights are kept as integers (k, 256 - k): every interpolated colour carries a factor 2^16, which is folded into the
-//     centre colours and into the gammaC factor (powers of two commute with fp32 rounding; the NCC itself is scale-free).
+// 4 cycles per SIMD, so packing is what cuts the instruction count), and the fp16 texels consumed without unpacking:
+//   * FIXED8 weights are k/256, k = 0..256; they are kept as integers (k, 256 - k), exactly representable in fp16, so every
+//     interpolated colour carries a factor 2^16, which is folded into the centre colours and into the gammaC factor (powers of
+//     two commute with fp32 rounding; the NCC itself is scale-free);
+//   * the horizontal half of each tap is one v_perm_b32 + one v_dot2_f32_f16 per channel on the fp16 texel pairs (no unpack);
+//   * window-relative texel indices are formed in fp32 (exact integers) with one packed FMA for both images.
 // ---------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ v2h pk_half_weights(float w0, float w1) { return __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(w0, w1)); }
-// v_dot2_f32_f16 with the inline constant 0 as addend: the builtin selects the accumulate-in-place VOP2 form (v_dot2c) and pays a
-// v_mov 0 per call; a plain VALU instruction in asm needs no wait-count or hazard handling (cdna_hip_programming.md §5.7)
-__device__ __forceinline__ float dot2_h(unsigned pair, v2h w)
-{
-    float r;
-    asm("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(r) : "v"(pair), "v"(w));
-    return r;
-}
 __device__ __forceinline__ v2f floor2(v2f v) { return v2f{floorf(v.x), floorf(v.y)}; }
-#define AVDM_PERM_LO 0x05040100u // {lo16(src1), lo16(src0)}
-#define AVDM_PERM_HI 0x07060302u // {hi16(src1), hi16(src0)}
 
+typedef __attribute__((address_space(3))) const unsigned long long* lds_texel_ptr; // one ds_read_b64
 struct LdsWindows
 {
-    const uint2* lds; // base of the dynamic LDS array (R tile at 0, T window at rcap)
-    int rPitch, tPitch;
-    float rPitchF, tPitchF;
-    float rOff, tOff; // -(y0 * pitch + x0) (+ rcap for T): integer-valued, |.| < 2^24
+    unsigned rPitchB, tPitchB; // row pitches in bytes
+    float rPitchBF, tPitchBF;
+    float rOffB, tOffB;        // LDS byte address of texel (0, 0) of each window: base + 8 * (-(y0 * pitch + x0) [+ rcap]); |.| < 2^24
 };
+__device__ __forceinline__ uint2 lds_texel(unsigned byteAddr)
+{
+    const unsigned long long v = *(lds_texel_ptr)(size_t)byteAddr;
+    uint2 r;
+    r.x = (unsigned)v;
+    r.y = (unsigned)(v >> 32);
+    return r;
+}
 
-// horizontal lerp of the three colour channels of one row: taps t0 (left) and t1 (right), weights {256 - A, A} as fp16 pair
+// Horizontal half of a bilinear tap for the three colour channels of one texel row: v_perm_b32 pairs the two taps' fp16
+// values of a channel, v_dot2_f32_f16 multiplies them with the fp16 weight pair {256 - A, A} (exact: k <= 256) and adds in fp32
+// — products of two fp16 values are exact in fp32, so the row lerp has a single rounding.
+// The builtin is used on purpose: written as inline asm the compiler no longer pads the DOT-result read hazard of gfx950 and
+// the kernel silently returns wrong similarities (measured; see DESIGN.md "dead ends").
 struct Lab3
 {
     float L, a, b;
 };
+#define AVDM_PERM_LO 0x05040100u // {lo16(src1), lo16(src0)}
+#define AVDM_PERM_HI 0x07060302u // {hi16(src1), hi16(src0)}
+__device__ __forceinline__ v2h pk_half_weights(float w0, float w1) { return __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(w0, w1)); }
+__device__ __forceinline__ float dot2_h(unsigned pair, v2h w) { return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, pair), w, 0.0f, false); }
 __device__ __forceinline__ Lab3 hlerp3(uint2 t0, uint2 t1, v2h w)
 {
     Lab3 r;
@@ -270,7 +279,7 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
     const v2f bx = {Q.ray.x, Q.tay.x}, by = {Q.ray.y, Q.tay.y}, bz = {Q.ray.z, Q.tay.z};
     const v2f h0x = {Q.hr0.x, Q.ht0.x}, h0y = {Q.hr0.y, Q.ht0.y}, h0z = {Q.hr0.z, Q.ht0.z};
     const v2f Sx = {A.rcSx, A.tcSx}, Ox = {A.rcOx, A.tcOx}, Sy = {A.rcSy, A.tcSy}, Oy = {A.rcOy, A.tcOy};
-    const v2f pitch2 = {Wn.rPitchF, Wn.tPitchF}, off2 = {Wn.rOff, Wn.tOff};
+    const v2f pitch2 = {Wn.rPitchBF, Wn.tPitchBF}, off2 = {Wn.rOffB, Wn.tOffB};
     const float S16 = 65536.0f;
     const v2f cL = v2f{rcCenter.x, tcCenter.x} * S16, ca = v2f{rcCenter.y, tcCenter.y} * S16, cb = v2f{rcCenter.z, tcCenter.z} * S16;
     const float kC = A.negInvGammaC_log2e * (1.0f / 65536.0f);
@@ -300,17 +309,17 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
             // quant8(): weights in units of 1/256
             const v2f wa = floor2((X - fX) * 256.0f + 0.5f), wb = floor2((Y - fY) * 256.0f + 0.5f);
             const v2f na = 256.0f - wa, nb = 256.0f - wb;
-            // window-relative texel index, in fp32 (exact integers), then one conversion per image
-            const v2f oidx = fY * pitch2 + (fX + off2);
-            const int oR = (int)oidx.x, oT = (int)oidx.y;
-            int oR1 = oR + 1, oT1 = oT + 1;
+            // LDS byte address of the top-left tap, formed in fp32 (exact integers), then one conversion per image
+            const v2f oidx = fY * pitch2 + (fX * 8.0f + off2);
+            const unsigned oR = (unsigned)(int)oidx.x, oT = (unsigned)(int)oidx.y;
+            unsigned oR1 = oR + 8u, oT1 = oT + 8u;
             if(kLdsSplitReads)
-            {
+            { // keep the two horizontally adjacent taps as two ds_read_b64 (a fused ds_read2_b64 runs at half the LDS rate)
                 asm volatile("" : "+v"(oR1));
                 asm volatile("" : "+v"(oT1));
             }
-            const uint2 r00 = Wn.lds[oR], r10 = Wn.lds[oR1], r01 = Wn.lds[oR + Wn.rPitch], r11 = Wn.lds[oR1 + Wn.rPitch];
-            const uint2 t00 = Wn.lds[oT], t10 = Wn.lds[oT1], t01 = Wn.lds[oT + Wn.tPitch], t11 = Wn.lds[oT1 + Wn.tPitch];
+            const uint2 r00 = lds_texel(oR), r10 = lds_texel(oR1), r01 = lds_texel(oR + Wn.rPitchB), r11 = lds_texel(oR1 + Wn.rPitchB);
+            const uint2 t00 = lds_texel(oT), t10 = lds_texel(oT1), t01 = lds_texel(oT + Wn.tPitchB), t11 = lds_texel(oT1 + Wn.tPitchB);
 
             const v2h wr = pk_half_weights(na.x, wa.x), wt = pk_half_weights(na.y, wa.y);
             const Lab3 rt = hlerp3(r00, r10, wr), tt = hlerp3(t00, t10, wt), rb = hlerp3(r01, r11, wr), tb = hlerp3(t01, t11, wt);
@@ -345,13 +354,13 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
 __device__ __forceinline__ LdsWindows make_windows(const uint2* smem, int rcap, int rPitch, int rx0, int ry0, int tPitch, int tx0, int ty0)
 {
     LdsWindows W;
-    W.lds = smem;
-    W.rPitch = rPitch;
-    W.tPitch = tPitch;
-    W.rPitchF = (float)rPitch;
-    W.tPitchF = (float)tPitch;
-    W.rOff = -(float)(ry0 * rPitch + rx0);
-    W.tOff = (float)(rcap - (ty0 * tPitch + tx0));
+    const int base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem; // LDS byte address of the dynamic segment
+    W.rPitchB = (unsigned)rPitch * 8u;
+    W.tPitchB = (unsigned)tPitch * 8u;
+    W.rPitchBF = (float)(rPitch * 8);
+    W.tPitchBF = (float)(tPitch * 8);
+    W.rOffB = (float)(base - 8 * (ry0 * rPitch + rx0));
+    W.tOffB = (float)(base + 8 * (rcap - (ty0 * tPitch + tx0)));
     return W;
 }
 
@@ -616,7 +625,7 @@ __global__ void __launch_bounds__(256, 3)
         if(valid)
         {
             float s;
-            if(Wd.ok && FIXED8)
+            if(Wd.ok && FIXED8 && !A.noPacked)
                 s = ncc_accumulate_lds_fixed8<WSH, false>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0), rcCenter,
                                                           tcCenter);
             else if(Wd.ok)
@@ -750,7 +759,7 @@ __global__ void __launch_bounds__(256, 3)
         if(valid)
         {
             float s;
-            if(Wd.ok && FIXED8)
+            if(Wd.ok && FIXED8 && !A.noPacked)
                 s = ncc_accumulate_lds_fixed8<WSH, true>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0), rcCenter,
                                                          tcCenter);
             else if(Wd.ok)
@@ -830,6 +839,8 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
     const char* e = getenv("AVDM_SIM_LDS");
     if(e && e[0] == '0')
         A.forceGeneric = 1;
+    const char* pk = getenv("AVDM_SIM_PACKED");
+    A.noPacked = (pk && pk[0] == '0') ? 1 : 0;
     A.stats = nullptr;
     const char* st = getenv("AVDM_SIM_STATS");
     if(st && st[0] == '1')
