@@ -75,6 +75,12 @@ class RefineParams(C.Structure):
         return p
 
 
+class SgmTile(C.Structure):
+    """avdm_sgm_tile_t"""
+    _fields_ = [("out_vol", C.c_void_p), ("in_vol", C.c_void_p), ("pitch_y", C.c_longlong), ("pitch_x", C.c_int), ("last_depth_index", C.c_int),
+                ("roi", ROI), ("rc_pyr", C.POINTER(Pyramid))]
+
+
 P = C.POINTER
 vp, i32, i64, f32, u8 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ubyte
 
@@ -100,6 +106,7 @@ SIGNATURES = {
                                             Range, ROI, vp]),
     "avdm_volume_optimize_scratch_bytes": (C.c_size_t, [i32, i32, i32]),
     "avdm_volume_optimize": (i32, [vp, vp, i64, i32, vp, P(Pyramid), P(SgmParams), i32, ROI, vp]),
+    "avdm_volume_optimize_tiles": (i32, [i32, P(SgmTile), vp, P(SgmParams), vp]),
     "avdm_volume_retrieve_best_depth": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, i32, P(Camera), P(SgmParams), Range, ROI, vp]),
     "avdm_volume_refine_best_depth": (i32, [vp, i32, vp, i32, vp, i64, i32, i32, P(RefineParams), ROI, vp]),
     "avdm_depth_sim_map_copy_depth_only": (i32, [vp, i32, vp, i32, i32, i32, f32, vp]),

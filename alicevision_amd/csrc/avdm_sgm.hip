@@ -1,5 +1,5 @@
 // avdm_sgm.hip — SGM path aggregation of the uint8 cost volume + winner-take-all depth retrieval, for gfx950.
-//   avdm_volume_optimize            <-> cuda_volumeOptimize / cuda_volumeAggregatePath (planeSweeping/deviceSimilarityVolume.cu:262-425;
+//   avdm_volume_optimize[_tiles]    <-> cuda_volumeOptimize / cuda_volumeAggregatePath (planeSweeping/deviceSimilarityVolume.cu:262-425;
 //                                       kernels planeSweeping/deviceSimilarityVolumeKernels.cuh:596-744)
 //   avdm_volume_retrieve_best_depth <-> cuda_volumeRetrieveBestDepth (deviceSimilarityVolume.cu:427-467; kernels.cuh:393-512)
 //
@@ -7,22 +7,36 @@
 // and every fp32 operation below is written in the reference's order so that the stage is BIT-EXACT against the oracle.
 //
 // CDNA4 design (the reference issues ~3 tiny kernels per slice, ~10^4 launches per volume, through uint32 slice copies):
-//   * ONE launch per path.  One wave64 (= one workgroup) owns one column (fixed position on the non-scanned image axis) and
-//     walks the scanned axis as a persistent loop; the previous-slice path costs L(z) never leave VGPRs.
+//   * ONE launch per path for ALL tiles of a batch.  One wave64 (= one workgroup) owns one column (fixed position on the
+//     non-scanned image axis of one tile) and walks the scanned axis as a persistent loop; the previous-slice path costs L(z)
+//     never leave VGPRs.  Columns are the only parallelism of this recurrence (~1000 per path for an undivided 12 MP frame, one
+//     wave per SIMD); batching the tiles of a frame (DepthMapEstimator's tile list) is what puts several waves on every SIMD.
 //   * z-fastest volume: a lane owns 4*NW consecutive planes, so a step is one coalesced 256*NW-byte read of the input
 //     volume, (for paths 1..3) one of the output volume, and one coalesced write.  Algorithmic traffic only: 11 B/voxel total.
-//   * min over z  = lane-local min + 6 DPP v_min steps (row_shr / row_bcast) + v_readlane; z±1 neighbours = wave_shr/shl DPP.
+//   * the plain VALU issues one wave instruction per 4 cycles per SIMD, so the step is written for instruction count: path
+//     costs are carried as PACKED uint16 pairs (v_pk_min_u16 / v_pk_add_u16 / v_pk_mad_u16: two planes per instruction).
+//     Everything in the recurrence is an integer except the adaptive P2 (a float in [80, 255]): with frac(P2) < 1 - 2^-13
+//     no fp32 rounding of the reference's expression can carry into the integer part (proof in DESIGN.md), so
+//         trunc(L) = cur + min(min(prev, min(prev[z-1], prev[z+1]) + P1), best + floor(P2)) - best
+//         out      = (out*K + min(trunc(L), 255)) div (K + 1)
+//     exactly; the (rare, wave-uniform) steps whose P2 fraction is closer to 1 run the fp32 restatement instead.
+//   * min over z = in-lane packed min + 6 v_min_u32_dpp on the replicated pair (row_shr / row_bcast) + v_readlane;
+//     z±1 neighbours = v_alignbit on adjacent pairs, wave_shr/shl DPP across lanes.
 //   * the colour-adaptive P2 is evaluated once per (column, slice) by a small map kernel per axis (one map serves the forward
 //     and the reverse path); the path kernel reads 64 consecutive steps of it per lane-coalesced load and picks with v_readlane.
-//   * only ~1000 columns exist per path (one wave per SIMD), so latency is hidden by ILP, not occupancy: a 4-slot register ring
-//     keeps the loads of the next 24-32 slices in flight; the recurrence depends on registers only.
-//   * the running average (out*K + L)/(K+1) -> uint8 is evaluated without an IEEE division: one exact FMA, then the integer
-//     quotient through exact fp32 scalings (equality with the reference's float expression checked over every fp32 input).
+//   * a 4-slot register ring keeps the loads of the next 24-32 slices in flight; the recurrence depends on registers only.
 #include "avdm_device.h"
 
 #include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+#include <vector>
 
 namespace avdm {
+
+#define AVDM_SGM_MAX_TILES 24 // tiles per launch (kernarg budget); larger batches are split
 
 // Fully specified exp of the P2 sigmoid — identical operation sequence to oracle/avdm_oracle.c:avo_exp_p2.
 __device__ __forceinline__ float exp_p2(float x)
@@ -45,15 +59,21 @@ __device__ __forceinline__ float exp_p2(float x)
 }
 
 // ---- adaptive P2 (kernels.cuh:696-720), evaluated once per (column, slice) into a float map ----------------------------
-struct SgmP2Args
+struct SgmP2Tile
 {
     TexLevel L;         // R image at the SGM mip level
     float rcW, rcH;     // nominal level dims (DeviceMipmapImage::getDimensions)
     int beginX, beginY; // ROI offsets as the reference applies them to (v.x, v.y)
-    int scanIsX;        // 1: the scanned axis is volume x (axisT.y == 0), 0: volume y
+    int A, B;
+    float* p2;          // [A][B]
+};
+struct SgmP2Batch
+{
+    int scanIsX; // 1: the scanned axis is volume x (axisT.y == 0), 0: volume y
     float step;
     float P2w;
-    int A, B;
+    int fixed8;
+    SgmP2Tile t[AVDM_SGM_MAX_TILES];
 };
 
 #define SGM_BIG 3.0e38f
@@ -62,46 +82,51 @@ struct SgmP2Args
 // The reverse path at slice b compares pixel b with b + 1 — the same texel pair as the forward path at b + 1, with the
 // two fetches swapped; deltaC is a sum of squared differences, so the value is bit-identical and ONE map serves both
 // directions of an axis (reverse reads entry b + 1).
-template <bool FIXED8>
-__global__ void __launch_bounds__(256) sgm_p2_map_kernel(float* __restrict__ p2, SgmP2Args S)
+__global__ void __launch_bounds__(256) sgm_p2_map_kernel(SgmP2Batch S)
 {
+    const SgmP2Tile& T = S.t[blockIdx.z];
     const int b = blockIdx.x * 16 + (threadIdx.x & 15);
     const int a = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if(a >= S.A || b >= S.B)
+    if(a >= T.A || b >= T.B)
         return;
     float P2;
     if(S.P2w < 0)
         P2 = fabsf(S.P2w);
     else if(b == 0)
-        P2 = 0.f; // never read
+        P2 = 80.0f; // never read
     else
     {
         const int vx = S.scanIsX ? b : a, vy = S.scanIsX ? a : b;
-        const int imX0 = (int)((float)(S.beginX + vx) * S.step);
-        const int imY0 = (int)((float)(S.beginY + vy) * S.step);
+        const int imX0 = (int)((float)(T.beginX + vx) * S.step);
+        const int imY0 = (int)((float)(T.beginY + vy) * S.step);
         const int imX1 = (int)((float)imX0 - S.step * (float)(S.scanIsX ? 1 : 0));
         const int imY1 = (int)((float)imY0 - S.step * (float)(S.scanIsX ? 0 : 1));
-        const float u0 = ((float)imX0 + 0.5f) / S.rcW, v0 = ((float)imY0 + 0.5f) / S.rcH;
-        const float u1 = ((float)imX1 + 0.5f) / S.rcW, v1 = ((float)imY1 + 0.5f) / S.rcH;
-        const float4 c0 = tex2D_level<FIXED8>(S.L, u0, v0);
-        const float4 c1 = tex2D_level<FIXED8>(S.L, u1, v1);
+        const float u0 = ((float)imX0 + 0.5f) / T.rcW, v0 = ((float)imY0 + 0.5f) / T.rcH;
+        const float u1 = ((float)imX1 + 0.5f) / T.rcW, v1 = ((float)imY1 + 0.5f) / T.rcH;
+        const float4 c0 = S.fixed8 ? tex2D_level<true>(T.L, u0, v0) : tex2D_level<false>(T.L, u0, v0);
+        const float4 c1 = S.fixed8 ? tex2D_level<true>(T.L, u1, v1) : tex2D_level<false>(T.L, u1, v1);
         const float dx = c0.x - c1.x, dy = c0.y - c1.y, dz = c0.z - c1.z;
         const float deltaC = sqrtf(dx * dx + dy * dy + dz * dz);
         P2 = 80.f + (255.f - 80.f) * (1.0f / (1.0f + exp_p2(10.0f * ((deltaC - S.P2w) / 80.f))));
     }
-    p2[(long long)a * S.B + b] = P2;
+    T.p2[(long long)a * T.B + b] = P2;
 }
 
-// ---- one aggregation path ------------------------------------------------------------------------------------------
-struct SgmPathArgs
+// ---- one aggregation path over a batch of tiles -----------------------------------------------------------------------
+struct SgmPathTile
 {
     const uint8_t* in;
     uint8_t* out;
     const float* p2;            // [A][B], see sgm_p2_map_kernel
     long long strideA, strideB; // bytes between consecutive columns / consecutive slices
     int A, B, Z;
+    int colEnd;                 // exclusive prefix sum of A over the batch: workgroups [colEnd[t-1], colEnd[t]) belong to tile t
+};
+struct SgmPathBatch
+{
     int rev;
     float P1;
+    SgmPathTile t[AVDM_SGM_MAX_TILES];
 };
 
 __device__ __forceinline__ float ubyte_f32(unsigned w, int j)
@@ -111,7 +136,7 @@ __device__ __forceinline__ float ubyte_f32(unsigned w, int j)
 }
 
 // Path costs are non-negative, finite fp32 values: their bit patterns order like unsigned integers, so every min of the
-// recurrence is an integer min on the bits — no NaN canonicalisation, and the DPP lane permutes fold into v_min_u32_dpp
+// fp32 restatement is an integer min on the bits — no NaN canonicalisation, and the DPP lane permutes fold into v_min_u32_dpp
 // (old = 0xffffffff is the identity of min_u32, which is what lets the compiler fold row_mask-ed broadcasts too).
 __device__ __forceinline__ unsigned fbits(float v) { return __float_as_uint(v); }
 __device__ __forceinline__ float bitsf(unsigned v) { return __uint_as_float(v); }
@@ -126,61 +151,267 @@ __device__ __forceinline__ unsigned wave_min_bits(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// per-lane constants of a column walk
+template <int NW>
+struct SgmLane
+{
+    unsigned offw[NW];  // byte offset of each of my dwords inside a (column, slice) run of planes
+    bool wAny[NW];      // dword holds at least one valid plane
+    unsigned vmask[NW]; // 0xff per valid plane of the dword
+    int lane, z0, Z;
+};
+
+// One step of the fp32 restatement (the reference's expression, operation by operation).  prev = fp32 bit patterns.
+template <int NW, int K, bool FULL>
+__device__ __forceinline__ void sgm_step_f32(unsigned (&prev)[4 * NW], const unsigned (&inw)[NW], const unsigned (&oldw)[NW], float P2, float P1,
+                                             const SgmLane<NW>& Ln, uint8_t* outSlice)
+{
+    constexpr int ZL = 4 * NW;
+    // best cost of the previous slice over all planes (computeBestZInSlice)
+    unsigned m = prev[0];
+#pragma unroll
+    for(int i = 1; i < ZL; ++i)
+        m = min(m, prev[i]);
+    const float best = bitsf(wave_min_bits(m));
+    const unsigned bestP2 = fbits(best + P2);
+
+    // z-1 / z+1 neighbours across lanes (wave_shr:1 / wave_shl:1), folded into the min with the in-lane neighbour
+    const unsigned nbLo = min(dpp_u32<0x138>(0xffffffffu, prev[ZL - 1]), prev[1]); // min(prev[z0-1], prev[z0+1])
+    const unsigned nbHi = min(dpp_u32<0x130>(0xffffffffu, prev[0]), prev[ZL - 2]); // min(prev[z0+ZL], prev[z0+ZL-2])
+
+    unsigned nprev[ZL];
+#pragma unroll
+    for(int w = 0; w < NW; ++w)
+    {
+        unsigned neww = 0;
+#pragma unroll
+        for(int j = 0; j < 4; ++j)
+        {
+            const int i = 4 * w + j;
+            const float cur = ubyte_f32(inw[w], j);
+            const unsigned nb = (i == 0) ? nbLo : ((i == ZL - 1) ? nbHi : min(prev[i - 1], prev[i + 1]));
+            // fminf(fminf(fminf(p, pm1 + P1), pp1 + P1), best + P2): x -> x + P1 is monotone, so the two middle terms are
+            // min(pm1, pp1) + P1; all operands are non-negative floats -> integer min on the bits
+            const unsigned minCost = min(min(prev[i], fbits(bitsf(nb) + P1)), bestP2);
+            float pathCost = (cur + bitsf(minCost)) - best;
+            // planes 0 and Z-1 are forced to 255 (kernels.cuh:692-730)
+            if(FULL)
+            {
+                if(i == 0)
+                    pathCost = (Ln.lane == 0) ? 255.0f : pathCost;
+                if(i == ZL - 1)
+                    pathCost = (Ln.lane == 63) ? 255.0f : pathCost;
+            }
+            else
+                pathCost = ((Ln.z0 + i == 0) || (Ln.z0 + i >= Ln.Z - 1)) ? 255.0f : pathCost;
+            const float tr = truncf(pathCost); // TSimAcc(pathCost): float -> uint32 truncation (pathCost >= 0)
+            nprev[i] = (FULL || ((Ln.vmask[w] >> (8 * j)) & 1u)) ? fbits(tr) : fbits(SGM_BIG);
+            float q; // integer-valued float in [0, 255]: the byte to store
+            if(K == 0)
+                q = __builtin_amdgcn_fmed3f(tr, 0.0f, 255.0f); // trunc(clamp(x)) == clamp(trunc(x))
+            else
+            {
+                const float lc = __builtin_amdgcn_fmed3f(pathCost, 0.0f, 255.0f);
+                const float n = fmaf(ubyte_f32(oldw[w], j), (float)K, lc); // o*K is exact: == fl(fl(o*K) + lc)
+                // (uint8)(n / (K+1)) == floor(floor(n) / (K+1)) for every fp32 n in [0, 1021) (exhaustively checked)
+                if(K == 1)
+                    q = truncf(n * 0.5f);
+                else if(K == 3)
+                    q = truncf(n * 0.25f);
+                else
+                    q = truncf(truncf(n) * 0.33333334f);
+            }
+            neww = __builtin_amdgcn_cvt_pk_u8_f32(q, j, neww);
+        }
+        unsigned* po = reinterpret_cast<unsigned*>(outSlice + Ln.offw[w]);
+        if(FULL)
+            *po = neww;
+        else if(Ln.wAny[w])
+            *po = (neww & Ln.vmask[w]) | (oldw[w] & ~Ln.vmask[w]);
+    }
+#pragma unroll
+    for(int i = 0; i < ZL; ++i)
+        prev[i] = nprev[i];
+}
+
+// ---- packed uint16 helpers (one VGPR = two planes) ----
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_pk(unsigned v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b) { return as_u32(__builtin_elementwise_min(as_pk(a), as_pk(b))); }
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b) { return as_u32(as_pk(a) + as_pk(b)); }
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) { return as_u32(as_pk(a) - as_pk(b)); }
+#define SGM_BIG16 0x3fffu
+#define SGM_BIG16_PAIR 0x3fff3fffu
+
+// One step in packed uint16 arithmetic (see the header comment for the equivalence).  P = plane pairs (lo = even plane).
+template <int NW, int K, bool FULL>
+__device__ __forceinline__ void sgm_step_u16(unsigned (&P)[2 * NW], const unsigned (&inw)[NW], const unsigned (&oldw)[NW], unsigned iP2Pair,
+                                             unsigned P1Pair, const unsigned (&keepM)[2 * NW], const unsigned (&forceV)[2 * NW],
+                                             const SgmLane<NW>& Ln, uint8_t* outSlice)
+{
+    constexpr int NR = 2 * NW;
+    // best cost of the previous slice: in-lane packed min, both halves replicated, then a u32 min over the wave
+    unsigned m = P[0];
+#pragma unroll
+    for(int r = 1; r < NR; ++r)
+        m = pk_min(m, P[r]);
+    m = pk_min(m, __builtin_amdgcn_alignbit(m, m, 16));
+    const unsigned bestPair = wave_min_bits(m); // (best, best)
+    const unsigned FPair = bestPair + iP2Pair;  // (best + floor(P2)) in both halves: no carry between halves (values < 2^15)
+
+    // Lp[r] = (plane 2r-1, plane 2r): adjacent pairs shifted by one plane; the ends come from the neighbour lanes
+    unsigned Lp[NR + 1];
+    Lp[0] = __builtin_amdgcn_alignbit(P[0], dpp_u32<0x138>(SGM_BIG16_PAIR, P[NR - 1]), 16);
+#pragma unroll
+    for(int r = 1; r < NR; ++r)
+        Lp[r] = __builtin_amdgcn_alignbit(P[r], P[r - 1], 16);
+    Lp[NR] = __builtin_amdgcn_alignbit(dpp_u32<0x130>(SGM_BIG16_PAIR, P[0]), P[NR - 1], 16);
+
+    unsigned q[NR];
+#pragma unroll
+    for(int r = 0; r < NR; ++r)
+    {
+        const unsigned nb = pk_min(Lp[r], Lp[r + 1]); // min(prev[z-1], prev[z+1]) for both planes of the pair
+        const unsigned mF = pk_min(pk_min(P[r], pk_add(nb, P1Pair)), FPair);
+        const unsigned cur = __builtin_amdgcn_perm(0u, inw[r >> 1], (r & 1) ? 0x0c030c02u : 0x0c010c00u); // two bytes -> two uint16
+        unsigned L = pk_add(cur, pk_sub(mF, bestPair));
+        L = (L & keepM[r]) | forceV[r]; // planes 0 / Z-1 -> 255, planes past Z -> BIG
+        P[r] = L;
+        const unsigned Lc = pk_min(L, 0x00ff00ffu);
+        if(K == 0)
+            q[r] = Lc;
+        else
+        {
+            const unsigned o = __builtin_amdgcn_perm(0u, oldw[r >> 1], (r & 1) ? 0x0c030c02u : 0x0c010c00u);
+            const unsigned n = as_u32(as_pk(o) * (unsigned short)K + as_pk(Lc)); // v_pk_mad_u16, <= 1020
+            if(K == 1)
+                q[r] = as_u32(as_pk(n) >> (unsigned short)1);
+            else if(K == 3)
+                q[r] = as_u32(as_pk(n) >> (unsigned short)2);
+            else
+            { // n div 3 == (n * 683) >> 11 for n <= 1020 (checked exhaustively); 32-bit products
+                const unsigned lo = ((n & 0xffffu) * 683u) >> 11, hi = ((n >> 16) * 683u) >> 11;
+                q[r] = lo | (hi << 16);
+            }
+        }
+    }
+#pragma unroll
+    for(int w = 0; w < NW; ++w)
+    {
+        const unsigned neww = __builtin_amdgcn_perm(q[2 * w + 1], q[2 * w], 0x06040200u); // low bytes of the four uint16
+        unsigned* po = reinterpret_cast<unsigned*>(outSlice + Ln.offw[w]);
+        if(FULL)
+            *po = neww;
+        else if(Ln.wAny[w])
+            *po = (neww & Ln.vmask[w]) | (oldw[w] & ~Ln.vmask[w]);
+    }
+}
+
 // NW dwords (4 planes each) per lane; K = index of the path (the running average weight); FULL: Z == 256 * NW, i.e. every
 // lane owns 4 * NW valid planes and every access is a whole dword (the production shapes); otherwise ragged tails are
 // handled with byte masks (read-modify-write of the partially valid dword, padding planes z >= Z are left untouched).
-template <int NW, int K, bool FULL>
-__global__ void __launch_bounds__(64) sgm_path_kernel(SgmPathArgs S)
+// INT16: packed uint16 recurrence (integer P1 required) with the fp32 step for the rare P2 fractions close to 1.
+#define AVDM_SGM_WPB 4 // waves (= adjacent columns) per workgroup: their loads of a slice form one contiguous run in memory
+template <int NW, int K, bool FULL, bool INT16>
+__global__ void __launch_bounds__(64 * AVDM_SGM_WPB) sgm_path_kernel(SgmPathBatch S)
 {
     constexpr int ZL = 4 * NW;
+    constexpr int NR = 2 * NW;
     constexpr int PF = NW == 1 ? 8 : (NW == 2 ? 4 : 2); // slices per ring slot
     constexpr int NSETS = 4;                             // ring slots: loads run (NSETS - 1) * PF .. NSETS * PF slices ahead
     constexpr bool LOAD_OUT = (K > 0) || !FULL;
-    const int lane = threadIdx.x;
-    const int a = blockIdx.x;
-    const int Z = S.Z;
-    const int z0 = lane * ZL;
-    const int nSteps = S.B - 1; // ib = 1 .. B-1
 
-    unsigned offw[NW];
-    bool wAny[NW];
-    unsigned vmask[NW];
+    // colEnd counts workgroups (AVDM_SGM_WPB columns each, never straddling two tiles)
+    int ti = 0;
+    while(ti < AVDM_SGM_MAX_TILES - 1 && (int)blockIdx.x >= S.t[ti].colEnd)
+        ++ti;
+    const SgmPathTile& T = S.t[ti];
+    const int a = ((int)blockIdx.x - (ti > 0 ? S.t[ti - 1].colEnd : 0)) * AVDM_SGM_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if(a >= T.A)
+        return; // whole wave
+    const int rev = S.rev;
+    const int B = T.B;
+    const long long strideB = T.strideB;
+
+    SgmLane<NW> Ln;
+    Ln.lane = threadIdx.x & 63;
+    Ln.Z = T.Z;
+    Ln.z0 = Ln.lane * ZL;
+    const int nSteps = B - 1; // ib = 1 .. B-1
+
 #pragma unroll
     for(int w = 0; w < NW; ++w)
     {
-        const int zw = z0 + 4 * w;
-        const int nv = FULL ? 4 : min(max(Z - zw, 0), 4);
-        wAny[w] = nv > 0;
-        vmask[w] = nv >= 4 ? 0xffffffffu : ((1u << (8 * (nv & 3))) - 1u);
-        offw[w] = (unsigned)(wAny[w] ? zw : ((Z - 1) & ~3)); // lanes past the last plane re-read the last valid dword (never stored)
+        const int zw = Ln.z0 + 4 * w;
+        const int nv = FULL ? 4 : min(max(Ln.Z - zw, 0), 4);
+        Ln.wAny[w] = nv > 0;
+        Ln.vmask[w] = nv >= 4 ? 0xffffffffu : ((1u << (8 * (nv & 3))) - 1u);
+        Ln.offw[w] = (unsigned)(Ln.wAny[w] ? zw : ((Ln.Z - 1) & ~3)); // lanes past the last plane re-read the last valid dword (never stored)
     }
 
-    const uint8_t* __restrict__ inCol = S.in + (long long)a * S.strideA;
-    uint8_t* __restrict__ outCol = S.out + (long long)a * S.strideA;
+    const uint8_t* __restrict__ inCol = T.in + (long long)a * T.strideA;
+    uint8_t* __restrict__ outCol = T.out + (long long)a * T.strideA;
 
     // ---- slice 0: prev = in(b = 0) (always slice 0, also for the reverse path), out(b = 0) = 255 ----
-    unsigned prev[ZL]; // bit patterns of non-negative floats
+    unsigned prevF[ZL]; // fp32 bit patterns (fp32 kernel)
+    unsigned P[NR];     // packed uint16 pairs (INT16 kernel)
 #pragma unroll
     for(int w = 0; w < NW; ++w)
     {
-        const unsigned v = *reinterpret_cast<const unsigned*>(inCol + offw[w]);
+        const unsigned v = *reinterpret_cast<const unsigned*>(inCol + Ln.offw[w]);
 #pragma unroll
         for(int j = 0; j < 4; ++j)
-            prev[4 * w + j] = (FULL || ((vmask[w] >> (8 * j)) & 1u)) ? fbits(ubyte_f32(v, j)) : fbits(SGM_BIG);
-        if(FULL)
-            *reinterpret_cast<unsigned*>(outCol + offw[w]) = 0xffffffffu;
-        else if(wAny[w])
+            prevF[4 * w + j] = (FULL || ((Ln.vmask[w] >> (8 * j)) & 1u)) ? fbits(ubyte_f32(v, j)) : fbits(SGM_BIG);
+#pragma unroll
+        for(int h = 0; h < 2; ++h)
         {
-            const unsigned old = *reinterpret_cast<const unsigned*>(outCol + offw[w]);
-            *reinterpret_cast<unsigned*>(outCol + offw[w]) = old | vmask[w];
+            unsigned pr = __builtin_amdgcn_perm(0u, v, h ? 0x0c030c02u : 0x0c010c00u);
+            if(!FULL)
+            {
+                if(!((Ln.vmask[w] >> (16 * h)) & 1u))
+                    pr = (pr & 0xffff0000u) | SGM_BIG16;
+                if(!((Ln.vmask[w] >> (16 * h + 8)) & 1u))
+                    pr = (pr & 0x0000ffffu) | (SGM_BIG16 << 16);
+            }
+            P[2 * w + h] = pr;
+        }
+        if(FULL)
+            *reinterpret_cast<unsigned*>(outCol + Ln.offw[w]) = 0xffffffffu;
+        else if(Ln.wAny[w])
+        {
+            const unsigned old = *reinterpret_cast<const unsigned*>(outCol + Ln.offw[w]);
+            *reinterpret_cast<unsigned*>(outCol + Ln.offw[w]) = old | Ln.vmask[w];
         }
     }
     if(nSteps <= 0)
         return;
 
+    // packed kernel: per pair, what survives of the computed L (keep) and what is forced (255 on planes 0 / Z-1, BIG past Z)
+    unsigned keepM[NR], forceV[NR];
+#pragma unroll
+    for(int r = 0; r < NR; ++r)
+    {
+        unsigned keep = 0, force = 0;
+#pragma unroll
+        for(int h = 0; h < 2; ++h)
+        {
+            const int z = Ln.z0 + 2 * r + h;
+            const bool valid = FULL || z < Ln.Z;
+            const bool border = (z == 0) || (z >= Ln.Z - 1);
+            const unsigned k16 = (valid && !border) ? 0xffffu : 0u;
+            const unsigned f16 = !valid ? SGM_BIG16 : (border ? 255u : 0u);
+            keep |= k16 << (16 * h);
+            force |= f16 << (16 * h);
+        }
+        keepM[r] = keep;
+        forceV[r] = force;
+    }
+    const unsigned P1Pair = (unsigned)(int)S.P1 * 0x00010001u;
+
     // uniform slice pointers, advanced by one slice per step (scalar 64-bit adds; the lane part is a 32-bit offset)
-    const long long dirStride = S.rev ? -S.strideB : S.strideB;
-    const long long firstOff = (long long)(S.rev ? S.B - 2 : 1) * S.strideB; // slice of ib = 1
+    const long long dirStride = rev ? -strideB : strideB;
+    const long long firstOff = (long long)(rev ? B - 2 : 1) * strideB; // slice of ib = 1
     const uint8_t* inLoad = inCol + firstOff;
     const uint8_t* outLoad = outCol + firstOff;
     uint8_t* outStore = outCol + firstOff;
@@ -195,9 +426,9 @@ __global__ void __launch_bounds__(64) sgm_path_kernel(SgmPathArgs S)
 #pragma unroll
             for(int w = 0; w < NW; ++w)
             {
-                ri[t][w] = *reinterpret_cast<const unsigned*>(inLoad + offw[w]);
+                ri[t][w] = *reinterpret_cast<const unsigned*>(inLoad + Ln.offw[w]);
                 if(LOAD_OUT)
-                    ro[t][w] = *reinterpret_cast<const unsigned*>(outLoad + offw[w]);
+                    ro[t][w] = *reinterpret_cast<const unsigned*>(outLoad + Ln.offw[w]);
             }
             if(ibLoad < nSteps) // past the end: keep re-reading the last slice (harmless)
             {
@@ -209,95 +440,65 @@ __global__ void __launch_bounds__(64) sgm_path_kernel(SgmPathArgs S)
     };
 
     auto load_p2 = [&](int blk) -> float {
-        const int ib = min(blk * 64 + 1 + lane, nSteps);
-        return S.p2[(long long)a * S.B + (S.rev ? S.B - ib : ib)];
+        const int ib = min(blk * 64 + 1 + Ln.lane, nSteps);
+        return T.p2[(long long)a * B + (rev ? B - ib : ib)];
     };
 
-    auto step = [&](int ib, const unsigned (&inw)[NW], const unsigned (&oldw)[NW], float p2vec) {
-        const float P2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2vec), (ib - 1) & 63));
-
-        // best cost of the previous slice over all planes (computeBestZInSlice)
-        unsigned m = prev[0];
-#pragma unroll
-        for(int i = 1; i < ZL; ++i)
-            m = min(m, prev[i]);
-        const float best = bitsf(wave_min_bits(m));
-        const unsigned bestP2 = fbits(best + P2);
-
-        // z-1 / z+1 neighbours across lanes (wave_shr:1 / wave_shl:1), folded into the min with the in-lane neighbour
-        const unsigned nbLo = min(dpp_u32<0x138>(0xffffffffu, prev[ZL - 1]), prev[1]);      // min(prev[z0-1], prev[z0+1])
-        const unsigned nbHi = min(dpp_u32<0x130>(0xffffffffu, prev[0]), prev[ZL - 2]);      // min(prev[z0+ZL], prev[z0+ZL-2])
-
-        unsigned nprev[ZL];
-#pragma unroll
-        for(int w = 0; w < NW; ++w)
+    // per 64-step block: P2 of my step, its integer part replicated in both halves, and which steps need the fp32 step
+    float p2vec = 0.f;
+    unsigned ip2vec = 0;
+    unsigned long long riskyMask = 0;
+    auto set_p2_block = [&](float v) {
+        p2vec = v;
+        if(INT16)
         {
-            unsigned neww = 0;
+            const float fl = floorf(v);
+            ip2vec = (unsigned)(int)fl * 0x00010001u;
+            // frac(P2) >= 1 - 2^-13 (or a value outside the uint16 budget): fp32 roundings of the reference's expression may carry
+            riskyMask = __ballot(!((v - fl) < (1.0f - 1.0f / 8192.0f)) || !(v >= 0.0f) || !(v < 8192.0f));
+        }
+    };
+
+    // one slice; FAST = packed uint16 step (only when no step of the current 32-step span needs fp32), else the fp32 step
+    auto step = [&](auto fastTag, int ib, const unsigned (&inw)[NW], const unsigned (&oldw)[NW]) {
+        constexpr bool FAST = decltype(fastTag)::value;
+        const int idx = (ib - 1) & 63;
+        if(FAST)
+        {
+            const unsigned iP2Pair = (unsigned)__builtin_amdgcn_readlane((int)ip2vec, idx);
+            sgm_step_u16<NW, K, FULL>(P, inw, oldw, iP2Pair, P1Pair, keepM, forceV, Ln, outStore);
+        }
+        else
+        {
+            const float P2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2vec), idx));
+            if(INT16)
+            { // state converted both ways (values are integers <= 510 or BIG)
 #pragma unroll
-            for(int j = 0; j < 4; ++j)
-            {
-                const int i = 4 * w + j;
-                const float cur = ubyte_f32(inw[w], j);
-                const unsigned nb = (i == 0) ? nbLo : ((i == ZL - 1) ? nbHi : min(prev[i - 1], prev[i + 1]));
-                // fminf(fminf(fminf(p, pm1 + P1), pp1 + P1), best + P2): x -> x + P1 is monotone, so the two middle terms are
-                // min(pm1, pp1) + P1; all operands are non-negative floats -> integer min on the bits
-                const unsigned minCost = min(min(prev[i], fbits(bitsf(nb) + S.P1)), bestP2);
-                float pathCost = (cur + bitsf(minCost)) - best;
-                // planes 0 and Z-1 are forced to 255 (kernels.cuh:692-730)
-                if(FULL)
+                for(int r = 0; r < NR; ++r)
                 {
-                    if(i == 0)
-                        pathCost = (lane == 0) ? 255.0f : pathCost;
-                    if(i == ZL - 1)
-                        pathCost = (lane == 63) ? 255.0f : pathCost;
+                    const unsigned lo = P[r] & 0xffffu, hi = P[r] >> 16;
+                    prevF[2 * r] = lo >= SGM_BIG16 ? fbits(SGM_BIG) : fbits((float)lo);
+                    prevF[2 * r + 1] = hi >= SGM_BIG16 ? fbits(SGM_BIG) : fbits((float)hi);
                 }
-                else
-                    pathCost = ((z0 + i == 0) || (z0 + i >= Z - 1)) ? 255.0f : pathCost;
-                const float tr = truncf(pathCost); // TSimAcc(pathCost): float -> uint32 truncation (pathCost >= 0)
-                nprev[i] = (FULL || ((vmask[w] >> (8 * j)) & 1u)) ? fbits(tr) : fbits(SGM_BIG);
-                float q; // integer-valued float in [0, 255]: the byte to store
-                if(K == 0)
-                    q = __builtin_amdgcn_fmed3f(tr, 0.0f, 255.0f); // trunc(clamp(x)) == clamp(trunc(x))
-                else
-                {
-                    const float lc = __builtin_amdgcn_fmed3f(pathCost, 0.0f, 255.0f);
-                    const float n = fmaf(ubyte_f32(oldw[w], j), (float)K, lc); // o*K is exact: == fl(fl(o*K) + lc)
-                    // (uint8)(n / (K+1)) == floor(floor(n) / (K+1)) for every fp32 n in [0, 1021) (exhaustively checked)
-                    if(K == 1)
-                        q = truncf(n * 0.5f);
-                    else if(K == 3)
-                        q = truncf(n * 0.25f);
-                    else
-                        q = truncf(truncf(n) * 0.33333334f);
-                }
-                neww = __builtin_amdgcn_cvt_pk_u8_f32(q, j, neww);
             }
-            unsigned* po = reinterpret_cast<unsigned*>(outStore + offw[w]);
-            if(FULL)
-                *po = neww;
-            else if(wAny[w])
-                *po = (neww & vmask[w]) | (oldw[w] & ~vmask[w]);
+            sgm_step_f32<NW, K, FULL>(prevF, inw, oldw, P2, S.P1, Ln, outStore);
+            if(INT16)
+            {
+#pragma unroll
+                for(int r = 0; r < NR; ++r)
+                {
+                    const float lo = bitsf(prevF[2 * r]), hi = bitsf(prevF[2 * r + 1]);
+                    const unsigned ulo = lo > 60000.0f ? SGM_BIG16 : (unsigned)lo, uhi = hi > 60000.0f ? SGM_BIG16 : (unsigned)hi;
+                    P[r] = ulo | (uhi << 16);
+                }
+            }
         }
         outStore += dirStride;
-#pragma unroll
-        for(int i = 0; i < ZL; ++i)
-            prev[i] = nprev[i];
     };
 
-#pragma unroll
-    for(int s = 0; s < NSETS; ++s)
-        load_group(rin[s], rout[s]);
-    float p2vec = load_p2(0);
-    float p2next = load_p2(1);
-
     const int nGroups = (nSteps + PF - 1) / PF;
-    for(int G = 0; G < nGroups; G += NSETS)
-    {
-        if(G > 0 && ((G * PF) & 63) == 0)
-        {
-            p2vec = p2next;
-            p2next = load_p2((G * PF) / 64 + 1);
-        }
+    // NSETS * PF consecutive slices, statically unrolled so that every ring register is addressed by name
+    auto span = [&](auto fastTag, int G) {
 #pragma unroll
         for(int s = 0; s < NSETS; ++s)
         {
@@ -308,17 +509,38 @@ __global__ void __launch_bounds__(64) sgm_path_kernel(SgmPathArgs S)
             {
 #pragma unroll
                 for(int t = 0; t < PF; ++t)
-                    step(g * PF + 1 + t, rin[s][t], rout[s][t], p2vec);
+                    step(fastTag, g * PF + 1 + t, rin[s][t], rout[s][t]);
             }
             else
             {
 #pragma unroll
                 for(int t = 0; t < PF; ++t)
                     if(g * PF + 1 + t <= nSteps)
-                        step(g * PF + 1 + t, rin[s][t], rout[s][t], p2vec);
+                        step(fastTag, g * PF + 1 + t, rin[s][t], rout[s][t]);
             }
             load_group(rin[s], rout[s]);
         }
+    };
+
+#pragma unroll
+    for(int s = 0; s < NSETS; ++s)
+        load_group(rin[s], rout[s]);
+    set_p2_block(load_p2(0));
+    float p2next = load_p2(1);
+
+    for(int G = 0; G < nGroups; G += NSETS)
+    {
+        if(G > 0 && ((G * PF) & 63) == 0)
+        {
+            set_p2_block(p2next);
+            p2next = load_p2((G * PF) / 64 + 1);
+        }
+        // which of the NSETS * PF (<= 32) steps of this span need the fp32 step (wave-uniform; almost never any)
+        const unsigned riskyBits = (unsigned)(riskyMask >> ((G * PF) & 63)) & (NSETS * PF >= 32 ? 0xffffffffu : ((1u << (NSETS * PF)) - 1u));
+        if(INT16 && riskyBits == 0u)
+            span(std::true_type{}, G);
+        else
+            span(std::false_type{}, G);
     }
 }
 
@@ -403,14 +625,18 @@ __global__ void __launch_bounds__(256)
 }
 
 template <int NW>
-static void launch_path(const SgmPathArgs& S, int K, bool full, hipStream_t st)
+static void launch_path(const SgmPathBatch& S, int ncols, int K, bool full, bool int16, hipStream_t st)
 {
-    dim3 grid(S.A);
+    dim3 grid(ncols);
+#define AVDM_SGM_LAUNCH2(KK, FF, II) hipLaunchKernelGGL((sgm_path_kernel<NW, KK, FF, II>), grid, dim3(64 * AVDM_SGM_WPB), 0, st, S)
+    // the fp32 kernel (non-integer P1) is only instantiated in its general form: FULL shapes run it with FULL = false
 #define AVDM_SGM_LAUNCH(KK)                                                                                                                           \
-    if(full)                                                                                                                                          \
-        hipLaunchKernelGGL((sgm_path_kernel<NW, KK, true>), grid, dim3(64), 0, st, S);                                                                \
+    if(full && int16)                                                                                                                                 \
+        AVDM_SGM_LAUNCH2(KK, true, true);                                                                                                             \
+    else if(int16)                                                                                                                                    \
+        AVDM_SGM_LAUNCH2(KK, false, true);                                                                                                            \
     else                                                                                                                                              \
-        hipLaunchKernelGGL((sgm_path_kernel<NW, KK, false>), grid, dim3(64), 0, st, S)
+        AVDM_SGM_LAUNCH2(KK, false, false)
     switch(K)
     {
         case 0: AVDM_SGM_LAUNCH(0); break;
@@ -419,6 +645,96 @@ static void launch_path(const SgmPathArgs& S, int K, bool full, hipStream_t st)
         default: AVDM_SGM_LAUNCH(3); break;
     }
 #undef AVDM_SGM_LAUNCH
+#undef AVDM_SGM_LAUNCH2
+}
+
+static size_t p2_map_bytes(int dimX, int dimY) { return ((size_t)dimX * (size_t)dimY * sizeof(float) + 255) & ~(size_t)255; }
+
+// all tiles of one launch group share (NW, FULL); `idx` lists their positions in `tiles`
+static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, const size_t* p2off, void* scratch, const avdm_sgm_params_t* sp,
+                          hipStream_t st)
+{
+    const avdm_sgm_tile_t& t0 = tiles[idx[0]];
+    const int NW = (t0.last_depth_index + 255) / 256;
+    const bool full = (t0.last_depth_index == 256 * NW);
+    const float P1 = (float)sp->p1;
+    bool int16 = P1 >= 0.0f && P1 <= 8192.0f && P1 == floorf(P1);
+    const char* e = getenv("AVDM_SGM_INT16");
+    if(e && e[0] == '0')
+        int16 = false;
+
+    SgmP2Batch Q;
+    SgmPathBatch S;
+    Q.step = (float)sp->stepXY;
+    Q.P2w = (float)sp->p2Weighting;
+    S.P1 = P1;
+    int npaths = 0;
+    for(const char* ax = sp->filteringAxes; *ax; ++ax)
+    {
+        if(*ax != 'X' && *ax != 'Y')
+            continue;
+        if(npaths > 2)
+            return set_error_msg(1, "avdm_volume_optimize: at most 2 filtering axes");
+        const bool scanX = (*ax == 'X');
+        Q.scanIsX = scanX ? 1 : 0;
+        int cols = 0, maxA = 0, maxB = 0;
+        for(int i = 0; i < n; ++i)
+        {
+            const avdm_sgm_tile_t& t = tiles[idx[i]];
+            const int dimX = (int)(t.roi.x.end - t.roi.x.begin), dimY = (int)(t.roi.y.end - t.roi.y.begin);
+            int level;
+            if(!lod_is_integral(t.rc_pyr, sp->scale, &level))
+                return set_error_msg(1, "avdm_volume_optimize: non-integral mip level");
+            const Tex tex = make_tex(t.rc_pyr);
+            SgmPathTile& P = S.t[i];
+            P.in = t.in_vol;
+            P.out = t.out_vol;
+            P.p2 = (const float*)((char*)scratch + p2off[idx[i]]);
+            P.Z = t.last_depth_index;
+            P.A = scanX ? dimY : dimX;
+            P.B = scanX ? dimX : dimY;
+            P.strideA = scanX ? t.pitch_y : (long long)t.pitch_x;
+            P.strideB = scanX ? (long long)t.pitch_x : t.pitch_y;
+            cols += (P.A + AVDM_SGM_WPB - 1) / AVDM_SGM_WPB; // workgroups
+            P.colEnd = cols;
+            SgmP2Tile& R = Q.t[i];
+            R.L = tex.lv[level];
+            R.rcW = (float)tex_dim_w(t.rc_pyr, sp->scale);
+            R.rcH = (float)tex_dim_h(t.rc_pyr, sp->scale);
+            // deviceSimilarityVolumeKernels.cuh:688-689: beginX = (axisT.x == 0) ? roi.x.begin : roi.y.begin, applied to v.x (sic)
+            const bool swap = sp->strictRoiQuirk && scanX;
+            R.beginX = swap ? (int)t.roi.y.begin : (int)t.roi.x.begin;
+            R.beginY = swap ? (int)t.roi.x.begin : (int)t.roi.y.begin;
+            R.A = P.A;
+            R.B = P.B;
+            R.p2 = (float*)((char*)scratch + p2off[idx[i]]);
+            Q.fixed8 = t.rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
+            maxA = P.A > maxA ? P.A : maxA;
+            maxB = P.B > maxB ? P.B : maxB;
+        }
+        for(int i = n; i < AVDM_SGM_MAX_TILES; ++i)
+        {
+            S.t[i] = S.t[n - 1];
+            S.t[i].colEnd = 0x7fffffff;
+            Q.t[i] = Q.t[n - 1];
+        }
+        S.t[n - 1].colEnd = (n == AVDM_SGM_MAX_TILES) ? cols : S.t[n - 1].colEnd;
+        hipLaunchKernelGGL(sgm_p2_map_kernel, dim3(divUp(maxB, 16), divUp(maxA, 16), n), dim3(256), 0, st, Q);
+        for(int rev = 0; rev < 2; ++rev)
+        {
+            S.rev = rev;
+            const int K = npaths++;
+            switch(NW)
+            {
+                case 1: launch_path<1>(S, cols, K, full, int16, st); break;
+                case 2: launch_path<2>(S, cols, K, full, int16, st); break;
+                case 3: launch_path<3>(S, cols, K, full, int16, st); break;
+                case 4: launch_path<4>(S, cols, K, full, int16, st); break;
+                default: launch_path<6>(S, cols, K, full && NW == 6, int16, st); break; // 1025..1536 planes (5 dwords/lane runs as 6)
+            }
+        }
+    }
+    return 0;
 }
 
 } // namespace avdm
@@ -434,86 +750,75 @@ size_t avdm_volume_optimize_scratch_bytes(int dimX, int dimY, int dimZ)
         return 0;
     // one fp32 adaptive-P2 map per axis pass (the path costs of the previous slice live in registers: no uint32 slice
     // buffers like Sgm.hpp:144-148 of the reference)
-    return ((size_t)dimX * (size_t)dimY * sizeof(float) + 255) & ~(size_t)255;
+    return p2_map_bytes(dimX, dimY);
+}
+
+int avdm_volume_optimize_tiles(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* sp, void* stream)
+{
+    if(n_tiles <= 0)
+        return 0;
+    if(scratch == nullptr || ((uintptr_t)scratch & 3))
+        return set_error_msg(1, "avdm_volume_optimize: scratch (sum of avdm_volume_optimize_scratch_bytes() over the tiles, 4-byte aligned) is required");
+    std::vector<size_t> p2off(n_tiles);
+    std::vector<int> order;
+    size_t off = 0;
+    for(int i = 0; i < n_tiles; ++i)
+    {
+        const avdm_sgm_tile_t& t = tiles[i];
+        const int dimX = (int)(t.roi.x.end - t.roi.x.begin), dimY = (int)(t.roi.y.end - t.roi.y.begin), Z = t.last_depth_index;
+        p2off[i] = off;
+        if(dimX <= 0 || dimY <= 0 || Z <= 0)
+            continue; // nothing to do for this tile (cuda_volumeOptimize on an empty ROI)
+        off += p2_map_bytes(dimX, dimY);
+        if((t.pitch_x & 3) || (t.pitch_y & 3) || ((uintptr_t)t.out_vol & 3) || ((uintptr_t)t.in_vol & 3))
+            return set_error_msg(1, "avdm_volume_optimize: volume base / pitches must be multiples of 4 bytes");
+        if(((Z + 3) & ~3) > t.pitch_x)
+            return set_error_msg(1, "avdm_volume_optimize: pitch_x must cover the 4-aligned depth count");
+        if(Z > 1536)
+            return set_error_msg(1, "avdm_volume_optimize: more than 1536 depth planes are not supported");
+        order.push_back(i);
+    }
+    // group by (NW, FULL): one kernel instantiation per launch
+    std::vector<char> done(n_tiles, 0);
+    for(size_t s = 0; s < order.size(); ++s)
+    {
+        if(done[order[s]])
+            continue;
+        const int Zs = tiles[order[s]].last_depth_index, NWs = (Zs + 255) / 256;
+        const bool fulls = Zs == 256 * NWs;
+        std::vector<int> grp;
+        for(size_t j = s; j < order.size(); ++j)
+        {
+            const int Zj = tiles[order[j]].last_depth_index, NWj = (Zj + 255) / 256;
+            if(!done[order[j]] && NWj == NWs && (Zj == 256 * NWj) == fulls)
+            {
+                grp.push_back(order[j]);
+                done[order[j]] = 1;
+            }
+        }
+        for(size_t g0 = 0; g0 < grp.size(); g0 += AVDM_SGM_MAX_TILES)
+        {
+            const int n = (int)std::min<size_t>(AVDM_SGM_MAX_TILES, grp.size() - g0);
+            const int rc = optimize_group(tiles, grp.data() + g0, n, p2off.data(), scratch, sp, (hipStream_t)stream);
+            if(rc)
+                return rc;
+        }
+    }
+    AVDM_LAUNCH_CHECK("avdm_volume_optimize");
 }
 
 int avdm_volume_optimize(uint8_t* out_vol, const uint8_t* in_vol, long long pitch_y, int pitch_x, void* scratch, const avdm_pyramid_t* rc_pyr,
                          const avdm_sgm_params_t* sp, int last_depth_index, avdm_roi_t roi, void* stream)
 {
-    const int dimX = (int)(roi.x.end - roi.x.begin), dimY = (int)(roi.y.end - roi.y.begin), Z = last_depth_index;
-    if(dimX <= 0 || dimY <= 0 || Z <= 0)
-        return 0;
-    if((pitch_x & 3) || (pitch_y & 3) || ((uintptr_t)out_vol & 3) || ((uintptr_t)in_vol & 3))
-        return set_error_msg(1, "avdm_volume_optimize: volume base / pitches must be multiples of 4 bytes");
-    if(((Z + 3) & ~3) > pitch_x)
-        return set_error_msg(1, "avdm_volume_optimize: pitch_x must cover the 4-aligned depth count");
-    if(Z > 1536)
-        return set_error_msg(1, "avdm_volume_optimize: more than 1536 depth planes are not supported");
-    if(scratch == nullptr || ((uintptr_t)scratch & 3))
-        return set_error_msg(1, "avdm_volume_optimize: scratch of avdm_volume_optimize_scratch_bytes() bytes (4-byte aligned) is required");
-    int level;
-    if(!lod_is_integral(rc_pyr, sp->scale, &level))
-        return set_error_msg(1, "avdm_volume_optimize: non-integral mip level");
-    const Tex t = make_tex(rc_pyr);
-    hipStream_t st = (hipStream_t)stream;
-
-    SgmP2Args Q;
-    Q.L = t.lv[level];
-    Q.rcW = (float)tex_dim_w(rc_pyr, sp->scale);
-    Q.rcH = (float)tex_dim_h(rc_pyr, sp->scale);
-    Q.step = (float)sp->stepXY;
-    Q.P2w = (float)sp->p2Weighting;
-    const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
-
-    SgmPathArgs S;
-    S.in = in_vol;
-    S.out = out_vol;
-    S.p2 = (const float*)scratch;
-    S.Z = Z;
-    S.P1 = (float)sp->p1;
-
-    const int NW = (Z + 255) / 256;
-    const bool full = (Z == 256 * NW);
-    int npaths = 0;
-    for(const char* ax = sp->filteringAxes; *ax; ++ax)
-    {
-        if(*ax != 'X' && *ax != 'Y')
-            continue;
-        if(npaths > 2)
-            return set_error_msg(1, "avdm_volume_optimize: at most 2 filtering axes");
-        const bool scanX = (*ax == 'X');
-        S.A = scanX ? dimY : dimX;
-        S.B = scanX ? dimX : dimY;
-        S.strideA = scanX ? pitch_y : (long long)pitch_x;
-        S.strideB = scanX ? (long long)pitch_x : pitch_y;
-        // deviceSimilarityVolumeKernels.cuh:688-689: beginX = (axisT.x == 0) ? roi.x.begin : roi.y.begin, applied to v.x (sic)
-        const bool swap = sp->strictRoiQuirk && scanX;
-        Q.scanIsX = scanX ? 1 : 0;
-        Q.beginX = swap ? (int)roi.y.begin : (int)roi.x.begin;
-        Q.beginY = swap ? (int)roi.x.begin : (int)roi.y.begin;
-        Q.A = S.A;
-        Q.B = S.B;
-        const dim3 pgrid(divUp(S.B, 16), divUp(S.A, 16));
-        if(fixed8)
-            hipLaunchKernelGGL(sgm_p2_map_kernel<true>, pgrid, dim3(256), 0, st, (float*)scratch, Q);
-        else
-            hipLaunchKernelGGL(sgm_p2_map_kernel<false>, pgrid, dim3(256), 0, st, (float*)scratch, Q);
-        for(int rev = 0; rev < 2; ++rev)
-        {
-            S.rev = rev;
-            const int K = npaths++;
-            switch(NW)
-            {
-                case 1: launch_path<1>(S, K, full, st); break;
-                case 2: launch_path<2>(S, K, full, st); break;
-                case 3: launch_path<3>(S, K, full, st); break;
-                case 4: launch_path<4>(S, K, full, st); break;
-                case 5: launch_path<5>(S, K, full, st); break;
-                default: launch_path<6>(S, K, full, st); break;
-            }
-        }
-    }
-    AVDM_LAUNCH_CHECK("avdm_volume_optimize");
+    avdm_sgm_tile_t t;
+    t.out_vol = out_vol;
+    t.in_vol = in_vol;
+    t.pitch_y = pitch_y;
+    t.pitch_x = pitch_x;
+    t.last_depth_index = last_depth_index;
+    t.roi = roi;
+    t.rc_pyr = rc_pyr;
+    return avdm_volume_optimize_tiles(1, &t, scratch, sp, stream);
 }
 
 int avdm_volume_retrieve_best_depth(float* out_depth_thickness, int dt_pitch, float* out_depth_sim, int ds_pitch, const float* depths,

@@ -158,10 +158,24 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
                                   const avdm_camera_t* rc, const avdm_camera_t* tc,
                                   const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
                                   const avdm_refine_params_t* params, avdm_range_t depth_range, avdm_roi_t roi, void* stream);
-/* cuda_volumeOptimize :120-129.  `scratch` must hold avdm_volume_optimize_scratch_bytes() bytes (may be NULL if that is 0). */
+/* cuda_volumeOptimize :120-129.  `scratch` must hold avdm_volume_optimize_scratch_bytes() bytes (device memory, 4-byte aligned). */
 size_t avdm_volume_optimize_scratch_bytes(int dimX, int dimY, int dimZ);
 int avdm_volume_optimize(uint8_t* out_vol, const uint8_t* in_vol, long long pitch_y, int pitch_x, void* scratch,
                          const avdm_pyramid_t* rc_pyr, const avdm_sgm_params_t* params, int last_depth_index, avdm_roi_t roi, void* stream);
+/* cuda_volumeOptimize :120-129 for ALL tiles of a batch in one launch per path (the reference runs one tile per CUDA stream,
+ * DepthMapEstimator.cpp:375-444; the path recurrence only parallelises over columns, so tiles are batched instead).
+ * `scratch` must hold the SUM of avdm_volume_optimize_scratch_bytes() over the tiles.  Tiles may belong to different R cameras. */
+typedef struct avdm_sgm_tile
+{
+    uint8_t* out_vol;
+    const uint8_t* in_vol;
+    long long pitch_y;
+    int pitch_x;
+    int last_depth_index;
+    avdm_roi_t roi;
+    const avdm_pyramid_t* rc_pyr;
+} avdm_sgm_tile_t;
+int avdm_volume_optimize_tiles(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* params, void* stream);
 /* cuda_volumeRetrieveBestDepth :143-151 (out_depth_sim may be NULL); vol_dimZ = allocated depth of the volume (kernels.cuh:459) */
 int avdm_volume_retrieve_best_depth(float* out_depth_thickness, int dt_pitch, float* out_depth_sim, int ds_pitch,
                                     const float* depths, const uint8_t* vol, long long pitch_y, int pitch_x, int vol_dimZ,

@@ -133,14 +133,19 @@ def test_sgm_aggregation_bit_exact(case):
     assert np.array_equal(got, want), level_mismatch(got, want)
 
 
-@pytest.mark.parametrize("Z,axes,p2", [(5, b"YX", 100.0), (67, b"Y", 100.0), (130, b"X", -40.0), (256, b"YX", 100.0), (300, b"XY", 100.0), (512, b"YX", 100.0),
-                                       (1027, b"XY", 100.0)])
-def test_sgm_aggregation_shapes(Z, axes, p2):
-    """ragged depth counts (tail bytes, several dwords per lane), single axes, fixed P2, non-square ROI with an offset"""
+@pytest.mark.parametrize("Z,axes,p2,p1", [(5, b"YX", 100.0, 10.0), (67, b"Y", 100.0, 10.0), (130, b"X", -40.0, 10.0), (256, b"YX", 100.0, 10.0),
+                                          (300, b"XY", 100.0, 10.0), (512, b"YX", 100.0, 10.0), (1027, b"XY", 100.0, 10.0),
+                                          (64, b"YX", -99.99995, 10.0),   # frac(P2) ~ 1: every step takes the fp32 step of the packed kernel
+                                          (256, b"XY", -120.9999, 3.0),   # idem on the full-dword kernel
+                                          (41, b"YX", 100.0, 10.5),       # non-integer P1: fp32 kernel
+                                          (256, b"YX", 100.0, 0.25)])
+def test_sgm_aggregation_shapes(Z, axes, p2, p1):
+    """ragged depth counts (tail bytes, several dwords per lane), single axes, fixed P2, non-square ROI with an offset; the packed
+    uint16 kernel, its fp32 fallback step and the pure fp32 kernel must all be bit-exact"""
     torch = _torch()
     from oracle import oracle
     rng = np.random.RandomState(Z)
-    sc, sgm, ref, _ = small_case(width=128, height=96, filteringAxes=axes, p2Weighting=p2)
+    sc, sgm, ref, _ = small_case(width=128, height=96, filteringAxes=axes, p2Weighting=p2, p1=p1)
     o = make_oracle(sc, sgm, ref)
     lib, olib = abi.load(), oracle.load()
     X, Y = 23, 17
@@ -158,6 +163,39 @@ def test_sgm_aggregation_shapes(Z, axes, p2):
     torch.cuda.synchronize()
     got = tout.cpu().numpy()
     assert np.array_equal(got, want), level_mismatch(got, want)  # including the untouched padding planes z >= Z
+
+
+def test_sgm_aggregation_tiles_batch():
+    """several tiles (different sizes, ROI offsets and depth counts, two R images) in ONE batched call == one call per tile"""
+    torch = _torch()
+    from alicevision_amd.pipeline import optimize_scratch
+    rng = np.random.RandomState(11)
+    sc, sgm, ref, _ = small_case(width=160, height=128)
+    o = make_oracle(sc, sgm, ref)
+    pyrs = make_hip_from_oracle(o, sc, sgm, ref).pyr
+    lib = abi.load()
+    specs = [(23, 17, 64, 3, 5, 0), (31, 9, 64, 0, 0, 1), (8, 40, 256, 7, 2, 0), (16, 16, 256, 1, 1, 1), (12, 5, 37, 2, 9, 0)]
+    vin, single, tiles = [], [], (abi.SgmTile * len(specs))()
+    batch_out, keep = [], []
+    total = 0
+    for i, (X, Y, Z, x0, y0, cam) in enumerate(specs):
+        Zp = (Z + 3) // 4 * 4
+        v = torch.from_numpy(rng.randint(0, 256, size=(Y, X, Zp)).astype(np.uint8)).cuda()
+        roi = abi.ROI.make(x0, x0 + X, y0, y0 + Y)
+        out1 = torch.full_like(v, 9)
+        sc1 = optimize_scratch(lib, X, Y, Z)
+        abi.check(lib.avdm_volume_optimize(_ptr(out1), _ptr(v), X * Zp, Zp, _ptr(sc1), C.byref(pyrs[cam].desc), C.byref(sgm), Z, roi, _st()))
+        single.append(out1)
+        out2 = torch.full_like(v, 9)
+        batch_out.append(out2)
+        vin.append(v)
+        tiles[i] = abi.SgmTile(out2.data_ptr(), v.data_ptr(), X * Zp, Zp, Z, roi, C.pointer(pyrs[cam].desc))
+        total += int(lib.avdm_volume_optimize_scratch_bytes(X, Y, Z))
+    scratch = torch.empty(total, dtype=torch.uint8, device="cuda")
+    abi.check(lib.avdm_volume_optimize_tiles(len(specs), tiles, _ptr(scratch), C.byref(sgm), _st()))
+    torch.cuda.synchronize()
+    for a, b in zip(single, batch_out):
+        assert torch.equal(a, b)
 
 
 def test_retrieve_best_depth_bit_exact(case):
