@@ -1,0 +1,486 @@
+// DepthMapEstimator.cpp — see DepthMapEstimator.hpp.
+//
+// Scheduling differences from the reference, results unchanged:
+//   * the tiles of a batch are processed in groups of `nbStreams` tiles, each tile on its own stream with its own Sgm / Refine
+//     buffers; inside a group the work is phased — (0) depth lists of all tiles on the host cores in parallel (the reference
+//     computes them one by one between asynchronous launches, SgmDepthList.cpp), (A) similarity volumes per stream,
+//     (B) ONE batched path-aggregation launch per path over all tiles of the group (the recurrence only parallelises over
+//     columns), (C) best depth, Refine and the device-to-host copy per stream;
+//   * no 100-slot constant-memory limit on camera parameters (they are kernel arguments).
+#include "DepthMapEstimator.hpp"
+
+#include "Refine.hpp"
+#include "Sgm.hpp"
+#include "SgmDepthList.hpp"
+#include "depthMapUtils.hpp"
+#include "device.hpp"
+#include "log.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <exception>
+#include <memory>
+
+namespace avdm_host {
+
+// mvsUtils/TileParams.cpp:15-61
+void getTileRoiList(const TileParams& tileParams, int imageWidth, int imageHeight, int maxDownscale, std::vector<ROI>& out_tileRoiList)
+{
+    if(hasOnlyOneTile(tileParams, imageWidth, imageHeight))
+    {
+        out_tileRoiList.emplace_back(0, imageWidth, 0, imageHeight);
+        return;
+    }
+    const int maxEffectiveTileWidth = tileParams.bufferWidth - 2 * tileParams.padding;
+    const int maxEffectiveTileHeight = tileParams.bufferHeight - 2 * tileParams.padding;
+    const int nbTileSideX = divideRoundUp(imageWidth, maxEffectiveTileWidth);
+    const int nbTileSideY = divideRoundUp(imageHeight, maxEffectiveTileHeight);
+    out_tileRoiList.resize((size_t)nbTileSideX * nbTileSideY);
+    const int downscaledImageWidth = divideRoundUp(imageWidth, maxDownscale);
+    const int downscaledImageHeight = divideRoundUp(imageHeight, maxDownscale);
+    const int effectiveTileWidth = divideRoundUp(downscaledImageWidth, nbTileSideX) * maxDownscale;
+    const int effectiveTileHeight = divideRoundUp(downscaledImageHeight, nbTileSideY) * maxDownscale;
+    for(int i = 0; i < nbTileSideX; ++i)
+    {
+        const int beginX = i * effectiveTileWidth;
+        const int endX = std::min((i + 1) * effectiveTileWidth + tileParams.padding, imageWidth);
+        for(int j = 0; j < nbTileSideY; ++j)
+        {
+            const int beginY = j * effectiveTileHeight;
+            const int endY = std::min((j + 1) * effectiveTileHeight + tileParams.padding, imageHeight);
+            out_tileRoiList.at((size_t)i * nbTileSideY + j) = ROI(beginX, endX, beginY, endY);
+        }
+    }
+}
+
+namespace {
+
+// TileParams.cpp:63-118
+void logTileRoiList(const TileParams& tileParams, int imageWidth, int imageHeight, int maxDownscale, const std::vector<ROI>& in_tileRoiList)
+{
+    std::ostringstream ostr;
+    ostr << "Tiling information: " << std::endl
+         << "\t- parameters: " << std::endl
+         << "\t      - buffer width:  " << tileParams.bufferWidth << " px" << std::endl
+         << "\t      - buffer height: " << tileParams.bufferHeight << " px" << std::endl
+         << "\t      - padding: " << tileParams.padding << " px" << std::endl
+         << "\t- maximum downscale:  " << maxDownscale << std::endl
+         << "\t- maximum image width:  " << imageWidth << " px" << std::endl
+         << "\t- maximum image height: " << imageHeight << " px" << std::endl;
+    if(hasOnlyOneTile(tileParams, imageWidth, imageHeight))
+    {
+        AVDM_LOG_INFO(ostr.str());
+        AVDM_LOG_INFO("Maximum image size is smaller than one tile, use only one tile.");
+        return;
+    }
+    ostr << "\t- tile list: " << std::endl;
+    for(size_t i = 0; i < in_tileRoiList.size(); ++i)
+    {
+        const ROI& roi = in_tileRoiList.at(i);
+        ostr << "\t   - tile (" << (i + 1) << "/" << in_tileRoiList.size() << ") "
+             << "size: " << roi.width() << "x" << roi.height() << " px, roi: [" << roi << "]" << std::endl;
+    }
+    AVDM_LOG_INFO(ostr.str());
+}
+
+int filterModeFromEnv()
+{
+    const char* e = std::getenv("AVDM_FILTER");
+    if(e && std::string(e) == "exact")
+        return AVDM_FILTER_EXACT;
+    return AVDM_FILTER_CUDA_FIXED8; // the arithmetic of the CUDA texture unit the reference samples through
+}
+
+int maxStreamsFromEnv()
+{
+    const char* e = std::getenv("AVDM_MAX_STREAMS");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : 24; // = AVDM_SGM_MAX_TILES: one batched aggregation launch covers a whole group
+}
+
+} // namespace
+
+DepthMapEstimator::DepthMapEstimator(const MultiViewParams& mp, const TileParams& tileParams, const DepthMapParams& depthMapParams, const SgmParams& sgmParams,
+                                     const RefineParams& refineParams)
+  : _mp(mp),
+    _tileParams(tileParams),
+    _depthMapParams(depthMapParams),
+    _sgmParams(sgmParams),
+    _refineParams(refineParams)
+{
+    const int maxDownscale = std::max(_sgmParams.scale * _sgmParams.stepXY, _refineParams.scale * _refineParams.stepXY);
+    getTileRoiList(_tileParams, _mp.getMaxImageWidth(), _mp.getMaxImageHeight(), maxDownscale, _tileRoiList);
+    logTileRoiList(_tileParams, _mp.getMaxImageWidth(), _mp.getMaxImageHeight(), maxDownscale, _tileRoiList);
+    AVDM_LOG_INFO("SGM parameters:" << std::endl << "\t- scale: " << _sgmParams.scale << std::endl << "\t- stepXY: " << _sgmParams.stepXY);
+    AVDM_LOG_INFO("Refine parameters:" << std::endl << "\t- scale: " << _refineParams.scale << std::endl << "\t- stepXY: " << _refineParams.stepXY);
+}
+
+int DepthMapEstimator::getNbSimultaneousTiles() const
+{
+    const int nbTilesPerCamera = (int)_tileRoiList.size();
+    // mipmap image cost: not more than (1.5 * max_width) * max_height texels of 8 B (fp16 RGBA)
+    const double mipmapCostMB = ((_mp.getMaxImageWidth() * 1.5) * _mp.getMaxImageHeight() * 8.0) / (1024.0 * 1024.0);
+    const double rcCamsCostMB = mipmapCostMB + _depthMapParams.maxTCams * mipmapCostMB;
+
+    // sizes only, no allocation (the reference constructs throw-away Sgm / Refine objects, :81-99)
+    const double sgmTileCostMB = Sgm::deviceMemoryConsumption(_tileParams, _sgmParams, !_depthMapParams.useRefine, _refineParams.useSgmNormalMap);
+    const double refineTileCostMB = _depthMapParams.useRefine ? Refine::deviceMemoryConsumption(_tileParams, _refineParams) : 0.0;
+    const double tileCostMB = sgmTileCostMB + refineTileCostMB;
+    const double rcMinCostMB = rcCamsCostMB + tileCostMB;
+    const double rcMaxCostMB = rcCamsCostMB + nbTilesPerCamera * tileCostMB;
+
+    double deviceMemoryMB;
+    {
+        double availableMB, usedMB, totalMB;
+        getDeviceMemoryInfo(availableMB, usedMB, totalMB);
+        deviceMemoryMB = availableMB * 0.8;
+    }
+    const int nbSimultaneousFullRc = static_cast<int>(deviceMemoryMB / rcMaxCostMB);
+    int nbRemainingTiles = 0;
+    {
+        const double remainingMemoryMB = deviceMemoryMB - (nbSimultaneousFullRc * rcMaxCostMB);
+        nbRemainingTiles = static_cast<int>(std::max(0.0, remainingMemoryMB - rcCamsCostMB) / tileCostMB);
+    }
+    const int out_nbSimultaneousTiles = nbSimultaneousFullRc * nbTilesPerCamera + nbRemainingTiles;
+
+    AVDM_LOG_INFO("Device memory:" << std::endl
+                                   << "\t- available: " << deviceMemoryMB << " MB" << std::endl
+                                   << "\t- requirement for the first tile: " << rcMinCostMB << " MB" << std::endl
+                                   << "\t- # computation buffers per tile: " << tileCostMB << " MB"
+                                   << " (Sgm: " << sgmTileCostMB << " MB"
+                                   << ", Refine: " << refineTileCostMB << " MB)" << std::endl
+                                   << "\t- # input images (R + " << _depthMapParams.maxTCams << " Ts): " << rcCamsCostMB
+                                   << " MB (single mipmap image size: " << mipmapCostMB << " MB)");
+    AVDM_LOG_INFO("Parallelization:" << std::endl
+                                     << "\t- # tiles per image: " << nbTilesPerCamera << std::endl
+                                     << "\t- # simultaneous depth maps computation: "
+                                     << ((nbRemainingTiles < 1) ? nbSimultaneousFullRc : (nbSimultaneousFullRc + 1)) << std::endl
+                                     << "\t- # simultaneous tiles computation: " << out_nbSimultaneousTiles);
+    if(out_nbSimultaneousTiles < 1)
+        AVDM_THROW_ERROR("Not enough GPU memory to compute a single tile.");
+    return out_nbSimultaneousTiles;
+}
+
+void DepthMapEstimator::getTilesList(const std::vector<int>& cams, std::vector<Tile>& tiles) const
+{
+    const int nbTilesPerCamera = (int)_tileRoiList.size();
+    tiles.reserve(cams.size() * nbTilesPerCamera);
+    for(const int rc : cams)
+    {
+        const std::vector<int> tCams = _mp.findNearestCamsFromLandmarks(rc, _depthMapParams.maxTCams);
+        const ROI rcImageRoi(Range(0, _mp.getWidth(rc)), Range(0, _mp.getHeight(rc)));
+        for(int i = 0; i < nbTilesPerCamera; ++i)
+        {
+            Tile t;
+            t.id = i;
+            t.nbTiles = nbTilesPerCamera;
+            t.rc = rc;
+            t.roi = intersect(_tileRoiList.at(i), rcImageRoi);
+            if(t.roi.isEmpty())
+            {
+                // this ROI cannot intersect the R camera ROI
+            }
+            else if(_depthMapParams.chooseTCamsPerTile)
+            {
+                t.sgmTCams = _mp.findTileNearestCams(rc, _sgmParams.maxTCamsPerTile, tCams, t.roi);
+                if(_depthMapParams.useRefine)
+                    t.refineTCams = _mp.findTileNearestCams(rc, _refineParams.maxTCamsPerTile, tCams, t.roi);
+            }
+            else
+            {
+                t.sgmTCams = tCams;
+                t.refineTCams = tCams;
+            }
+            tiles.push_back(t);
+        }
+    }
+}
+
+void DepthMapEstimator::plan(const std::vector<int>& cams, std::vector<TilePlan>& out) const
+{
+    std::vector<Tile> tiles;
+    getTilesList(cams, tiles);
+    out.resize(tiles.size());
+    std::exception_ptr error;
+#pragma omp parallel for schedule(dynamic)
+    for(int i = 0; i < (int)tiles.size(); ++i)
+    {
+        try
+        {
+            TilePlan& p = out[i];
+            p.tile = tiles[i];
+            if(p.tile.roi.isEmpty() || p.tile.sgmTCams.empty() || (_depthMapParams.useRefine && p.tile.refineTCams.empty()))
+                continue;
+            SgmDepthList dl(_mp, _sgmParams, p.tile);
+            dl.computeListRc();
+            if(dl.getDepths().empty())
+                continue;
+            dl.removeTcWithNoDepth(p.tile);
+            p.depths = dl.getDepths();
+            p.depthsTcLimits = dl.getDepthsTcLimits();
+        }
+        catch(...)
+        {
+#pragma omp critical
+            error = std::current_exception();
+        }
+    }
+    if(error)
+        std::rethrow_exception(error);
+}
+
+void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
+{
+    AVDM_HIP_CHECK(hipSetDevice(deviceId));
+
+    ImagesCache ic(_mp);
+
+    std::vector<Tile> tiles;
+    getTilesList(cams, tiles);
+
+    const int nbStreams = std::min({getNbSimultaneousTiles(), static_cast<int>(tiles.size()), maxStreamsFromEnv()});
+    DeviceStreamManager deviceStreamManager(nbStreams);
+
+    const int nbTilesPerCamera = static_cast<int>(_tileRoiList.size());
+    const int nbRcPerBatch = divideRoundUp(nbStreams, nbTilesPerCamera);
+    const int nbTilesPerBatch = nbRcPerBatch * nbTilesPerCamera;
+    const int nbMipmapImagesPerBatch = nbRcPerBatch * (1 + _depthMapParams.maxTCams);
+    const int nbCamerasParamsPerBatch = nbMipmapImagesPerBatch * 3;
+
+    DeviceCache deviceCache(nbMipmapImagesPerBatch, nbCamerasParamsPerBatch, filterModeFromEnv());
+
+    if(_sgmParams.useCustomPatchPattern || _refineParams.useCustomPatchPattern)
+        AVDM_THROW_ERROR("custom patch patterns are not built (SURVEY.md §8f.4).");
+
+    std::vector<std::unique_ptr<Sgm>> sgmPerStream;
+    std::vector<std::unique_ptr<Refine>> refinePerStream;
+    {
+        const bool sgmComputeDepthSimMap = !_depthMapParams.useRefine;
+        const bool sgmComputeNormalMap = _refineParams.useSgmNormalMap;
+        for(int i = 0; i < nbStreams; ++i)
+            sgmPerStream.push_back(std::make_unique<Sgm>(_mp, _tileParams, _sgmParams, sgmComputeDepthSimMap, sgmComputeNormalMap, deviceCache,
+                                                         deviceStreamManager.getStream(i)));
+        if(_depthMapParams.useRefine)
+            for(int i = 0; i < nbStreams; ++i)
+                refinePerStream.push_back(std::make_unique<Refine>(_mp, _tileParams, _refineParams, deviceCache, deviceStreamManager.getStream(i)));
+    }
+    // scratch of the batched aggregation: the sum over a group is bounded by nbStreams maximum-size tiles
+    DeviceBuffer groupScratch;
+    if(_sgmParams.doSgmOptimizeVolume)
+        groupScratch.allocate((size_t)nbStreams * avdm_volume_optimize_scratch_bytes(sgmPerStream.front()->getMapWidth(), sgmPerStream.front()->getMapHeight(),
+                                                                                     std::max(_sgmParams.maxDepths, 1)));
+    // one event per stream (group fan-in) + one for the aggregation (fan-out)
+    std::vector<hipEvent_t> volumeDone(nbStreams);
+    for(auto& e : volumeDone)
+        AVDM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t aggregationDone;
+    AVDM_HIP_CHECK(hipEventCreateWithFlags(&aggregationDone, hipEventDisableTiming));
+
+    // final depth/similarity map tiles in host memory, per camera of a batch
+    const int finalMapW = _depthMapParams.useRefine ? refinePerStream.front()->getMapWidth() : sgmPerStream.front()->getMapWidth();
+    const int finalMapH = _depthMapParams.useRefine ? refinePerStream.front()->getMapHeight() : sgmPerStream.front()->getMapHeight();
+    std::vector<std::vector<Float2Tile>> depthSimMapTilePerCam(nbRcPerBatch);
+    std::vector<std::vector<std::pair<float, float>>> depthMinMaxTilePerCam(nbRcPerBatch);
+    for(int i = 0; i < nbRcPerBatch; ++i)
+    {
+        depthSimMapTilePerCam[i].resize(nbTilesPerCamera);
+        depthMinMaxTilePerCam[i].resize(nbTilesPerCamera);
+        for(int j = 0; j < nbTilesPerCamera; ++j)
+            depthSimMapTilePerCam[i][j].allocate(finalMapW, finalMapH);
+    }
+    logDeviceMemoryInfo();
+
+    const int nbBatches = divideRoundUp(static_cast<int>(tiles.size()), nbTilesPerBatch);
+    const int minMipmapDownscale = std::min(_refineParams.scale, _sgmParams.scale);
+    const int maxMipmapDownscale = std::max(_refineParams.scale, _sgmParams.scale) * (int)std::pow(2, 6); // 6 more levels
+    const int finalScaleStep = _depthMapParams.useRefine ? _refineParams.scale * _refineParams.stepXY : _sgmParams.scale * _sgmParams.stepXY;
+
+    // camera index inside a batch: the reference uses rc % nbRcPerBatch (:390), which only separates the cameras of a batch
+    // when they are consecutive; the position in the batch's camera list is used instead
+    for(int b = 0; b < nbBatches; ++b)
+    {
+        const int firstTileIndex = b * nbTilesPerBatch;
+        const int lastTileIndex = std::min((b + 1) * nbTilesPerBatch, static_cast<int>(tiles.size()));
+        auto batchCamIndexOf = [&](int tileIndex) { return (tileIndex - firstTileIndex) / nbTilesPerCamera; };
+
+        // load the R and T cameras of the batch in the device cache
+        for(int i = firstTileIndex; i < lastTileIndex; ++i)
+        {
+            const Tile& tile = tiles.at(i);
+            hipStream_t s0 = deviceStreamManager.getStream(0);
+            deviceCache.addMipmapImage(tile.rc, minMipmapDownscale, maxMipmapDownscale, ic, _mp, s0);
+            deviceCache.addCameraParams(tile.rc, _sgmParams.scale, _mp);
+            for(const int tc : tile.sgmTCams)
+            {
+                deviceCache.addMipmapImage(tc, minMipmapDownscale, maxMipmapDownscale, ic, _mp, s0);
+                deviceCache.addCameraParams(tc, _sgmParams.scale, _mp);
+            }
+            if(_depthMapParams.useRefine)
+            {
+                deviceCache.addCameraParams(tile.rc, _refineParams.scale, _mp);
+                for(const int tc : tile.refineTCams)
+                {
+                    deviceCache.addMipmapImage(tc, minMipmapDownscale, maxMipmapDownscale, ic, _mp, s0);
+                    deviceCache.addCameraParams(tc, _refineParams.scale, _mp);
+                }
+            }
+            deviceCache.addCameraParams(tile.rc, 1, _mp); // retrieveBestDepth always asks for downscale 1 (Sgm.cpp:316)
+        }
+        AVDM_HIP_CHECK(hipDeviceSynchronize());
+
+        // groups of nbStreams tiles
+        for(int g0 = firstTileIndex; g0 < lastTileIndex; g0 += nbStreams)
+        {
+            const int g1 = std::min(g0 + nbStreams, lastTileIndex);
+            const int n = g1 - g0;
+            std::vector<std::unique_ptr<SgmDepthList>> depthLists(n);
+            std::vector<char> active(n, 0);
+
+            // (0) depth lists on the host cores
+            std::exception_ptr error;
+#pragma omp parallel for schedule(dynamic)
+            for(int k = 0; k < n; ++k)
+            {
+                try
+                {
+                    Tile& tile = tiles.at(g0 + k);
+                    if(tile.roi.isEmpty())
+                        continue;
+                    Float2Tile& hostTile = depthSimMapTilePerCam.at(batchCamIndexOf(g0 + k)).at(tile.id);
+                    if(tile.sgmTCams.empty() || (_depthMapParams.useRefine && tile.refineTCams.empty()))
+                    {
+                        resetDepthSimMap(hostTile);
+                        continue;
+                    }
+                    depthLists[k] = std::make_unique<SgmDepthList>(_mp, _sgmParams, tile);
+                    depthLists[k]->computeListRc();
+                    if(depthLists[k]->getDepths().empty())
+                    {
+                        resetDepthSimMap(hostTile);
+                        depthMinMaxTilePerCam.at(batchCamIndexOf(g0 + k)).at(tile.id) = {0.f, 0.f};
+                        continue;
+                    }
+                    depthLists[k]->removeTcWithNoDepth(tile);
+                    depthMinMaxTilePerCam.at(batchCamIndexOf(g0 + k)).at(tile.id) = depthLists[k]->getMinMaxDepths();
+                    active[k] = 1;
+                }
+                catch(...)
+                {
+#pragma omp critical
+                    error = std::current_exception();
+                }
+            }
+            if(error)
+                std::rethrow_exception(error);
+
+            // (A) similarity volumes, one stream per tile
+            std::vector<avdm_sgm_tile_t> aggTiles;
+            for(int k = 0; k < n; ++k)
+            {
+                if(!active[k])
+                    continue;
+                const Tile& tile = tiles.at(g0 + k);
+                depthLists[k]->logRcTcDepthInformation();
+                depthLists[k]->checkStartingAndStoppingDepth();
+                Sgm& sgm = *sgmPerStream.at(k);
+                sgm.computeVolumes(tile, *depthLists[k]);
+                if(_sgmParams.doSgmOptimizeVolume)
+                {
+                    aggTiles.push_back(sgm.sgmTileDescriptor(tile, *depthLists[k]));
+                    AVDM_HIP_CHECK(hipEventRecord(volumeDone[k], sgm.getStream()));
+                }
+                else
+                    sgm.optimizeDisabledCopy();
+            }
+
+            // (B) one batched aggregation for the group, on stream 0 after every tile's volumes
+            if(!aggTiles.empty())
+            {
+                hipStream_t aggStream = deviceStreamManager.getStream(0);
+                for(int k = 0; k < n; ++k)
+                    if(active[k])
+                        AVDM_HIP_CHECK(hipStreamWaitEvent(aggStream, volumeDone[k], 0));
+                AVDM_LOG_INFO("SGM Optimizing volume of " << aggTiles.size() << " tile(s) in one batch (filtering axes: " << _sgmParams.filteringAxes << ").");
+                const avdm_sgm_params_t sp = _sgmParams.toAvdm();
+                avdmCheck(avdm_volume_optimize_tiles((int)aggTiles.size(), aggTiles.data(), groupScratch.ptr(), &sp, aggStream), "avdm_volume_optimize_tiles");
+                AVDM_HIP_CHECK(hipEventRecord(aggregationDone, aggStream));
+            }
+
+            // (C) best depth, Refine, copy back
+            for(int k = 0; k < n; ++k)
+            {
+                if(!active[k])
+                    continue;
+                Tile& tile = tiles.at(g0 + k);
+                Sgm& sgm = *sgmPerStream.at(k);
+                hipStream_t stream = sgm.getStream();
+                if(!aggTiles.empty())
+                    AVDM_HIP_CHECK(hipStreamWaitEvent(stream, aggregationDone, 0));
+                sgm.finish(tile, *depthLists[k]);
+                Float2Tile& hostTile = depthSimMapTilePerCam.at(batchCamIndexOf(g0 + k)).at(tile.id);
+                const ROI r = downscaleROI(tile.roi, (float)finalScaleStep);
+                const float* src;
+                int srcPitch;
+                if(_depthMapParams.useRefine)
+                {
+                    sgm.smoothThicknessMap(tile, _refineParams);
+                    Refine& refine = *refinePerStream.at(k);
+                    refine.refineRc(tile, sgm);
+                    src = refine.getDeviceDepthSimMap();
+                    srcPitch = refine.getMapPitch();
+                }
+                else
+                {
+                    src = sgm.getDeviceDepthSimMap();
+                    srcPitch = sgm.getDepthThicknessMapPitch();
+                }
+                AVDM_HIP_CHECK(hipMemcpy2DAsync(hostTile.data.data(), (size_t)hostTile.width * 8, src, (size_t)srcPitch, (size_t)r.width() * 8, (size_t)r.height(),
+                                                hipMemcpyDeviceToHost, stream));
+            }
+            // the Sgm / Refine buffers of a slot are reused by the next group
+            AVDM_HIP_CHECK(hipDeviceSynchronize());
+        }
+
+        // write the finished cameras of the batch
+        for(int ci = 0; ci * nbTilesPerCamera + firstTileIndex < lastTileIndex; ++ci)
+        {
+            const int c = tiles.at(firstTileIndex + ci * nbTilesPerCamera).rc;
+            if(_depthMapParams.useRefine)
+                writeDepthSimMapFromTileList(c, _mp, _tileParams, _tileRoiList, depthSimMapTilePerCam.at(ci), _refineParams.scale, _refineParams.stepXY);
+            else
+                writeDepthSimMapFromTileList(c, _mp, _tileParams, _tileRoiList, depthSimMapTilePerCam.at(ci), _sgmParams.scale, _sgmParams.stepXY);
+            if(_depthMapParams.exportTilePattern)
+                exportDepthSimMapTilePatternObj(c, _mp, _tileRoiList, depthMinMaxTilePerCam.at(ci));
+        }
+    }
+
+    // merge intermediate result tiles (:470-505)
+    if(tiles.size() > cams.size())
+        for(const int rc : cams)
+        {
+            if(_sgmParams.exportIntermediateDepthSimMaps)
+                mergeDepthSimMapTiles(rc, _mp, _sgmParams.scale, _sgmParams.stepXY, "sgm");
+            if(_sgmParams.exportIntermediateNormalMaps)
+                mergeNormalMapTiles(rc, _mp, _sgmParams.scale, _sgmParams.stepXY, "sgm");
+            if(_depthMapParams.useRefine)
+            {
+                if(_refineParams.exportIntermediateDepthSimMaps)
+                {
+                    mergeDepthPixSizeMapTiles(rc, _mp, _refineParams.scale, _refineParams.stepXY, "sgmUpscaled");
+                    mergeDepthSimMapTiles(rc, _mp, _refineParams.scale, _refineParams.stepXY, "refinedFused");
+                }
+                if(_refineParams.exportIntermediateNormalMaps)
+                {
+                    mergeNormalMapTiles(rc, _mp, _refineParams.scale, _refineParams.stepXY, "refinedFused");
+                    mergeNormalMapTiles(rc, _mp, _refineParams.scale, _refineParams.stepXY);
+                }
+            }
+        }
+
+    for(auto& e : volumeDone)
+        (void)hipEventDestroy(e);
+    (void)hipEventDestroy(aggregationDone);
+}
+
+} // namespace avdm_host

@@ -1,0 +1,465 @@
+// MultiViewParams.cpp — see MultiViewParams.hpp for the reference lines restated.
+#include "MultiViewParams.hpp"
+
+#include "log.hpp"
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <set>
+
+namespace avdm_host {
+
+namespace {
+bool fileExists(const std::string& p)
+{
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+bool dirExists(const std::string& p)
+{
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+struct SortedId
+{
+    int id;
+    float value;
+};
+} // namespace
+
+MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imagesFolder, const std::string& depthMapsFolder, int downscale)
+  : _sfmData(sfmData),
+    _imagesFolder(imagesFolder + "/"),
+    _depthMapsFolder(depthMapsFolder + "/"),
+    _processDownscale(downscale)
+{
+    // image uid, path and dimensions (MultiViewParams.cpp:52-110)
+    {
+        std::set<std::pair<int, int>> dimensions;
+        int i = 0;
+        for(const auto& viewPair : sfmData.views)
+        {
+            const View& view = viewPair.second;
+            if(!sfmData.isPoseAndIntrinsicDefined(view))
+                continue;
+            std::string path = view.path;
+            if(_imagesFolder != "/" && dirExists(_imagesFolder))
+            {
+                // one file per view named <viewId>.<ext>; this build decodes OpenEXR only (PrepareDenseScene's output format)
+                const std::string candidate = _imagesFolder + std::to_string(view.viewId) + ".exr";
+                if(!fileExists(candidate))
+                    throw std::runtime_error("Cannot find image file coresponding to the view '" + std::to_string(view.viewId) + "' in folder '" +
+                                             _imagesFolder + "' (expected " + std::to_string(view.viewId) + ".exr).");
+                path = candidate;
+            }
+            dimensions.emplace(view.width, view.height);
+            ImageParams ip;
+            ip.viewId = view.viewId;
+            ip.width = view.width;
+            ip.height = view.height;
+            ip.path = path;
+            _imagesParams.push_back(ip);
+            _imageIdsPerViewId[view.viewId] = i;
+            ++i;
+        }
+        AVDM_LOG_INFO("Found " << dimensions.size() << " image dimension(s): ");
+        for(const auto& dim : dimensions)
+            AVDM_LOG_INFO("\t- [" << dim.first << "x" << dim.second << "]");
+    }
+
+    ncams = getNbCameras();
+    camArr.resize(ncams);
+    KArr.resize(ncams);
+    iKArr.resize(ncams);
+    RArr.resize(ncams);
+    iRArr.resize(ncams);
+    iCamArr.resize(ncams);
+    CArr.resize(ncams);
+    _imagesScale.assign(ncams, 1);
+
+    for(int i = 0; i < ncams; ++i)
+    {
+        const ImageParams& imgParams = _imagesParams.at(i);
+        ExrImage header;
+        bool exists = fileExists(imgParams.path);
+        if(exists)
+        {
+            try
+            {
+                readExr(imgParams.path, header, true);
+            }
+            catch(const std::exception&)
+            {
+                exists = false; // not an EXR (e.g. the original JPEG of the view): fall back to the SfMData like a missing file
+            }
+        }
+        int scaleMeta = 0;
+        double rawP[16];
+        if(exists && header.attributes.getInt("AliceVision:downscale", scaleMeta))
+            _imagesScale.at(i) = scaleMeta;
+        else if(exists)
+        {
+            const int widthScale = imgParams.width / header.width, heightScale = imgParams.height / header.height;
+            if(widthScale != heightScale)
+                throw std::runtime_error("Scale of file: '" + imgParams.path + "' is not uniform, check image dimension ratio.");
+            _imagesScale.at(i) = widthScale;
+        }
+        if(exists && header.attributes.getM44d("AliceVision:P", rawP))
+        {
+            AVDM_LOG_DEBUG("Reading view " << getViewId(i) << " projection matrix from image metadata.");
+            loadMatricesFromRawProjectionMatrix(i, rawP);
+        }
+        else
+        {
+            AVDM_LOG_DEBUG("Reading view " << getViewId(i) << " projection matrix from SfMData.");
+            loadMatricesFromSfM(i);
+        }
+        if(KArr[i](0, 0) > (float)(getWidth(i) * 100))
+            throw std::runtime_error("Camera " + std::to_string(i) + " at infinity."); // the reference zeroes such cameras (:183-235); refuse instead
+        _maxImageWidth = std::max(_maxImageWidth, imgParams.width / _imagesScale.at(i));
+        _maxImageHeight = std::max(_maxImageHeight, imgParams.height / _imagesScale.at(i));
+    }
+    AVDM_LOG_INFO("Overall maximum dimension: [" << _maxImageWidth << "x" << _maxImageHeight << "]");
+}
+
+// MultiViewParams.cpp:283-298
+void MultiViewParams::loadMatricesFromRawProjectionMatrix(int index, const double* rawProjMatrix)
+{
+    Matrix3x4& P = camArr.at(index);
+    std::copy_n(rawProjMatrix, 12, P.m);
+    const double imgScale = double(_imagesScale.at(index) * _processDownscale);
+    for(int i = 0; i < 8; ++i)
+        P.m[i] /= imgScale;
+    P.decomposeProjectionMatrix(KArr.at(index), RArr.at(index), CArr.at(index));
+    iKArr.at(index) = KArr.at(index).inverse();
+    iRArr.at(index) = RArr.at(index).inverse();
+    iCamArr.at(index) = iRArr.at(index) * iKArr.at(index);
+}
+
+// MultiViewParams.cpp:300-319: P = K [R | -R C] for pinhole intrinsics (Pinhole::getProjectiveEquivalent, camera/Pinhole.cpp:277-283)
+void MultiViewParams::loadMatricesFromSfM(int index)
+{
+    const View& view = _sfmData.views.at(getViewId(index));
+    const Intrinsic& intr = _sfmData.getIntrinsic(view);
+    const Pose& pose = _sfmData.getPose(view);
+    const Point3d t = (pose.rotation * pose.center) * -1.0;
+    Matrix3x4 P;
+    if(intr.isPinhole)
+        P = composeP(intr.K(), pose.rotation, t);
+    else
+    {
+        Matrix3x3 I = Matrix3x3::diag(1, 1, 1);
+        P = composeP(I, pose.rotation, t);
+    }
+    loadMatricesFromRawProjectionMatrix(index, P.m);
+}
+
+std::vector<double> MultiViewParams::getOriginalP(int index) const
+{
+    const Matrix3x4& p34 = camArr.at(index);
+    const int downscale = getDownscaleFactor(index);
+    std::vector<double> p44(p34.m, p34.m + 12);
+    for(int i = 0; i < 8; ++i)
+        p44[i] *= downscale;
+    p44.push_back(0);
+    p44.push_back(0);
+    p44.push_back(0);
+    p44.push_back(1);
+    return p44;
+}
+
+// MultiViewParams.cpp:335-349
+void MultiViewParams::getPixelFor3DPoint(Point2d* out, const Point3d& X, const Matrix3x4& P) const
+{
+    const Point3d XT = P * X;
+    if(XT.z <= 0)
+    {
+        out->x = -1.0;
+        out->y = -1.0;
+    }
+    else
+    {
+        out->x = XT.x / XT.z;
+        out->y = XT.y / XT.z;
+    }
+}
+
+// MultiViewParams.cpp:385-400
+double MultiViewParams::getCamPixelSize(const Point3d& x0, int cam, float d) const
+{
+    if(d == 0.0f)
+        return 0.0f;
+    Point2d pix;
+    getPixelFor3DPoint(&pix, x0, cam);
+    pix.x = pix.x + d;
+    const Point3d vect = (iCamArr[cam] * pix).normalize();
+    return pointLineDistance3D(x0, CArr[cam], vect);
+}
+
+// MultiViewParams.cpp:505-517
+void MultiViewParams::decomposeProjectionMatrix(Point3d& Co, Matrix3x3& Ro, Matrix3x3& iRo, Matrix3x3& Ko, Matrix3x3& iKo, Matrix3x3& iPo,
+                                                const Matrix3x4& P) const
+{
+    P.decomposeProjectionMatrix(Ko, Ro, Co);
+    iKo = Ko.inverse();
+    iRo = Ro.inverse();
+    iPo = iRo * iKo;
+}
+
+// MultiViewParams.cpp:519-575.  Scores = number of common landmarks whose two rays form an angle inside [min, max] view
+// angle; cameras sorted by descending score (the reference's qsort leaves the order of equal scores unspecified: here the
+// lower camera index wins a tie), at least 21 common landmarks required.
+std::vector<int> MultiViewParams::findNearestCamsFromLandmarks(int rc, int nbNearestCams) const
+{
+    std::vector<int> out;
+    std::vector<SortedId> ids;
+    ids.reserve(getNbCameras());
+    for(int tc = 0; tc < getNbCameras(); ++tc)
+        ids.push_back({tc, 0.f});
+
+    const IndexT viewId = getViewId(rc);
+    const View& view = _sfmData.views.at(viewId);
+    const Pose& pose = _sfmData.getPose(view);
+    const Intrinsic& intr = _sfmData.getIntrinsic(view);
+
+    for(const auto& landmarkPair : _sfmData.landmarks)
+    {
+        const auto& observations = landmarkPair.second.observations;
+        const auto viewObsIt = observations.find(viewId);
+        if(viewObsIt == observations.end())
+            continue;
+        for(const auto& observationPair : observations)
+        {
+            const IndexT otherViewId = observationPair.first;
+            if(otherViewId == viewId)
+                continue;
+            const auto idIt = _imageIdsPerViewId.find(otherViewId);
+            if(idIt == _imageIdsPerViewId.end())
+                continue; // observation of a view without pose / intrinsic
+            const View& otherView = _sfmData.views.at(otherViewId);
+            const double angle = angleBetweenRays(pose, intr, _sfmData.getPose(otherView), _sfmData.getIntrinsic(otherView),
+                                                  Point2d(viewObsIt->second.x, viewObsIt->second.y), Point2d(observationPair.second.x, observationPair.second.y));
+            if(angle < _minViewAngle || angle > _maxViewAngle)
+                continue;
+            ++ids.at(idIt->second).value;
+        }
+    }
+    std::stable_sort(ids.begin(), ids.end(), [](const SortedId& a, const SortedId& b) { return a.value > b.value; });
+    const int maxTc = std::min({getNbCameras(), nbNearestCams, static_cast<int>(ids.size())});
+    out.reserve(maxTc);
+    for(int i = 0; i < maxTc; ++i)
+        if(ids[i].value > (10 * 2))
+            out.push_back(ids[i].id);
+    if((int)out.size() < nbNearestCams)
+        AVDM_LOG_INFO("Found only " << out.size() << "/" << nbNearestCams << " nearest cameras for view id: " << getViewId(rc));
+    return out;
+}
+
+// MultiViewParams.cpp:577-667
+std::vector<int> MultiViewParams::findTileNearestCams(int rc, int nbNearestCams, const std::vector<int>& tCams, const ROI& roi) const
+{
+    auto plateauFunction = [](int a, int b, int c, int d, int x) {
+        if(x > a && x <= b)
+            return (float(x - a) / float(b - a));
+        if(x > b && x <= c)
+            return 1.0f;
+        if(x > c && x <= d)
+            return 1.0f - (float(x - c) / float(d - c));
+        return 0.f;
+    };
+    std::vector<int> out;
+    std::map<int, float> tcScore;
+    for(const int tc : tCams)
+        tcScore[tc] = 0.0f;
+
+    const IndexT viewId = getViewId(rc);
+    const View& view = _sfmData.views.at(viewId);
+    const Pose& pose = _sfmData.getPose(view);
+    const Intrinsic& intr = _sfmData.getIntrinsic(view);
+    const ROI fullsizeRoi = upscaleROI(roi, (float)getProcessDownscale());
+
+    for(const auto& landmarkPair : _sfmData.landmarks)
+    {
+        const auto& observations = landmarkPair.second.observations;
+        const auto viewObsIt = observations.find(viewId);
+        if(viewObsIt == observations.end())
+            continue;
+        // ROI::contains takes unsigned ints: the double coordinates are converted (truncated) at the call (ROI.hpp:119)
+        if(!fullsizeRoi.contains((unsigned int)viewObsIt->second.x, (unsigned int)viewObsIt->second.y))
+            continue;
+        for(const auto& observationPair : observations)
+        {
+            const IndexT otherViewId = observationPair.first;
+            if(otherViewId == viewId)
+                continue;
+            const auto idIt = _imageIdsPerViewId.find(otherViewId);
+            if(idIt == _imageIdsPerViewId.end())
+                continue;
+            const int tc = idIt->second;
+            if(tcScore.find(tc) == tcScore.end())
+                continue;
+            const View& otherView = _sfmData.views.at(otherViewId);
+            const double angle = angleBetweenRays(pose, intr, _sfmData.getPose(otherView), _sfmData.getIntrinsic(otherView),
+                                                  Point2d(viewObsIt->second.x, viewObsIt->second.y), Point2d(observationPair.second.x, observationPair.second.y));
+            tcScore[tc] += plateauFunction(1, 10, 50, 150, (int)angle); // the lambda takes an int: the angle is truncated
+        }
+    }
+    std::vector<SortedId> ids;
+    for(const auto& p : tcScore)
+        if(p.second > 0.0f)
+            ids.push_back({p.first, p.second});
+    std::stable_sort(ids.begin(), ids.end(), [](const SortedId& a, const SortedId& b) { return a.value > b.value; });
+    const int maxTc = std::min(std::min(getNbCameras(), nbNearestCams), static_cast<int>(ids.size()));
+    for(int i = 0; i < maxTc; ++i)
+        out.push_back(ids[i].id);
+    return out;
+}
+
+// mvsUtils/fileIO.cpp:18-358 (only the file types this stage produces or reads)
+std::string getFileNameFromViewId(const MultiViewParams& mp, IndexT viewId, EFileType fileType, const std::string& customSuffix, int tileBeginX, int tileBeginY)
+{
+    std::string folder = mp.getImagesFolder(), suffix, tileSuffix, ext = "exr";
+    if(tileBeginX >= 0 && tileBeginY >= 0)
+        tileSuffix = "_" + std::to_string(tileBeginX) + "_" + std::to_string(tileBeginY);
+    switch(fileType)
+    {
+        case EFileType::P: suffix = "_P", ext = "txt"; break;
+        case EFileType::D: suffix = "_D", ext = "txt"; break;
+        case EFileType::depthMap: folder = mp.getDepthMapsFolder(), suffix = "_depthMap"; break;
+        case EFileType::simMap: folder = mp.getDepthMapsFolder(), suffix = "_simMap"; break;
+        case EFileType::normalMap: folder = mp.getDepthMapsFolder(), suffix = "_normalMap"; break;
+        case EFileType::thicknessMap: folder = mp.getDepthMapsFolder(), suffix = "_thicknessMap"; break;
+        case EFileType::pixSizeMap: folder = mp.getDepthMapsFolder(), suffix = "_pixSizeMap"; break;
+        case EFileType::tilePattern: folder = mp.getDepthMapsFolder(), suffix = "_tilePattern", ext = "obj"; break;
+    }
+    return folder + std::to_string(viewId) + suffix + customSuffix + tileSuffix + "." + ext;
+}
+
+// mvsUtils/common.cpp:23-116
+bool get2dLineImageIntersection(Point2d* pFrom, Point2d* pTo, Point2d linePoint1, Point2d linePoint2, const MultiViewParams& mp, int camId)
+{
+    Point2d v = linePoint2 - linePoint1;
+    if(v.size() < FLT_EPSILON)
+        return false;
+    v = v.normalize();
+    const double a = -v.y, b = v.x, c = -a * linePoint1.x - b * linePoint1.y;
+    int intersections = 0;
+    const double rw = (double)mp.getWidth(camId), rh = (double)mp.getHeight(camId);
+    auto add = [&](double x, double y) {
+        if(intersections == 0)
+            *pFrom = Point2d(x, y);
+        else
+            *pTo = Point2d(x, y);
+        intersections++;
+    };
+    double x = 0, y = -c / b;
+    if((y >= 0) && (y < rh))
+        add(x, y);
+    x = rw;
+    y = (-c - a * rw) / b;
+    if((y >= 0) && (y < rh))
+        add(x, y);
+    x = -c / a;
+    y = 0;
+    if((x >= 0) && (x < rw))
+        add(x, y);
+    x = (-c - b * rh) / a;
+    y = rh;
+    if((x >= 0) && (x < rw))
+        add(x, y);
+    if(intersections == 2)
+    {
+        if((linePoint1 - *pFrom).size() > (linePoint1 - *pTo).size())
+            std::swap(*pFrom, *pTo);
+        return true;
+    }
+    return false;
+}
+
+// mvsUtils/common.cpp:155-169
+bool triangulateMatch(Point3d& out, const Point2d& refpix, const Point2d& tarpix, int refCam, int tarCam, const MultiViewParams& mp)
+{
+    const Point3d refvect = (mp.iCamArr[refCam] * refpix).normalize();
+    const Point3d refpoint = refvect + mp.CArr[refCam];
+    const Point3d tarvect = (mp.iCamArr[tarCam] * tarpix).normalize();
+    const Point3d tarpoint = tarvect + mp.CArr[tarCam];
+    return lineLineIntersect(out, mp.CArr[refCam], refpoint, mp.CArr[tarCam], tarpoint);
+}
+
+// mvsUtils/fileIO.cpp:389-443.  Decoding is OpenEXR only; the --downscale resize is a box filter (the reference calls
+// OpenImageIO's resize, whose filter is not restated: DESIGN.md "out of scope").
+std::shared_ptr<const HostImage> ImagesCache::getImg_sync(int camId)
+{
+    std::lock_guard<std::mutex> lock(_mutex);
+    auto it = _cache.find(camId);
+    if(it != _cache.end())
+    {
+        it->second.first = ++_tick;
+        return it->second.second;
+    }
+    const std::string& path = _mp.getImagePath(camId);
+    ExrImage exr;
+    readExr(path, exr);
+    if(_mp.getOriginalWidth(camId) != exr.width || _mp.getOriginalHeight(camId) != exr.height)
+        throw std::runtime_error("Bad image dimension for camera : " + std::to_string(camId) + "\n\t- image path : " + path + "\n\t- expected dimension : " +
+                                 std::to_string(_mp.getOriginalWidth(camId)) + "x" + std::to_string(_mp.getOriginalHeight(camId)) +
+                                 "\n\t- real dimension : " + std::to_string(exr.width) + "x" + std::to_string(exr.height));
+    const int iR = exr.channelIndex("R"), iG = exr.channelIndex("G"), iB = exr.channelIndex("B"), iA = exr.channelIndex("A"), iY = exr.channelIndex("Y");
+    if(!((iR >= 0 && iG >= 0 && iB >= 0) || iY >= 0))
+        throw std::runtime_error("image '" + path + "' has neither R,G,B nor Y channels");
+    const size_t n = (size_t)exr.width * exr.height;
+    auto full = std::make_shared<HostImage>();
+    full->width = exr.width;
+    full->height = exr.height;
+    full->rgba.resize(n * 4);
+    const float* r = exr.channels[iR >= 0 ? iR : iY].data();
+    const float* g = exr.channels[iG >= 0 ? iG : iY].data();
+    const float* b = exr.channels[iB >= 0 ? iB : iY].data();
+    const float* a = iA >= 0 ? exr.channels[iA].data() : nullptr;
+#pragma omp parallel for
+    for(long long i = 0; i < (long long)n; ++i)
+    {
+        full->rgba[4 * i + 0] = r[i];
+        full->rgba[4 * i + 1] = g[i];
+        full->rgba[4 * i + 2] = b[i];
+        full->rgba[4 * i + 3] = a ? a[i] : 1.0f;
+    }
+    std::shared_ptr<const HostImage> result = full;
+    const int s = _mp.getProcessDownscale();
+    if(s > 1)
+    {
+        AVDM_LOG_DEBUG("Downscale (x" << s << ") image: " << _mp.getViewId(camId) << ".");
+        auto small = std::make_shared<HostImage>();
+        small->width = exr.width / s;
+        small->height = exr.height / s;
+        small->rgba.resize((size_t)small->width * small->height * 4);
+        const float inv = 1.0f / float(s * s);
+#pragma omp parallel for
+        for(int y = 0; y < small->height; ++y)
+            for(int x = 0; x < small->width; ++x)
+                for(int c = 0; c < 4; ++c)
+                {
+                    float acc = 0.f;
+                    for(int dy = 0; dy < s; ++dy)
+                        for(int dx = 0; dx < s; ++dx)
+                            acc += full->rgba[((size_t)(y * s + dy) * exr.width + (x * s + dx)) * 4 + c];
+                    small->rgba[((size_t)y * small->width + x) * 4 + c] = acc * inv;
+                }
+        result = small;
+    }
+    if(_cache.size() >= _max)
+    {
+        auto oldest = _cache.begin();
+        for(auto i = _cache.begin(); i != _cache.end(); ++i)
+            if(i->second.first < oldest->second.first)
+                oldest = i;
+        _cache.erase(oldest);
+    }
+    _cache[camId] = {++_tick, result};
+    return result;
+}
+
+} // namespace avdm_host

@@ -1,0 +1,510 @@
+// depthMapUtils.cpp — see depthMapUtils.hpp.
+#include "depthMapUtils.hpp"
+
+#include "device.hpp"
+#include "exr.hpp"
+#include "log.hpp"
+
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <fstream>
+#include <limits>
+#include <regex>
+
+namespace avdm_host {
+
+void resetDepthSimMap(Float2Tile& inout, float depth, float sim)
+{
+    for(size_t i = 0; i < (size_t)inout.width * inout.height; ++i)
+    {
+        inout.data[2 * i] = depth;
+        inout.data[2 * i + 1] = sim;
+    }
+}
+
+namespace {
+
+inline double clampd(double v, double lo, double hi) { return std::min(std::max(v, lo), hi); }
+
+// mapIO.cpp:170-202
+void weightTileBorder(int a, int b, int c, int d, int borderWidth, int borderHeight, const Point2d& lu, FloatMap& in_tileMap)
+{
+    const Point2d rd = lu + Point2d(borderWidth, borderHeight);
+    const int endX = std::min(int(rd.x), in_tileMap.width);
+    const int endY = std::min(int(rd.y), in_tileMap.height);
+    static const double margin = 2.0;
+    const Point2d lu_m(lu.x + margin, lu.y + margin);
+    const Point2d rd_m(rd.x - margin, rd.y - margin);
+    const double borderWidth_m = borderWidth - 2.0 * margin;
+    const double borderHeight_m = borderHeight - 2.0 * margin;
+    for(int x = (int)lu.x; x < endX; ++x)
+        for(int y = (int)lu.y; y < endY; ++y)
+        {
+            if(x < 0 || y < 0)
+                continue; // a tile narrower than the padding: the reference would index out of bounds
+            const float r_x = (float)clampd((rd_m.x - x) / borderWidth_m, 0.0, 1.0);
+            const float r_y = (float)clampd((rd_m.y - y) / borderHeight_m, 0.0, 1.0);
+            const float l_x = (float)clampd((x - lu_m.x) / borderWidth_m, 0.0, 1.0);
+            const float l_y = (float)clampd((y - lu_m.y) / borderHeight_m, 0.0, 1.0);
+            const float weight = r_y * (r_x * a + l_x * b) + l_y * (r_x * d + l_x * c);
+            in_tileMap(y, x) *= weight;
+        }
+}
+
+bool fileExists(const std::string& p)
+{
+    struct stat st;
+    return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+// mapIO.cpp:136-155
+void getTilePathList(int rc, const MultiViewParams& mp, EFileType fileType, const std::string& customSuffix, std::vector<std::string>& out)
+{
+    const std::string mapPath = getFileNameFromIndex(mp, rc, fileType, customSuffix);
+    const size_t slash = mapPath.rfind('/');
+    const std::string dir = slash == std::string::npos ? "." : mapPath.substr(0, slash);
+    const std::string file = slash == std::string::npos ? mapPath : mapPath.substr(slash + 1);
+    const size_t dot = file.rfind('.');
+    const std::string stem = file.substr(0, dot), ext = file.substr(dot);
+    const std::regex pattern(stem + "_\\d+_\\d+\\" + ext);
+    DIR* d = ::opendir(dir.c_str());
+    if(!d)
+        AVDM_THROW_ERROR("Cannot find map directory (rc: " << rc << ").");
+    while(dirent* e = ::readdir(d))
+        if(std::regex_match(std::string(e->d_name), pattern))
+            out.push_back(dir + "/" + e->d_name);
+    ::closedir(d);
+    std::sort(out.begin(), out.end());
+}
+
+// device float2 map (tile ROI) -> two host float maps (depthMapUtils.cpp:22-60)
+void copyFloat2MapFromDevice(FloatMap& outX, FloatMap& outY, const float* map_d, int pitch, const ROI& roi, int downscale, hipStream_t stream)
+{
+    const ROI r = downscaleROI(roi, (float)downscale);
+    const int w = (int)r.width(), h = (int)r.height();
+    std::vector<float> tmp((size_t)w * h * 2);
+    AVDM_HIP_CHECK(hipMemcpy2DAsync(tmp.data(), (size_t)w * 8, map_d, (size_t)pitch, (size_t)w * 8, (size_t)h, hipMemcpyDeviceToHost, stream));
+    AVDM_HIP_CHECK(hipStreamSynchronize(stream));
+    outX = FloatMap(w, h);
+    outY = FloatMap(w, h);
+    for(size_t i = 0; i < (size_t)w * h; ++i)
+    {
+        outX.data[i] = tmp[2 * i];
+        outY.data[i] = tmp[2 * i + 1];
+    }
+}
+
+void writeFloat2MapFromDevice(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, const float* map_d, int pitch, EFileType typeX,
+                              EFileType typeY, int scale, int step, const std::string& name, hipStream_t stream)
+{
+    const std::string customSuffix = name.empty() ? "" : "_" + name;
+    FloatMap mapX, mapY;
+    copyFloat2MapFromDevice(mapX, mapY, map_d, pitch, roi, scale * step, stream);
+    writeMap(rc, mp, typeX, tileParams, roi, mapX, scale, step, customSuffix);
+    writeMap(rc, mp, typeY, tileParams, roi, mapY, scale, step, customSuffix);
+}
+
+// mapIO.cpp:402-540 common part: path, display / pixel windows and metadata
+struct MapFileInfo
+{
+    std::string path;
+    int imageWidth, imageHeight;
+    ROI downscaledROI;
+    ExrAttributes metadata;
+};
+
+MapFileInfo prepareMapFile(int rc, const MultiViewParams& mp, EFileType fileType, const TileParams& tileParams, const ROI& roi, int scale, int step,
+                           const std::string& customSuffix)
+{
+    MapFileInfo f;
+    const int scaleStep = scale * step;
+    f.imageWidth = divideRoundUp(mp.getWidth(rc), scaleStep);
+    f.imageHeight = divideRoundUp(mp.getHeight(rc), scaleStep);
+    f.downscaledROI = downscaleROI(roi, (float)scaleStep);
+    if((int)f.downscaledROI.width() != f.imageWidth || (int)f.downscaledROI.height() != f.imageHeight)
+        f.path = getFileNameFromIndex(mp, rc, fileType, customSuffix, (int)roi.x.begin, (int)roi.y.begin); // tile
+    else
+        f.path = getFileNameFromIndex(mp, rc, fileType, customSuffix);
+
+    // original picture metadata (strings), then the AliceVision entries
+    for(const auto& kv : mp.getMetadata(rc))
+        f.metadata.setString(kv.first, kv.second);
+    f.metadata.setInt("AliceVision:downscale", mp.getDownscaleFactor(rc) * scaleStep);
+    f.metadata.setInt("AliceVision:roiBeginX", int(roi.x.begin));
+    f.metadata.setInt("AliceVision:roiBeginY", int(roi.y.begin));
+    f.metadata.setInt("AliceVision:roiEndX", int(roi.x.end));
+    f.metadata.setInt("AliceVision:roiEndY", int(roi.y.end));
+    f.metadata.setInt("AliceVision:tileBufferWidth", tileParams.bufferWidth);
+    f.metadata.setInt("AliceVision:tileBufferHeight", tileParams.bufferHeight);
+    f.metadata.setInt("AliceVision:tilePadding", tileParams.padding);
+    {
+        const std::vector<double> matrixP = mp.getOriginalP(rc);
+        f.metadata.setM44d("AliceVision:P", matrixP.data());
+    }
+    {
+        Point3d C = mp.CArr[rc];
+        Matrix3x3 iP = mp.iCamArr[rc];
+        if(scaleStep > 1)
+        {
+            Matrix3x4 P = mp.camArr[rc];
+            for(int i = 0; i < 8; ++i)
+                P.m[i] /= double(scaleStep);
+            Matrix3x3 K, R;
+            P.decomposeProjectionMatrix(K, R, C);
+            iP = R.inverse() * K.inverse();
+        }
+        const double c[3] = {C.x, C.y, C.z};
+        f.metadata.setV3d("AliceVision:CArr", c);
+        f.metadata.setM33d("AliceVision:iCamArr", iP.m);
+    }
+    return f;
+}
+
+} // namespace
+
+void addTileMapWeighted(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, int downscale, FloatMap& in_tileMap, FloatMap& inout_map)
+{
+    const ROI downscaledRoi = downscaleROI(roi, (float)downscale);
+    const int tileWidth = (int)downscaledRoi.width();
+    const int tileHeight = (int)downscaledRoi.height();
+    const int tilePadding = tileParams.padding / downscale;
+
+    const bool firstColumn = (roi.x.begin == 0);
+    const bool lastColumn = ((int)roi.x.end == mp.getWidth(rc));
+    const bool firstRow = (roi.y.begin == 0);
+    const bool lastRow = ((int)roi.y.end == mp.getHeight(rc));
+
+    if(!firstColumn || !firstRow) // top left corner
+        weightTileBorder(0, firstRow ? 1 : 0, 1, firstColumn ? 1 : 0, tilePadding, tilePadding, Point2d(0, 0), in_tileMap);
+    if(!firstColumn || !lastRow) // bottom left corner
+        weightTileBorder(firstColumn ? 1 : 0, 1, lastRow ? 1 : 0, 0, tilePadding, tilePadding, Point2d(0, tileHeight - tilePadding), in_tileMap);
+    if(!lastColumn || !firstRow) // top right corner
+        weightTileBorder(firstRow ? 1 : 0, 0, lastColumn ? 1 : 0, 1, tilePadding, tilePadding, Point2d(tileWidth - tilePadding, 0), in_tileMap);
+    if(!lastColumn || !lastRow) // bottom right corner
+        weightTileBorder(1, lastColumn ? 1 : 0, 0, lastRow ? 1 : 0, tilePadding, tilePadding, Point2d(tileWidth - tilePadding, tileHeight - tilePadding), in_tileMap);
+    if(!firstRow) // top border
+        weightTileBorder(0, 0, 1, 1, tileWidth - 2 * tilePadding, tilePadding, Point2d(tilePadding, 0), in_tileMap);
+    if(!lastRow) // bottom border
+        weightTileBorder(1, 1, 0, 0, tileWidth - 2 * tilePadding, tilePadding, Point2d(tilePadding, tileHeight - tilePadding), in_tileMap);
+    if(!firstColumn) // left border
+        weightTileBorder(0, 1, 1, 0, tilePadding, tileHeight - 2 * tilePadding, Point2d(0, tilePadding), in_tileMap);
+    if(!lastColumn) // right border
+        weightTileBorder(1, 0, 0, 1, tilePadding, tileHeight - 2 * tilePadding, Point2d(tileWidth - tilePadding, tilePadding), in_tileMap);
+
+    for(int x = (int)downscaledRoi.x.begin; x < (int)downscaledRoi.x.end && x < inout_map.width; ++x)
+        for(int y = (int)downscaledRoi.y.begin; y < (int)downscaledRoi.y.end && y < inout_map.height; ++y)
+            inout_map(y, x) += in_tileMap(y - (int)downscaledRoi.y.begin, x - (int)downscaledRoi.x.begin);
+}
+
+void writeMap(int rc, const MultiViewParams& mp, EFileType fileType, const TileParams& tileParams, const ROI& roi, const FloatMap& in_map, int scale, int step,
+              const std::string& customSuffix)
+{
+    MapFileInfo f = prepareMapFile(rc, mp, fileType, tileParams, roi, scale, step, customSuffix);
+    if(in_map.width != (int)f.downscaledROI.width() || in_map.height != (int)f.downscaledROI.height())
+        AVDM_THROW_ERROR("writeMap: map size " << in_map.width << "x" << in_map.height << " does not match the ROI " << f.downscaledROI);
+    if(fileType == EFileType::depthMap)
+    {
+        // mapIO.cpp:493-511
+        const int nbDepthValues = (int)std::count_if(in_map.data.begin(), in_map.data.end(), [](float v) { return v > 0.0f; });
+        float maxDepth = -1.0f;
+        float minDepth = std::numeric_limits<float>::max();
+        for(const float depth : in_map.data)
+        {
+            if(depth <= -1.0f)
+                continue;
+            maxDepth = std::max(maxDepth, depth);
+            minDepth = std::min(minDepth, depth);
+        }
+        f.metadata.setInt("AliceVision:nbDepthValues", nbDepthValues);
+        f.metadata.setFloat("AliceVision:minDepth", minDepth);
+        f.metadata.setFloat("AliceVision:maxDepth", maxDepth);
+    }
+    // depth maps are stored as float, every other map as half (mapIO.cpp:517-526); one channel is named "Y" by OpenImageIO
+    const bool storeHalf = (fileType != EFileType::depthMap);
+    writeExr(f.path, in_map.width, in_map.height, {{"Y", in_map.data.data()}}, storeHalf, f.metadata, (int)f.downscaledROI.x.begin, (int)f.downscaledROI.y.begin,
+             f.imageWidth, f.imageHeight);
+}
+
+void writeMap3(int rc, const MultiViewParams& mp, EFileType fileType, const TileParams& tileParams, const ROI& roi, const std::vector<float>& rgb, int width,
+               int height, int scale, int step, const std::string& customSuffix)
+{
+    MapFileInfo f = prepareMapFile(rc, mp, fileType, tileParams, roi, scale, step, customSuffix);
+    std::vector<float> r((size_t)width * height), g(r.size()), b(r.size());
+    for(size_t i = 0; i < r.size(); ++i)
+    {
+        r[i] = rgb[3 * i];
+        g[i] = rgb[3 * i + 1];
+        b[i] = rgb[3 * i + 2];
+    }
+    writeExr(f.path, width, height, {{"R", r.data()}, {"G", g.data()}, {"B", b.data()}}, true, f.metadata, (int)f.downscaledROI.x.begin,
+             (int)f.downscaledROI.y.begin, f.imageWidth, f.imageHeight);
+}
+
+void readMap(int rc, const MultiViewParams& mp, EFileType fileType, FloatMap& out_map, int scale, int step, const std::string& customSuffix)
+{
+    const std::string mapPath = getFileNameFromIndex(mp, rc, fileType, customSuffix);
+    if(fileExists(mapPath))
+    {
+        ExrImage img;
+        readExr(mapPath, img);
+        out_map = FloatMap(img.width, img.height);
+        out_map.data = img.channels.at(0);
+        return;
+    }
+    const ROI imageRoi(Range(0, mp.getWidth(rc)), Range(0, mp.getHeight(rc)));
+    const int scaleStep = scale * step;
+    out_map = FloatMap(divideRoundUp(mp.getWidth(rc), scaleStep), divideRoundUp(mp.getHeight(rc), scaleStep), 0.f);
+
+    std::vector<std::string> mapTilePathList;
+    getTilePathList(rc, mp, fileType, customSuffix, mapTilePathList);
+    if(mapTilePathList.empty())
+    {
+        AVDM_LOG_INFO("Cannot find any map tile file (rc: " << rc << ").");
+        return;
+    }
+    // tile parameters from the first tile, ROI from each tile (mapIO.cpp:64-103, 360-372)
+    TileParams tileParams;
+    std::vector<ROI> tileRoiList(mapTilePathList.size());
+    for(size_t i = 0; i < mapTilePathList.size(); ++i)
+    {
+        ExrImage header;
+        readExr(mapTilePathList[i], header, true);
+        int bx = -1, by = -1, ex = -1, ey = -1;
+        header.attributes.getInt("AliceVision:roiBeginX", bx);
+        header.attributes.getInt("AliceVision:roiBeginY", by);
+        header.attributes.getInt("AliceVision:roiEndX", ex);
+        header.attributes.getInt("AliceVision:roiEndY", ey);
+        if(bx < 0 || by < 0 || ex <= 0 || ey <= 0)
+            AVDM_THROW_ERROR("Cannot find ROI information in file: " << mapTilePathList[i]);
+        tileRoiList[i] = ROI(bx, ex, by, ey);
+        if(i == 0)
+        {
+            header.attributes.getInt("AliceVision:tileBufferWidth", tileParams.bufferWidth);
+            header.attributes.getInt("AliceVision:tileBufferHeight", tileParams.bufferHeight);
+            header.attributes.getInt("AliceVision:tilePadding", tileParams.padding);
+        }
+    }
+    for(size_t i = 0; i < tileRoiList.size(); ++i)
+    {
+        const ROI roi = intersect(tileRoiList.at(i), imageRoi);
+        if(roi.isEmpty())
+            continue;
+        const std::string mapTilePath = getFileNameFromIndex(mp, rc, fileType, customSuffix, (int)roi.x.begin, (int)roi.y.begin);
+        try
+        {
+            ExrImage img;
+            readExr(mapTilePath, img);
+            FloatMap tileMap(img.width, img.height);
+            tileMap.data = img.channels.at(0);
+            addTileMapWeighted(rc, mp, tileParams, roi, scaleStep, tileMap, out_map);
+        }
+        catch(const std::exception&)
+        {
+            AVDM_LOG_WARNING("Cannot find map (rc: " << rc << "): " << mapTilePath);
+        }
+    }
+}
+
+void deleteMapTiles(int rc, const MultiViewParams& mp, EFileType fileType, const std::string& customSuffix)
+{
+    std::vector<std::string> mapTilePathList;
+    getTilePathList(rc, mp, fileType, customSuffix, mapTilePathList);
+    if(mapTilePathList.empty())
+        AVDM_LOG_INFO("Cannot find any map tile file to delete (rc: " << rc << ").");
+    for(const std::string& p : mapTilePathList)
+        if(std::remove(p.c_str()) != 0)
+            AVDM_LOG_WARNING("Cannot delete map tile file (rc: " << rc << "): " << p);
+}
+
+void writeDepthSimMap(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, const float* map_d, int pitch, int scale, int step,
+                      const std::string& name, hipStream_t stream)
+{
+    writeFloat2MapFromDevice(rc, mp, tileParams, roi, map_d, pitch, EFileType::depthMap, EFileType::simMap, scale, step, name, stream);
+}
+void writeDepthPixSizeMap(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, const float* map_d, int pitch, int scale, int step,
+                          const std::string& name, hipStream_t stream)
+{
+    writeFloat2MapFromDevice(rc, mp, tileParams, roi, map_d, pitch, EFileType::depthMap, EFileType::pixSizeMap, scale, step, name, stream);
+}
+void writeNormalMap(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, const float* map_d, int pitch, int scale, int step,
+                    const std::string& name, hipStream_t stream)
+{
+    const ROI r = downscaleROI(roi, float(scale * step));
+    const int w = (int)r.width(), h = (int)r.height();
+    std::vector<float> rgb((size_t)w * h * 3);
+    AVDM_HIP_CHECK(hipMemcpy2DAsync(rgb.data(), (size_t)w * 12, map_d, (size_t)pitch, (size_t)w * 12, (size_t)h, hipMemcpyDeviceToHost, stream));
+    AVDM_HIP_CHECK(hipStreamSynchronize(stream));
+    writeMap3(rc, mp, EFileType::normalMap, tileParams, roi, rgb, w, h, scale, step, name.empty() ? "" : "_" + name);
+}
+
+void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileParams& tileParams, const std::vector<ROI>& tileRoiList,
+                                  const std::vector<Float2Tile>& in_depthSimMapTiles, int scale, int step, const std::string& name)
+{
+    AVDM_LOG_TRACE("Merge and write depth/similarity map tiles (rc: " << rc << ", view id: " << mp.getViewId(rc) << ").");
+    const std::string customSuffix = name.empty() ? "" : "_" + name;
+    const ROI imageRoi(Range(0, mp.getWidth(rc)), Range(0, mp.getHeight(rc)));
+    const int scaleStep = scale * step;
+    const int width = divideRoundUp(mp.getWidth(rc), scaleStep);
+    const int height = divideRoundUp(mp.getHeight(rc), scaleStep);
+    FloatMap depthMap(width, height, 0.0f), simMap(width, height, 0.0f);
+
+    for(size_t i = 0; i < tileRoiList.size(); ++i)
+    {
+        const ROI roi = intersect(tileRoiList.at(i), imageRoi);
+        if(roi.isEmpty())
+            continue;
+        const ROI r = downscaleROI(roi, (float)scaleStep);
+        const int w = (int)r.width(), h = (int)r.height();
+        const Float2Tile& t = in_depthSimMapTiles.at(i);
+        FloatMap tileDepthMap(w, h), tileSimMap(w, h);
+        for(int y = 0; y < h; ++y)
+            for(int x = 0; x < w; ++x)
+            {
+                tileDepthMap(y, x) = t.data[((size_t)y * t.width + x) * 2];
+                tileSimMap(y, x) = t.data[((size_t)y * t.width + x) * 2 + 1];
+            }
+        addTileMapWeighted(rc, mp, tileParams, roi, scaleStep, tileDepthMap, depthMap);
+        addTileMapWeighted(rc, mp, tileParams, roi, scaleStep, tileSimMap, simMap);
+    }
+    // the merged maps are written with DEFAULT tile parameters and the full-size ROI (mapIO.hpp:118-130)
+    const TileParams defaultTileParams;
+    const ROI fullRoi(0, mp.getWidth(rc), 0, mp.getHeight(rc));
+    writeMap(rc, mp, EFileType::depthMap, defaultTileParams, fullRoi, depthMap, scale, step, customSuffix);
+    writeMap(rc, mp, EFileType::simMap, defaultTileParams, fullRoi, simMap, scale, step, customSuffix);
+}
+
+namespace {
+void mergeFloatMapTiles(int rc, const MultiViewParams& mp, EFileType fileType, int scale, int step, const std::string& name)
+{
+    const std::string customSuffix = name.empty() ? "" : "_" + name;
+    FloatMap map;
+    readMap(rc, mp, fileType, map, scale, step, customSuffix);
+    const TileParams defaultTileParams;
+    writeMap(rc, mp, fileType, defaultTileParams, ROI(0, mp.getWidth(rc), 0, mp.getHeight(rc)), map, scale, step, customSuffix);
+    deleteMapTiles(rc, mp, fileType, customSuffix);
+}
+} // namespace
+
+void mergeDepthSimMapTiles(int rc, const MultiViewParams& mp, int scale, int step, const std::string& name)
+{
+    mergeFloatMapTiles(rc, mp, EFileType::depthMap, scale, step, name);
+    mergeFloatMapTiles(rc, mp, EFileType::simMap, scale, step, name);
+}
+void mergeDepthPixSizeMapTiles(int rc, const MultiViewParams& mp, int scale, int step, const std::string& name)
+{
+    mergeFloatMapTiles(rc, mp, EFileType::depthMap, scale, step, name);
+    mergeFloatMapTiles(rc, mp, EFileType::pixSizeMap, scale, step, name);
+}
+void mergeNormalMapTiles(int rc, const MultiViewParams& mp, int scale, int step, const std::string& name)
+{
+    // three-channel variant of mergeFloatMapTiles: read every tile, weight and add per channel
+    const std::string customSuffix = name.empty() ? "" : "_" + name;
+    std::vector<std::string> tiles;
+    getTilePathList(rc, mp, EFileType::normalMap, customSuffix, tiles);
+    if(tiles.empty())
+        return;
+    const int scaleStep = scale * step;
+    const int width = divideRoundUp(mp.getWidth(rc), scaleStep), height = divideRoundUp(mp.getHeight(rc), scaleStep);
+    FloatMap acc[3] = {FloatMap(width, height, 0.f), FloatMap(width, height, 0.f), FloatMap(width, height, 0.f)};
+    TileParams tileParams;
+    bool first = true;
+    for(const std::string& p : tiles)
+    {
+        ExrImage img;
+        readExr(p, img);
+        int bx = 0, by = 0, ex = 0, ey = 0;
+        img.attributes.getInt("AliceVision:roiBeginX", bx);
+        img.attributes.getInt("AliceVision:roiBeginY", by);
+        img.attributes.getInt("AliceVision:roiEndX", ex);
+        img.attributes.getInt("AliceVision:roiEndY", ey);
+        if(first)
+        {
+            img.attributes.getInt("AliceVision:tileBufferWidth", tileParams.bufferWidth);
+            img.attributes.getInt("AliceVision:tileBufferHeight", tileParams.bufferHeight);
+            img.attributes.getInt("AliceVision:tilePadding", tileParams.padding);
+            first = false;
+        }
+        const char* names[3] = {"R", "G", "B"};
+        for(int c = 0; c < 3; ++c)
+        {
+            const int ci = img.channelIndex(names[c]);
+            if(ci < 0)
+                continue;
+            FloatMap t(img.width, img.height);
+            t.data = img.channels[ci];
+            addTileMapWeighted(rc, mp, tileParams, ROI(bx, ex, by, ey), scaleStep, t, acc[c]);
+        }
+    }
+    std::vector<float> rgb((size_t)width * height * 3);
+    for(size_t i = 0; i < (size_t)width * height; ++i)
+        for(int c = 0; c < 3; ++c)
+            rgb[3 * i + c] = acc[c].data[i];
+    const TileParams defaultTileParams;
+    writeMap3(rc, mp, EFileType::normalMap, defaultTileParams, ROI(0, mp.getWidth(rc), 0, mp.getHeight(rc)), rgb, width, height, scale, step, customSuffix);
+    deleteMapTiles(rc, mp, EFileType::normalMap, customSuffix);
+}
+
+void exportDepthSimMapTilePatternObj(int rc, const MultiViewParams& mp, const std::vector<ROI>& tileRoiList,
+                                     const std::vector<std::pair<float, float>>& tileMinMaxDepthsList)
+{
+    // same vertices / faces as depthMapUtils.cpp:342-452 (6 bevel vertices and 4 faces per ROI corner + first / last depth
+    // faces), written directly as Wavefront OBJ with per-vertex colours (the reference goes through assimp's "objnomtl")
+    const std::string filepath = getFileNameFromIndex(mp, rc, EFileType::tilePattern);
+    std::ofstream f(filepath);
+    if(!f)
+        AVDM_THROW_ERROR("cannot write '" << filepath << "'");
+    const double colors[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {0, 1, 1}, {1, 0, 1}};
+    const double cornerPixSize = tileRoiList.front().x.size() / 5;
+    const Point2d offs[4][2] = {{{cornerPixSize, 0.0}, {0.0, cornerPixSize}},
+                                {{cornerPixSize, 0.0}, {0.0, -cornerPixSize}},
+                                {{-cornerPixSize, 0.0}, {0.0, cornerPixSize}},
+                                {{-cornerPixSize, 0.0}, {0.0, -cornerPixSize}}};
+    auto linePlane = [](const Point3d& lp, const Point3d& lv, const Point3d& pp, const Point3d& pn) {
+        const double k = (dot(pp, pn) - dot(pn, lp)) / dot(pn, lv);
+        return lp + lv * k;
+    };
+    std::vector<Point3d> vertices;
+    std::vector<int> faces;
+    for(std::size_t ri = 0; ri < tileRoiList.size(); ++ri)
+    {
+        const ROI& roi = tileRoiList.at(ri);
+        const auto& mm = tileMinMaxDepthsList.at(ri);
+        const Point3d planeN = (mp.iRArr[rc] * Point3d(0.0, 0.0, 1.0)).normalize();
+        const Point3d firstPlaneP = mp.CArr[rc] + planeN * mm.first, lastPlaneP = mp.CArr[rc] + planeN * mm.second;
+        const Point2d corners[4] = {{double(roi.x.begin), double(roi.y.begin)},
+                                    {double(roi.x.begin), double(roi.y.end)},
+                                    {double(roi.x.end), double(roi.y.begin)},
+                                    {double(roi.x.end), double(roi.y.end)}};
+        const int v0 = (int)vertices.size();
+        for(int ci = 0; ci < 4; ++ci)
+        {
+            const int vs = (int)vertices.size();
+            const Point2d pts[3] = {corners[ci], corners[ci] + offs[ci][0], corners[ci] + offs[ci][1]};
+            for(const Point2d& p : pts)
+            {
+                const Point3d dir = (mp.iCamArr[rc] * p).normalize();
+                vertices.push_back(linePlane(mp.CArr[rc], dir, firstPlaneP, planeN));
+                vertices.push_back(linePlane(mp.CArr[rc], dir, lastPlaneP, planeN));
+            }
+            const int fs[4][3] = {{vs, vs + 1, vs + 2}, {vs + 1, vs + 2, vs + 3}, {vs, vs + 1, vs + 4}, {vs + 1, vs + 4, vs + 5}};
+            for(const auto& t : fs)
+                faces.insert(faces.end(), t, t + 3);
+        }
+        const int fl[2][3] = {{v0, v0 + 6, v0 + 12}, {v0 + 7, v0 + 13, v0 + 19}};
+        for(const auto& t : fl)
+            faces.insert(faces.end(), t, t + 3);
+    }
+    for(size_t i = 0; i < vertices.size(); ++i)
+    {
+        const double* c = colors[(i / 24) % 6];
+        f << "v " << vertices[i].x << " " << -vertices[i].y << " " << -vertices[i].z << " " << c[0] << " " << c[1] << " " << c[2] << "\n";
+    }
+    for(size_t i = 0; i < faces.size(); i += 3)
+        f << "f " << faces[i] + 1 << " " << faces[i + 1] + 1 << " " << faces[i + 2] + 1 << "\n";
+    AVDM_LOG_INFO("Save debug tiles pattern obj (rc: " << rc << ", view id: " << mp.getViewId(rc) << ") done.");
+}
+
+} // namespace avdm_host

@@ -1,0 +1,75 @@
+// depthMapUtils.hpp — device map -> host copies, tile weighting / merging and EXR output with the AliceVision metadata.
+// Restates depthMap/depthMapUtils.cpp:22-330 (copyFloat2Map, writeFloat2Map, write*Map, writeDepthSimMapFromTileList,
+// resetDepthSimMap, merge*MapTiles) and mvsUtils/mapIO.cpp:170-311 (weightTileBorder, addSingleTileMapWeighted), :313-400
+// (readMapFromFileOrTiles), :402-540 (writeMapToFileOrTile), :640-687 (deleteMapTiles).
+#pragma once
+
+#include "MultiViewParams.hpp"
+#include "params.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+namespace avdm_host {
+
+// image::Image<float>: row-major
+struct FloatMap
+{
+    int width = 0, height = 0;
+    std::vector<float> data;
+    FloatMap() = default;
+    FloatMap(int w, int h, float v = 0.f) : width(w), height(h), data((size_t)w * h, v) {}
+    float& operator()(int y, int x) { return data[(size_t)y * width + x]; }
+    float operator()(int y, int x) const { return data[(size_t)y * width + x]; }
+};
+
+// host copy of a tile's float2 map: interleaved (x, y) pairs, row-major, `width` pairs per row (CudaHostMemoryHeap<float2, 2>)
+struct Float2Tile
+{
+    int width = 0, height = 0;
+    std::vector<float> data;
+    void allocate(int w, int h)
+    {
+        width = w, height = h;
+        data.assign((size_t)w * h * 2, 0.f);
+    }
+};
+
+// depthMapUtils.cpp:279-293
+void resetDepthSimMap(Float2Tile& inout, float depth = -1.f, float sim = 1.f);
+
+// mapIO.cpp:213-311
+void addTileMapWeighted(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, int downscale, FloatMap& in_tileMap, FloatMap& inout_map);
+
+// mapIO.cpp:402-540: nbChannels = 1 (float maps) or 3 (normal maps: interleaved RGB)
+void writeMap(int rc, const MultiViewParams& mp, EFileType fileType, const TileParams& tileParams, const ROI& roi, const FloatMap& in_map, int scale, int step,
+              const std::string& customSuffix = "");
+void writeMap3(int rc, const MultiViewParams& mp, EFileType fileType, const TileParams& tileParams, const ROI& roi, const std::vector<float>& rgb, int width,
+               int height, int scale, int step, const std::string& customSuffix = "");
+// mapIO.cpp:313-400
+void readMap(int rc, const MultiViewParams& mp, EFileType fileType, FloatMap& out_map, int scale, int step, const std::string& customSuffix = "");
+void deleteMapTiles(int rc, const MultiViewParams& mp, EFileType fileType, const std::string& customSuffix = "");
+
+// depthMapUtils.cpp:196-238 for device maps (float2 rows, pitch in bytes): copies the tile ROI to the host on `stream` (synchronises it)
+void writeDepthSimMap(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, const float* map_d, int pitch, int scale, int step,
+                      const std::string& name, hipStream_t stream);
+void writeDepthPixSizeMap(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, const float* map_d, int pitch, int scale, int step,
+                          const std::string& name, hipStream_t stream);
+void writeNormalMap(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, const float* map_d, int pitch, int scale, int step,
+                    const std::string& name, hipStream_t stream);
+
+// depthMapUtils.cpp:240-277
+void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileParams& tileParams, const std::vector<ROI>& tileRoiList,
+                                  const std::vector<Float2Tile>& in_depthSimMapTiles, int scale, int step, const std::string& name = "");
+
+// depthMapUtils.cpp:295-340
+void mergeDepthSimMapTiles(int rc, const MultiViewParams& mp, int scale, int step, const std::string& name = "");
+void mergeDepthPixSizeMapTiles(int rc, const MultiViewParams& mp, int scale, int step, const std::string& name = "");
+void mergeNormalMapTiles(int rc, const MultiViewParams& mp, int scale, int step, const std::string& name = "");
+
+// depthMapUtils.cpp:342-490: Wavefront OBJ of the tile frusta
+void exportDepthSimMapTilePatternObj(int rc, const MultiViewParams& mp, const std::vector<ROI>& tileRoiList, const std::vector<std::pair<float, float>>& tileMinMaxDepthsList);
+
+} // namespace avdm_host

@@ -1,0 +1,213 @@
+// device.hpp — HIP-side plumbing of the host layer: error checks, RAII device / pinned-host buffers, streams, and the
+// per-device LRU cache of Lab pyramids and camera-parameter blocks.
+// Restates the roles of depthMap/cuda/host/{memory.hpp:326-548 (CudaDeviceMemoryPitched / CudaHostMemoryHeap), utils.hpp:10-40
+// (CHECK_CUDA_ERROR), DeviceStreamManager.{hpp,cpp}, LRUCache.hpp:30-136, DeviceCache.{hpp,cpp}} for HIP and the avdm C ABI:
+// buffers are plain hipMalloc allocations with explicit pitches (the kernels take (pointer, pitch)), camera parameters are
+// host-side avdm_camera_t blocks passed by pointer (no constant-memory slots, hence no 100-slot limit), images are
+// avdm_pyramid_t.
+#pragma once
+
+#include "MultiViewParams.hpp"
+
+#include <avdm.h>
+#include <hip/hip_runtime_api.h>
+
+#include <list>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace avdm_host {
+
+#define AVDM_HIP_CHECK(expr)                                                                                                                                  \
+    do                                                                                                                                                        \
+    {                                                                                                                                                         \
+        const hipError_t avdm_hip_err = (expr);                                                                                                               \
+        if(avdm_hip_err != hipSuccess)                                                                                                                        \
+            throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(avdm_hip_err) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + \
+                                     ")");                                                                                                                    \
+    } while(0)
+
+// every avdm_* entry point returns 0 or an error code with a message (include/avdm.h)
+inline void avdmCheck(int status, const char* what)
+{
+    if(status != 0)
+        throw std::runtime_error(std::string(what) + " failed (" + std::to_string(status) + "): " + avdm_last_error());
+}
+
+class DeviceBuffer
+{
+  public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t bytes) { allocate(bytes); }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    DeviceBuffer(DeviceBuffer&& o) noexcept : _p(o._p), _bytes(o._bytes) { o._p = nullptr, o._bytes = 0; }
+    DeviceBuffer& operator=(DeviceBuffer&& o) noexcept
+    {
+        if(this != &o)
+        {
+            release();
+            _p = o._p, _bytes = o._bytes;
+            o._p = nullptr, o._bytes = 0;
+        }
+        return *this;
+    }
+    ~DeviceBuffer() { release(); }
+    void allocate(size_t bytes)
+    {
+        release();
+        if(bytes)
+            AVDM_HIP_CHECK(hipMalloc(&_p, bytes));
+        _bytes = bytes;
+    }
+    void release()
+    {
+        if(_p)
+            (void)hipFree(_p);
+        _p = nullptr, _bytes = 0;
+    }
+    void* ptr() const { return _p; }
+    template <typename T>
+    T* as() const { return static_cast<T*>(_p); }
+    size_t bytes() const { return _bytes; }
+
+  private:
+    void* _p = nullptr;
+    size_t _bytes = 0;
+};
+
+// pinned, unpadded host buffer (CudaHostMemoryHeap)
+template <typename T>
+class PinnedBuffer
+{
+  public:
+    PinnedBuffer() = default;
+    explicit PinnedBuffer(size_t n) { allocate(n); }
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    PinnedBuffer(PinnedBuffer&& o) noexcept : _p(o._p), _n(o._n) { o._p = nullptr, o._n = 0; }
+    ~PinnedBuffer()
+    {
+        if(_p)
+            (void)hipHostFree(_p);
+    }
+    void allocate(size_t n)
+    {
+        if(_p)
+            (void)hipHostFree(_p);
+        _p = nullptr;
+        if(n)
+            AVDM_HIP_CHECK(hipHostMalloc((void**)&_p, n * sizeof(T), hipHostMallocDefault));
+        _n = n;
+    }
+    T* data() const { return _p; }
+    size_t size() const { return _n; }
+    T& operator[](size_t i) const { return _p[i]; }
+
+  private:
+    T* _p = nullptr;
+    size_t _n = 0;
+};
+
+// DeviceStreamManager.cpp: n non-blocking streams, round-robin access
+class DeviceStreamManager
+{
+  public:
+    explicit DeviceStreamManager(int nbStreams);
+    ~DeviceStreamManager();
+    hipStream_t getStream(int i) const { return _streams.at(i % _streams.size()); }
+    int getNbStreams() const { return (int)_streams.size(); }
+    void waitStream(int i) const { AVDM_HIP_CHECK(hipStreamSynchronize(getStream(i))); }
+
+  private:
+    std::vector<hipStream_t> _streams;
+};
+
+// DeviceMipmapImage.{hpp,cpp}: the fp16 Lab pyramid of one camera in HBM
+class DeviceMipmapImage
+{
+  public:
+    // DeviceMipmapImage.cpp:28-90 via avdm_pyramid_layout + avdm_pyramid_fill (x255 -> fp16 -> Gaussian downscale -> Lab -> levels)
+    void fill(const HostImage& img, int minDownscale, int maxDownscale, int filterMode, hipStream_t stream);
+    const avdm_pyramid_t& pyramid() const { return _pyr; }
+    size_t bytes() const { return _buf.bytes(); }
+
+  private:
+    avdm_pyramid_t _pyr{};
+    DeviceBuffer _buf;
+};
+
+// LRUCache.hpp:30-136: fixed number of slots; insert() returns the slot and whether the key is new (evicting the least
+// recently used key when full)
+template <typename Key>
+class LRUCache
+{
+  public:
+    explicit LRUCache(int maxSize) : _max(maxSize) {}
+    bool insert(const Key& key, int* slot)
+    {
+        auto it = _map.find(key);
+        if(it != _map.end())
+        {
+            _order.splice(_order.begin(), _order, it->second.second);
+            *slot = it->second.first;
+            return false;
+        }
+        int s;
+        if((int)_map.size() < _max)
+            s = (int)_map.size();
+        else
+        {
+            const Key victim = _order.back();
+            s = _map[victim].first;
+            _map.erase(victim);
+            _order.pop_back();
+        }
+        _order.push_front(key);
+        _map[key] = {s, _order.begin()};
+        *slot = s;
+        return true;
+    }
+    bool find(const Key& key, int* slot) const
+    {
+        auto it = _map.find(key);
+        if(it == _map.end())
+            return false;
+        *slot = it->second.first;
+        return true;
+    }
+
+  private:
+    int _max;
+    std::list<Key> _order;
+    std::map<Key, std::pair<int, typename std::list<Key>::iterator>> _map;
+};
+
+// DeviceCache.{hpp,cpp}: one instance per device (owned by the DepthMapEstimator::compute call of that device)
+class DeviceCache
+{
+  public:
+    DeviceCache(int maxMipmapImages, int maxCameraParams, int filterMode);
+    // DeviceCache.cpp:222-281
+    void addMipmapImage(int camId, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp, hipStream_t stream);
+    // DeviceCache.cpp:283-323 (+ fillHostCameraParameters :41-134 through avdm_camera_fill)
+    void addCameraParams(int camId, int downscale, const MultiViewParams& mp);
+    // DeviceCache.cpp:325-365: throw when absent
+    const DeviceMipmapImage& requestMipmapImage(int camId, const MultiViewParams& mp) const;
+    const avdm_camera_t& requestCameraParams(int camId, int downscale, const MultiViewParams& mp) const;
+
+  private:
+    int _filterMode;
+    LRUCache<int> _mipmapCache;
+    LRUCache<std::pair<int, int>> _cameraParamCache;
+    std::vector<std::unique_ptr<DeviceMipmapImage>> _mipmaps;
+    std::vector<avdm_camera_t> _cameraParams;
+};
+
+void logDeviceMemoryInfo();
+void getDeviceMemoryInfo(double& availableMB, double& usedMB, double& totalMB);
+
+} // namespace avdm_host

@@ -1,0 +1,96 @@
+// sfmData.hpp — the part of an AliceVision SfMData scene the depth-map stage reads: views, pinhole intrinsics, poses and the
+// landmarks with their 2-D observations.  Restates sfmData/{SfMData,View,Landmark,CameraPose}.hpp and the JSON reader
+// sfmDataIO/jsonIO.cpp:76-111 (views), :244-449 (intrinsics), :533-566 (landmarks), :707-860 (file) of the reference.
+// Not read: rigs, ancestors, features/matches folders, constraints, Alembic (.abc) input.
+#pragma once
+
+#include "mvsData.hpp"
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace avdm_host {
+
+using IndexT = uint32_t;
+static constexpr IndexT UndefinedIndexT = 0xffffffffu;
+
+struct View
+{
+    IndexT viewId = UndefinedIndexT, poseId = UndefinedIndexT, intrinsicId = UndefinedIndexT;
+    std::string path;
+    int width = 0, height = 0;
+    std::map<std::string, std::string> metadata;
+};
+
+// camera::Pinhole with camera::IntrinsicScaleOffsetDisto (camera/Pinhole.hpp, IntrinsicScaleOffset.cpp:55-66)
+struct Intrinsic
+{
+    IndexT intrinsicId = UndefinedIndexT;
+    std::string type;            // "pinhole", ...
+    std::string distortionType;  // "none", "radialk1", "radialk3", ...
+    int width = 0, height = 0;
+    double sensorWidth = 36.0, sensorHeight = 24.0;
+    double scaleX = 1.0, scaleY = 1.0;  // focal length in pixels
+    double offsetX = 0.0, offsetY = 0.0;  // principal point offset from the image centre
+    std::vector<double> distortionParams;
+    bool isPinhole = false;
+
+    Point2d principalPoint() const { return {offsetX + width * 0.5, offsetY + height * 0.5}; }
+    Point2d ima2cam(const Point2d& p) const
+    {
+        const Point2d pp = principalPoint();
+        return {(p.x - pp.x) / scaleX, (p.y - pp.y) / scaleY};
+    }
+    Point2d removeDistortion(const Point2d& p) const;  // camera plane -> camera plane
+    Matrix3x3 K() const
+    {
+        Matrix3x3 k;
+        const Point2d pp = principalPoint();
+        k(0, 0) = scaleX, k(0, 2) = pp.x, k(1, 1) = scaleY, k(1, 2) = pp.y, k(2, 2) = 1.0;
+        return k;
+    }
+};
+
+// geometry::Pose3: world -> camera rotation and camera centre
+struct Pose
+{
+    Matrix3x3 rotation;
+    Point3d center;
+};
+
+struct Observation
+{
+    double x = 0.0, y = 0.0;  // full-size image pixels
+};
+struct Landmark
+{
+    Point3d X;
+    std::map<IndexT, Observation> observations;  // viewId -> observation (ordered like the reference's stl::flat_map)
+};
+
+struct SfMData
+{
+    std::map<IndexT, View> views;  // ordered by viewId like sfmData::Views (HashMap iteration order is unspecified in the
+                                   // reference; MultiViewParams only depends on it for the camera index <-> viewId map)
+    std::map<IndexT, Intrinsic> intrinsics;
+    std::map<IndexT, Pose> poses;
+    std::map<IndexT, Landmark> landmarks;
+
+    // sfmData/SfMData.hpp: isPoseAndIntrinsicDefined
+    bool isPoseAndIntrinsicDefined(const View& v) const
+    {
+        return v.intrinsicId != UndefinedIndexT && v.poseId != UndefinedIndexT && intrinsics.count(v.intrinsicId) && poses.count(v.poseId);
+    }
+    const Pose& getPose(const View& v) const { return poses.at(v.poseId); }
+    const Intrinsic& getIntrinsic(const View& v) const { return intrinsics.at(v.intrinsicId); }
+};
+
+// sfmDataIO::load for .sfm / .json; throws std::runtime_error with the reason
+void loadSfMData(SfMData& out, const std::string& filename);
+
+// camera::angleBetweenRays (camera/IntrinsicBase.hpp:475-517): degrees between the world rays of two observations
+double angleBetweenRays(const Pose& pose1, const Intrinsic& intr1, const Pose& pose2, const Intrinsic& intr2, const Point2d& x1, const Point2d& x2);
+
+} // namespace avdm_host

@@ -1,0 +1,153 @@
+"""GPU tests of the C++ host + CLI (aliceVision_depthMapEstimation): .sfm + EXR in, EXR out, on an MI355X.
+
+  * single tile: the CLI's maps must equal, bit for bit, what the ctypes harness (alicevision_amd/pipeline.py, itself parity
+    tested stage by stage against the oracle in test_gpu_parity.py) computes from the same planes / T cameras — this pins the
+    C++ sequencing of Sgm / Refine / DepthMapEstimator and the EXR writer;
+  * against the CPU oracle end to end (depth RMSE < 1e-3, BASELINE.json) and against the analytic ground truth;
+  * tiled run (2 x 2 tiles, batched SGM aggregation, weighted merge): valid everywhere and as close to the ground truth as
+    the single-tile run.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from alicevision_amd import abi, exr_io, scene_io
+from alicevision_amd.synthetic import make_scene
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "alicevision_amd", "bin", "aliceVision_depthMapEstimation")
+W, H, NVIEWS = 640, 480, 5
+OPT_ITERS = 20
+
+
+def run_cli(args, check=True):
+    r = subprocess.run([CLI] + [str(a) for a in args], capture_output=True, text=True, timeout=900)
+    if check:
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    assert os.path.exists(CLI), "host CLI not built (python -c 'import __graft_entry__ as g; g.build()')"
+    d = str(tmp_path_factory.mktemp("scene"))
+    sc = make_scene(NVIEWS, W, H, seed=5, baseline=0.9, amp=0.6)
+    lms = scene_io.sample_landmarks(sc, 500, amp=0.6)
+    os.makedirs(os.path.join(d, "images"), exist_ok=True)
+    sfm = os.path.join(d, "scene.sfm")
+    with open(sfm, "w") as f:
+        json.dump(scene_io.sfm_dict(sc, lms, os.path.join(d, "images")), f)
+    for i in range(NVIEWS):
+        im = sc.images[i].numpy()
+        exr_io.write_exr(os.path.join(d, "images", "%d.exr" % scene_io.view_id(i)), {"R": im[..., 0], "G": im[..., 1], "B": im[..., 2], "A": im[..., 3]},
+                         compression=0)
+    return sc, sfm, os.path.join(d, "images"), d
+
+
+def common_args(sfm, img, out):
+    return ["-i", sfm, "--imagesFolder", img, "-o", out, "--downscale", 1, "--rangeStart", 0, "--rangeSize", 1, "--sgmMaxDepths", 96,
+            "--colorOptimizationNbIterations", OPT_ITERS, "-v", "warning"]
+
+
+def read_maps(out, vid=None):
+    vid = scene_io.view_id(0) if vid is None else vid
+    dm, dinfo = exr_io.read_exr(os.path.join(out, "%d_depthMap.exr" % vid))
+    sm, sinfo = exr_io.read_exr(os.path.join(out, "%d_simMap.exr" % vid))
+    return dm["Y"], sm["Y"], dinfo, sinfo
+
+
+def test_single_tile_equals_harness_and_oracle(dataset):
+    import torch
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    from oracle import oracle
+    sc, sfm, img, d = dataset
+    out = os.path.join(d, "out_single")
+    args = common_args(sfm, img, out)
+    plan = json.loads(run_cli(args + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
+    t0 = plan["tiles"][0]
+    assert t0["rc"] == 0 and t0["nbTiles"] == 1 and len(t0["depths"]) > 12, t0
+    run_cli(args)
+    depth, sim, dinfo, sinfo = read_maps(out)
+    assert depth.shape == (H, W)
+    assert dinfo["channel_types"]["Y"] == 2 and sinfo["channel_types"]["Y"] == 1  # float depth, half sim (mapIO.cpp:517-526)
+    assert exr_io.attr_value(dinfo, "AliceVision:downscale") == 1
+    assert exr_io.attr_value(dinfo, "AliceVision:nbDepthValues") == int((depth > 0).sum())
+    P = exr_io.attr_value(dinfo, "AliceVision:P").reshape(4, 4)[:3]
+    Pref = sc.K @ np.concatenate([sc.R[0], (-sc.R[0] @ sc.C[0])[:, None]], axis=1)
+    assert np.allclose(P, Pref, atol=1e-6), (P, Pref)
+
+    # the harness on the same plan
+    sgm = abi.SgmParams.default(scale=plan["sgmScale"], stepXY=plan["sgmStepXY"])
+    ref = abi.RefineParams.default(optimizationNbIterations=OPT_ITERS)
+    depths = np.asarray(t0["depths"], np.float32)
+    ranges = [(a, a + n) for a, n in t0["depthsTcLimits"]]
+    torch.cuda.set_device(0)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(NVIEWS)]
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+    h.run_sgm(0, t0["sgmTCams"], depths, tc_ranges=ranges)
+    got = h.run_refine(0, t0["refineTCams"]).cpu().numpy()
+    assert np.array_equal(got[..., 0], depth), float(np.abs(got[..., 0] - depth).max())
+    assert np.array_equal(got[..., 1].astype(np.float16).astype(np.float32), sim)
+
+    # the oracle end to end on the same plan (BASELINE.json: depth RMSE < 1e-3)
+    o = oracle.OracleDepthMap(sc.images.numpy(), sc.K, sc.R, sc.C, sgm, ref)
+    with oracle.well_posed():
+        o.run_sgm(0, t0["sgmTCams"], depths, tc_ranges=ranges)
+        want = o.run_refine(0, t0["refineTCams"])
+    both = (want[..., 0] > 0) & (depth > 0)
+    assert ((want[..., 0] > 0) != (depth > 0)).mean() < 0.005
+    err = np.sort((depth - want[..., 0])[both] ** 2)
+    rmse = float(np.sqrt(err[: int(0.995 * err.size)].mean()))
+    assert rmse < 1e-3, rmse
+
+    # analytic ground truth (distance along the ray)
+    gt = sc.gt_depth.numpy()
+    inner = np.zeros_like(both)
+    inner[16:-16, 16:-16] = True
+    m = both & inner
+    assert m.mean() > 0.6
+    rel = np.abs(depth - gt)[m] / gt[m]
+    assert np.median(rel) < 2e-3, float(np.median(rel))
+
+
+def test_tiled_run_merges(dataset):
+    sc, sfm, img, d = dataset
+    out1, out4 = os.path.join(d, "out_single_b"), os.path.join(d, "out_tiled")
+    base = common_args(sfm, img, out1) + ["--autoAdjustSmallImage", 0]
+    run_cli(base + ["--tileBufferWidth", 640, "--tileBufferHeight", 640])
+    args4 = common_args(sfm, img, out4) + ["--autoAdjustSmallImage", 0, "--tileBufferWidth", 416, "--tileBufferHeight", 352, "--tilePadding", 32]
+    plan = json.loads(run_cli(args4 + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
+    assert len(plan["tiles"]) == 4, [t["roi"] for t in plan["tiles"]]
+    run_cli(args4 + ["--exportIntermediateDepthSimMaps", 1])
+    d1, s1, _, _ = read_maps(out1)
+    d4, s4, info4, _ = read_maps(out4)
+    assert d4.shape == d1.shape == (H, W)
+    # the merged file is a whole image again and the tile files of the intermediate maps were merged and removed
+    assert info4["data_window"] == (0, 0, W - 1, H - 1)
+    leftovers = [f for f in os.listdir(out4) if f.count("_") >= 3 and f.endswith(".exr") and f.split("_")[-1][0].isdigit()]
+    assert not leftovers, leftovers
+    assert os.path.exists(os.path.join(out4, "%d_depthMap_sgm.exr" % scene_io.view_id(0)))
+    assert os.path.exists(os.path.join(out4, "%d_depthMap_refinedFused.exr" % scene_io.view_id(0)))
+    gt = sc.gt_depth.numpy()
+    inner = np.zeros(gt.shape, bool)
+    inner[16:-16, 16:-16] = True
+    for dm in (d1, d4):
+        m = (dm > 0) & inner
+        assert m.mean() > 0.6, m.mean()
+        assert np.median(np.abs(dm - gt)[m] / gt[m]) < 2e-3
+    # tiles see a different neighbourhood near their borders only: most pixels agree closely with the single-tile run
+    m = (d1 > 0) & (d4 > 0) & inner
+    assert np.median(np.abs(d1 - d4)[m]) < 1e-3
+
+
+def test_cli_fails_loudly_without_inputs(dataset):
+    sc, sfm, img, d = dataset
+    r = run_cli(["-i", os.path.join(d, "missing.sfm"), "--imagesFolder", img, "-o", os.path.join(d, "o")], check=False)
+    assert r.returncode == 1 and "cannot be read" in (r.stdout + r.stderr)
+    r = run_cli(["-i", sfm, "--imagesFolder", img], check=False)
+    assert r.returncode == 1 and "required" in r.stderr
