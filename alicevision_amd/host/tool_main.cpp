@@ -1,0 +1,106 @@
+// avdm_host_tool — small command-line probes of the host library for the CPU test-suite (no GPU needed):
+//   tiles W H bufW bufH padding maxDownscale           print the tile ROI list (getTileRoiList)
+//   exr-copy in.exr out.exr half(0|1)                   decode an EXR and write it back (reader + writer round trip)
+//   exr-info in.exr                                     print size, windows, channels and attribute names / types
+//   merge-ones sfm imagesFolder outFolder downscale bufW bufH padding scaleStep
+//                                                       merge all-ones tiles of camera 0 with addTileMapWeighted and write the sum
+//   quantile left|right p v0 v1 ...                     boost-style tail quantile used by SgmDepthList
+#include "DepthMapEstimator.hpp"
+#include "MultiViewParams.hpp"
+#include "depthMapUtils.hpp"
+#include "exr.hpp"
+#include "log.hpp"
+#include "params.hpp"
+#include "sfmData.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+
+using namespace avdm_host;
+
+static int usage()
+{
+    std::cerr << "usage: avdm_host_tool tiles|exr-copy|exr-info|merge-ones ..." << std::endl;
+    return 2;
+}
+
+int main(int argc, char** argv)
+{
+    try
+    {
+        if(argc < 2)
+            return usage();
+        const std::string cmd = argv[1];
+        Logger::setLevel("error");
+        if(cmd == "tiles" && argc == 8)
+        {
+            TileParams tp;
+            const int W = std::atoi(argv[2]), H = std::atoi(argv[3]);
+            tp.bufferWidth = std::atoi(argv[4]);
+            tp.bufferHeight = std::atoi(argv[5]);
+            tp.padding = std::atoi(argv[6]);
+            std::vector<ROI> rois;
+            getTileRoiList(tp, W, H, std::atoi(argv[7]), rois);
+            for(const ROI& r : rois)
+                std::cout << r.x.begin << " " << r.x.end << " " << r.y.begin << " " << r.y.end << "\n";
+            return 0;
+        }
+        if(cmd == "exr-copy" && argc == 5)
+        {
+            ExrImage img;
+            readExr(argv[2], img);
+            std::vector<ExrChannelIn> ch;
+            for(size_t i = 0; i < img.channelNames.size(); ++i)
+                ch.push_back({img.channelNames[i], img.channels[i].data()});
+            writeExr(argv[3], img.width, img.height, ch, std::atoi(argv[4]) != 0, img.attributes, img.dataX0, img.dataY0, img.displayW, img.displayH);
+            return 0;
+        }
+        if(cmd == "exr-info" && argc == 3)
+        {
+            ExrImage img;
+            readExr(argv[2], img, true);
+            std::cout << "size " << img.width << " " << img.height << "\norigin " << img.dataX0 << " " << img.dataY0 << "\ndisplay " << img.displayW << " "
+                      << img.displayH << "\nchannels";
+            for(const auto& n : img.channelNames)
+                std::cout << " " << n;
+            std::cout << "\n";
+            for(const auto& a : img.attributes.list)
+                std::cout << "attr " << a.name << " " << a.type << " " << a.data.size() << "\n";
+            return 0;
+        }
+        if(cmd == "merge-ones" && argc == 10)
+        {
+            SfMData sfm;
+            loadSfMData(sfm, argv[2]);
+            MultiViewParams mp(sfm, argv[3], argv[4], std::atoi(argv[5]));
+            TileParams tp;
+            tp.bufferWidth = std::atoi(argv[6]);
+            tp.bufferHeight = std::atoi(argv[7]);
+            tp.padding = std::atoi(argv[8]);
+            const int scaleStep = std::atoi(argv[9]);
+            std::vector<ROI> rois;
+            getTileRoiList(tp, mp.getMaxImageWidth(), mp.getMaxImageHeight(), scaleStep, rois);
+            std::vector<Float2Tile> tiles(rois.size());
+            const int tw = divideRoundUp(tp.bufferWidth, scaleStep), th = divideRoundUp(tp.bufferHeight, scaleStep);
+            for(size_t i = 0; i < rois.size(); ++i)
+            {
+                tiles[i].allocate(std::max(tw, divideRoundUp(mp.getWidth(0), scaleStep)), std::max(th, divideRoundUp(mp.getHeight(0), scaleStep)));
+                for(size_t k = 0; k < tiles[i].data.size(); k += 2)
+                {
+                    tiles[i].data[k] = 1.0f;       // "depth"
+                    tiles[i].data[k + 1] = 0.5f;   // "sim"
+                }
+            }
+            writeDepthSimMapFromTileList(0, mp, tp, rois, tiles, scaleStep, 1);
+            return 0;
+        }
+        return usage();
+    }
+    catch(const std::exception& e)
+    {
+        std::cerr << "error: " << e.what() << std::endl;
+        return 1;
+    }
+}

@@ -1,0 +1,290 @@
+"""CPU tests of the C++ host (alicevision_amd/host): no GPU needed.
+
+The C++ code is exercised through the CLI's --dryRun (tiles, T cameras and depth-plane lists as JSON) and through
+bin/avdm_host_tool, and compared with the independent Python restatement oracle/host_oracle.py and with the numpy EXR codec
+alicevision_amd/exr_io.py.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from alicevision_amd import exr_io, scene_io
+from alicevision_amd.synthetic import make_scene
+from oracle import host_oracle as ho
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "alicevision_amd", "bin", "aliceVision_depthMapEstimation")
+TOOL = os.path.join(ROOT, "alicevision_amd", "bin", "avdm_host_tool")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "alicevision_amd", "host"), "-s", "-j8"], check=True)
+    assert os.path.exists(CLI) and os.path.exists(TOOL)
+
+
+def run(cmd, check=True):
+    r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=600)
+    if check:
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r
+
+
+@pytest.fixture(scope="module")
+def scene(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("host_scene"))
+    sc = make_scene(6, 640, 480, seed=9, baseline=0.9, amp=0.6)
+    lms = scene_io.sample_landmarks(sc, 600, amp=0.6)
+    os.makedirs(os.path.join(d, "images"))
+    sfm = os.path.join(d, "scene.sfm")
+    with open(sfm, "w") as f:
+        json.dump(scene_io.sfm_dict(sc, lms, os.path.join(d, "images")), f)
+    for i in range(6):
+        im = sc.images[i].numpy()
+        exr_io.write_exr(os.path.join(d, "images", "%d.exr" % scene_io.view_id(i)), {"R": im[..., 0], "G": im[..., 1], "B": im[..., 2], "A": im[..., 3]},
+                         compression=0)
+    return sc, lms, sfm, os.path.join(d, "images"), d
+
+
+def plan_of(sfm, img, out, extra=()):
+    r = run([CLI, "-i", sfm, "--imagesFolder", img, "-o", out, "--downscale", 1, "--dryRun", 1, "-v", "error"] + list(extra))
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+# ------------------------------------------------------------------------------------------------------------- tiling
+@pytest.mark.parametrize("case", [(4000, 3000, 1024, 1024, 64, 4), (6000, 4000, 1664, 1152, 64, 4), (1920, 1080, 1024, 1024, 64, 4),
+                                  (640, 480, 1024, 1024, 64, 2), (1001, 777, 300, 260, 32, 4), (5000, 900, 1024, 1024, 128, 8)])
+def test_tile_roi_list(case):
+    W, H, bw, bh, pad, md = case
+    got = [tuple(int(v) for v in l.split()) for l in run([TOOL, "tiles", W, H, bw, bh, pad, md]).stdout.strip().splitlines()]
+    want = ho.tile_roi_list(bw, bh, pad, W, H, md)
+    assert got == want
+    # the tiles cover the image and each fits its buffer
+    cover = np.zeros((H, W), bool)
+    for x0, x1, y0, y1 in got:
+        cover[y0:y1, x0:x1] = True
+        if len(got) > 1:
+            assert x1 - x0 <= bw and y1 - y0 <= bh
+    assert cover.all()
+    if case == (6000, 4000, 1664, 1152, 64, 4):
+        assert len(got) == 16  # BASELINE cfg5: 4 x 4 tiles
+
+
+# ------------------------------------------------------------------------------------- T cameras and depth-plane lists
+def test_plan_matches_restatement_single_tile(scene):
+    sc, lms, sfm, img, d = scene
+    plan = plan_of(sfm, img, os.path.join(d, "o1"), ["--sgmMaxDepths", 96])
+    assert plan["sgmStepXY"] == 1 and plan["sgmMaxTCamsPerTile"] == 10  # single-tile auto adjustment (main_depthMapEstimation.cpp:360-390)
+    cams = ho.Cameras(sc.K, sc.R, sc.C, sc.width, sc.height)
+    assert len(plan["tiles"]) == 6
+    for t in plan["tiles"]:
+        rc = t["rc"]
+        assert t["viewId"] == scene_io.view_id(rc) and t["roi"] == [0, 640, 0, 480]
+        tc = ho.nearest_cams_from_landmarks(cams, lms, rc, 10)
+        sgm_t = ho.tile_nearest_cams(cams, lms, rc, 10, tc, tuple(t["roi"]))
+        assert t["sgmTCams"] == sgm_t and t["refineTCams"] == sgm_t
+        depths, limits = ho.depth_list(cams, lms, rc, sgm_t, tuple(t["roi"]), sgm_scale=plan["sgmScale"], max_depths=96)
+        assert len(depths) == len(t["depths"]) > 8
+        assert np.allclose(np.asarray(depths, np.float64), np.asarray(t["depths"]), rtol=2e-6), np.abs(np.asarray(depths) - np.asarray(t["depths"])).max()
+        assert [list(l) for l in limits] == t["depthsTcLimits"]
+        assert np.all(np.diff(t["depths"]) > 0)
+        zmin, zmax = sc.z_range
+        assert t["depths"][0] < zmin + 0.2 and t["depths"][-1] > zmax - 0.4
+
+
+def test_plan_matches_restatement_tiled_and_capped(scene):
+    sc, lms, sfm, img, d = scene
+    extra = ["--autoAdjustSmallImage", 0, "--tileBufferWidth", 416, "--tileBufferHeight", 352, "--tilePadding", 32, "--sgmMaxDepths", 12,
+             "--sgmDepthListPerTile", 1, "--maxTCams", 4, "--sgmMaxTCamsPerTile", 3, "--refineMaxTCamsPerTile", 2, "--rangeStart", 1, "--rangeSize", 2]
+    plan = plan_of(sfm, img, os.path.join(d, "o2"), extra)
+    cams = ho.Cameras(sc.K, sc.R, sc.C, sc.width, sc.height)
+    rois = ho.tile_roi_list(416, 352, 32, 640, 480, 4)
+    assert len(plan["tiles"]) == 2 * len(rois) == 8
+    assert [t["rc"] for t in plan["tiles"]] == [1] * 4 + [2] * 4
+    for t in plan["tiles"]:
+        rc, roi = t["rc"], tuple(t["roi"])
+        assert roi == rois[t["id"]]
+        tc = ho.nearest_cams_from_landmarks(cams, lms, rc, 4)
+        assert t["sgmTCams"] == ho.tile_nearest_cams(cams, lms, rc, 3, tc, roi)
+        assert t["refineTCams"] == ho.tile_nearest_cams(cams, lms, rc, 2, tc, roi)
+        depths, limits = ho.depth_list(cams, lms, rc, t["sgmTCams"], roi, sgm_scale=2, max_depths=12, depth_list_per_tile=True)
+        assert len(t["depths"]) == len(depths) <= 12
+        assert np.allclose(np.asarray(depths, np.float64), np.asarray(t["depths"]), rtol=2e-6)
+        assert [list(l) for l in limits] == t["depthsTcLimits"]
+
+
+def test_plan_from_image_metadata_equals_plan_from_sfm(scene, tmp_path):
+    """MultiViewParams prefers the AliceVision:P matrix stored in the image (MultiViewParams.cpp:150-156)"""
+    sc, lms, sfm, img, d = scene
+    img2 = str(tmp_path / "images_p")
+    os.makedirs(img2)
+    for i in range(6):
+        P = sc.K @ np.concatenate([sc.R[i], (-sc.R[i] @ sc.C[i])[:, None]], axis=1)
+        tiny = np.zeros((sc.height, sc.width), np.float32)
+        exr_io.write_exr(os.path.join(img2, "%d.exr" % scene_io.view_id(i)), {"R": tiny, "G": tiny, "B": tiny},
+                         attributes={"AliceVision:P": exr_io.m44d(list(P.flatten()) + [0, 0, 0, 1]), "AliceVision:downscale": 1}, compression=3)
+    a = plan_of(sfm, img, str(tmp_path / "oa"), ["--sgmMaxDepths", 64])
+    b = plan_of(sfm, img2, str(tmp_path / "ob"), ["--sgmMaxDepths", 64])
+    for ta, tb in zip(a["tiles"], b["tiles"]):
+        assert ta["sgmTCams"] == tb["sgmTCams"] and ta["depthsTcLimits"] == tb["depthsTcLimits"]
+        assert np.allclose(ta["depths"], tb["depths"], rtol=1e-6)
+
+
+def test_process_downscale_plan(scene):
+    sc, lms, sfm, img, d = scene
+    r = run([CLI, "-i", sfm, "--imagesFolder", img, "-o", os.path.join(d, "o3"), "--downscale", 2, "--dryRun", 1, "-v", "error", "--sgmMaxDepths", 64])
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    cams = ho.Cameras(sc.K, sc.R, sc.C, sc.width, sc.height, process_downscale=2)
+    t = plan["tiles"][0]
+    assert t["roi"] == [0, 320, 0, 240]
+    tc = ho.nearest_cams_from_landmarks(cams, lms, 0, 10)
+    sgm_t = ho.tile_nearest_cams(cams, lms, 0, 10, tc, tuple(t["roi"]))
+    assert t["sgmTCams"] == sgm_t
+    depths, limits = ho.depth_list(cams, lms, 0, sgm_t, tuple(t["roi"]), sgm_scale=plan["sgmScale"], max_depths=64)
+    assert np.allclose(np.asarray(depths, np.float64), np.asarray(t["depths"]), rtol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------- EXR
+@pytest.mark.parametrize("compression", [0, 2, 3])
+@pytest.mark.parametrize("half", [False, True])
+def test_exr_cpp_reads_python_writes_and_back(tmp_path, compression, half):
+    rng = np.random.RandomState(3)
+    h, w = 37, 53
+    chans = {"R": rng.rand(h, w).astype(np.float32), "G": (rng.rand(h, w) * 1000).astype(np.float32), "B": -rng.rand(h, w).astype(np.float32),
+             "A": np.ones((h, w), np.float32)}
+    chans["G"][3, 5] = 0.0
+    chans["R"][0, 0] = 6.1e-5  # near the half subnormal boundary
+    a, b = str(tmp_path / "a.exr"), str(tmp_path / "b.exr")
+    attrs = {"AliceVision:downscale": 2, "note": "hello", "AliceVision:P": exr_io.m44d(range(16)), "f": 1.5}
+    exr_io.write_exr(a, chans, attributes=attrs, half=half, compression=compression, data_origin=(4, 6), display_size=(100, 90))
+    run([TOOL, "exr-copy", a, b, 1 if half else 0])
+    got, info = exr_io.read_exr(b)
+    src, _ = exr_io.read_exr(a)
+    assert info["data_window"] == (4, 6, 4 + w - 1, 6 + h - 1) and info["display_window"] == (0, 0, 99, 89)
+    for n in chans:
+        assert np.array_equal(got[n], src[n]), n
+        if not half:
+            assert np.array_equal(got[n], chans[n])
+    assert exr_io.attr_value(info, "AliceVision:downscale") == 2 and exr_io.attr_value(info, "note") == "hello"
+    assert np.array_equal(exr_io.attr_value(info, "AliceVision:P"), np.arange(16.0)) and exr_io.attr_value(info, "f") == 1.5
+    lines = run([TOOL, "exr-info", b]).stdout
+    assert "channels A B G R" in lines and "attr AliceVision:P m44d 128" in lines
+
+
+def test_half_conversion_matches_numpy(tmp_path):
+    """the C++ float -> half rounding (round to nearest even, subnormals, overflow) against numpy's"""
+    vals = np.concatenate([np.linspace(-70000, 70000, 4001), np.logspace(-9, 5, 3000), -np.logspace(-9, 5, 500), [0.0, 65504.0, 65519.9, 65520.0, 5.96e-8,
+                           2.98e-8, 2.99e-8, 1e-10]]).astype(np.float32)
+    n = vals.size
+    w = 64
+    pad = (-n) % w
+    arr = np.concatenate([vals, np.zeros(pad, np.float32)]).reshape(-1, w)
+    a, b = str(tmp_path / "h_in.exr"), str(tmp_path / "h_out.exr")
+    exr_io.write_exr(a, {"Y": arr}, half=False, compression=0)
+    run([TOOL, "exr-copy", a, b, 1])
+    got, _ = exr_io.read_exr(b)
+    with np.errstate(over="ignore"):
+        want = arr.astype(np.float16).astype(np.float32)
+    assert np.array_equal(got["Y"], want)
+
+
+# --------------------------------------------------------------------------------------------------- tile merge weights
+def test_tile_merge_is_a_partition_of_unity(scene, tmp_path):
+    sc, lms, sfm, img, d = scene
+    out = str(tmp_path / "merge")
+    os.makedirs(out)
+    bw, bh, pad, ss = 416, 352, 32, 1
+    run([TOOL, "merge-ones", sfm, img, out, 1, bw, bh, pad, ss])
+    dm, dinfo = exr_io.read_exr(os.path.join(out, "%d_depthMap.exr" % scene_io.view_id(0)))
+    sm, sinfo = exr_io.read_exr(os.path.join(out, "%d_simMap.exr" % scene_io.view_id(0)))
+    want = np.zeros((480, 640), np.float32)
+    for roi in ho.tile_roi_list(bw, bh, pad, 640, 480, ss):
+        wmap, (bx, ex, by, ey) = ho.tile_weight_map(roi, 640, 480, pad, ss)
+        want[by:ey, bx:ex] += wmap
+    assert np.array_equal(dm["Y"], want)
+    assert np.allclose(dm["Y"], 1.0, atol=1e-6)  # overlapping tiles blend with weights that sum to one
+    assert np.allclose(sm["Y"], 0.5, atol=1e-3)
+    # metadata of a merged full-size map (mapIO.cpp:440-512)
+    assert exr_io.attr_value(dinfo, "AliceVision:roiEndX") == 640 and exr_io.attr_value(dinfo, "AliceVision:tileBufferWidth") == 1024
+    assert exr_io.attr_value(dinfo, "AliceVision:nbDepthValues") == 640 * 480
+    assert abs(exr_io.attr_value(dinfo, "AliceVision:minDepth") - 1.0) < 1e-6
+    assert np.allclose(exr_io.attr_value(dinfo, "AliceVision:CArr"), sc.C[0], atol=1e-9)
+    iCam = exr_io.attr_value(dinfo, "AliceVision:iCamArr").reshape(3, 3)
+    assert np.allclose(iCam, np.linalg.inv(sc.R[0]) @ np.linalg.inv(sc.K), atol=1e-9)
+    assert "AliceVision:SensorWidth" in dinfo["attributes"]  # the view's own metadata is carried over
+
+
+def test_quarter_resolution_merge(scene, tmp_path):
+    sc, lms, sfm, img, d = scene
+    out = str(tmp_path / "merge4")
+    os.makedirs(out)
+    run([TOOL, "merge-ones", sfm, img, out, 1, 416, 352, 32, 4])
+    dm, dinfo = exr_io.read_exr(os.path.join(out, "%d_depthMap.exr" % scene_io.view_id(0)))
+    assert dm["Y"].shape == (120, 160)
+    want = np.zeros((120, 160), np.float32)
+    for roi in ho.tile_roi_list(416, 352, 32, 640, 480, 4):
+        wmap, (bx, ex, by, ey) = ho.tile_weight_map(roi, 640, 480, 32, 4)
+        want[by:ey, bx:ex] += wmap
+    assert np.array_equal(dm["Y"], want)
+    assert exr_io.attr_value(dinfo, "AliceVision:downscale") == 4
+
+
+# ---------------------------------------------------------------------------------------------------------------- CLI
+def test_cli_argument_errors(scene):
+    sc, lms, sfm, img, d = scene
+    base = [CLI, "-i", sfm, "--imagesFolder", img, "-o", os.path.join(d, "oe"), "--dryRun", 1]
+    assert run(base + ["--downscale", 0], check=False).returncode == 1
+    assert run(base + ["--sgmScale", 1, "--sgmStepXY", 1, "--refineScale", 2], check=False).returncode == 1  # SGM scale step < Refine scale step
+    assert run(base + ["--sgmScale", 3, "--sgmStepXY", 1, "--refineScale", 2], check=False).returncode == 1  # not a multiple
+    assert run(base + ["--minViewAngle", 80, "--maxViewAngle", 70], check=False).returncode == 1
+    assert run(base + ["--nosuchflag", 1], check=False).returncode == 1
+    assert run(base + ["--sgmWSH", "abc"], check=False).returncode == 1
+    assert run(base + ["--rangeStart", -1, "--rangeSize", 2], check=False).returncode == 1
+    r = run(base + ["--rangeStart", 50, "--rangeSize", 2, "--downscale", 1], check=False)
+    assert r.returncode == 0 and "No camera to process" in r.stdout
+    assert run(base + ["--sgmUseCustomPatchPattern", 1], check=False).returncode == 1  # not built: refused loudly
+    assert run([CLI, "--help"], check=False).returncode == 0
+    r = run([CLI, "-i", os.path.join(d, "nope.abc"), "--imagesFolder", img, "-o", d, "--dryRun", 1], check=False)
+    assert r.returncode == 1 and "Alembic" in r.stdout + r.stderr
+
+
+def test_sfm_reader_variants(scene, tmp_path):
+    """bare (unquoted) numbers and an older file version with pxFocalLength are read to the same cameras"""
+    sc, lms, sfm, img, d = scene
+    doc = json.load(open(sfm))
+
+    def unquote(o):
+        if isinstance(o, dict):
+            return {k: (v if k in ("path", "type", "serialNumber", "descType", "initializationMode", "distortionType", "undistortionType",
+                                   "distortionInitializationMode") else unquote(v)) for k, v in o.items()}
+        if isinstance(o, list):
+            return [unquote(v) for v in o]
+        try:
+            return int(o)
+        except (TypeError, ValueError):
+            try:
+                return float(o)
+            except (TypeError, ValueError):
+                return o
+
+    bare = unquote(doc)
+    bare["version"] = ["1", "2", "11"]
+    p2 = str(tmp_path / "bare.sfm")
+    json.dump(bare, open(p2, "w"))
+    old = json.loads(json.dumps(doc))
+    old["version"] = ["1", "2", "1"]
+    for it in old["intrinsics"]:
+        it["pxFocalLength"] = [str(sc.K[0, 0]), str(sc.K[1, 1])]
+        it["type"] = "radial3"
+        it["distortionParams"] = ["0", "0", "0"]
+        del it["focalLength"], it["distortionType"]
+    p3 = str(tmp_path / "old.sfm")
+    json.dump(old, open(p3, "w"))
+    ref = plan_of(sfm, img, str(tmp_path / "o_ref"), ["--sgmMaxDepths", 48])
+    for p in (p2, p3):
+        got = plan_of(p, img, str(tmp_path / "o_x"), ["--sgmMaxDepths", 48])
+        for ta, tb in zip(ref["tiles"], got["tiles"]):
+            assert ta["sgmTCams"] == tb["sgmTCams"] and np.allclose(ta["depths"], tb["depths"], rtol=1e-6)
