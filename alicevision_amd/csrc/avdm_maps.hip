@@ -187,6 +187,120 @@ __global__ void __launch_bounds__(256) normal_upscale_kernel(float* out, int out
     d[2] = s[2];
 }
 
+// depthSimMapComputeNormal_kernel (mapKernels.cuh:393-477, wsh = 3) + cuda_stat3d (cuda/device/eig33.cuh:351-445): plane fit by PCA of
+// the 7 x 7 neighbourhood's 3-D points, normal = eigenvector of the smallest eigenvalue of the (double precision) covariance matrix,
+// oriented towards the camera.  The reference solves the symmetric 3 x 3 problem with tred2 / tql2; any accurate solver yields the same
+// vector up to rounding: here cyclic Jacobi rotations in double (tolerance class).  Neighbours outside the ROI are skipped
+// on all four sides — the reference only checks the lower bounds and reads whatever the allocated map holds beyond the tile.
+__device__ __forceinline__ void jacobi_rotate(double (&A)[3][3], double (&V)[3][3], int p, int q)
+{
+    if(fabs(A[p][q]) < 1e-300)
+        return;
+    const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+    for(int k = 0; k < 3; ++k)
+    {
+        const double akp = A[k][p], akq = A[k][q];
+        A[k][p] = c * akp - sn * akq;
+        A[k][q] = sn * akp + c * akq;
+    }
+#pragma unroll
+    for(int k = 0; k < 3; ++k)
+    {
+        const double apk = A[p][k], aqk = A[q][k];
+        A[p][k] = c * apk - sn * aqk;
+        A[q][k] = sn * apk + c * aqk;
+    }
+#pragma unroll
+    for(int k = 0; k < 3; ++k)
+    {
+        const double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - sn * vkq;
+        V[k][q] = sn * vkp + c * vkq;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+  compute_normal_kernel(float* out, int out_pitch, const float2* __restrict__ depthSim, int in_pitch, avdm_camera_t rc, int stepXY, avdm_roi_t roi)
+{
+    MAP_XY();
+    const int roiW = (int)(roi.x.end - roi.x.begin), roiH = (int)(roi.y.end - roi.y.begin);
+    if((int)roiX >= roiW || (int)roiY >= roiH)
+        return;
+    float* o = (float*)((char*)out + (long long)roiY * out_pitch) + 3 * roiX;
+    const unsigned x = (roi.x.begin + roiX) * (unsigned)stepXY, y = (roi.y.begin + roiY) * (unsigned)stepXY;
+    const float in_depth = ((const float2*)((const char*)depthSim + (long long)roiY * in_pitch))[roiX].x;
+    if(in_depth <= 0.0f)
+    {
+        o[0] = o[1] = o[2] = -1.f;
+        return;
+    }
+    const f3 p = get3DPointForPixelAndDepthFromRC(rc, (float)x, (float)y, in_depth);
+    const float pixSize = size(p - get3DPointForPixelAndDepthFromRC(rc, (float)(x + 1), (float)y, in_depth));
+    double xs = 0, ys = 0, zs = 0, xx = 0, yy = 0, zz = 0, xy = 0, xz = 0, yz = 0, count = 0;
+    for(int yp = -3; yp <= 3; ++yp)
+    {
+        const int ry = (int)roiY + yp;
+        if(ry < 0 || ry >= roiH)
+            continue;
+        for(int xp = -3; xp <= 3; ++xp)
+        {
+            const int rx = (int)roiX + xp;
+            if(rx < 0 || rx >= roiW)
+                continue;
+            const float depthP = ((const float2*)((const char*)depthSim + (long long)ry * in_pitch))[rx].x;
+            if((depthP > 0.0f) && (fabsf(depthP - in_depth) < 30.0f * pixSize))
+            {
+                const f3 q = get3DPointForPixelAndDepthFromRC(rc, (float)((int)x + xp), (float)((int)y + yp), depthP);
+                xx += (double)q.x * (double)q.x;
+                yy += (double)q.y * (double)q.y;
+                zz += (double)q.z * (double)q.z;
+                xy += (double)q.x * (double)q.y;
+                xz += (double)q.x * (double)q.z;
+                yz += (double)q.y * (double)q.z;
+                xs += (double)q.x;
+                ys += (double)q.y;
+                zs += (double)q.z;
+                count += 1.0;
+            }
+        }
+    }
+    if(count < 3.0)
+    {
+        o[0] = o[1] = o[2] = -1.f;
+        return;
+    }
+    const double xm = xs / count, ym = ys / count, zm = zs / count;
+    double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    A[0][0] = (xx - xs * xm - xs * xm + xm * xm * count) / count;
+    A[0][1] = A[1][0] = (xy - ys * xm - xs * ym + xm * ym * count) / count;
+    A[0][2] = A[2][0] = (xz - zs * xm - xs * zm + xm * zm * count) / count;
+    A[1][1] = (yy - ys * ym - ys * ym + ym * ym * count) / count;
+    A[1][2] = A[2][1] = (yz - zs * ym - ys * zm + ym * zm * count) / count;
+    A[2][2] = (zz - zs * zm - zs * zm + zm * zm * count) / count;
+    for(int sweep = 0; sweep < 8; ++sweep)
+    {
+        jacobi_rotate(A, V, 0, 1);
+        jacobi_rotate(A, V, 0, 2);
+        jacobi_rotate(A, V, 1, 2);
+    }
+    int k = 0;
+    if(A[1][1] < A[k][k])
+        k = 1;
+    if(A[2][2] < A[k][k])
+        k = 2;
+    f3 nn = normalize(f3{(float)V[0][k], (float)V[1][k], (float)V[2][k]});
+    const f3 pp = f3{(float)xm, (float)ym, (float)zm};
+    const f3 nc = normalize(ld3(rc.C) - p);
+    if((dot(pp + nn, nc) - dot(pp, nc)) < 0.0f)
+        nn = f3{-nn.x, -nn.y, -nn.z};
+    o[0] = nn.x;
+    o[1] = nn.y;
+    o[2] = nn.z;
+}
+
 __global__ void __launch_bounds__(256)
   smooth_thickness_kernel(float2* map, int pitch, float minThicknessInflate, float maxThicknessInflate, avdm_roi_t roi)
 {
@@ -594,8 +708,12 @@ int avdm_compute_sgm_upscaled_depth_pixsize_map(float* out_map, int out_pitch, c
 int avdm_depth_sim_map_compute_normal(float* out_normal, int out_pitch, const float* in_depth_sim, int in_pitch, const avdm_camera_t* rc, int stepXY,
                                       avdm_roi_t roi, void* stream)
 {
-    (void)out_normal; (void)out_pitch; (void)in_depth_sim; (void)in_pitch; (void)rc; (void)stepXY; (void)roi; (void)stream;
-    return set_error_msg(1, "avdm_depth_sim_map_compute_normal: not implemented yet (SURVEY §8f.1, off the default path)");
+    const unsigned roiW = roi.x.end - roi.x.begin, roiH = roi.y.end - roi.y.begin;
+    if(roiW == 0 || roiH == 0)
+        return 0;
+    hipLaunchKernelGGL(compute_normal_kernel, map_grid(roiW, roiH), dim3(256), 0, (hipStream_t)stream, out_normal, out_pitch, (const float2*)in_depth_sim,
+                       in_pitch, *rc, stepXY, roi);
+    AVDM_LAUNCH_CHECK("avdm_depth_sim_map_compute_normal");
 }
 
 int avdm_depth_sim_map_optimize_gradient_descent(float* out_opt_depth_sim, int out_pitch, float* img_variance, int var_pitch, float* tmp_depth,

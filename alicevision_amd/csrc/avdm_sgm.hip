@@ -65,11 +65,11 @@ struct SgmP2Tile
     float rcW, rcH;     // nominal level dims (DeviceMipmapImage::getDimensions)
     int beginX, beginY; // ROI offsets as the reference applies them to (v.x, v.y)
     int A, B;
+    int scanIsX;        // 1: the scanned axis is volume x (axisT.y == 0), 0: volume y
     float* p2;          // [A][B]
 };
 struct SgmP2Batch
 {
-    int scanIsX; // 1: the scanned axis is volume x (axisT.y == 0), 0: volume y
     float step;
     float P2w;
     int fixed8;
@@ -96,11 +96,11 @@ __global__ void __launch_bounds__(256) sgm_p2_map_kernel(SgmP2Batch S)
         P2 = 80.0f; // never read
     else
     {
-        const int vx = S.scanIsX ? b : a, vy = S.scanIsX ? a : b;
+        const int vx = T.scanIsX ? b : a, vy = T.scanIsX ? a : b;
         const int imX0 = (int)((float)(T.beginX + vx) * S.step);
         const int imY0 = (int)((float)(T.beginY + vy) * S.step);
-        const int imX1 = (int)((float)imX0 - S.step * (float)(S.scanIsX ? 1 : 0));
-        const int imY1 = (int)((float)imY0 - S.step * (float)(S.scanIsX ? 0 : 1));
+        const int imX1 = (int)((float)imX0 - S.step * (float)(T.scanIsX ? 1 : 0));
+        const int imY1 = (int)((float)imY0 - S.step * (float)(T.scanIsX ? 0 : 1));
         const float u0 = ((float)imX0 + 0.5f) / T.rcW, v0 = ((float)imY0 + 0.5f) / T.rcH;
         const float u1 = ((float)imX1 + 0.5f) / T.rcW, v1 = ((float)imY1 + 0.5f) / T.rcH;
         const float4 c0 = S.fixed8 ? tex2D_level<true>(T.L, u0, v0) : tex2D_level<false>(T.L, u0, v0);
@@ -121,6 +121,8 @@ struct SgmPathTile
     long long strideA, strideB; // bytes between consecutive columns / consecutive slices
     int A, B, Z;
     int colEnd;                 // exclusive prefix sum of A over the batch: workgroups [colEnd[t-1], colEnd[t]) belong to tile t
+    uint8_t* tmp;               // pair kernel only: scratch volume (tightly packed, z-fastest) for the reverse path's costs
+    long long tStrideA, tStrideB;
 };
 struct SgmPathBatch
 {
@@ -430,12 +432,12 @@ __global__ void __launch_bounds__(64 * AVDM_SGM_WPB) sgm_path_kernel(SgmPathBatc
                 if(LOAD_OUT)
                     ro[t][w] = *reinterpret_cast<const unsigned*>(outLoad + Ln.offw[w]);
             }
-            if(ibLoad < nSteps) // past the end: keep re-reading the last slice (harmless)
-            {
-                inLoad += dirStride;
-                outLoad += dirStride;
-                ++ibLoad;
-            }
+            // past the end: keep re-reading the last slice (harmless); selects, not a branch (see sgm_pair_kernel)
+            const bool more = ibLoad < nSteps;
+            const long long dIn = more ? dirStride : 0ll;
+            inLoad += dIn;
+            outLoad += dIn;
+            ibLoad += more ? 1 : 0;
         }
     };
 
@@ -624,6 +626,504 @@ __global__ void __launch_bounds__(256)
         *ds = make_float2(bestDepth, out_bestSim);
 }
 
+// =====================================================================================================================
+// PAIR kernel: the forward and the reverse path of one axis in ONE launch, two waves per column.
+//
+// The four path recurrences only read the INPUT volume; what is ordered is the running average into the output volume:
+//     out_k = (out_{k-1} * k + min(L_k, 255)) div (k + 1),   k = 0..3   (k = 2 * axis + direction)
+// A voxel of slice s is reached by the forward wave at step s and by the reverse wave at step B-1-s.  Whoever comes
+// first cannot always finish the average, so the column is cut at slice M ~ B/2:
+//   phase 1   forward wave: slices 1 .. M-1     out = avg_K(out, L_f)              (K = 0: plain store of L_f)
+//             reverse wave: slices B-2 .. M     stores L_r — into `out` when K = 0 (the average is symmetric then),
+//                                               into the scratch volume otherwise (out still holds out_{K-1})
+//   __syncthreads (both waves of a column live in the same workgroup)
+//   phase 2   forward wave: slices M .. B-2     out = avg_{K+1}(avg_K(out, L_f), L_r)   (K = 0: (L_f + L_r) >> 1)
+//                           slice  B-1          out = avg_K(out, L_f)              (the reverse path never touches it)
+//             reverse wave: slices M-1 .. 0     out = avg_{K+1}(out, L_r)          (slice 0 holds the 255 the forward
+//                                                                                    path writes first, as in the reference)
+// Per voxel the traffic is what the two sequential launches move (2 + 3 bytes for K = 0, 3 + 3 for K = 2): the pair
+// kernel halves the launches and DOUBLES the waves in flight (columns are the only parallelism of the recurrence).
+// Integer P1 only (the packed uint16 step with its fp32 fallback for P2 fractions close to 1); the sequential kernels remain
+// for non-integer P1.
+// =====================================================================================================================
+enum { SGM_FIRST_FWD = 0, SGM_FIRST_REV = 1, SGM_SECOND_FWD = 2, SGM_SECOND_REV = 3 };
+
+// n div (K+1) on packed uint16 pairs, n <= 1020
+template <int KP1>
+__device__ __forceinline__ unsigned pk_div(unsigned n)
+{
+    if(KP1 == 1)
+        return n;
+    if(KP1 == 2)
+        return as_u32(as_pk(n) >> (unsigned short)1);
+    if(KP1 == 4)
+        return as_u32(as_pk(n) >> (unsigned short)2);
+    const unsigned lo = ((n & 0xffffu) * 683u) >> 11, hi = ((n >> 16) * 683u) >> 11; // n div 3, exhaustively checked for n <= 1020
+    return lo | (hi << 16);
+}
+// (o * K + c) div (K + 1)
+template <int K>
+__device__ __forceinline__ unsigned pk_avg(unsigned o, unsigned c)
+{
+    if(K == 0)
+        return c;
+    return pk_div<K + 1>(as_u32(as_pk(o) * (unsigned short)K + as_pk(c)));
+}
+
+// packed uint16 step WITHOUT the output stage: updates P, returns min(L, 255) per plane pair in q
+template <int NW>
+__device__ __forceinline__ void sgm_lstep_u16(unsigned (&P)[2 * NW], const unsigned (&inw)[NW], unsigned iP2Pair, unsigned P1Pair,
+                                              const unsigned (&keepM)[2 * NW], const unsigned (&forceV)[2 * NW], unsigned (&q)[2 * NW])
+{
+    constexpr int NR = 2 * NW;
+    unsigned m = P[0];
+#pragma unroll
+    for(int r = 1; r < NR; ++r)
+        m = pk_min(m, P[r]);
+    // min of the two halves in ONE instruction (v_min_u32_sdwa WORD_0 / WORD_1), zero-extended; the wave-wide minimum is
+    // replicated into both halves on the scalar unit
+    const unsigned mlo = (unsigned)(unsigned short)m, mhi = m >> 16;
+    const unsigned bestPair = wave_min_bits(min(mlo, mhi)) * 0x00010001u;
+    const unsigned FPair = bestPair + iP2Pair;
+    // z-1 / z+1 across lanes: wave_shr:1 / wave_shl:1 with bound_ctrl (out-of-wave lanes read 0).  What lane 0 gets for "plane -1"
+    // and lane 63 for the plane past its last one only ever feeds plane 0 and the last plane of the wave, which are forced below
+    // (255 on planes 0 / Z-1, BIG past Z): no "old" register to initialise, one v_mov_b32_dpp each
+    unsigned Lp[NR + 1];
+    Lp[0] = __builtin_amdgcn_alignbit(P[0], (unsigned)__builtin_amdgcn_mov_dpp((int)P[NR - 1], 0x138, 0xf, 0xf, true), 16);
+#pragma unroll
+    for(int r = 1; r < NR; ++r)
+        Lp[r] = __builtin_amdgcn_alignbit(P[r], P[r - 1], 16);
+    Lp[NR] = __builtin_amdgcn_alignbit((unsigned)__builtin_amdgcn_mov_dpp((int)P[0], 0x130, 0xf, 0xf, true), P[NR - 1], 16);
+#pragma unroll
+    for(int r = 0; r < NR; ++r)
+    {
+        const unsigned nb = pk_min(Lp[r], Lp[r + 1]);
+        const unsigned mF = pk_min(pk_min(P[r], pk_add(nb, P1Pair)), FPair);
+        const unsigned cur = __builtin_amdgcn_perm(0u, inw[r >> 1], (r & 1) ? 0x0c030c02u : 0x0c010c00u);
+        unsigned L = pk_add(cur, pk_sub(mF, bestPair));
+        L = (L & keepM[r]) | forceV[r];
+        P[r] = L;
+        q[r] = pk_min(L, 0x00ff00ffu);
+    }
+}
+
+// fp32 restatement of one step WITHOUT the output stage (same expression order as sgm_step_f32); q = min(trunc(L), 255)
+template <int NW, bool FULL>
+__device__ __forceinline__ void sgm_lstep_f32(unsigned (&prev)[4 * NW], const unsigned (&inw)[NW], float P2, float P1, const SgmLane<NW>& Ln,
+                                              unsigned (&q)[2 * NW])
+{
+    constexpr int ZL = 4 * NW;
+    unsigned m = prev[0];
+#pragma unroll
+    for(int i = 1; i < ZL; ++i)
+        m = min(m, prev[i]);
+    const float best = bitsf(wave_min_bits(m));
+    const unsigned bestP2 = fbits(best + P2);
+    const unsigned nbLo = min(dpp_u32<0x138>(0xffffffffu, prev[ZL - 1]), prev[1]);
+    const unsigned nbHi = min(dpp_u32<0x130>(0xffffffffu, prev[0]), prev[ZL - 2]);
+    unsigned nprev[ZL];
+#pragma unroll
+    for(int i = 0; i < ZL; ++i)
+    {
+        const int w = i >> 2, j = i & 3;
+        const float cur = ubyte_f32(inw[w], j);
+        const unsigned nb = (i == 0) ? nbLo : ((i == ZL - 1) ? nbHi : min(prev[i - 1], prev[i + 1]));
+        const unsigned minCost = min(min(prev[i], fbits(bitsf(nb) + P1)), bestP2);
+        float pathCost = (cur + bitsf(minCost)) - best;
+        if(FULL)
+        {
+            if(i == 0)
+                pathCost = (Ln.lane == 0) ? 255.0f : pathCost;
+            if(i == ZL - 1)
+                pathCost = (Ln.lane == 63) ? 255.0f : pathCost;
+        }
+        else
+            pathCost = ((Ln.z0 + i == 0) || (Ln.z0 + i >= Ln.Z - 1)) ? 255.0f : pathCost;
+        const float tr = truncf(pathCost);
+        nprev[i] = (FULL || ((Ln.vmask[w] >> (8 * j)) & 1u)) ? fbits(tr) : fbits(SGM_BIG);
+        const unsigned c = (unsigned)__builtin_amdgcn_fmed3f(tr, 0.0f, 255.0f);
+        if(i & 1)
+            q[i >> 1] |= c << 16;
+        else
+            q[i >> 1] = c;
+    }
+#pragma unroll
+    for(int i = 0; i < ZL; ++i)
+        prev[i] = nprev[i];
+}
+
+#define AVDM_SGM_PAIR_WPB 4 // columns per workgroup: 2 * WPB waves
+#ifndef AVDM_SGM_AUX_LD
+#define AVDM_SGM_AUX_LD 2 // cache policy of the ring loads / the stores: 0 = default, 2 = non-temporal (gfx94x/95x aux bit 1)
+#endif
+#ifndef AVDM_SGM_AUX_ST
+#define AVDM_SGM_AUX_ST 2
+#endif
+#ifndef AVDM_SGM_SLOTS_1LD
+#define AVDM_SGM_SLOTS_1LD 4 // ring slots of the walks that load one dword per step (the others use 4)
+#endif
+#ifndef AVDM_SGM_PROLOGUE_DRAIN
+#define AVDM_SGM_PROLOGUE_DRAIN 0
+#endif
+#ifndef AVDM_SGM_USE_BUFFER
+#define AVDM_SGM_USE_BUFFER 0 // 1: raw buffer instructions (descriptor + SGPR slice offset), 0: global_load / global_store
+#endif
+// one dword of slice `sliceOff` (bytes from the column base) at lane offset `laneOff`
+__device__ __forceinline__ unsigned ld_slice(__amdgpu_buffer_rsrc_t rsrc, const uint8_t* col, unsigned laneOff, unsigned sliceOff)
+{
+#if AVDM_SGM_USE_BUFFER
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)laneOff, (int)sliceOff, AVDM_SGM_AUX_LD);
+#else
+    const unsigned* p = reinterpret_cast<const unsigned*>(col + (size_t)sliceOff + laneOff);
+    return AVDM_SGM_AUX_LD ? __builtin_nontemporal_load(p) : *p;
+#endif
+}
+__device__ __forceinline__ void st_slice(unsigned v, __amdgpu_buffer_rsrc_t rsrc, uint8_t* col, unsigned laneOff, unsigned sliceOff)
+{
+#if AVDM_SGM_USE_BUFFER
+    __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, (int)laneOff, (int)sliceOff, AVDM_SGM_AUX_ST);
+#else
+    unsigned* p = reinterpret_cast<unsigned*>(col + (size_t)sliceOff + laneOff);
+    if(AVDM_SGM_AUX_ST)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+#endif
+}
+template <int NW, int K, bool FULL>
+__global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPathBatch S)
+{
+    constexpr int ZL = 4 * NW;
+    constexpr int NR = 2 * NW;
+    constexpr int PF = NW == 1 ? 8 : (NW == 2 ? 4 : 2);
+    constexpr int NSETS = 4;
+
+    int ti = 0;
+    while(ti < AVDM_SGM_MAX_TILES - 1 && (int)blockIdx.x >= S.t[ti].colEnd)
+        ++ti;
+    const SgmPathTile& T = S.t[ti];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int rev = wv >= AVDM_SGM_PAIR_WPB ? 1 : 0;
+    const int a = ((int)blockIdx.x - (ti > 0 ? S.t[ti - 1].colEnd : 0)) * AVDM_SGM_PAIR_WPB + (wv - rev * AVDM_SGM_PAIR_WPB);
+    const bool active = a < T.A; // inactive waves only take part in the barrier
+    const int B = T.B;
+    const long long strideB = T.strideB;
+
+    SgmLane<NW> Ln;
+    Ln.lane = threadIdx.x & 63;
+    Ln.Z = T.Z;
+    Ln.z0 = Ln.lane * ZL;
+#pragma unroll
+    for(int w = 0; w < NW; ++w)
+    {
+        const int zw = Ln.z0 + 4 * w;
+        const int nv = FULL ? 4 : min(max(Ln.Z - zw, 0), 4);
+        Ln.wAny[w] = nv > 0;
+        Ln.vmask[w] = nv >= 4 ? 0xffffffffu : ((1u << (8 * (nv & 3))) - 1u);
+        Ln.offw[w] = (unsigned)(Ln.wAny[w] ? zw : ((Ln.Z - 1) & ~3));
+    }
+    const int aa = active ? a : 0;
+    const uint8_t* __restrict__ inCol = T.in + (long long)aa * T.strideA;
+    uint8_t* outCol = T.out + (long long)aa * T.strideA;
+    uint8_t* tmpCol = T.tmp + (long long)aa * T.tStrideA;
+    const long long tStrideB = T.tStrideB;
+    // Raw buffer resources (base = my column, no stride, no range limit): an access is  base + lane offset (VGPR) + slice offset
+    // (SGPR soffset), so walking the slices costs scalar adds only — no 64-bit VALU address arithmetic per load / store.
+    // The host guarantees that a column spans less than 4 GiB (32-bit soffset).
+    const __amdgpu_buffer_rsrc_t rsrcIn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(inCol), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcOut = __builtin_amdgcn_make_buffer_rsrc(outCol, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcTmp = __builtin_amdgcn_make_buffer_rsrc(tmpCol, 0, -1, 0x00020000);
+
+    unsigned prevF[ZL];
+    unsigned P[NR];
+    unsigned keepM[NR], forceV[NR];
+    if(active)
+    {
+#pragma unroll
+        for(int w = 0; w < NW; ++w)
+        {
+            const unsigned v = *reinterpret_cast<const unsigned*>(inCol + Ln.offw[w]);
+#pragma unroll
+            for(int h = 0; h < 2; ++h)
+            {
+                unsigned pr = __builtin_amdgcn_perm(0u, v, h ? 0x0c030c02u : 0x0c010c00u);
+                if(!FULL)
+                {
+                    if(!((Ln.vmask[w] >> (16 * h)) & 1u))
+                        pr = (pr & 0xffff0000u) | SGM_BIG16;
+                    if(!((Ln.vmask[w] >> (16 * h + 8)) & 1u))
+                        pr = (pr & 0x0000ffffu) | (SGM_BIG16 << 16);
+                }
+                P[2 * w + h] = pr;
+            }
+            // out(slice 0) = 255: written by the forward wave only; the reverse wave reads it back in its last step (phase 2)
+            if(!rev)
+            {
+                if(FULL)
+                    *reinterpret_cast<unsigned*>(outCol + Ln.offw[w]) = 0xffffffffu;
+                else if(Ln.wAny[w])
+                {
+                    const unsigned old = *reinterpret_cast<const unsigned*>(outCol + Ln.offw[w]);
+                    *reinterpret_cast<unsigned*>(outCol + Ln.offw[w]) = old | Ln.vmask[w];
+                }
+            }
+        }
+#pragma unroll
+        for(int r = 0; r < NR; ++r)
+        {
+            unsigned keep = 0, force = 0;
+#pragma unroll
+            for(int h = 0; h < 2; ++h)
+            {
+                const int z = Ln.z0 + 2 * r + h;
+                const bool valid = FULL || z < Ln.Z;
+                const bool border = (z == 0) || (z >= Ln.Z - 1);
+                const unsigned k16 = (valid && !border) ? 0xffffu : 0u;
+                const unsigned f16 = !valid ? SGM_BIG16 : (border ? 255u : 0u);
+                keep |= k16 << (16 * h);
+                force |= f16 << (16 * h);
+            }
+            keepM[r] = keep;
+            forceV[r] = force;
+        }
+    }
+    const float P1f = S.P1;
+    const float* __restrict__ p2col = T.p2 + (long long)aa * B;
+    const unsigned P1Pair = (unsigned)(int)P1f * 0x00010001u;
+    const long long dirStride = rev ? -strideB : strideB;
+    const long long tDirStride = rev ? -tStrideB : tStrideB;
+
+    // walk the steps ib0 <= ib < ib1 of my path in the given role (the state P carries over between walks)
+    auto walk = [&](auto roleTag, int ib0, int ib1) __attribute__((always_inline)) {
+        constexpr int ROLE = decltype(roleTag)::value;
+        // which volumes this role reads besides the input, and where it writes
+        constexpr bool STORE_TMP = (ROLE == SGM_FIRST_REV) && (K > 0);
+        constexpr bool LOAD_OUT = (ROLE == SGM_SECOND_FWD) || (ROLE == SGM_SECOND_REV) || (ROLE == SGM_FIRST_FWD && (K > 0 || !FULL)) ||
+                                  (ROLE == SGM_FIRST_REV && K == 0 && !FULL);
+        constexpr bool LOAD_TMP = (ROLE == SGM_SECOND_FWD) && (K > 0);
+        // ring slots: the waits the compiler derives are bounded by the number of younger LOADS (7 + (slots - 1) * PF * loads per
+        // step) and by the 6-bit counter; with one load per step four slots give vmcnt(31), eight give the full vmcnt(63)
+        constexpr int NS = (1 + (LOAD_OUT ? 1 : 0) + (LOAD_TMP ? 1 : 0)) * NW == 1 ? AVDM_SGM_SLOTS_1LD : NSETS;
+        const int nSteps = ib1 - ib0;
+        if(nSteps <= 0)
+            return;
+        const long long slice0 = rev ? (long long)(B - 1 - ib0) : (long long)ib0; // slice of step ib0
+        // 32-bit slice offsets (soffset of the buffer instructions); the reverse path counts down (two's complement adds)
+        unsigned inLoad = (unsigned)(slice0 * strideB);
+        unsigned tmpLoad = (unsigned)(slice0 * tStrideB);
+        unsigned outStore = (unsigned)(slice0 * (STORE_TMP ? tStrideB : strideB));
+        const unsigned storeStride = (unsigned)(STORE_TMP ? tDirStride : dirStride);
+        int nLoaded = 0;
+
+        unsigned rin[NS][PF][NW], rout[NS][PF][NW], rtmp[NS][PF][NW];
+        auto load_group = [&](unsigned (&ri)[PF][NW], unsigned (&ro)[PF][NW], unsigned (&rt)[PF][NW]) __attribute__((always_inline)) {
+#pragma unroll
+            for(int t = 0; t < PF; ++t)
+            {
+#pragma unroll
+                for(int w = 0; w < NW; ++w)
+                {
+                    ri[t][w] = ld_slice(rsrcIn, inCol, Ln.offw[w], inLoad);
+                    if(LOAD_OUT)
+                        ro[t][w] = ld_slice(rsrcOut, outCol, Ln.offw[w], inLoad);
+                    if(LOAD_TMP)
+                        rt[t][w] = ld_slice(rsrcTmp, tmpCol, Ln.offw[w], tmpLoad);
+                }
+                // past the end: keep re-reading the last slice of the walk (harmless).  Written as selects: a branch here splits
+                // the loads over basic blocks and makes the waitcnt insertion fall back to vmcnt(0) at the joins
+                const bool more = nLoaded + 1 < nSteps;
+                inLoad += more ? (unsigned)dirStride : 0u;
+                tmpLoad += more ? (unsigned)tDirStride : 0u;
+                nLoaded += more ? 1 : 0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // adaptive P2 of 64 consecutive steps of this walk, one per lane
+        auto load_p2 = [&](int blk) __attribute__((always_inline)) -> float {
+            const int ib = min(ib0 + blk * 64 + Ln.lane, ib1 - 1);
+            return p2col[rev ? B - ib : ib];
+        };
+        float p2vec = 0.f;
+        unsigned ip2vec = 0;
+        unsigned long long riskyMask = 0;
+        auto set_p2_block = [&](float v) __attribute__((always_inline)) {
+            p2vec = v;
+            const float fl = floorf(v);
+            ip2vec = (unsigned)(int)fl * 0x00010001u;
+            riskyMask = __ballot(!((v - fl) < (1.0f - 1.0f / 8192.0f)) || !(v >= 0.0f) || !(v < 8192.0f));
+        };
+
+        auto step = [&](auto fastTag, int i, const unsigned (&inw)[NW], const unsigned (&ow)[NW], const unsigned (&tw)[NW]) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fastTag)::value;
+            const int idx = i & 63;
+            unsigned q[NR];
+            if(FAST)
+            {
+                const unsigned iP2Pair = (unsigned)__builtin_amdgcn_readlane((int)ip2vec, idx);
+                sgm_lstep_u16<NW>(P, inw, iP2Pair, P1Pair, keepM, forceV, q);
+            }
+            else
+            {
+                const float P2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2vec), idx));
+#pragma unroll
+                for(int r = 0; r < NR; ++r)
+                {
+                    const unsigned lo = P[r] & 0xffffu, hi = P[r] >> 16;
+                    prevF[2 * r] = lo >= SGM_BIG16 ? fbits(SGM_BIG) : fbits((float)lo);
+                    prevF[2 * r + 1] = hi >= SGM_BIG16 ? fbits(SGM_BIG) : fbits((float)hi);
+                }
+                sgm_lstep_f32<NW, FULL>(prevF, inw, P2, P1f, Ln, q);
+#pragma unroll
+                for(int r = 0; r < NR; ++r)
+                {
+                    const float lo = bitsf(prevF[2 * r]), hi = bitsf(prevF[2 * r + 1]);
+                    const unsigned ulo = lo > 60000.0f ? SGM_BIG16 : (unsigned)lo, uhi = hi > 60000.0f ? SGM_BIG16 : (unsigned)hi;
+                    P[r] = ulo | (uhi << 16);
+                }
+            }
+            // output stage
+#pragma unroll
+            for(int w = 0; w < NW; ++w)
+            {
+                unsigned res[2];
+#pragma unroll
+                for(int h = 0; h < 2; ++h)
+                {
+                    const unsigned c = q[2 * w + h];
+                    const unsigned o = LOAD_OUT ? __builtin_amdgcn_perm(0u, ow[w], h ? 0x0c030c02u : 0x0c010c00u) : 0u;
+                    if(ROLE == SGM_FIRST_FWD)
+                        res[h] = pk_avg<K>(o, c);
+                    else if(ROLE == SGM_FIRST_REV)
+                        res[h] = c;
+                    else if(ROLE == SGM_SECOND_REV)
+                        res[h] = pk_avg<K + 1>(o, c);
+                    else if(K == 0)
+                        res[h] = pk_avg<1>(o, c); // o = L of the reverse path
+                    else
+                    {
+                        const unsigned t = __builtin_amdgcn_perm(0u, tw[w], h ? 0x0c030c02u : 0x0c010c00u);
+                        res[h] = pk_avg<K + 1>(pk_avg<K>(o, c), t);
+                    }
+                }
+                const unsigned neww = __builtin_amdgcn_perm(res[1], res[0], 0x06040200u);
+                if(FULL)
+                    st_slice(neww, STORE_TMP ? rsrcTmp : rsrcOut, STORE_TMP ? tmpCol : outCol, Ln.offw[w], outStore);
+                else if(Ln.wAny[w])
+                {
+                    if(STORE_TMP)
+                        st_slice(neww, rsrcTmp, tmpCol, Ln.offw[w], outStore); // scratch padding is free
+                    else
+                        st_slice((neww & Ln.vmask[w]) | (ow[w] & ~Ln.vmask[w]), rsrcOut, outCol, Ln.offw[w], outStore);
+                }
+            }
+            outStore += storeStride;
+            __builtin_amdgcn_sched_barrier(0); // keep the steps and the ring loads in source order: the waitcnt values follow it
+        };
+
+        const int nGroups = (nSteps + PF - 1) / PF;
+        // One group = PF consecutive steps on ring slot s, then the reload of that slot.  The reload is COMMON code after the
+        // fast / generic alternatives: the ring registers then have a single definition site per slot, so no copies of just-issued
+        // loads appear at control-flow joins (such copies force the wait counter to zero and drain the prefetch ring).
+        auto group = [&](int g, unsigned (&ri)[PF][NW], unsigned (&ro)[PF][NW], unsigned (&rt)[PF][NW]) __attribute__((always_inline)) {
+            const unsigned risky = (unsigned)(riskyMask >> ((g * PF) & 63)) & ((1u << PF) - 1u);
+            if(g * PF + PF <= nSteps && risky == 0u)
+            {
+#pragma unroll
+                for(int t = 0; t < PF; ++t)
+                    step(std::true_type{}, g * PF + t, ri[t], ro[t], rt[t]);
+            }
+            else
+            {
+#pragma unroll
+                for(int t = 0; t < PF; ++t)
+                    if(g * PF + t < nSteps)
+                    {
+                        if((risky >> t) & 1u)
+                            step(std::false_type{}, g * PF + t, ri[t], ro[t], rt[t]);
+                        else
+                            step(std::true_type{}, g * PF + t, ri[t], ro[t], rt[t]);
+                    }
+            }
+            load_group(ri, ro, rt);
+        };
+#pragma unroll
+        for(int s = 0; s < NS; ++s)
+            load_group(rin[s], rout[s], rtmp[s]);
+        set_p2_block(load_p2(0));
+        float p2next = load_p2(1);
+#if AVDM_SGM_PROLOGUE_DRAIN
+        // every prologue load has landed before the loop: the loop-header state of the wait counter is then the back edge's alone
+        // (slot loaded 3 groups + 7 loads ago -> vmcnt(55)); without this the prologue path (slot loaded 31 ops ago) caps every
+        // wait of the steady state at vmcnt(31), half the depth the ring was sized for
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only
+#endif
+        // main loop: whole spans of NS groups with NO per-group guards — every control-flow path that cannot happen at run
+        // time but exists in the CFG (e.g. group 0 -> skip 1..3 -> group 0) makes the waitcnt insertion assume the ring slot was
+        // reloaded one group ago and wait for it with vmcnt(7), which drains the ring
+        int G = 0;
+        for(; G + NS <= nGroups; G += NS)
+        {
+            if(G > 0 && ((G * PF) & 63) == 0)
+            {
+                set_p2_block(p2next);
+                p2next = load_p2((G * PF) / 64 + 1);
+            }
+#pragma unroll
+            for(int s = 0; s < NS; ++s)
+                group(G + s, rin[s], rout[s], rtmp[s]);
+        }
+        if(G < nGroups) // last, partial span
+        {
+            if(G > 0 && ((G * PF) & 63) == 0)
+                set_p2_block(p2next);
+#pragma unroll
+            for(int s = 0; s < NS - 1; ++s)
+                if(G + s < nGroups)
+                    group(G + s, rin[s], rout[s], rtmp[s]);
+        }
+    };
+
+    const int M = max(1, B / 2);
+    if(active && B > 1)
+    {
+        if(!rev)
+            walk(std::integral_constant<int, SGM_FIRST_FWD>{}, 1, M); // slices 1 .. M-1
+        else
+            walk(std::integral_constant<int, SGM_FIRST_REV>{}, 1, B - M); // slices B-2 .. M
+    }
+    __syncthreads(); // phase 1 stores of the whole workgroup are visible (same CU, workgroup-scope release / acquire)
+    if(active && B > 1)
+    {
+        if(!rev)
+        {
+            walk(std::integral_constant<int, SGM_SECOND_FWD>{}, M, B - 1);    // slices M .. B-2
+            walk(std::integral_constant<int, SGM_FIRST_FWD>{}, B - 1, B);     // slice B-1: the reverse path never writes it
+        }
+        else
+            walk(std::integral_constant<int, SGM_SECOND_REV>{}, B - M, B);    // slices M-1 .. 0
+    }
+}
+
+template <int NW>
+static void launch_pair(const SgmPathBatch& S, int nWorkgroups, int K, bool full, hipStream_t st)
+{
+    dim3 grid(nWorkgroups), block(128 * AVDM_SGM_PAIR_WPB);
+    if(K == 0)
+    {
+        if(full)
+            hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, true>), grid, block, 0, st, S);
+        else
+            hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, false>), grid, block, 0, st, S);
+    }
+    else
+    {
+        if(full)
+            hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, true>), grid, block, 0, st, S);
+        else
+            hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, false>), grid, block, 0, st, S);
+    }
+}
+
 template <int NW>
 static void launch_path(const SgmPathBatch& S, int ncols, int K, bool full, bool int16, hipStream_t st)
 {
@@ -649,6 +1149,8 @@ static void launch_path(const SgmPathBatch& S, int ncols, int K, bool full, bool
 }
 
 static size_t p2_map_bytes(int dimX, int dimY) { return ((size_t)dimX * (size_t)dimY * sizeof(float) + 255) & ~(size_t)255; }
+// scratch volume of the pair kernel (reverse-path costs of the second axis): tightly packed, z-fastest, 4-aligned planes
+static size_t tmp_vol_bytes(int dimX, int dimY, int dimZ) { return ((size_t)dimX * (size_t)dimY * (size_t)((dimZ + 3) & ~3) + 255) & ~(size_t)255; }
 
 // all tiles of one launch group share (NW, FULL); `idx` lists their positions in `tiles`
 static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, const size_t* p2off, void* scratch, const avdm_sgm_params_t* sp,
@@ -662,22 +1164,37 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
     const char* e = getenv("AVDM_SGM_INT16");
     if(e && e[0] == '0')
         int16 = false;
+    // forward + reverse path of an axis in one launch (two waves per column); AVDM_SGM_PAIR=0 selects the sequential kernels
+    bool pair = int16;
+    const char* ep = getenv("AVDM_SGM_PAIR");
+    if(ep && ep[0] == '0')
+        pair = false;
 
     SgmP2Batch Q;
     SgmPathBatch S;
     Q.step = (float)sp->stepXY;
     Q.P2w = (float)sp->p2Weighting;
     S.P1 = P1;
-    int npaths = 0;
+    // the filtering axes, in order
+    bool axisIsX[2];
+    int nAxes = 0;
     for(const char* ax = sp->filteringAxes; *ax; ++ax)
     {
         if(*ax != 'X' && *ax != 'Y')
             continue;
-        if(npaths > 2)
+        if(nAxes >= 2)
             return set_error_msg(1, "avdm_volume_optimize: at most 2 filtering axes");
-        const bool scanX = (*ax == 'X');
-        Q.scanIsX = scanX ? 1 : 0;
-        int cols = 0, maxA = 0, maxB = 0;
+        axisIsX[nAxes++] = (*ax == 'X');
+    }
+    // pass 1: the adaptive-P2 map of every (axis, tile) — ONE launch for all of them when they fit the kernel-argument table
+    // (the maps only depend on the R image), otherwise one launch per axis
+    const bool oneP2Launch = nAxes * n <= AVDM_SGM_MAX_TILES;
+    int maxA = 0, maxB = 0, nq = 0;
+    for(int ai = 0; ai < nAxes; ++ai)
+    {
+        const bool scanX = axisIsX[ai];
+        if(!oneP2Launch)
+            maxA = maxB = nq = 0;
         for(int i = 0; i < n; ++i)
         {
             const avdm_sgm_tile_t& t = tiles[idx[i]];
@@ -686,18 +1203,7 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
             if(!lod_is_integral(t.rc_pyr, sp->scale, &level))
                 return set_error_msg(1, "avdm_volume_optimize: non-integral mip level");
             const Tex tex = make_tex(t.rc_pyr);
-            SgmPathTile& P = S.t[i];
-            P.in = t.in_vol;
-            P.out = t.out_vol;
-            P.p2 = (const float*)((char*)scratch + p2off[idx[i]]);
-            P.Z = t.last_depth_index;
-            P.A = scanX ? dimY : dimX;
-            P.B = scanX ? dimX : dimY;
-            P.strideA = scanX ? t.pitch_y : (long long)t.pitch_x;
-            P.strideB = scanX ? (long long)t.pitch_x : t.pitch_y;
-            cols += (P.A + AVDM_SGM_WPB - 1) / AVDM_SGM_WPB; // workgroups
-            P.colEnd = cols;
-            SgmP2Tile& R = Q.t[i];
+            SgmP2Tile& R = Q.t[nq++];
             R.L = tex.lv[level];
             R.rcW = (float)tex_dim_w(t.rc_pyr, sp->scale);
             R.rcH = (float)tex_dim_h(t.rc_pyr, sp->scale);
@@ -705,25 +1211,85 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
             const bool swap = sp->strictRoiQuirk && scanX;
             R.beginX = swap ? (int)t.roi.y.begin : (int)t.roi.x.begin;
             R.beginY = swap ? (int)t.roi.x.begin : (int)t.roi.y.begin;
-            R.A = P.A;
-            R.B = P.B;
-            R.p2 = (float*)((char*)scratch + p2off[idx[i]]);
+            R.A = scanX ? dimY : dimX;
+            R.B = scanX ? dimX : dimY;
+            R.scanIsX = scanX ? 1 : 0;
+            R.p2 = (float*)((char*)scratch + p2off[idx[i]] + (size_t)ai * p2_map_bytes(dimX, dimY));
             Q.fixed8 = t.rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
-            maxA = P.A > maxA ? P.A : maxA;
-            maxB = P.B > maxB ? P.B : maxB;
+            maxA = R.A > maxA ? R.A : maxA;
+            maxB = R.B > maxB ? R.B : maxB;
+        }
+        if(!oneP2Launch || ai == nAxes - 1)
+        {
+            for(int i = nq; i < AVDM_SGM_MAX_TILES; ++i)
+                Q.t[i] = Q.t[nq - 1];
+            hipLaunchKernelGGL(sgm_p2_map_kernel, dim3(divUp(maxB, 16), divUp(maxA, 16), nq), dim3(256), 0, st, Q);
+        }
+    }
+    // pass 2: the paths
+    int npaths = 0;
+    for(int ai = 0; ai < nAxes; ++ai)
+    {
+        const bool scanX = axisIsX[ai];
+        int cols = 0;
+        for(int i = 0; i < n; ++i)
+        {
+            const avdm_sgm_tile_t& t = tiles[idx[i]];
+            const int dimX = (int)(t.roi.x.end - t.roi.x.begin), dimY = (int)(t.roi.y.end - t.roi.y.begin);
+            SgmPathTile& P = S.t[i];
+            P.in = t.in_vol;
+            P.out = t.out_vol;
+            P.p2 = (const float*)((char*)scratch + p2off[idx[i]] + (size_t)ai * p2_map_bytes(dimX, dimY));
+            P.Z = t.last_depth_index;
+            P.A = scanX ? dimY : dimX;
+            P.B = scanX ? dimX : dimY;
+            P.strideA = scanX ? t.pitch_y : (long long)t.pitch_x;
+            P.strideB = scanX ? (long long)t.pitch_x : t.pitch_y;
+            const int wpb = pair ? AVDM_SGM_PAIR_WPB : AVDM_SGM_WPB;
+            cols += (P.A + wpb - 1) / wpb; // workgroups
+            P.colEnd = cols;
+            const int Zp = (t.last_depth_index + 3) & ~3;
+            P.tmp = (uint8_t*)scratch + p2off[idx[i]] + 2 * p2_map_bytes(dimX, dimY);
+            const long long tpy = (long long)dimX * Zp;
+            P.tStrideA = scanX ? tpy : (long long)Zp;
+            P.tStrideB = scanX ? (long long)Zp : tpy;
         }
         for(int i = n; i < AVDM_SGM_MAX_TILES; ++i)
         {
             S.t[i] = S.t[n - 1];
             S.t[i].colEnd = 0x7fffffff;
-            Q.t[i] = Q.t[n - 1];
         }
         S.t[n - 1].colEnd = (n == AVDM_SGM_MAX_TILES) ? cols : S.t[n - 1].colEnd;
-        hipLaunchKernelGGL(sgm_p2_map_kernel, dim3(divUp(maxB, 16), divUp(maxA, 16), n), dim3(256), 0, st, Q);
+        if(pair)
+        {
+            S.rev = 0;
+            const int K = npaths;
+            npaths += 2;
+#ifdef AVDM_SGM_FAST_BUILD // experiments: NW = 1 only (the other instantiations take minutes to compile)
+            if(NW != 1)
+                return set_error_msg(1, "AVDM_SGM_FAST_BUILD: only <= 256 planes");
+            launch_pair<1>(S, cols, K, full, st);
+#else
+            switch(NW)
+            {
+                case 1: launch_pair<1>(S, cols, K, full, st); break;
+                case 2: launch_pair<2>(S, cols, K, full, st); break;
+                case 3: launch_pair<3>(S, cols, K, full, st); break;
+                case 4: launch_pair<4>(S, cols, K, full, st); break;
+                default: launch_pair<6>(S, cols, K, full && NW == 6, st); break;
+            }
+#endif
+            continue;
+        }
         for(int rev = 0; rev < 2; ++rev)
         {
             S.rev = rev;
             const int K = npaths++;
+#ifdef AVDM_SGM_FAST_BUILD
+            if(NW != 1)
+                return set_error_msg(1, "AVDM_SGM_FAST_BUILD: only <= 256 planes");
+            launch_path<1>(S, cols, K, full, int16, st);
+#else
             switch(NW)
             {
                 case 1: launch_path<1>(S, cols, K, full, int16, st); break;
@@ -732,6 +1298,7 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
                 case 4: launch_path<4>(S, cols, K, full, int16, st); break;
                 default: launch_path<6>(S, cols, K, full && NW == 6, int16, st); break; // 1025..1536 planes (5 dwords/lane runs as 6)
             }
+#endif
         }
     }
     return 0;
@@ -745,12 +1312,11 @@ extern "C" {
 
 size_t avdm_volume_optimize_scratch_bytes(int dimX, int dimY, int dimZ)
 {
-    (void)dimZ;
-    if(dimX <= 0 || dimY <= 0)
+    if(dimX <= 0 || dimY <= 0 || dimZ <= 0)
         return 0;
-    // one fp32 adaptive-P2 map per axis pass (the path costs of the previous slice live in registers: no uint32 slice
-    // buffers like Sgm.hpp:144-148 of the reference)
-    return p2_map_bytes(dimX, dimY);
+    // one fp32 adaptive-P2 map per filtering axis (the path costs of the previous slice live in registers: no uint32 slice
+    // buffers like Sgm.hpp:144-148 of the reference) + the scratch volume of the pair kernel
+    return 2 * p2_map_bytes(dimX, dimY) + tmp_vol_bytes(dimX, dimY, dimZ);
 }
 
 int avdm_volume_optimize_tiles(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* sp, void* stream)
@@ -769,7 +1335,7 @@ int avdm_volume_optimize_tiles(int n_tiles, const avdm_sgm_tile_t* tiles, void* 
         p2off[i] = off;
         if(dimX <= 0 || dimY <= 0 || Z <= 0)
             continue; // nothing to do for this tile (cuda_volumeOptimize on an empty ROI)
-        off += p2_map_bytes(dimX, dimY);
+        off += 2 * p2_map_bytes(dimX, dimY) + tmp_vol_bytes(dimX, dimY, Z);
         if((t.pitch_x & 3) || (t.pitch_y & 3) || ((uintptr_t)t.out_vol & 3) || ((uintptr_t)t.in_vol & 3))
             return set_error_msg(1, "avdm_volume_optimize: volume base / pitches must be multiples of 4 bytes");
         if(((Z + 3) & ~3) > t.pitch_x)

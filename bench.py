@@ -150,11 +150,15 @@ def main():
         # roofline of the SGM path-aggregation kernel (BASELINE.json: "SGM HBM GB/s vs roofline")
         ds = sgm.scale * sgm.stepXY
         X, Y = (W + ds - 1) // ds, (H + ds - 1) // ds
-        alg_bytes_per_launch = 11.0 * X * Y * Z / 4.0 + 64.0 * X * Y / 4.0  # 11 B/voxel + 64 B/pixel over 4 path launches
-        sgm_ms_per_launch = stages["sgm_optimize"] / 4.0
+        # 11 B/voxel + 64 B/pixel for the four paths = two launches of sgm_pair_kernel (forward + reverse path of one
+        # axis per launch); AVDM_SGM_PAIR=0 runs the four sequential sgm_path_kernel launches instead
+        n_launches = 4 if os.environ.get("AVDM_SGM_PAIR") == "0" else 2
+        alg_bytes_per_launch = (11.0 * X * Y * Z + 64.0 * X * Y) / n_launches
+        sgm_ms_per_launch = stages["sgm_optimize"] / n_launches
         achieved = alg_bytes_per_launch / (sgm_ms_per_launch * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "sgm_path_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": None, "alg_bytes_per_launch": alg_bytes_per_launch, "ms_per_launch": sgm_ms_per_launch}
+        roof = {"bound": "hbm", "kernel": "sgm_pair_kernel" if n_launches == 2 else "sgm_path_kernel", "achieved": achieved, "peak": 8000.0,
+                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "alg_bytes_per_launch": alg_bytes_per_launch,
+                "ms_per_launch": sgm_ms_per_launch, "launches_per_volume": n_launches}
         pmc = os.path.join(ROOT, "profiles", "r01_sgm_pmc.json")
         if os.path.exists(pmc):
             try:

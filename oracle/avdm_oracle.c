@@ -1194,6 +1194,115 @@ void avo_normal_map_upscale(float* out, int out_pitch, const float* in, int in_p
         }
 }
 
+/* mapKernels.cuh:393-477 (wsh = 3) + cuda_stat3d (cuda/device/eig33.cuh:351-445): normal = eigenvector of the smallest eigenvalue of the
+ * double-precision covariance matrix of the neighbourhood's 3-D points, oriented towards the camera.  The reference calls its tred2 / tql2
+ * routines; the oracle uses the closed-form (trigonometric) eigenvalues of a symmetric 3 x 3 matrix and the cross product of two rows of
+ * (A - lambda I) — a third, independent solver; tests/ also check against numpy.linalg.eigh.  Neighbours outside the ROI are skipped on all
+ * four sides (the reference reads beyond the tile on the upper sides: stale data of the allocated map). */
+static void smallest_eigvec_sym3(const double A[3][3], double v[3])
+{
+    const double p1 = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double q = (A[0][0] + A[1][1] + A[2][2]) / 3.0;
+    double lmin;
+    if(p1 == 0.0)
+    {
+        lmin = A[0][0];
+        if(A[1][1] < lmin) lmin = A[1][1];
+        if(A[2][2] < lmin) lmin = A[2][2];
+    }
+    else
+    {
+        const double p2 = (A[0][0] - q) * (A[0][0] - q) + (A[1][1] - q) * (A[1][1] - q) + (A[2][2] - q) * (A[2][2] - q) + 2.0 * p1;
+        const double pp = sqrt(p2 / 6.0);
+        double B[3][3];
+        for(int i = 0; i < 3; ++i)
+            for(int j = 0; j < 3; ++j)
+                B[i][j] = (A[i][j] - (i == j ? q : 0.0)) / pp;
+        double r = (B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1]) - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0]) +
+                    B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0])) / 2.0;
+        r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+        const double phi = acos(r) / 3.0;
+        lmin = q + 2.0 * pp * cos(phi + 2.0 * 3.14159265358979323846 / 3.0); /* the smallest of the three roots */
+    }
+    double M[3][3];
+    for(int i = 0; i < 3; ++i)
+        for(int j = 0; j < 3; ++j)
+            M[i][j] = A[i][j] - (i == j ? lmin : 0.0);
+    /* the null vector of M is orthogonal to its rows: take the largest cross product of two rows */
+    double best = -1.0;
+    for(int a = 0; a < 3; ++a)
+        for(int b = a + 1; b < 3; ++b)
+        {
+            const double c[3] = {M[a][1] * M[b][2] - M[a][2] * M[b][1], M[a][2] * M[b][0] - M[a][0] * M[b][2], M[a][0] * M[b][1] - M[a][1] * M[b][0]};
+            const double n2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+            if(n2 > best)
+            {
+                best = n2;
+                v[0] = c[0], v[1] = c[1], v[2] = c[2];
+            }
+        }
+    const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if(n > 0.0)
+        v[0] /= n, v[1] /= n, v[2] /= n;
+}
+
+void avo_depth_sim_map_compute_normal(float* out, int out_pitch, const float* depthSim, int in_pitch, const avdm_camera_t* rc, int stepXY, avdm_roi_t roi)
+{
+    const int roiW = (int)(roi.x.end - roi.x.begin), roiH = (int)(roi.y.end - roi.y.begin);
+#pragma omp parallel for schedule(dynamic, 4)
+    for(int ry = 0; ry < roiH; ++ry)
+        for(int rx = 0; rx < roiW; ++rx)
+        {
+            float* o = MAP3(out, out_pitch, rx, ry);
+            const unsigned x = (roi.x.begin + (unsigned)rx) * (unsigned)stepXY, y = (roi.y.begin + (unsigned)ry) * (unsigned)stepXY;
+            const float in_depth = MAP2(depthSim, in_pitch, rx, ry)[0];
+            if(in_depth <= 0.0f)
+            {
+                o[0] = o[1] = o[2] = -1.f;
+                continue;
+            }
+            const f3 p = get3DPointForPixelAndDepthFromRC(rc, mk2((float)x, (float)y), in_depth);
+            const float pixSize = size3(sub3(p, get3DPointForPixelAndDepthFromRC(rc, mk2((float)(x + 1), (float)y), in_depth)));
+            double xs = 0, ys = 0, zs = 0, xx = 0, yy = 0, zz = 0, xy = 0, xz = 0, yz = 0, count = 0;
+            for(int yp = -3; yp <= 3; ++yp)
+                for(int xp = -3; xp <= 3; ++xp)
+                {
+                    const int qx = rx + xp, qy = ry + yp;
+                    if(qx < 0 || qy < 0 || qx >= roiW || qy >= roiH)
+                        continue;
+                    const float depthP = MAP2(depthSim, in_pitch, qx, qy)[0];
+                    if((depthP > 0.0f) && (fabsf(depthP - in_depth) < 30.0f * pixSize))
+                    {
+                        const f3 q = get3DPointForPixelAndDepthFromRC(rc, mk2((float)((int)x + xp), (float)((int)y + yp)), depthP);
+                        xx += (double)q.x * (double)q.x, yy += (double)q.y * (double)q.y, zz += (double)q.z * (double)q.z;
+                        xy += (double)q.x * (double)q.y, xz += (double)q.x * (double)q.z, yz += (double)q.y * (double)q.z;
+                        xs += (double)q.x, ys += (double)q.y, zs += (double)q.z;
+                        count += 1.0;
+                    }
+                }
+            if(count < 3.0)
+            {
+                o[0] = o[1] = o[2] = -1.f;
+                continue;
+            }
+            const double xm = xs / count, ym = ys / count, zm = zs / count;
+            double A[3][3], v[3] = {0, 0, 1};
+            A[0][0] = (xx - xs * xm - xs * xm + xm * xm * count) / count;
+            A[0][1] = A[1][0] = (xy - ys * xm - xs * ym + xm * ym * count) / count;
+            A[0][2] = A[2][0] = (xz - zs * xm - xs * zm + xm * zm * count) / count;
+            A[1][1] = (yy - ys * ym - ys * ym + ym * ym * count) / count;
+            A[1][2] = A[2][1] = (yz - zs * ym - ys * zm + ym * zm * count) / count;
+            A[2][2] = (zz - zs * zm - zs * zm + zm * zm * count) / count;
+            smallest_eigvec_sym3(A, v);
+            f3 nn = normalize3(mk3((float)v[0], (float)v[1], (float)v[2]));
+            const f3 pp = mk3((float)xm, (float)ym, (float)zm);
+            const f3 nc = normalize3(sub3(cam3(rc->C), p));
+            if((dot3(add3(pp, nn), nc) - dot3(pp, nc)) < 0.0f)
+                nn = mk3(-nn.x, -nn.y, -nn.z);
+            o[0] = nn.x, o[1] = nn.y, o[2] = nn.z;
+        }
+}
+
 /* mapKernels.cuh:151-211, launch constants Map.cu:72-104.  In place; only the centre pixel's .y is written and
  * neighbours are read for .x only, so the sequential order is immaterial. */
 void avo_depth_thickness_smooth_thickness(float* map, int pitch, const avdm_sgm_params_t* sp, const avdm_refine_params_t* rp, avdm_roi_t roi)

@@ -48,6 +48,7 @@ void avo_volume_refine_best_depth(float* out, int out_pitch, const float* sgmDep
 
 void avo_depth_sim_map_copy_depth_only(float* out, int out_pitch, const float* in, int in_pitch, int width, int height, float defaultSim);
 void avo_normal_map_upscale(float* out, int out_pitch, const float* in, int in_pitch, float ratio, avdm_roi_t roi);
+void avo_depth_sim_map_compute_normal(float* out, int out_pitch, const float* depthSim, int in_pitch, const avdm_camera_t* rc, int stepXY, avdm_roi_t roi);
 void avo_depth_thickness_smooth_thickness(float* map, int pitch, const avdm_sgm_params_t* sp, const avdm_refine_params_t* rp, avdm_roi_t roi);
 void avo_compute_sgm_upscaled_depth_pixsize_map(float* out, int out_pitch, const float* in, int in_pitch, const avdm_camera_t* rc,
                                                 const avdm_pyramid_t* rcPyr, const avdm_refine_params_t* rp, float ratio, avdm_roi_t roi);

@@ -47,6 +47,7 @@ _SIG = {
     "avo_volume_refine_best_depth": (None, [vp, i32, vp, i32, vp, i64, i32, i32, P(abi.RefineParams), abi.ROI]),
     "avo_depth_sim_map_copy_depth_only": (None, [vp, i32, vp, i32, i32, i32, f32]),
     "avo_normal_map_upscale": (None, [vp, i32, vp, i32, f32, abi.ROI]),
+    "avo_depth_sim_map_compute_normal": (None, [vp, i32, vp, i32, P(abi.Camera), i32, abi.ROI]),
     "avo_depth_thickness_smooth_thickness": (None, [vp, i32, P(abi.SgmParams), P(abi.RefineParams), abi.ROI]),
     "avo_compute_sgm_upscaled_depth_pixsize_map": (None, [vp, i32, vp, i32, P(abi.Camera), P(abi.Pyramid), P(abi.RefineParams), f32, abi.ROI]),
     "avo_depth_sim_map_optimize_gradient_descent": (None, [vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, i32, P(abi.Camera), P(abi.Pyramid),

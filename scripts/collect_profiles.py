@@ -26,7 +26,7 @@ def main(tag):
     write = {r["kernel"]: float(r["WRITE_SIZE_per_launch"]) for r in csv.DictReader(open(os.path.join(src, "pmc_WRITE_SIZE.csv")))}
     per = {}
     for k in fetch:
-        if "sgm_path_kernel" in k:
+        if "sgm_path_kernel" in k or "sgm_pair_kernel" in k:
             per[k] = (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
     out = {"source": f"profiles/{tag}_pmc_FETCH_SIZE.csv + {tag}_pmc_WRITE_SIZE.csv", "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB -> B)",
            "per_kernel_bytes": per, "hbm_bytes_per_launch": sum(per.values()) / max(len(per), 1)}

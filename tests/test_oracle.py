@@ -254,3 +254,49 @@ def test_golden_fixture(oracle_lib, name, mode):
     assert v.mean() > 0.6
     assert np.median(np.abs(d - gt)[v]) < 0.06
     assert np.corrcoef(d[v], gt[v])[0, 1] > 0.85
+
+
+def test_normal_map_oracle_matches_numpy_pca_and_analytic_plane(oracle_lib):
+    """avo_depth_sim_map_compute_normal: on the depth map of a slanted plane the PCA normal is the plane normal; on a relief surface it
+    equals numpy's eigh-based PCA of the same 7 x 7 neighbourhoods (independent restatement of mapKernels.cuh:393-477)."""
+    import ctypes as C
+    from alicevision_amd import abi
+    from oracle import oracle
+    sc = make_scene(1, 96, 72, seed=4)
+    cam = abi.camera_fill(sc.K, sc.R[0], sc.C[0], 1)
+    H, W = 72, 96
+    roi = abi.ROI.make(0, W, 0, H)
+    Kinv = np.linalg.inv(sc.K)
+    v, u = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    rays = np.stack([u, v, np.ones_like(u)], -1) @ Kinv.T @ sc.R[0]   # world ray directions (R^T K^-1 x), rows
+    rays /= np.linalg.norm(rays, axis=-1, keepdims=True)
+    # plane n.X = d in world coordinates
+    n_true = np.array([0.2, -0.1, 1.0])
+    n_true /= np.linalg.norm(n_true)
+    d = 4.0
+    depth = ((d - sc.C[0] @ n_true) / (rays @ n_true)).astype(np.float32)
+    dm = np.zeros((H, W, 2), np.float32)
+    dm[..., 0] = depth
+    dm[5, 7, 0] = -1.0  # a hole
+    out = np.zeros((H, W, 3), np.float32)
+    oracle_lib.avo_depth_sim_map_compute_normal(oracle.ptr(out), W * 12, oracle.ptr(dm), W * 8, C.byref(cam), 1, roi)
+    assert np.all(out[5, 7] == -1.0)
+    ok = np.ones((H, W), bool)
+    ok[5, 7] = False
+    cosang = np.abs(out[ok] @ n_true)
+    assert cosang.min() > 1.0 - 1e-6, cosang.min()
+    # oriented towards the camera: n . (C - p) > 0
+    P = sc.C[0] + rays * depth[..., None]
+    assert np.all(np.einsum("ijk,ijk->ij", out, sc.C[0] - P)[ok] > 0)
+
+    # relief surface: compare with numpy PCA
+    dm2 = np.zeros((H, W, 2), np.float32)
+    dm2[..., 0] = (4.0 + 0.2 * np.sin(0.21 * u) * np.cos(0.17 * v)).astype(np.float32)
+    oracle_lib.avo_depth_sim_map_compute_normal(oracle.ptr(out), W * 12, oracle.ptr(dm2), W * 8, C.byref(cam), 1, roi)
+    rng = np.random.RandomState(0)
+    P2 = (sc.C[0] + rays * dm2[..., :1].astype(np.float64)).astype(np.float32).astype(np.float64)
+    for _ in range(60):
+        y, x = rng.randint(0, H), rng.randint(0, W)
+        pts = P2[max(y - 3, 0):y + 4, max(x - 3, 0):x + 4].reshape(-1, 3)
+        w_, vecs = np.linalg.eigh(np.cov(pts.T, bias=True))
+        assert abs(out[y, x] @ vecs[:, 0]) > 1.0 - 1e-4, (y, x)
