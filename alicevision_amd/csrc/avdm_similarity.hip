@@ -269,6 +269,57 @@ __device__ __forceinline__ Lab3 hlerp3(uint2 t0, uint2 t1, v2h w)
     return r;
 }
 
+#ifndef AVDM_DOT2_ASM
+#define AVDM_DOT2_ASM 1
+#endif
+// The four horizontal lerps of a sample (R / T image x top / bottom texel row, three channels each) as ONE block of twelve
+// VOP3P v_dot2_f32_f16 with the inline constant 0 as accumulator.  The builtin only ever selects the VOP2 form v_dot2c_f32_f16,
+// which accumulates into its destination and therefore costs a v_mov_b32 0 per product (12 of the ~104 VALU instructions of a
+// sample).  The compiler does not see the DOT inside an asm statement and would not pad its result hazard (3 wait states before
+// another VALU reads a DOT result on gfx94x/95x — what made an earlier asm attempt return wrong similarities): the block ends
+// with s_nop 2, and the twelve products are independent of each other.
+struct Lab3x4
+{
+    Lab3 rt, tt, rb, tb;
+};
+__device__ __forceinline__ Lab3x4 hlerp3x4(uint2 r00, uint2 r10, uint2 r01, uint2 r11, uint2 t00, uint2 t10, uint2 t01, uint2 t11, v2h wr, v2h wt)
+{
+    Lab3x4 o;
+#if AVDM_DOT2_ASM
+    const unsigned uwr = __builtin_bit_cast(unsigned, wr), uwt = __builtin_bit_cast(unsigned, wt);
+    const unsigned p0 = __builtin_amdgcn_perm(r10.x, r00.x, AVDM_PERM_LO), p1 = __builtin_amdgcn_perm(r10.x, r00.x, AVDM_PERM_HI),
+                   p2 = __builtin_amdgcn_perm(r10.y, r00.y, AVDM_PERM_LO);
+    const unsigned p3 = __builtin_amdgcn_perm(t10.x, t00.x, AVDM_PERM_LO), p4 = __builtin_amdgcn_perm(t10.x, t00.x, AVDM_PERM_HI),
+                   p5 = __builtin_amdgcn_perm(t10.y, t00.y, AVDM_PERM_LO);
+    const unsigned p6 = __builtin_amdgcn_perm(r11.x, r01.x, AVDM_PERM_LO), p7 = __builtin_amdgcn_perm(r11.x, r01.x, AVDM_PERM_HI),
+                   p8 = __builtin_amdgcn_perm(r11.y, r01.y, AVDM_PERM_LO);
+    const unsigned p9 = __builtin_amdgcn_perm(t11.x, t01.x, AVDM_PERM_LO), p10 = __builtin_amdgcn_perm(t11.x, t01.x, AVDM_PERM_HI),
+                   p11 = __builtin_amdgcn_perm(t11.y, t01.y, AVDM_PERM_LO);
+    asm("v_dot2_f32_f16 %0, %12, %24, 0\n\t"
+        "v_dot2_f32_f16 %1, %13, %24, 0\n\t"
+        "v_dot2_f32_f16 %2, %14, %24, 0\n\t"
+        "v_dot2_f32_f16 %3, %15, %25, 0\n\t"
+        "v_dot2_f32_f16 %4, %16, %25, 0\n\t"
+        "v_dot2_f32_f16 %5, %17, %25, 0\n\t"
+        "v_dot2_f32_f16 %6, %18, %24, 0\n\t"
+        "v_dot2_f32_f16 %7, %19, %24, 0\n\t"
+        "v_dot2_f32_f16 %8, %20, %24, 0\n\t"
+        "v_dot2_f32_f16 %9, %21, %25, 0\n\t"
+        "v_dot2_f32_f16 %10, %22, %25, 0\n\t"
+        "v_dot2_f32_f16 %11, %23, %25, 0\n\t"
+        "s_nop 2"
+        : "=&v"(o.rt.L), "=&v"(o.rt.a), "=&v"(o.rt.b), "=&v"(o.tt.L), "=&v"(o.tt.a), "=&v"(o.tt.b), "=&v"(o.rb.L), "=&v"(o.rb.a), "=&v"(o.rb.b),
+          "=&v"(o.tb.L), "=&v"(o.tb.a), "=&v"(o.tb.b)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7), "v"(p8), "v"(p9), "v"(p10), "v"(p11), "v"(uwr), "v"(uwt));
+#else
+    o.rt = hlerp3(r00, r10, wr);
+    o.tt = hlerp3(t00, t10, wt);
+    o.rb = hlerp3(r01, r11, wr);
+    o.tb = hlerp3(t01, t11, wt);
+#endif
+    return o;
+}
+
 template <int WSH, bool TInvert>
 __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const LdsWindows& Wn,
                                                            float4 rcCenter, float4 tcCenter)
@@ -322,7 +373,8 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
             const uint2 t00 = lds_texel(oT), t10 = lds_texel(oT1), t01 = lds_texel(oT + Wn.tPitchB), t11 = lds_texel(oT1 + Wn.tPitchB);
 
             const v2h wr = pk_half_weights(na.x, wa.x), wt = pk_half_weights(na.y, wa.y);
-            const Lab3 rt = hlerp3(r00, r10, wr), tt = hlerp3(t00, t10, wt), rb = hlerp3(r01, r11, wr), tb = hlerp3(t01, t11, wt);
+            const Lab3x4 h = hlerp3x4(r00, r10, r01, r11, t00, t10, t01, t11, wr, wt);
+            const Lab3 &rt = h.rt, &tt = h.tt, &rb = h.rb, &tb = h.tb;
             const v2f L2 = v2f{rt.L, tt.L} * nb + v2f{rb.L, tb.L} * wb; // x 2^16
             const v2f a2 = v2f{rt.a, tt.a} * nb + v2f{rb.a, tb.a} * wb;
             const v2f b2 = v2f{rt.b, tt.b} * nb + v2f{rb.b, tb.b} * wb;
@@ -828,6 +880,15 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
     A.rcap = lds_pitch_for(rw) * rw;
     const int tw = rw + 1;
     A.tcap = lds_pitch_for(tw) * tw;
+    // both kernels run 3 workgroups per CU (168 VGPRs): the T window may use what is left of a third of the 160 KiB — a T view at a
+    // larger scale or a slanted surface then still runs from LDS (3 % of the plane-workgroups of cfg3 overflowed the R-sized window
+    // and paid the ~4x slower generic path)
+    {
+        const int third = (160 * 1024) / 3 - 1024; // minus the static shared state and allocation granularity
+        const int room = third / 8 - A.rcap;
+        if(room > A.tcap)
+            A.tcap = room;
+    }
     if((A.rcap + A.tcap) * 8 > 60 * 1024)
     { // keep >= 2 workgroups per CU; larger steps take the generic path
         A.rcap = 16;
