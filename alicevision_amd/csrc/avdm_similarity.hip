@@ -330,6 +330,7 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
     const v2f bx = {Q.ray.x, Q.tay.x}, by = {Q.ray.y, Q.tay.y}, bz = {Q.ray.z, Q.tay.z};
     const v2f h0x = {Q.hr0.x, Q.ht0.x}, h0y = {Q.hr0.y, Q.ht0.y}, h0z = {Q.hr0.z, Q.ht0.z};
     const v2f Sx = {A.rcSx, A.tcSx}, Ox = {A.rcOx, A.tcOx}, Sy = {A.rcSy, A.tcSy}, Oy = {A.rcOy, A.tcOy};
+    const v2f axS = ax * Sx, ayS = ay * Sy;
     const v2f pitch2 = {Wn.rPitchBF, Wn.tPitchBF}, off2 = {Wn.rOffB, Wn.tOffB};
     const float S16 = 65536.0f;
     const v2f cL = v2f{rcCenter.x, tcCenter.x} * S16, ca = v2f{rcCenter.y, tcCenter.y} * S16, cb = v2f{rcCenter.z, tcCenter.z} * S16;
@@ -343,7 +344,8 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
     for(int yp = -wsh; yp <= wsh; ++yp)
     {
         const float fy = (float)yp;
-        const v2f rowx = fy * bx + h0x, rowy = fy * by + h0y, rowz = fy * bz + h0z; // == row_of()
+        // == row_of(), with the texel-space scale folded into the numerators: X = ((fx*ax + rowx) * Sx) / hz + Ox
+        const v2f rowx = (fy * bx + h0x) * Sx, rowy = (fy * by + h0y) * Sy, rowz = fy * bz + h0z;
         const float* trow = tab.c + (yp + wsh) * n + wsh;
 #pragma unroll kNccUnroll
         for(int xp = -wsh; xp <= wsh; ++xp)
@@ -352,10 +354,8 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
             // == sample_pos(): homogeneous coordinates, one v_rcp per image, texel-space transform
             const v2f hz = fx * az + rowz;
             const v2f inv = {fast_rcp(hz.x), fast_rcp(hz.y)};
-            v2f X = (fx * ax + rowx) * inv;
-            v2f Y = (fx * ay + rowy) * inv;
-            X = X * Sx + Ox;
-            Y = Y * Sy + Oy;
+            const v2f X = (fx * axS + rowx) * inv + Ox;
+            const v2f Y = (fx * ayS + rowy) * inv + Oy;
             const v2f fX = floor2(X), fY = floor2(Y);
             // quant8(): weights in units of 1/256
             const v2f wa = floor2((X - fX) * 256.0f + 0.5f), wb = floor2((Y - fY) * 256.0f + 0.5f);
