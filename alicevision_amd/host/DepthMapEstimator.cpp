@@ -17,6 +17,7 @@
 #include "log.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <exception>
@@ -287,7 +288,13 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
         depthSimMapTilePerCam[i].resize(nbTilesPerCamera);
         depthMinMaxTilePerCam[i].resize(nbTilesPerCamera);
         for(int j = 0; j < nbTilesPerCamera; ++j)
+        {
             depthSimMapTilePerCam[i][j].allocate(finalMapW, finalMapH);
+            // page-lock the result tiles (CudaHostMemoryHeap is pinned memory in the reference): the device-to-host copies of a
+            // group then run asynchronously on the tile streams instead of blocking the host thread that feeds them
+            std::vector<float>& v = depthSimMapTilePerCam[i][j].data;
+            (void)hipHostRegister(v.data(), v.size() * sizeof(float), hipHostRegisterDefault);
+        }
     }
     logDeviceMemoryInfo();
 
@@ -304,6 +311,37 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
         const int lastTileIndex = std::min((b + 1) * nbTilesPerBatch, static_cast<int>(tiles.size()));
         auto batchCamIndexOf = [&](int tileIndex) { return (tileIndex - firstTileIndex) / nbTilesPerCamera; };
 
+        const auto tBatch0 = std::chrono::steady_clock::now();
+        auto secondsSince = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+        // decode the images of the batch on the host cores first (the reference reads them one by one inside addMipmapImage)
+        {
+            std::vector<int> camsOfBatch;
+            for(int i = firstTileIndex; i < lastTileIndex; ++i)
+            {
+                const Tile& tile = tiles.at(i);
+                camsOfBatch.push_back(tile.rc);
+                camsOfBatch.insert(camsOfBatch.end(), tile.sgmTCams.begin(), tile.sgmTCams.end());
+                camsOfBatch.insert(camsOfBatch.end(), tile.refineTCams.begin(), tile.refineTCams.end());
+            }
+            std::sort(camsOfBatch.begin(), camsOfBatch.end());
+            camsOfBatch.erase(std::unique(camsOfBatch.begin(), camsOfBatch.end()), camsOfBatch.end());
+            std::exception_ptr loadError;
+#pragma omp parallel for schedule(dynamic, 1)
+            for(int k = 0; k < (int)camsOfBatch.size(); ++k)
+            {
+                try
+                {
+                    ic.getImg_sync(camsOfBatch[k]);
+                }
+                catch(...)
+                {
+#pragma omp critical
+                    loadError = std::current_exception();
+                }
+            }
+            if(loadError)
+                std::rethrow_exception(loadError);
+        }
         // load the R and T cameras of the batch in the device cache
         for(int i = firstTileIndex; i < lastTileIndex; ++i)
         {
@@ -328,6 +366,7 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
             deviceCache.addCameraParams(tile.rc, 1, _mp); // retrieveBestDepth always asks for downscale 1 (Sgm.cpp:316)
         }
         AVDM_HIP_CHECK(hipDeviceSynchronize());
+        AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": images decoded, uploaded and converted to pyramids in " << secondsSince(tBatch0) << " s.");
 
         // groups of nbStreams tiles
         for(int g0 = firstTileIndex; g0 < lastTileIndex; g0 += nbStreams)
@@ -440,6 +479,7 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
             }
             // the Sgm / Refine buffers of a slot are reused by the next group
             AVDM_HIP_CHECK(hipDeviceSynchronize());
+            AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": " << n << " tile(s) computed, " << secondsSince(tBatch0) << " s since the batch started.");
         }
 
         // write the finished cameras of the batch
@@ -453,6 +493,7 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
             if(_depthMapParams.exportTilePattern)
                 exportDepthSimMapTilePatternObj(c, _mp, _tileRoiList, depthMinMaxTilePerCam.at(ci));
         }
+        AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": depth / similarity maps merged and written, " << secondsSince(tBatch0) << " s since the batch started.");
     }
 
     // merge intermediate result tiles (:470-505)
@@ -478,6 +519,9 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
             }
         }
 
+    for(auto& perCam : depthSimMapTilePerCam)
+        for(auto& t : perCam)
+            (void)hipHostUnregister(t.data.data());
     for(auto& e : volumeDone)
         (void)hipEventDestroy(e);
     (void)hipEventDestroy(aggregationDone);

@@ -393,13 +393,16 @@ bool triangulateMatch(Point3d& out, const Point2d& refpix, const Point2d& tarpix
 // OpenImageIO's resize, whose filter is not restated: DESIGN.md "out of scope").
 std::shared_ptr<const HostImage> ImagesCache::getImg_sync(int camId)
 {
-    std::lock_guard<std::mutex> lock(_mutex);
-    auto it = _cache.find(camId);
-    if(it != _cache.end())
     {
-        it->second.first = ++_tick;
-        return it->second.second;
+        std::lock_guard<std::mutex> lock(_mutex);
+        auto it = _cache.find(camId);
+        if(it != _cache.end())
+        {
+            it->second.first = ++_tick;
+            return it->second.second;
+        }
     }
+    // decode outside the lock: several images can be read at once (DepthMapEstimator pre-warms the cache of a batch in parallel)
     const std::string& path = _mp.getImagePath(camId);
     ExrImage exr;
     readExr(path, exr);
@@ -450,6 +453,7 @@ std::shared_ptr<const HostImage> ImagesCache::getImg_sync(int camId)
                 }
         result = small;
     }
+    std::lock_guard<std::mutex> lock(_mutex);
     if(_cache.size() >= _max)
     {
         auto oldest = _cache.begin();

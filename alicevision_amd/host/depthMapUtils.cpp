@@ -40,8 +40,9 @@ void weightTileBorder(int a, int b, int c, int d, int borderWidth, int borderHei
     const Point2d rd_m(rd.x - margin, rd.y - margin);
     const double borderWidth_m = borderWidth - 2.0 * margin;
     const double borderHeight_m = borderHeight - 2.0 * margin;
-    for(int x = (int)lu.x; x < endX; ++x)
-        for(int y = (int)lu.y; y < endY; ++y)
+    // row-major maps: y outer, x inner (the reference iterates column by column; the weight of a pixel does not depend on the order)
+    for(int y = (int)lu.y; y < endY; ++y)
+        for(int x = (int)lu.x; x < endX; ++x)
         {
             if(x < 0 || y < 0)
                 continue; // a tile narrower than the padding: the reference would index out of bounds
@@ -194,8 +195,10 @@ void addTileMapWeighted(int rc, const MultiViewParams& mp, const TileParams& til
     if(!lastColumn) // right border
         weightTileBorder(1, 0, 0, 1, tilePadding, tileHeight - 2 * tilePadding, Point2d(tileWidth - tilePadding, tilePadding), in_tileMap);
 
-    for(int x = (int)downscaledRoi.x.begin; x < (int)downscaledRoi.x.end && x < inout_map.width; ++x)
-        for(int y = (int)downscaledRoi.y.begin; y < (int)downscaledRoi.y.end && y < inout_map.height; ++y)
+    const int xEnd = std::min((int)downscaledRoi.x.end, inout_map.width), yEnd = std::min((int)downscaledRoi.y.end, inout_map.height);
+#pragma omp parallel for schedule(static) num_threads(8)
+    for(int y = (int)downscaledRoi.y.begin; y < yEnd; ++y)
+        for(int x = (int)downscaledRoi.x.begin; x < xEnd; ++x)
             inout_map(y, x) += in_tileMap(y - (int)downscaledRoi.y.begin, x - (int)downscaledRoi.x.begin);
 }
 
@@ -350,6 +353,19 @@ void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileP
     const int width = divideRoundUp(mp.getWidth(rc), scaleStep);
     const int height = divideRoundUp(mp.getHeight(rc), scaleStep);
     FloatMap depthMap(width, height, 0.0f), simMap(width, height, 0.0f);
+    // the two tile maps are allocated once (largest tile) and reshaped per tile: allocating and freeing multi-megabyte vectors per
+    // tile means mmap / munmap each time, and every munmap interrupts all the cores the OpenMP team runs on
+    FloatMap tileDepthMap, tileSimMap;
+    {
+        size_t maxPixels = 0;
+        for(const ROI& t : tileRoiList)
+        {
+            const ROI r = downscaleROI(intersect(t, imageRoi), (float)scaleStep);
+            maxPixels = std::max(maxPixels, (size_t)r.width() * r.height());
+        }
+        tileDepthMap.data.reserve(maxPixels);
+        tileSimMap.data.reserve(maxPixels);
+    }
 
     for(size_t i = 0; i < tileRoiList.size(); ++i)
     {
@@ -359,7 +375,9 @@ void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileP
         const ROI r = downscaleROI(roi, (float)scaleStep);
         const int w = (int)r.width(), h = (int)r.height();
         const Float2Tile& t = in_depthSimMapTiles.at(i);
-        FloatMap tileDepthMap(w, h), tileSimMap(w, h);
+        tileDepthMap.reshape(w, h);
+        tileSimMap.reshape(w, h);
+#pragma omp parallel for schedule(static) num_threads(8)
         for(int y = 0; y < h; ++y)
             for(int x = 0; x < w; ++x)
             {

@@ -21,6 +21,12 @@ struct FloatMap
     std::vector<float> data;
     FloatMap() = default;
     FloatMap(int w, int h, float v = 0.f) : width(w), height(h), data((size_t)w * h, v) {}
+    // change the shape, keeping the allocation when it is large enough (contents unspecified)
+    void reshape(int w, int h)
+    {
+        width = w, height = h;
+        data.resize((size_t)w * h);
+    }
     float& operator()(int y, int x) { return data[(size_t)y * width + x]; }
     float operator()(int y, int x) const { return data[(size_t)y * width + x]; }
 };

@@ -13,6 +13,7 @@
 #include "params.hpp"
 #include "sfmData.hpp"
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -86,14 +87,16 @@ int main(int argc, char** argv)
             const int tw = divideRoundUp(tp.bufferWidth, scaleStep), th = divideRoundUp(tp.bufferHeight, scaleStep);
             for(size_t i = 0; i < rois.size(); ++i)
             {
-                tiles[i].allocate(std::max(tw, divideRoundUp(mp.getWidth(0), scaleStep)), std::max(th, divideRoundUp(mp.getHeight(0), scaleStep)));
+                tiles[i].allocate(rois.size() > 1 ? tw : divideRoundUp(mp.getWidth(0), scaleStep), rois.size() > 1 ? th : divideRoundUp(mp.getHeight(0), scaleStep));
                 for(size_t k = 0; k < tiles[i].data.size(); k += 2)
                 {
                     tiles[i].data[k] = 1.0f;       // "depth"
                     tiles[i].data[k + 1] = 0.5f;   // "sim"
                 }
             }
+            const auto t0 = std::chrono::steady_clock::now();
             writeDepthSimMapFromTileList(0, mp, tp, rois, tiles, scaleStep, 1);
+            std::cout << "merge+write " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s" << std::endl;
             return 0;
         }
         return usage();

@@ -39,7 +39,7 @@ r = subprocess.run(args, capture_output=True, text=True)
 wall = time.time() - t0
 print("exit", r.returncode, "wall %.2f s for %d camera(s) -> %.3f depth-maps/s (including image decode, upload, EXR output)" % (wall, ncam, ncam / wall))
 for l in r.stdout.splitlines():
-    if any(k in l for k in ("Task done", "simultaneous", "tiles per image", "Optimizing volume of", "depth planes:")):
+    if any(k in l for k in ("Task done", "simultaneous", "tiles per image", "Optimizing volume of", "Batch ", "Found ", "Device memory (")):
         print("  ", l.strip()[:160])
 print(r.stderr[-1500:])
 if r.returncode == 0:

@@ -123,7 +123,18 @@ def test_tiled_run_merges(dataset):
     args4 = common_args(sfm, img, out4) + ["--autoAdjustSmallImage", 0, "--tileBufferWidth", 416, "--tileBufferHeight", 352, "--tilePadding", 32]
     plan = json.loads(run_cli(args4 + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
     assert len(plan["tiles"]) == 4, [t["roi"] for t in plan["tiles"]]
-    run_cli(args4 + ["--exportIntermediateDepthSimMaps", 1])
+    run_cli(args4 + ["--exportIntermediateDepthSimMaps", 1, "--exportIntermediateNormalMaps", 1])
+    # normal maps (SGM resolution, refined, final): merged from the tiles, unit vectors facing the camera where a depth exists
+    vid = scene_io.view_id(0)
+    for name, shape in (("normalMap_sgm", (H // 4, W // 4)), ("normalMap_refinedFused", (H, W)), ("normalMap", (H, W))):
+        nm, ninfo = exr_io.read_exr(os.path.join(out4, "%d_%s.exr" % (vid, name)))
+        assert set(nm) == {"R", "G", "B"} and nm["R"].shape == shape, (name, nm["R"].shape)
+        n = np.stack([nm["R"], nm["G"], nm["B"]], -1)
+        core = n[shape[0] // 4: -shape[0] // 4, shape[1] // 4: -shape[1] // 4]
+        good = np.abs(np.linalg.norm(core, axis=-1) - 1.0) < 2e-2  # half storage, blended at the tile seams
+        assert good.mean() > 0.7, (name, float(good.mean()))
+        # the surface faces the camera: the normal points against the viewing direction (camera z axis = row 2 of R)
+        assert (core[good] @ sc.R[0][2] < 0).mean() > 0.95, name
     d1, s1, _, _ = read_maps(out1)
     d4, s4, info4, _ = read_maps(out4)
     assert d4.shape == d1.shape == (H, W)
