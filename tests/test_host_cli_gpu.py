@@ -162,3 +162,36 @@ def test_cli_fails_loudly_without_inputs(dataset):
     assert r.returncode == 1 and "cannot be read" in (r.stdout + r.stderr)
     r = run_cli(["-i", sfm, "--imagesFolder", img], check=False)
     assert r.returncode == 1 and "required" in r.stderr
+
+
+def test_sweep_only_configuration(dataset):
+    """BASELINE cfg2 shape ("plane sweep only, no SGM"): --sgmOptimizeVolume 0 --useRefine 0 makes the SGM-resolution WTA map the
+    final output (DepthMapEstimator.cpp:285,314-315,441-442); it must equal the harness' run_sgm(optimize=False)."""
+    import torch
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    sc, sfm, img, d = dataset
+    out = os.path.join(d, "out_sweep")
+    args = common_args(sfm, img, out) + ["--sgmOptimizeVolume", 0, "--useRefine", 0, "--autoAdjustSmallImage", 0, "--tileBufferWidth", 640,
+                                         "--tileBufferHeight", 640, "--maxTCams", 4]
+    plan = json.loads(run_cli(args + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
+    t0 = plan["tiles"][0]
+    assert plan["sgmScale"] == 2 and plan["sgmStepXY"] == 2
+    run_cli(args)
+    depth, sim, dinfo, _ = read_maps(out)
+    assert depth.shape == (H // 4, W // 4) and exr_io.attr_value(dinfo, "AliceVision:downscale") == 4
+    sgm = abi.SgmParams.default()
+    ref = abi.RefineParams.default()
+    torch.cuda.set_device(0)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(NVIEWS)]
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+    ranges = [(a, a + n) for a, n in t0["depthsTcLimits"]]
+    _, ds = h.run_sgm(0, t0["sgmTCams"], np.asarray(t0["depths"], np.float32), tc_ranges=ranges, optimize=False)
+    ds = ds.cpu().numpy()
+    assert np.array_equal(ds[..., 0], depth)
+    assert np.array_equal(ds[..., 1].astype(np.float16).astype(np.float32), sim)
+    # the raw sweep already finds the surface on most pixels
+    gt = sc.gt_depth.numpy()[::4, ::4]
+    m = depth > 0
+    m[:4] = m[-4:] = False
+    m[:, :4] = m[:, -4:] = False
+    assert m.mean() > 0.5 and np.median(np.abs(depth - gt)[m] / gt[m]) < 2e-2
