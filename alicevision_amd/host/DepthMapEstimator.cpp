@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <exception>
+#include <future>
 #include <memory>
 
 namespace avdm_host {
@@ -281,21 +282,30 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
     // final depth/similarity map tiles in host memory, per camera of a batch
     const int finalMapW = _depthMapParams.useRefine ? refinePerStream.front()->getMapWidth() : sgmPerStream.front()->getMapWidth();
     const int finalMapH = _depthMapParams.useRefine ? refinePerStream.front()->getMapHeight() : sgmPerStream.front()->getMapHeight();
-    std::vector<std::vector<Float2Tile>> depthSimMapTilePerCam(nbRcPerBatch);
-    std::vector<std::vector<std::pair<float, float>>> depthMinMaxTilePerCam(nbRcPerBatch);
-    for(int i = 0; i < nbRcPerBatch; ++i)
+    // two sets: while the tiles of batch b are merged and written by a background task, batch b + 1 computes into the other set
+    // (the reference merges and writes between the batches, DepthMapEstimator.cpp:446-466, with the device idle)
+    const int nbHostSets = 2;
+    std::vector<std::vector<Float2Tile>> depthSimMapTileSets[nbHostSets];
+    std::vector<std::vector<std::pair<float, float>>> depthMinMaxTileSets[nbHostSets];
+    for(int s = 0; s < nbHostSets; ++s)
     {
-        depthSimMapTilePerCam[i].resize(nbTilesPerCamera);
-        depthMinMaxTilePerCam[i].resize(nbTilesPerCamera);
-        for(int j = 0; j < nbTilesPerCamera; ++j)
+        depthSimMapTileSets[s].resize(nbRcPerBatch);
+        depthMinMaxTileSets[s].resize(nbRcPerBatch);
+        for(int i = 0; i < nbRcPerBatch; ++i)
         {
-            depthSimMapTilePerCam[i][j].allocate(finalMapW, finalMapH);
-            // page-lock the result tiles (CudaHostMemoryHeap is pinned memory in the reference): the device-to-host copies of a
-            // group then run asynchronously on the tile streams instead of blocking the host thread that feeds them
-            std::vector<float>& v = depthSimMapTilePerCam[i][j].data;
-            (void)hipHostRegister(v.data(), v.size() * sizeof(float), hipHostRegisterDefault);
+            depthSimMapTileSets[s][i].resize(nbTilesPerCamera);
+            depthMinMaxTileSets[s][i].resize(nbTilesPerCamera);
+            for(int j = 0; j < nbTilesPerCamera; ++j)
+            {
+                depthSimMapTileSets[s][i][j].allocate(finalMapW, finalMapH);
+                // page-lock the result tiles (CudaHostMemoryHeap is pinned memory in the reference): the device-to-host copies of a
+                // group then run asynchronously on the tile streams instead of blocking the host thread that feeds them
+                std::vector<float>& v = depthSimMapTileSets[s][i][j].data;
+                (void)hipHostRegister(v.data(), v.size() * sizeof(float), hipHostRegisterDefault);
+            }
         }
     }
+    std::future<void> pendingWrite;
     logDeviceMemoryInfo();
 
     const int nbBatches = divideRoundUp(static_cast<int>(tiles.size()), nbTilesPerBatch);
@@ -310,6 +320,9 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
         const int firstTileIndex = b * nbTilesPerBatch;
         const int lastTileIndex = std::min((b + 1) * nbTilesPerBatch, static_cast<int>(tiles.size()));
         auto batchCamIndexOf = [&](int tileIndex) { return (tileIndex - firstTileIndex) / nbTilesPerCamera; };
+
+        std::vector<std::vector<Float2Tile>>& depthSimMapTilePerCam = depthSimMapTileSets[b % nbHostSets];
+        std::vector<std::vector<std::pair<float, float>>>& depthMinMaxTilePerCam = depthMinMaxTileSets[b % nbHostSets];
 
         const auto tBatch0 = std::chrono::steady_clock::now();
         auto secondsSince = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
@@ -482,19 +495,29 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
             AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": " << n << " tile(s) computed, " << secondsSince(tBatch0) << " s since the batch started.");
         }
 
-        // write the finished cameras of the batch
+        // write the finished cameras of the batch, in the background: the previous batch's task must be done first (it owns the other set)
+        if(pendingWrite.valid())
+            pendingWrite.get();
+        std::vector<int> batchCams;
         for(int ci = 0; ci * nbTilesPerCamera + firstTileIndex < lastTileIndex; ++ci)
-        {
-            const int c = tiles.at(firstTileIndex + ci * nbTilesPerCamera).rc;
-            if(_depthMapParams.useRefine)
-                writeDepthSimMapFromTileList(c, _mp, _tileParams, _tileRoiList, depthSimMapTilePerCam.at(ci), _refineParams.scale, _refineParams.stepXY);
-            else
-                writeDepthSimMapFromTileList(c, _mp, _tileParams, _tileRoiList, depthSimMapTilePerCam.at(ci), _sgmParams.scale, _sgmParams.stepXY);
-            if(_depthMapParams.exportTilePattern)
-                exportDepthSimMapTilePatternObj(c, _mp, _tileRoiList, depthMinMaxTilePerCam.at(ci));
-        }
-        AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": depth / similarity maps merged and written, " << secondsSince(tBatch0) << " s since the batch started.");
+            batchCams.push_back(tiles.at(firstTileIndex + ci * nbTilesPerCamera).rc);
+        pendingWrite = std::async(std::launch::async, [this, batchCams, b, nbBatches, tBatch0, &depthSimMapTilePerCam, &depthMinMaxTilePerCam]() {
+            for(size_t ci = 0; ci < batchCams.size(); ++ci)
+            {
+                const int c = batchCams[ci];
+                if(_depthMapParams.useRefine)
+                    writeDepthSimMapFromTileList(c, _mp, _tileParams, _tileRoiList, depthSimMapTilePerCam.at(ci), _refineParams.scale, _refineParams.stepXY);
+                else
+                    writeDepthSimMapFromTileList(c, _mp, _tileParams, _tileRoiList, depthSimMapTilePerCam.at(ci), _sgmParams.scale, _sgmParams.stepXY);
+                if(_depthMapParams.exportTilePattern)
+                    exportDepthSimMapTilePatternObj(c, _mp, _tileRoiList, depthMinMaxTilePerCam.at(ci));
+            }
+            AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": depth / similarity maps merged and written, "
+                                   << std::chrono::duration<double>(std::chrono::steady_clock::now() - tBatch0).count() << " s since the batch started.");
+        });
     }
+    if(pendingWrite.valid())
+        pendingWrite.get();
 
     // merge intermediate result tiles (:470-505)
     if(tiles.size() > cams.size())
@@ -519,9 +542,10 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
             }
         }
 
-    for(auto& perCam : depthSimMapTilePerCam)
-        for(auto& t : perCam)
-            (void)hipHostUnregister(t.data.data());
+    for(auto& set : depthSimMapTileSets)
+        for(auto& perCam : set)
+            for(auto& t : perCam)
+                (void)hipHostUnregister(t.data.data());
     for(auto& e : volumeDone)
         (void)hipEventDestroy(e);
     (void)hipEventDestroy(aggregationDone);
