@@ -119,6 +119,24 @@ SIGNATURES = {
     "avdm_camera_fill": (None, [P(Camera), P(C.c_double * 9), P(C.c_double * 9), P(C.c_double * 3), i32]),
 }
 
+
+
+class FuseCamera(C.Structure):
+    """avdm_fuse.h: camArr / iCamArr / CArr of a camera (row-major doubles) and its image size."""
+    _fields_ = [("P", C.c_double * 12), ("iP", C.c_double * 9), ("C", C.c_double * 3), ("width", C.c_int), ("height", C.c_int)]
+
+
+class FuseTc(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("depth_pitch", C.c_int), ("reserved", C.c_int), ("cam", FuseCamera)]
+
+
+# mirrors include/avdm_fuse.h one to one
+FUSE_SIGNATURES = {
+    "avdm_fuse_filter_groups_scratch_bytes": (C.c_size_t, [i32, i32]),
+    "avdm_fuse_filter_groups": (i32, [vp, i32, vp, i32, vp, i32, P(FuseCamera), i32, P(FuseTc), f32, i32, i32, vp, vp]),
+    "avdm_fuse_filter_depth_maps": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+}
+
 _lib = None
 
 
@@ -135,7 +153,7 @@ def load(path=None):
     if not os.path.exists(p):
         raise AvdmError(f"{p} not found: build it with `python -m alicevision_amd.build` (hipcc, gfx950). There is no CPU fallback.")
     lib = C.CDLL(p)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(FUSE_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

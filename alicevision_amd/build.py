@@ -21,6 +21,7 @@ SOURCES = {
     "avdm_similarity.hip": [],                       # fast-math intrinsics + FMA contraction allowed (tolerance class)
     "avdm_sgm.hip": ["-ffp-contract=off"],           # bit-exact class
     "avdm_maps.hip": ["-ffp-contract=off"],          # bit-exact / order-preserving class
+    "avdm_fuse.hip": ["-ffp-contract=off"],          # bit-exact class (double arithmetic in the reference's order)
 }
 
 
@@ -40,13 +41,14 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "avdm_device.h"), os.path.join(HERE, "..", "include", "avdm.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, "avdm_device.h"), os.path.join(HERE, "..", "include", "avdm.h")]
+    extra_headers = {"avdm_fuse.hip": [os.path.join(HERE, "..", "include", "avdm_fuse.h")]}
     objs, jobs = [], []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
+        if force or _stale(o, [s] + headers + extra_headers.get(src, [])):
             jobs.append([hipcc] + COMMON + extra + ["-c", s, "-o", o])
 
     def run(cmd):

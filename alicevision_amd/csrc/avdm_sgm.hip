@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 
 namespace avdm {
@@ -1104,10 +1105,54 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
     }
 }
 
+// Opt-in timing of the path kernels alone (avdm_debug_sgm_kernel_timing): a pair of HIP events on the launch stream around every launch,
+// read back (and recycled) by avdm_debug_sgm_kernel_timing_read.  Off by default: no events, no synchronisation.
+struct SgmKernelTimer
+{
+    std::mutex m;
+    bool enabled = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
+    double ms = 0.0;
+    long launches = 0;
+};
+static SgmKernelTimer g_sgmTimer;
+
+struct SgmKernelTimerScope
+{
+    hipStream_t st;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    explicit SgmKernelTimerScope(hipStream_t s) : st(s)
+    {
+        std::lock_guard<std::mutex> lock(g_sgmTimer.m);
+        if(!g_sgmTimer.enabled)
+            return;
+        if(!g_sgmTimer.pool.empty())
+        {
+            ev = g_sgmTimer.pool.back();
+            g_sgmTimer.pool.pop_back();
+        }
+        else if(hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess)
+        {
+            ev = {nullptr, nullptr};
+            return;
+        }
+        (void)hipEventRecord(ev.first, st);
+    }
+    ~SgmKernelTimerScope()
+    {
+        if(ev.first == nullptr)
+            return;
+        (void)hipEventRecord(ev.second, st);
+        std::lock_guard<std::mutex> lock(g_sgmTimer.m);
+        g_sgmTimer.pending.push_back(ev);
+    }
+};
+
 template <int NW>
 static void launch_pair(const SgmPathBatch& S, int nWorkgroups, int K, bool full, hipStream_t st)
 {
     dim3 grid(nWorkgroups), block(128 * AVDM_SGM_PAIR_WPB);
+    SgmKernelTimerScope timing(st);
     if(K == 0)
     {
         if(full)
@@ -1128,6 +1173,7 @@ template <int NW>
 static void launch_path(const SgmPathBatch& S, int ncols, int K, bool full, bool int16, hipStream_t st)
 {
     dim3 grid(ncols);
+    SgmKernelTimerScope timing(st);
 #define AVDM_SGM_LAUNCH2(KK, FF, II) hipLaunchKernelGGL((sgm_path_kernel<NW, KK, FF, II>), grid, dim3(64 * AVDM_SGM_WPB), 0, st, S)
     // the fp32 kernel (non-integer P1) is only instantiated in its general form: FULL shapes run it with FULL = false
 #define AVDM_SGM_LAUNCH(KK)                                                                                                                           \
@@ -1309,6 +1355,40 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
 using namespace avdm;
 
 extern "C" {
+
+/* measurement aids (not part of avdm.h; bench.py uses them for roofline.achieved): HIP events on the launch stream around every
+ * path-aggregation kernel launch; _read waits for the recorded events and returns the summed kernel time and the number of launches */
+int avdm_debug_sgm_kernel_timing(int enable)
+{
+    std::lock_guard<std::mutex> lock(g_sgmTimer.m);
+    g_sgmTimer.enabled = enable != 0;
+    return 0;
+}
+
+int avdm_debug_sgm_kernel_timing_read(double* total_ms, long* n_launches, int reset)
+{
+    std::lock_guard<std::mutex> lock(g_sgmTimer.m);
+    for(auto& ev : g_sgmTimer.pending)
+    {
+        float ms = 0.f;
+        if(hipEventSynchronize(ev.second) != hipSuccess || hipEventElapsedTime(&ms, ev.first, ev.second) != hipSuccess)
+            return set_error_msg(1, "avdm_debug_sgm_kernel_timing_read: reading a HIP event failed");
+        g_sgmTimer.ms += ms;
+        g_sgmTimer.launches += 1;
+        g_sgmTimer.pool.push_back(ev);
+    }
+    g_sgmTimer.pending.clear();
+    if(total_ms)
+        *total_ms = g_sgmTimer.ms;
+    if(n_launches)
+        *n_launches = g_sgmTimer.launches;
+    if(reset)
+    {
+        g_sgmTimer.ms = 0.0;
+        g_sgmTimer.launches = 0;
+    }
+    return 0;
+}
 
 size_t avdm_volume_optimize_scratch_bytes(int dimX, int dimY, int dimZ)
 {

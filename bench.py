@@ -13,6 +13,7 @@ timed region.  All compute goes through the C ABI of alicevision_amd/csrc/libavd
 used for the `cpu_baseline` leg on rank 0 at N = 1.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -111,6 +112,9 @@ def main():
     depths = plane_depths(sc, Z)
     tile = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, device=dev)
     tile.enable_timers(True)
+    lib = abi.load()
+    lib.avdm_debug_sgm_kernel_timing.argtypes = [ctypes.c_int]
+    lib.avdm_debug_sgm_kernel_timing_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]
     my_cams = cameras_of_rank(list(range(V)), rank, world)  # reference cameras of this rank (round-robin), cycled over steps
 
     def step(i):
@@ -127,6 +131,7 @@ def main():
         step(i)
     torch.cuda.synchronize()
     tile.reset_timers()
+    lib.avdm_debug_sgm_kernel_timing(1)  # HIP events on the launch stream around every path-aggregation kernel launch
     if world > 1:
         dist.barrier()
     t0 = time.time()
@@ -142,6 +147,9 @@ def main():
         elapsed = float(tt.item())
 
     stages = tile.stage_ms()  # mean ms per step and stage (HIP events on the launch stream)
+    k_ms, k_n = ctypes.c_double(0.0), ctypes.c_long(0)
+    abi.check(lib.avdm_debug_sgm_kernel_timing_read(ctypes.byref(k_ms), ctypes.byref(k_n), 1), "avdm_debug_sgm_kernel_timing_read")
+    lib.avdm_debug_sgm_kernel_timing(0)
     valid = float((out[..., 0] > 0).float().mean().item())
 
     if rank == 0:
@@ -154,11 +162,16 @@ def main():
         # axis per launch); AVDM_SGM_PAIR=0 runs the four sequential sgm_path_kernel launches instead
         n_launches = 4 if os.environ.get("AVDM_SGM_PAIR") == "0" else 2
         alg_bytes_per_launch = (11.0 * X * Y * Z + 64.0 * X * Y) / n_launches
-        sgm_ms_per_launch = stages["sgm_optimize"] / n_launches
+        # average duration of one path-aggregation kernel launch (events around the launches alone); stages["sgm_optimize"] is the
+        # whole avdm_volume_optimize call, i.e. these launches + the adaptive-P2 map kernel
+        if k_n.value != n_launches * args.steps:
+            raise SystemExit(f"expected {n_launches * args.steps} path-kernel launches in the timed region, the library timed {k_n.value}")
+        sgm_ms_per_launch = k_ms.value / k_n.value
         achieved = alg_bytes_per_launch / (sgm_ms_per_launch * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "sgm_pair_kernel" if n_launches == 2 else "sgm_path_kernel", "achieved": achieved, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "alg_bytes_per_launch": alg_bytes_per_launch,
-                "ms_per_launch": sgm_ms_per_launch, "launches_per_volume": n_launches}
+                "ms_per_launch": sgm_ms_per_launch, "launches_per_volume": n_launches,
+                "ms_whole_call_per_volume": stages["sgm_optimize"]}
         pmc = os.path.join(ROOT, "profiles", "r01_sgm_pmc.json")
         if os.path.exists(pmc):
             try:
@@ -176,7 +189,6 @@ def main():
             "stages_ms": stages, "valid_fraction": valid,
         }
         if os.environ.get("AVDM_SIM_STATS") == "1":
-            import ctypes
             st = (ctypes.c_uint * 4)()
             abi.load().avdm_debug_similarity_stats(st)
             line["similarity_plane_workgroups"] = {"lds": int(st[0]), "generic_r_tile": int(st[1]), "generic_t_outside": int(st[2]),

@@ -57,6 +57,22 @@ void avo_depth_sim_map_optimize_gradient_descent(float* outOpt, int out_pitch, f
                                                  int ref_pitch, const avdm_camera_t* rc, const avdm_pyramid_t* rcPyr,
                                                  const avdm_refine_params_t* rp, avdm_roi_t roi);
 
+/* ---- depth-map filtering (avdm_fuse_oracle.c; fuseCut/Fuser.cpp:66-304) ---- */
+/* camArr (3x4), iCamArr (3x3), CArr of a camera, row-major, and the image size MultiViewParams reports for it */
+typedef struct
+{
+    double P[12];
+    double iP[9];
+    double C[3];
+    int width, height;
+} avo_fuse_cam_t;
+
+int avo_fuse_filter_groups_rc(unsigned char* nmod, const float* depth, const float* sim, const avo_fuse_cam_t* rc, int n_tc, const avo_fuse_cam_t* tcs,
+                              const float* const* tc_depth, float pixToleranceFactor, int pixSizeBall, int pixSizeBallWSP);
+void avo_fuse_filter_depth_maps_rc(float* depthMap, float* simMap, const unsigned char* numOfModalsMap, size_t n, int minNumOfModals,
+                                   int minNumOfModalsWSP2SSP);
+double avo_fuse_pixel_size_plane_sweep_alpha(const double p[3], const avo_fuse_cam_t* rc, const avo_fuse_cam_t* tc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,33 +10,39 @@ from alicevision_amd import abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "avdm.h")).read()
+HEADERS = {"avdm.h": "SIGNATURES", "avdm_fuse.h": "FUSE_SIGNATURES"}
+
+
+def _declared_functions(header="avdm.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(avdm_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():
-    names = _declared_functions()
-    assert len(names) >= 28
+    assert len(_declared_functions()) >= 28
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == sorted(HEADERS)
     lib = abi.load()
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/avdm.h but not exported by libavdm.so"
-        assert n in abi.SIGNATURES, f"{n} has no ctypes signature in alicevision_amd/abi.py"
-    for n in abi.SIGNATURES:
-        assert n in names, f"{n} bound in abi.py but not declared in include/avdm.h"
+    for header, table in HEADERS.items():
+        names, bound = _declared_functions(header), getattr(abi, table)
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in include/{header} but not exported by libavdm.so"
+            assert n in bound, f"{n} has no ctypes signature in alicevision_amd/abi.py"
+        for n in bound:
+            assert n in names, f"{n} bound in abi.py but not declared in include/{header}"
 
 
 def test_every_entry_point_cites_the_reference():
     """each declaration is preceded by a comment naming the reference interface it replaces (file:line)"""
-    src = open(os.path.join(ROOT, "include", "avdm.h")).read()
-    for n in _declared_functions():
-        if n in ("avdm_last_error", "avdm_version"):
-            continue
-        i = src.index(n + "(")
-        ctx = src[max(0, i - 700):i]
-        last_comment = ctx[ctx.rfind("/*"):]
-        assert re.search(r"\.(cu|cuh|cpp|hpp)|:\d+", last_comment), n  # file:line (the file may be named once per header section)
+    for header in HEADERS:
+        src = open(os.path.join(ROOT, "include", header)).read()
+        for n in _declared_functions(header):
+            if n in ("avdm_last_error", "avdm_version"):
+                continue
+            i = src.index(n + "(")
+            ctx = src[max(0, i - 700):i]
+            last_comment = ctx[ctx.rfind("/*"):]
+            assert re.search(r"\.(cu|cuh|cpp|hpp)|:\d+", last_comment), n  # file:line (the file may be named once per header section)
 
 
 def test_struct_layouts_match_the_header():
@@ -45,6 +51,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(abi.ROI) == 16
     assert C.sizeof(abi.Pyramid) == 8 + 4 * 4 + 4 + 3 * 8 * 4 + 8 * 8 + 8 or C.sizeof(abi.Pyramid) % 8 == 0
     assert C.sizeof(abi.SgmParams) % 8 == 0 and C.sizeof(abi.RefineParams) % 8 == 0
+    assert C.sizeof(abi.FuseCamera) == 24 * 8 + 8 and C.sizeof(abi.FuseTc) == 16 + C.sizeof(abi.FuseCamera)
 
 
 def test_camera_fill_matches_oracle_and_projects(oracle_lib):
