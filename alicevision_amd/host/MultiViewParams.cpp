@@ -30,10 +30,12 @@ struct SortedId
 };
 } // namespace
 
-MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imagesFolder, const std::string& depthMapsFolder, int downscale)
+MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imagesFolder, const std::string& depthMapsFolder,
+                                 const std::string& depthMapsFilterFolder, EFileType fileType, int downscale)
   : _sfmData(sfmData),
     _imagesFolder(imagesFolder + "/"),
     _depthMapsFolder(depthMapsFolder + "/"),
+    _depthMapsFilterFolder(depthMapsFilterFolder + "/"),
     _processDownscale(downscale)
 {
     // image uid, path and dimensions (MultiViewParams.cpp:52-110)
@@ -46,7 +48,11 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
             if(!sfmData.isPoseAndIntrinsicDefined(view))
                 continue;
             std::string path = view.path;
-            if(_imagesFolder != "/" && dirExists(_imagesFolder))
+            if(fileType == EFileType::depthMap)
+                path = getFileNameFromViewId(*this, view.viewId, depthMapsFolder.empty() ? EFileType::depthMapFiltered : EFileType::depthMap);
+            else if(fileType == EFileType::normalMap)
+                path = getFileNameFromViewId(*this, view.viewId, EFileType::normalMap);
+            else if(_imagesFolder != "/" && dirExists(_imagesFolder))
             {
                 // one file per view named <viewId>.<ext>; this build decodes OpenEXR only (PrepareDenseScene's output format)
                 const std::string candidate = _imagesFolder + std::to_string(view.viewId) + ".exr";
@@ -334,6 +340,11 @@ std::string getFileNameFromViewId(const MultiViewParams& mp, IndexT viewId, EFil
         case EFileType::thicknessMap: folder = mp.getDepthMapsFolder(), suffix = "_thicknessMap"; break;
         case EFileType::pixSizeMap: folder = mp.getDepthMapsFolder(), suffix = "_pixSizeMap"; break;
         case EFileType::tilePattern: folder = mp.getDepthMapsFolder(), suffix = "_tilePattern", ext = "obj"; break;
+        case EFileType::depthMapFiltered: folder = mp.getDepthMapsFilterFolder(), suffix = "_depthMap"; break;
+        case EFileType::simMapFiltered: folder = mp.getDepthMapsFilterFolder(), suffix = "_simMap"; break;
+        case EFileType::normalMapFiltered: folder = mp.getDepthMapsFilterFolder(), suffix = "_normalMap"; break;
+        case EFileType::nmodMap: folder = mp.getDepthMapsFilterFolder(), suffix = "_nmodMap", ext = "png"; break;
+        case EFileType::none: break;
     }
     return folder + std::to_string(viewId) + suffix + customSuffix + tileSuffix + "." + ext;
 }

@@ -18,12 +18,17 @@ namespace avdm_host {
 
 enum class EFileType
 {
+    none, // image files (the reference's default, EFileType::img)
     depthMap,
     simMap,
     normalMap,
     thicknessMap,
     pixSizeMap,
     tilePattern,
+    depthMapFiltered,
+    simMapFiltered,
+    normalMapFiltered,
+    nmodMap,
     P,
     D
 };
@@ -44,11 +49,18 @@ class MultiViewParams
     int ncams = 0;
     int g_border = 2;
 
-    MultiViewParams(const SfMData& sfmData, const std::string& imagesFolder, const std::string& depthMapsFolder, int downscale);
+    // MultiViewParams.cpp:37-246.  fileType == depthMap: the per-view file whose metadata (downscale, P) is read is the depth map of
+    // the view — from depthMapsFolder, or the filtered one from depthMapsFilterFolder when depthMapsFolder is empty (:66-78)
+    MultiViewParams(const SfMData& sfmData, const std::string& imagesFolder, const std::string& depthMapsFolder, const std::string& depthMapsFilterFolder,
+                    EFileType fileType, int downscale = 1);
+    MultiViewParams(const SfMData& sfmData, const std::string& imagesFolder, const std::string& depthMapsFolder, int downscale)
+      : MultiViewParams(sfmData, imagesFolder, depthMapsFolder, "", EFileType::none, downscale)
+    {}
 
     const SfMData& getInputSfMData() const { return _sfmData; }
     const std::string& getImagesFolder() const { return _imagesFolder; }
     const std::string& getDepthMapsFolder() const { return _depthMapsFolder; }
+    const std::string& getDepthMapsFilterFolder() const { return _depthMapsFilterFolder; }
     const std::string& getImagePath(int index) const { return _imagesParams.at(index).path; }
     IndexT getViewId(int index) const { return _imagesParams.at(index).viewId; }
     int getOriginalWidth(int index) const { return _imagesParams.at(index).width; }
@@ -84,7 +96,7 @@ class MultiViewParams
 
   private:
     const SfMData& _sfmData;
-    std::string _imagesFolder, _depthMapsFolder;
+    std::string _imagesFolder, _depthMapsFolder, _depthMapsFilterFolder;
     int _processDownscale = 1;
     float _minViewAngle = 2.0f, _maxViewAngle = 70.0f;
     std::vector<ImageParams> _imagesParams;

@@ -208,7 +208,7 @@ void writeMap(int rc, const MultiViewParams& mp, EFileType fileType, const TileP
     MapFileInfo f = prepareMapFile(rc, mp, fileType, tileParams, roi, scale, step, customSuffix);
     if(in_map.width != (int)f.downscaledROI.width() || in_map.height != (int)f.downscaledROI.height())
         AVDM_THROW_ERROR("writeMap: map size " << in_map.width << "x" << in_map.height << " does not match the ROI " << f.downscaledROI);
-    if(fileType == EFileType::depthMap)
+    if(fileType == EFileType::depthMap || fileType == EFileType::depthMapFiltered)
     {
         // mapIO.cpp:493-511
         const int nbDepthValues = (int)std::count_if(in_map.data.begin(), in_map.data.end(), [](float v) { return v > 0.0f; });
@@ -226,7 +226,7 @@ void writeMap(int rc, const MultiViewParams& mp, EFileType fileType, const TileP
         f.metadata.setFloat("AliceVision:maxDepth", maxDepth);
     }
     // depth maps are stored as float, every other map as half (mapIO.cpp:517-526); one channel is named "Y" by OpenImageIO
-    const bool storeHalf = (fileType != EFileType::depthMap);
+    const bool storeHalf = (fileType != EFileType::depthMap && fileType != EFileType::depthMapFiltered);
     writeExr(f.path, in_map.width, in_map.height, {{"Y", in_map.data.data()}}, storeHalf, f.metadata, (int)f.downscaledROI.x.begin, (int)f.downscaledROI.y.begin,
              f.imageWidth, f.imageHeight);
 }

@@ -1,0 +1,168 @@
+// png.cpp — minimal PNG codec (ISO/IEC 15948): signature, IHDR / IDAT / IEND chunks with CRC-32, zlib stream, scan-line filters.
+#include "png.hpp"
+
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+
+namespace avdm_host {
+
+namespace {
+const unsigned char kSignature[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+
+void putU32(std::vector<unsigned char>& v, uint32_t x)
+{
+    v.push_back((unsigned char)(x >> 24));
+    v.push_back((unsigned char)(x >> 16));
+    v.push_back((unsigned char)(x >> 8));
+    v.push_back((unsigned char)x);
+}
+uint32_t getU32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
+
+void writeChunk(std::ofstream& f, const char type[4], const std::vector<unsigned char>& payload)
+{
+    std::vector<unsigned char> head;
+    putU32(head, (uint32_t)payload.size());
+    f.write((const char*)head.data(), 4);
+    f.write(type, 4);
+    if(!payload.empty())
+        f.write((const char*)payload.data(), (std::streamsize)payload.size());
+    uLong crc = crc32(0L, (const Bytef*)type, 4);
+    if(!payload.empty())
+        crc = crc32(crc, payload.data(), (uInt)payload.size());
+    std::vector<unsigned char> tail;
+    putU32(tail, (uint32_t)crc);
+    f.write((const char*)tail.data(), 4);
+}
+
+int paeth(int a, int b, int c)
+{
+    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    if(pa <= pb && pa <= pc)
+        return a;
+    return pb <= pc ? b : c;
+}
+} // namespace
+
+void writePngGray8(const std::string& path, int width, int height, const unsigned char* data)
+{
+    if(width <= 0 || height <= 0)
+        throw std::runtime_error("writePngGray8: empty image");
+    // filter type 0 on every row: the maps are small-valued and flat, deflate does the work
+    std::vector<unsigned char> raw((size_t)height * (width + 1));
+    for(int y = 0; y < height; ++y)
+    {
+        raw[(size_t)y * (width + 1)] = 0;
+        std::memcpy(&raw[(size_t)y * (width + 1) + 1], data + (size_t)y * width, (size_t)width);
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> z(zlen);
+    if(compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK)
+        throw std::runtime_error("writePngGray8: deflate failed");
+    z.resize(zlen);
+
+    std::ofstream f(path, std::ios::binary);
+    if(!f)
+        throw std::runtime_error("Cannot open '" + path + "' for writing.");
+    f.write((const char*)kSignature, 8);
+    std::vector<unsigned char> ihdr;
+    putU32(ihdr, (uint32_t)width);
+    putU32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); // bit depth
+    ihdr.push_back(0); // colour type: greyscale
+    ihdr.push_back(0); // compression
+    ihdr.push_back(0); // filter method
+    ihdr.push_back(0); // no interlace
+    writeChunk(f, "IHDR", ihdr);
+    writeChunk(f, "IDAT", z);
+    writeChunk(f, "IEND", {});
+    if(!f)
+        throw std::runtime_error("Error while writing '" + path + "'.");
+}
+
+void readPngGray8(const std::string& path, int& width, int& height, std::vector<unsigned char>& data)
+{
+    std::ifstream f(path, std::ios::binary);
+    if(!f)
+        throw std::runtime_error("Cannot open '" + path + "'.");
+    std::vector<unsigned char> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if(file.size() < 8 + 25 || std::memcmp(file.data(), kSignature, 8) != 0)
+        throw std::runtime_error("'" + path + "' is not a PNG file.");
+    size_t pos = 8;
+    int bitDepth = 0, colourType = 0, interlace = 0;
+    bool haveHeader = false;
+    std::vector<unsigned char> z;
+    while(pos + 12 <= file.size())
+    {
+        const uint32_t len = getU32(&file[pos]);
+        const char* type = (const char*)&file[pos + 4];
+        if(pos + 12 + (size_t)len > file.size())
+            throw std::runtime_error("'" + path + "': truncated PNG chunk.");
+        const unsigned char* payload = &file[pos + 8];
+        const uLong crc = crc32(crc32(0L, (const Bytef*)type, 4), payload, len);
+        if((uint32_t)crc != getU32(payload + len))
+            throw std::runtime_error("'" + path + "': PNG chunk CRC mismatch.");
+        if(std::memcmp(type, "IHDR", 4) == 0 && len == 13)
+        {
+            width = (int)getU32(payload);
+            height = (int)getU32(payload + 4);
+            bitDepth = payload[8], colourType = payload[9], interlace = payload[12];
+            haveHeader = true;
+        }
+        else if(std::memcmp(type, "IDAT", 4) == 0)
+            z.insert(z.end(), payload, payload + len);
+        else if(std::memcmp(type, "IEND", 4) == 0)
+            break;
+        pos += 12 + (size_t)len;
+    }
+    if(!haveHeader || width <= 0 || height <= 0)
+        throw std::runtime_error("'" + path + "': no PNG header.");
+    int channels;
+    switch(colourType)
+    {
+        case 0: channels = 1; break;
+        case 2: channels = 3; break;
+        case 4: channels = 2; break;
+        case 6: channels = 4; break;
+        default: throw std::runtime_error("'" + path + "': palette PNG files are not supported.");
+    }
+    if(bitDepth != 8 || interlace != 0)
+        throw std::runtime_error("'" + path + "': only 8-bit non-interlaced PNG files are supported.");
+    const size_t stride = (size_t)width * channels;
+    std::vector<unsigned char> raw((size_t)height * (stride + 1));
+    uLongf rawLen = (uLongf)raw.size();
+    if(uncompress(raw.data(), &rawLen, z.data(), (uLong)z.size()) != Z_OK || rawLen != raw.size())
+        throw std::runtime_error("'" + path + "': inflate failed.");
+    // undo the scan-line filters in place
+    std::vector<unsigned char> prev(stride, 0), cur(stride);
+    data.assign((size_t)width * height, 0);
+    for(int y = 0; y < height; ++y)
+    {
+        const unsigned char ft = raw[(size_t)y * (stride + 1)];
+        const unsigned char* in = &raw[(size_t)y * (stride + 1) + 1];
+        for(size_t i = 0; i < stride; ++i)
+        {
+            const int a = i >= (size_t)channels ? cur[i - channels] : 0, b = prev[i], c = i >= (size_t)channels ? prev[i - channels] : 0;
+            int v = in[i];
+            switch(ft)
+            {
+                case 0: break;
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) / 2; break;
+                case 4: v += paeth(a, b, c); break;
+                default: throw std::runtime_error("'" + path + "': unknown PNG filter type.");
+            }
+            cur[i] = (unsigned char)v;
+        }
+        for(int x = 0; x < width; ++x)
+            data[(size_t)y * width + x] = cur[(size_t)x * channels];
+        prev.swap(cur);
+    }
+}
+
+} // namespace avdm_host

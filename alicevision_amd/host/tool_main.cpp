@@ -5,17 +5,22 @@
 //   merge-ones sfm imagesFolder outFolder downscale bufW bufH padding scaleStep
 //                                                       merge all-ones tiles of camera 0 with addTileMapWeighted and write the sum
 //   quantile left|right p v0 v1 ...                     boost-style tail quantile used by SgmDepthList
+//   png-copy in.png out.png                             decode an 8-bit PNG (first channel) and write it back as greyscale
+//   fuse-cameras sfm depthMapsFolder filterFolder n     cameras as aliceVision_depthMapFiltering sees them (from the depth maps' metadata)
+//                                                       and the n nearest cameras of each, as JSON with round-trip precision
 #include "DepthMapEstimator.hpp"
 #include "MultiViewParams.hpp"
 #include "depthMapUtils.hpp"
 #include "exr.hpp"
 #include "log.hpp"
 #include "params.hpp"
+#include "png.hpp"
 #include "sfmData.hpp"
 
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <iomanip>
 #include <iostream>
 #include <string>
 
@@ -97,6 +102,40 @@ int main(int argc, char** argv)
             const auto t0 = std::chrono::steady_clock::now();
             writeDepthSimMapFromTileList(0, mp, tp, rois, tiles, scaleStep, 1);
             std::cout << "merge+write " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s" << std::endl;
+            return 0;
+        }
+        if(cmd == "png-copy" && argc == 4)
+        {
+            int w = 0, h = 0;
+            std::vector<unsigned char> data;
+            readPngGray8(argv[2], w, h, data);
+            writePngGray8(argv[3], w, h, data.data());
+            std::cout << w << " " << h << std::endl;
+            return 0;
+        }
+        if(cmd == "fuse-cameras" && argc == 6)
+        {
+            SfMData sfm;
+            loadSfMData(sfm, argv[2]);
+            MultiViewParams mp(sfm, "", argv[3], argv[4], EFileType::depthMap);
+            const int n = std::atoi(argv[5]);
+            std::cout << std::setprecision(17) << "{\"cams\": [";
+            for(int c = 0; c < mp.ncams; ++c)
+            {
+                std::cout << (c ? ", " : "") << "{\"viewId\": " << mp.getViewId(c) << ", \"width\": " << mp.getWidth(c) << ", \"height\": " << mp.getHeight(c)
+                          << ", \"P\": [";
+                for(int i = 0; i < 12; ++i)
+                    std::cout << (i ? ", " : "") << mp.camArr[c].m[i];
+                std::cout << "], \"iP\": [";
+                for(int i = 0; i < 9; ++i)
+                    std::cout << (i ? ", " : "") << mp.iCamArr[c].m[i];
+                std::cout << "], \"C\": [" << mp.CArr[c].x << ", " << mp.CArr[c].y << ", " << mp.CArr[c].z << "], \"tcams\": [";
+                const std::vector<int> t = mp.findNearestCamsFromLandmarks(c, n);
+                for(size_t i = 0; i < t.size(); ++i)
+                    std::cout << (i ? ", " : "") << t[i];
+                std::cout << "]}";
+            }
+            std::cout << "]}" << std::endl;
             return 0;
         }
         return usage();

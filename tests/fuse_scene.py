@@ -1,8 +1,11 @@
 """Inputs for the depth-map filtering tests: depth / similarity maps of every view of the analytic scene (alicevision_amd.synthetic),
 with controlled defects (noise, outliers, masked and weakly supported pixels)."""
+import os
+
 import numpy as np
 import torch
 
+from alicevision_amd import exr_io, scene_io
 from alicevision_amd.synthetic import _surface, look_at_rotation
 
 
@@ -73,3 +76,15 @@ def camera_structs(fs, maker, cls=None):
         P, iP, Cc = camera_arrays(fs.K, fs.R[i], fs.C[i])
         out.append(maker(P, iP, Cc, fs.width, fs.height))
     return out
+
+
+def write_depth_maps(folder, sc, depths, sims, downscale=1):
+    """<viewId>_depthMap.exr / _simMap.exr as aliceVision_depthMapEstimation writes them (float depth, half sim, AliceVision:P +
+    AliceVision:downscale metadata, mapIO.cpp:402-540)"""
+    os.makedirs(folder, exist_ok=True)
+    for i in range(len(depths)):
+        P = sc.K @ np.concatenate([sc.R[i], (-sc.R[i] @ sc.C[i])[:, None]], axis=1)
+        attrs = {"AliceVision:P": exr_io.m44d(list(P.flatten()) + [0, 0, 0, 1]), "AliceVision:downscale": int(downscale)}
+        vid = scene_io.view_id(i)
+        exr_io.write_exr(os.path.join(folder, "%d_depthMap.exr" % vid), {"Y": depths[i]}, attributes=attrs, compression=3)
+        exr_io.write_exr(os.path.join(folder, "%d_simMap.exr" % vid), {"Y": sims[i]}, attributes=attrs, compression=3, half=True)
