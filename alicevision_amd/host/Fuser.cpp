@@ -91,26 +91,13 @@ void Fuser::prefetch(const std::vector<int>& cams)
             missing.push_back(c);
     if(missing.empty())
         return;
-    std::vector<FloatMap> maps(missing.size());
-    std::exception_ptr error;
-#pragma omp parallel for schedule(dynamic, 1)
-    for(int i = 0; i < (int)missing.size(); ++i)
+    // one file after the other: the EXR codec spreads the blocks of a file over the host cores itself
+    for(const int c : missing)
     {
-        try
-        {
-            // read depth map from the depthMapEstimation folder (Fuser.cpp:159, :186)
-            readMap(missing[i], _mp, EFileType::depthMap, maps[i], 1, 1);
-        }
-        catch(...)
-        {
-#pragma omp critical
-            error = std::current_exception();
-        }
+        FloatMap map;
+        readMap(c, _mp, EFileType::depthMap, map, 1, 1); // read depth map from the depthMapEstimation folder (Fuser.cpp:159, :186)
+        upload(c, map);
     }
-    if(error)
-        std::rethrow_exception(error);
-    for(size_t i = 0; i < missing.size(); ++i)
-        upload(missing[i], maps[i]);
 }
 
 std::shared_ptr<Fuser::DeviceMap> Fuser::deviceDepthMap(int cam)
@@ -156,24 +143,9 @@ void Fuser::filterGroups(const std::vector<int>& cams, float pixToleranceFactor,
     AVDM_LOG_INFO("Groups of " << cams.size() << " camera(s) computed in " << secondsSince(t0) << " s.");
 }
 
-// Fuser.cpp:144-231
-bool Fuser::filterGroupsRC(int rc, float pixToleranceFactor, int pixSizeBall, int pixSizeBallWSP, int nNearestCams)
+void Fuser::runGroupsKernel(int rc, const FloatMap& simMap, const std::vector<int>& tcams, float pixToleranceFactor, int pixSizeBall, int pixSizeBallWSP)
 {
-    const std::string nmodPath = getFileNameFromIndex(_mp, rc, EFileType::nmodMap);
-    if(fileExists(nmodPath))
-        return true;
-    AVDM_HIP_CHECK(hipSetDevice(_deviceId));
     const int w = _mp.getWidth(rc), h = _mp.getHeight(rc);
-
-    const std::vector<int> tcams = _mp.findNearestCamsFromLandmarks(rc, nNearestCams);
-    {
-        std::vector<int> all(tcams);
-        all.push_back(rc);
-        prefetch(all);
-    }
-    // read the similarity map from the depthMapEstimation folder
-    FloatMap simMap;
-    readMap(rc, _mp, EFileType::simMap, simMap, 1, 1);
     const std::shared_ptr<DeviceMap> depthMap = deviceDepthMap(rc);
     if(depthMap->width * depthMap->height != w * h || simMap.width * simMap.height != w * h)
         AVDM_THROW_ERROR("filterGroupsRC: bad image dimension for camera: " << _mp.getViewId(rc) << "\n"
@@ -213,12 +185,148 @@ bool Fuser::filterGroupsRC(int rc, float pixToleranceFactor, int pixSizeBall, in
                                           w * (int)sizeof(float), &rcCam, (int)tcs.size(), tcs.data(), pixToleranceFactor, pixSizeBall, pixSizeBallWSP,
                                           _scratch.ptr(), _stream),
                   "avdm_fuse_filter_groups");
+    AVDM_HIP_CHECK(hipStreamSynchronize(_stream)); // `held` and `simMap` may go away
+}
+
+// Fuser.cpp:144-231
+bool Fuser::filterGroupsRC(int rc, float pixToleranceFactor, int pixSizeBall, int pixSizeBallWSP, int nNearestCams)
+{
+    const std::string nmodPath = getFileNameFromIndex(_mp, rc, EFileType::nmodMap);
+    if(fileExists(nmodPath))
+        return true;
+    AVDM_HIP_CHECK(hipSetDevice(_deviceId));
+    const int w = _mp.getWidth(rc), h = _mp.getHeight(rc);
+    const std::vector<int> tcams = _mp.findNearestCamsFromLandmarks(rc, nNearestCams);
+    {
+        std::vector<int> all(tcams);
+        all.push_back(rc);
+        prefetch(all);
+    }
+    // read the similarity map from the depthMapEstimation folder
+    FloatMap simMap;
+    readMap(rc, _mp, EFileType::simMap, simMap, 1, 1);
+    runGroupsKernel(rc, simMap, tcams, pixToleranceFactor, pixSizeBall, pixSizeBallWSP);
     std::vector<unsigned char> numOfModalsMap((size_t)w * h);
     AVDM_HIP_CHECK(hipMemcpyAsync(numOfModalsMap.data(), _nmod.ptr(), numOfModalsMap.size(), hipMemcpyDeviceToHost, _stream));
     AVDM_HIP_CHECK(hipStreamSynchronize(_stream));
     writePngGray8(nmodPath, w, h, numOfModalsMap.data());
     AVDM_LOG_DEBUG(rc << " solved.");
     return true;
+}
+
+void Fuser::filterGroupsAndDepthMaps(const std::vector<int>& cams, float pixToleranceFactor, int pixSizeBall, int pixSizeBallWSP, int nNearestCams,
+                                     int minNumOfModals, int minNumOfModalsWSP2SSP)
+{
+    AVDM_LOG_INFO("Precomputing groups and filtering depth maps.");
+    const auto t0 = std::chrono::steady_clock::now();
+    AVDM_HIP_CHECK(hipSetDevice(_deviceId));
+    struct Item
+    {
+        std::vector<int> tcams;
+        FloatMap depth, sim;
+        std::vector<unsigned char> nmod;
+        bool nmodFromFile = false;
+        int nw = 0, nh = 0;
+    };
+    for(size_t c0 = 0; c0 < cams.size(); c0 += kChunk)
+    {
+        const int n = (int)(std::min(cams.size(), c0 + kChunk) - c0);
+        std::vector<Item> items(n);
+        std::vector<int> needed;
+        for(int i = 0; i < n; ++i)
+        {
+            const int rc = cams[c0 + i];
+            items[i].nmodFromFile = fileExists(getFileNameFromIndex(_mp, rc, EFileType::nmodMap));
+            needed.push_back(rc);
+            if(!items[i].nmodFromFile)
+            {
+                items[i].tcams = _mp.findNearestCamsFromLandmarks(rc, nNearestCams);
+                needed.insert(needed.end(), items[i].tcams.begin(), items[i].tcams.end());
+            }
+        }
+        std::sort(needed.begin(), needed.end());
+        needed.erase(std::unique(needed.begin(), needed.end()), needed.end());
+        if(needed.size() > _maxDeviceMaps)
+            needed.resize(_maxDeviceMaps);
+        prefetch(needed);
+
+        // similarity maps (and modal counts left by an earlier run) of the chunk; file after file, the EXR codec is parallel inside
+        for(int i = 0; i < n; ++i)
+        {
+            const int rc = cams[c0 + i];
+            readMap(rc, _mp, EFileType::simMap, items[i].sim, 1, 1);
+            if(items[i].nmodFromFile)
+                readPngGray8(getFileNameFromIndex(_mp, rc, EFileType::nmodMap), items[i].nw, items[i].nh, items[i].nmod);
+        }
+
+        for(int i = 0; i < n; ++i)
+        {
+            Item& it = items[i];
+            const int rc = cams[c0 + i];
+            const int w = _mp.getWidth(rc), h = _mp.getHeight(rc);
+            const size_t bytes = (size_t)w * h * sizeof(float);
+            if(!it.nmodFromFile)
+            {
+                runGroupsKernel(rc, it.sim, it.tcams, pixToleranceFactor, pixSizeBall, pixSizeBallWSP);
+                it.nmod.resize((size_t)w * h);
+                AVDM_HIP_CHECK(hipMemcpyAsync(it.nmod.data(), _nmod.ptr(), it.nmod.size(), hipMemcpyDeviceToHost, _stream));
+            }
+            else
+            {
+                const std::shared_ptr<DeviceMap> dm = deviceDepthMap(rc);
+                if(dm->width != it.sim.width || dm->width != it.nw || dm->height != it.sim.height || dm->height != it.nh || dm->width != w || dm->height != h)
+                    throw std::invalid_argument("depthMap, simMap and numOfModalsMap must have same size");
+                if(_sim.bytes() < bytes)
+                    _sim.allocate(bytes);
+                if(_nmod.bytes() < (size_t)w * h)
+                    _nmod.allocate((size_t)w * h);
+                AVDM_HIP_CHECK(hipMemcpyAsync(_sim.ptr(), it.sim.data.data(), bytes, hipMemcpyHostToDevice, _stream));
+                AVDM_HIP_CHECK(hipMemcpyAsync(_nmod.ptr(), it.nmod.data(), (size_t)w * h, hipMemcpyHostToDevice, _stream));
+            }
+            // second pass on a copy of the depth map: the cached one stays unfiltered for the other cameras
+            const std::shared_ptr<DeviceMap> depthMap = deviceDepthMap(rc);
+            if(_depthTmp.bytes() < bytes)
+                _depthTmp.allocate(bytes);
+            AVDM_HIP_CHECK(hipMemcpyAsync(_depthTmp.ptr(), depthMap->buf.ptr(), bytes, hipMemcpyDeviceToDevice, _stream));
+            avdmFuseCheck(avdm_fuse_filter_depth_maps(_depthTmp.as<float>(), w * (int)sizeof(float), _sim.as<float>(), w * (int)sizeof(float),
+                                                      _nmod.as<unsigned char>(), w, w, h, minNumOfModals, minNumOfModalsWSP2SSP, _stream),
+                          "avdm_fuse_filter_depth_maps");
+            it.depth.reshape(w, h);
+            AVDM_HIP_CHECK(hipMemcpyAsync(it.depth.data.data(), _depthTmp.ptr(), bytes, hipMemcpyDeviceToHost, _stream));
+            AVDM_HIP_CHECK(hipMemcpyAsync(it.sim.data.data(), _sim.ptr(), bytes, hipMemcpyDeviceToHost, _stream));
+            AVDM_HIP_CHECK(hipStreamSynchronize(_stream));
+        }
+
+        // modal counts (Fuser.cpp:220-223) of the chunk: one deflate stream per file, so one file per core
+        std::exception_ptr error;
+#pragma omp parallel for schedule(dynamic, 1)
+        for(int i = 0; i < n; ++i)
+        {
+            try
+            {
+                const int rc = cams[c0 + i];
+                if(!items[i].nmodFromFile)
+                    writePngGray8(getFileNameFromIndex(_mp, rc, EFileType::nmodMap), _mp.getWidth(rc), _mp.getHeight(rc), items[i].nmod.data());
+            }
+            catch(...)
+            {
+#pragma omp critical
+                error = std::current_exception();
+            }
+        }
+        if(error)
+            std::rethrow_exception(error);
+        // filtered maps (:296-297)
+        for(int i = 0; i < n; ++i)
+        {
+            const int rc = cams[c0 + i];
+            const ROI fullRoi(0, _mp.getWidth(rc), 0, _mp.getHeight(rc));
+            const TileParams defaultTileParams;
+            writeMap(rc, _mp, EFileType::depthMapFiltered, defaultTileParams, fullRoi, items[i].depth, 1, 1);
+            writeMap(rc, _mp, EFileType::simMapFiltered, defaultTileParams, fullRoi, items[i].sim, 1, 1);
+        }
+    }
+    AVDM_LOG_INFO("Groups computed and depth maps filtered for " << cams.size() << " camera(s) in " << secondsSince(t0) << " s.");
 }
 
 // Fuser.cpp:234-247
@@ -237,30 +345,14 @@ void Fuser::filterDepthMaps(const std::vector<int>& cams, int minNumOfModals, in
     {
         const int n = (int)(std::min(cams.size(), c0 + kChunk) - c0);
         std::vector<Item> items(n);
-        std::exception_ptr error;
         // read depth / sim maps from the depthMapEstimation folder and the modal counts of the first pass (Fuser.cpp:258-264)
-#pragma omp parallel for schedule(dynamic, 1)
-        for(int i = 0; i < 3 * n; ++i)
+        for(int i = 0; i < n; ++i)
         {
-            try
-            {
-                Item& it = items[i / 3];
-                const int rc = cams[c0 + i / 3];
-                if(i % 3 == 0)
-                    readMap(rc, _mp, EFileType::depthMap, it.depth, 1, 1);
-                else if(i % 3 == 1)
-                    readMap(rc, _mp, EFileType::simMap, it.sim, 1, 1);
-                else
-                    readPngGray8(getFileNameFromIndex(_mp, rc, EFileType::nmodMap), it.nw, it.nh, it.nmod);
-            }
-            catch(...)
-            {
-#pragma omp critical
-                error = std::current_exception();
-            }
+            const int rc = cams[c0 + i];
+            readMap(rc, _mp, EFileType::depthMap, items[i].depth, 1, 1);
+            readMap(rc, _mp, EFileType::simMap, items[i].sim, 1, 1);
+            readPngGray8(getFileNameFromIndex(_mp, rc, EFileType::nmodMap), items[i].nw, items[i].nh, items[i].nmod);
         }
-        if(error)
-            std::rethrow_exception(error);
         for(int i = 0; i < n; ++i)
         {
             Item& it = items[i];
@@ -285,27 +377,14 @@ void Fuser::filterDepthMaps(const std::vector<int>& cams, int minNumOfModals, in
             AVDM_HIP_CHECK(hipStreamSynchronize(_stream));
         }
         // Fuser.cpp:296-297
-#pragma omp parallel for schedule(dynamic, 1)
-        for(int i = 0; i < 2 * n; ++i)
+        for(int i = 0; i < n; ++i)
         {
-            try
-            {
-                const int rc = cams[c0 + i / 2];
-                const ROI fullRoi(0, _mp.getWidth(rc), 0, _mp.getHeight(rc));
-                const TileParams defaultTileParams;
-                if(i % 2 == 0)
-                    writeMap(rc, _mp, EFileType::depthMapFiltered, defaultTileParams, fullRoi, items[i / 2].depth, 1, 1);
-                else
-                    writeMap(rc, _mp, EFileType::simMapFiltered, defaultTileParams, fullRoi, items[i / 2].sim, 1, 1);
-            }
-            catch(...)
-            {
-#pragma omp critical
-                error = std::current_exception();
-            }
+            const int rc = cams[c0 + i];
+            const ROI fullRoi(0, _mp.getWidth(rc), 0, _mp.getHeight(rc));
+            const TileParams defaultTileParams;
+            writeMap(rc, _mp, EFileType::depthMapFiltered, defaultTileParams, fullRoi, items[i].depth, 1, 1);
+            writeMap(rc, _mp, EFileType::simMapFiltered, defaultTileParams, fullRoi, items[i].sim, 1, 1);
         }
-        if(error)
-            std::rethrow_exception(error);
     }
     AVDM_LOG_INFO("Depth maps of " << cams.size() << " camera(s) filtered in " << secondsSince(t0) << " s.");
 }

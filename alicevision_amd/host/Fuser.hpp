@@ -28,6 +28,11 @@ class Fuser
     bool filterGroupsRC(int rc, float pixToleranceFactor, int pixSizeBall, int pixSizeBallWSP, int nNearestCams);
     void filterDepthMaps(const std::vector<int>& cams, int minNumOfModals, int minNumOfModalsWSP2SSP);
     bool filterDepthMapsRC(int rc, int minNumOfModals, int minNumOfModalsWSP2SSP);
+    // filterGroups followed by filterDepthMaps (main_depthMapFiltering.cpp:137-138) in ONE pass over the cameras: a camera's second
+    // pass only needs its own modal counts, so its maps are filtered while they are still in HBM instead of being decoded again.
+    // Same files, same contents as the two calls.
+    void filterGroupsAndDepthMaps(const std::vector<int>& cams, float pixToleranceFactor, int pixSizeBall, int pixSizeBallWSP, int nNearestCams,
+                                  int minNumOfModals, int minNumOfModalsWSP2SSP);
 
   private:
     struct DeviceMap
@@ -40,6 +45,8 @@ class Fuser
     // decode the depth maps of `cams` that are not in HBM yet on the host cores, then upload them
     void prefetch(const std::vector<int>& cams);
     void upload(int cam, const FloatMap& map);
+    // modal counts of `rc` into _nmod (device); simMap is uploaded into _sim
+    void runGroupsKernel(int rc, const FloatMap& simMap, const std::vector<int>& tcams, float pixToleranceFactor, int pixSizeBall, int pixSizeBallWSP);
 
     const MultiViewParams& _mp;
     int _deviceId;
@@ -47,7 +54,7 @@ class Fuser
     hipStream_t _stream = nullptr;
     std::map<int, std::pair<std::shared_ptr<DeviceMap>, std::list<int>::iterator>> _cache;
     std::list<int> _lru;
-    DeviceBuffer _scratch, _sim, _nmod;
+    DeviceBuffer _scratch, _sim, _nmod, _depthTmp;
 };
 
 } // namespace avdm_host

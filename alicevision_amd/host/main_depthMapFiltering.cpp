@@ -37,6 +37,7 @@ static int aliceVision_main(int argc, char* argv[])
     bool computeNormalMaps = false;
     int maxMemoryAvailable = 0, maxCoresAvailable = 0;
     int nbGPUs = 0; // hidden: the reference hard-codes 0 = all devices for the normal maps (:146)
+    bool twoPasses = false; // hidden: run the two filtering passes one after the other over all cameras, like the reference
 
     CmdLine cmdline("This program filters depth maps to remove values that are not consistent with other depth maps.\n"
                     "AliceVision depthMapFiltering");
@@ -59,6 +60,7 @@ static int aliceVision_main(int argc, char* argv[])
     cmdline.add("maxMemoryAvailable", &maxMemoryAvailable, "User specified available RAM");
     cmdline.add("maxCoresAvailable", &maxCoresAvailable, "User specified available number of cores");
     cmdline.add("nbGPUs", &nbGPUs, "", false, 0, true);
+    cmdline.add("twoPasses", &twoPasses, "", false, 0, true);
 
     bool cmdError = false;
     if(!cmdline.execute(argc, argv, cmdError))
@@ -132,9 +134,16 @@ static int aliceVision_main(int argc, char* argv[])
 
     AVDM_LOG_INFO("Filter depth maps.");
     {
+        // fs.filterGroups(...) then fs.filterDepthMaps(...) in the reference (:137-138); one pass here, same files (Fuser.hpp)
         Fuser fs(mp);
-        fs.filterGroups(cams, pixToleranceFactor, pixSizeBall, pixSizeBallWithLowSimilarity, nNearestCams);
-        fs.filterDepthMaps(cams, minNumOfConsistentCams, minNumOfConsistentCamsWithLowSimilarity);
+        if(twoPasses)
+        {
+            fs.filterGroups(cams, pixToleranceFactor, pixSizeBall, pixSizeBallWithLowSimilarity, nNearestCams);
+            fs.filterDepthMaps(cams, minNumOfConsistentCams, minNumOfConsistentCamsWithLowSimilarity);
+        }
+        else
+            fs.filterGroupsAndDepthMaps(cams, pixToleranceFactor, pixSizeBall, pixSizeBallWithLowSimilarity, nNearestCams, minNumOfConsistentCams,
+                                        minNumOfConsistentCamsWithLowSimilarity);
     }
 
     if(computeNormalMaps)

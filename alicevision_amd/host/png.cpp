@@ -52,7 +52,7 @@ void writePngGray8(const std::string& path, int width, int height, const unsigne
 {
     if(width <= 0 || height <= 0)
         throw std::runtime_error("writePngGray8: empty image");
-    // filter type 0 on every row: the maps are small-valued and flat, deflate does the work
+    // filter type 0 on every row, fastest deflate level: the maps are small-valued and flat (12 MP -> a few hundred KB either way)
     std::vector<unsigned char> raw((size_t)height * (width + 1));
     for(int y = 0; y < height; ++y)
     {
@@ -61,7 +61,7 @@ void writePngGray8(const std::string& path, int width, int height, const unsigne
     }
     uLongf zlen = compressBound((uLong)raw.size());
     std::vector<unsigned char> z(zlen);
-    if(compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK)
+    if(compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), Z_BEST_SPEED) != Z_OK)
         throw std::runtime_error("writePngGray8: deflate failed");
     z.resize(zlen);
 

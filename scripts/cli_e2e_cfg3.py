@@ -51,3 +51,23 @@ if r.returncode == 0:
     m[:, :32] = m[:, -32:] = False
     rel = np.abs(depth - gt)[m] / gt[m]
     print("valid %.4f, median |depth - gt| / gt = %.2e, 90th percentile %.2e" % (float((depth > 0).mean()), float(np.median(rel)), float(np.percentile(rel, 90))))
+
+# optional: the filtering step on the maps just written (aliceVision_depthMapFiltering), when every camera was estimated
+if r.returncode == 0 and ncam == 11 and os.environ.get("AVDM_E2E_FILTER", "1") == "1":
+    FCLI = os.path.join(ROOT, "alicevision_amd", "bin", "aliceVision_depthMapFiltering")
+    flt = os.path.join(d, "filtered")
+    t0 = time.time()
+    r2 = subprocess.run([FCLI, "-i", os.path.join(d, "scene.sfm"), "--depthMapsFolder", out, "-o", flt, "--computeNormalMaps", "1", "-v", "info"],
+                        capture_output=True, text=True)
+    wall = time.time() - t0
+    print("filtering: exit", r2.returncode, "wall %.2f s for 11 cameras (10 nearest cameras each, normal maps included)" % wall)
+    for l in r2.stdout.splitlines():
+        if any(k in l for k in ("Task done", "computed", "filtered", "normal maps of")):
+            print("  ", l.strip()[:160])
+    print(r2.stderr[-1500:])
+    if r2.returncode == 0:
+        fd = exr_io.read_exr(os.path.join(flt, "%d_depthMap.exr" % scene_io.view_id(0)))[0]["Y"]
+        kept = (fd > 0) & m
+        rel2 = np.abs(fd - gt)[kept] / gt[kept]
+        print("filtered: kept %.4f of the valid interior depths, median error %.2e, 99.9th percentile %.2e (before: %.2e)"
+              % (float(kept.sum()) / float(m.sum()), float(np.median(rel2)), float(np.percentile(rel2, 99.9)), float(np.percentile(rel, 99.9))))

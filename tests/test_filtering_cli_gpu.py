@@ -94,6 +94,13 @@ def test_filtering_cli_matches_the_restatement(oracle_lib, tmp_path):
     before = open(os.path.join(flt, "%d_depthMap.exr" % scene_io.view_id(0)), "rb").read()
     run([FILTER_CLI, "-i", sfm, "--depthMapsFolder", dm, "-o", flt, "--nNearestCams", nn, "-v", "warning"])
     assert open(os.path.join(flt, "%d_depthMap.exr" % scene_io.view_id(0)), "rb").read() == before
+    # the reference's order (all first passes, then all second passes; hidden switch) writes the same files as the single pass
+    flt3 = os.path.join(d, "filtered3")
+    run([FILTER_CLI, "-i", sfm, "--depthMapsFolder", dm, "-o", flt3, "--nNearestCams", nn, "--twoPasses", 1, "-v", "warning"])
+    for i in range(n):
+        for suffix in ("_nmodMap.png", "_depthMap.exr", "_simMap.exr"):
+            name = "%d%s" % (scene_io.view_id(i), suffix)
+            assert open(os.path.join(flt3, name), "rb").read() == open(os.path.join(flt, name), "rb").read(), name
     # a sub-range only touches its cameras
     flt2 = os.path.join(d, "filtered2")
     run([FILTER_CLI, "-i", sfm, "--depthMapsFolder", dm, "-o", flt2, "--nNearestCams", nn, "--rangeStart", 1, "--rangeSize", 2, "--pixSizeBall", 1,
