@@ -20,7 +20,7 @@ def main(tag):
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     for name in os.listdir(src):
-        if name.endswith(".csv") or name in ("bench.json", "bench_generic.json", "pytest.log"):
+        if name.endswith(".csv") or name in ("bench.json", "bench_generic.json", "pytest.log", "microbench.txt", "fuse_microbench.txt"):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
     fetch = {r["kernel"]: float(r["FETCH_SIZE_per_launch"]) for r in csv.DictReader(open(os.path.join(src, "pmc_FETCH_SIZE.csv")))}
     write = {r["kernel"]: float(r["WRITE_SIZE_per_launch"]) for r in csv.DictReader(open(os.path.join(src, "pmc_WRITE_SIZE.csv")))}

@@ -32,6 +32,11 @@ for PASS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_I
   python scripts/rocprof_csv_summary.py $OUT/pmc_$NAME $OUT/pmc_$NAME.csv counters >> $OUT/log.txt 2>&1
   cat $OUT/pmc_$NAME.csv | head -8
 done
+echo "== depth-map filtering: micro-benchmark + kernel trace" | tee -a $OUT/log.txt
+timeout 300 python scripts/fuse_microbench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/fuse_microbench.txt
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $ROOT/$OUT/fuse_trace -o kt -- python $ROOT/scripts/fuse_microbench.py 10 4000 3000 --no-cpu > $ROOT/$OUT/fuse_trace.log 2>&1)
+python scripts/rocprof_csv_summary.py $OUT/fuse_trace $OUT/fuse_kernel_stats.csv >> $OUT/log.txt 2>&1
+grep -i "fuse\|kernel" $OUT/fuse_kernel_stats.csv | head -6
 (cd /tmp && timeout 120 rocprofv3 --list-avail > $ROOT/$OUT/list_avail.txt 2>&1)
 grep -c "" $OUT/list_avail.txt
 find $OUT -name "*.csv" -size +2M -delete
