@@ -109,6 +109,38 @@ __device__ __forceinline__ void stage_window(uint2* dst, int pitch, const TexLev
     }
 }
 
+// "Paired" window layout for the FIXED8 LDS path: one 16-byte record per texel position holding, per colour channel, the fp16 pair
+// {texel c, texel c + 1} of the row — exactly the operand v_dot2_f32_f16 multiplies with the weight pair {256 - A, A}.  The pairing
+// (three v_perm_b32) is then done once per staged texel instead of once per tap (12 of the ~92 VALU instructions of a sample), and a
+// row tap is ONE ds_read_b128 instead of two ds_read_b64.  Costs twice the LDS per texel: used where the windows are small enough.
+#define AVDM_PERM_LO 0x05040100u // {lo16(src1), lo16(src0)}
+#define AVDM_PERM_HI 0x07060302u // {hi16(src1), hi16(src0)}
+__device__ __forceinline__ void stage_window_paired(uint4* dst, int pitch, const TexLevel& L, int x0, int y0, int w, int h)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for(int r = wave; r < h; r += 4)
+    {
+        const uint2* src = L.base + (long long)(y0 + r) * L.pitch8 + x0;
+        uint4* d = dst + r * pitch;
+        // 63 records per pass: every lane loads one texel, the right neighbour comes from the next lane (wave_shl:1); lane 63 only lends its texel
+        for(int c0 = 0; c0 < w; c0 += 63)
+        {
+            const int c = c0 + lane;
+            const uint2 t0 = src[min(c, w - 1)]; // the last column is never the left tap of a lerp: its record pairs it with itself
+            uint2 t1;
+            t1.x = (unsigned)__builtin_amdgcn_update_dpp((int)t0.x, (int)t0.x, 0x130, 0xf, 0xf, false);
+            t1.y = (unsigned)__builtin_amdgcn_update_dpp((int)t0.y, (int)t0.y, 0x130, 0xf, 0xf, false);
+            uint4 rec;
+            rec.x = __builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_LO);
+            rec.y = __builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_HI);
+            rec.z = __builtin_amdgcn_perm(t1.y, t0.y, AVDM_PERM_LO);
+            rec.w = 0u;
+            if(lane < 63 && c < w)
+                d[c] = rec;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-voxel patch: homogeneous image coordinates of the centre and of the two scaled patch axes in R and T
 // ---------------------------------------------------------------------------------------------
@@ -238,6 +270,13 @@ struct LdsWindows
     float rPitchBF, tPitchBF;
     float rOffB, tOffB;        // LDS byte address of texel (0, 0) of each window: base + 8 * (-(y0 * pitch + x0) [+ rcap]); |.| < 2^24
 };
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const v4u32* lds_record_ptr; // one ds_read_b128
+__device__ __forceinline__ uint4 lds_record(unsigned byteAddr)
+{
+    const v4u32 v = *(lds_record_ptr)(size_t)byteAddr;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ uint2 lds_texel(unsigned byteAddr)
 {
     const unsigned long long v = *(lds_texel_ptr)(size_t)byteAddr;
@@ -256,8 +295,6 @@ struct Lab3
 {
     float L, a, b;
 };
-#define AVDM_PERM_LO 0x05040100u // {lo16(src1), lo16(src0)}
-#define AVDM_PERM_HI 0x07060302u // {hi16(src1), hi16(src0)}
 __device__ __forceinline__ v2h pk_half_weights(float w0, float w1) { return __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(w0, w1)); }
 __device__ __forceinline__ float dot2_h(unsigned pair, v2h w) { return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, pair), w, 0.0f, false); }
 __device__ __forceinline__ Lab3 hlerp3(uint2 t0, uint2 t1, v2h w)
@@ -320,7 +357,32 @@ __device__ __forceinline__ Lab3x4 hlerp3x4(uint2 r00, uint2 r10, uint2 r01, uint
     return o;
 }
 
-template <int WSH, bool TInvert>
+// the twelve products of a sample from paired records (see stage_window_paired): no v_perm_b32 per tap
+__device__ __forceinline__ Lab3x4 hlerp3x4_paired(uint4 r0, uint4 r1, uint4 t0, uint4 t1, v2h wr, v2h wt)
+{
+    Lab3x4 o;
+    const unsigned uwr = __builtin_bit_cast(unsigned, wr), uwt = __builtin_bit_cast(unsigned, wt);
+    asm("v_dot2_f32_f16 %0, %12, %24, 0\n\t"
+        "v_dot2_f32_f16 %1, %13, %24, 0\n\t"
+        "v_dot2_f32_f16 %2, %14, %24, 0\n\t"
+        "v_dot2_f32_f16 %3, %15, %25, 0\n\t"
+        "v_dot2_f32_f16 %4, %16, %25, 0\n\t"
+        "v_dot2_f32_f16 %5, %17, %25, 0\n\t"
+        "v_dot2_f32_f16 %6, %18, %24, 0\n\t"
+        "v_dot2_f32_f16 %7, %19, %24, 0\n\t"
+        "v_dot2_f32_f16 %8, %20, %24, 0\n\t"
+        "v_dot2_f32_f16 %9, %21, %25, 0\n\t"
+        "v_dot2_f32_f16 %10, %22, %25, 0\n\t"
+        "v_dot2_f32_f16 %11, %23, %25, 0\n\t"
+        "s_nop 2"
+        : "=&v"(o.rt.L), "=&v"(o.rt.a), "=&v"(o.rt.b), "=&v"(o.tt.L), "=&v"(o.tt.a), "=&v"(o.tt.b), "=&v"(o.rb.L), "=&v"(o.rb.a), "=&v"(o.rb.b),
+          "=&v"(o.tb.L), "=&v"(o.tb.a), "=&v"(o.tb.b)
+        : "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(t0.x), "v"(t0.y), "v"(t0.z), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(t1.x), "v"(t1.y), "v"(t1.z), "v"(uwr),
+          "v"(uwt));
+    return o;
+}
+
+template <int WSH, bool TInvert, bool PAIRED>
 __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const LdsWindows& Wn,
                                                            float4 rcCenter, float4 tcCenter)
 {
@@ -361,19 +423,27 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
             const v2f wa = floor2((X - fX) * 256.0f + 0.5f), wb = floor2((Y - fY) * 256.0f + 0.5f);
             const v2f na = 256.0f - wa, nb = 256.0f - wb;
             // LDS byte address of the top-left tap, formed in fp32 (exact integers), then one conversion per image
-            const v2f oidx = fY * pitch2 + (fX * 8.0f + off2);
+            const v2f oidx = fY * pitch2 + (fX * (PAIRED ? 16.0f : 8.0f) + off2);
             const unsigned oR = (unsigned)(int)oidx.x, oT = (unsigned)(int)oidx.y;
-            unsigned oR1 = oR + 8u, oT1 = oT + 8u;
-            if(kLdsSplitReads)
-            { // keep the two horizontally adjacent taps as two ds_read_b64 (a fused ds_read2_b64 runs at half the LDS rate)
-                asm volatile("" : "+v"(oR1));
-                asm volatile("" : "+v"(oT1));
-            }
-            const uint2 r00 = lds_texel(oR), r10 = lds_texel(oR1), r01 = lds_texel(oR + Wn.rPitchB), r11 = lds_texel(oR1 + Wn.rPitchB);
-            const uint2 t00 = lds_texel(oT), t10 = lds_texel(oT1), t01 = lds_texel(oT + Wn.tPitchB), t11 = lds_texel(oT1 + Wn.tPitchB);
-
             const v2h wr = pk_half_weights(na.x, wa.x), wt = pk_half_weights(na.y, wa.y);
-            const Lab3x4 h = hlerp3x4(r00, r10, r01, r11, t00, t10, t01, t11, wr, wt);
+            Lab3x4 h;
+            if(PAIRED)
+            {
+                const uint4 r0 = lds_record(oR), r1 = lds_record(oR + Wn.rPitchB), t0 = lds_record(oT), t1 = lds_record(oT + Wn.tPitchB);
+                h = hlerp3x4_paired(r0, r1, t0, t1, wr, wt);
+            }
+            else
+            {
+                unsigned oR1 = oR + 8u, oT1 = oT + 8u;
+                if(kLdsSplitReads)
+                { // keep the two horizontally adjacent taps as two ds_read_b64 (a fused ds_read2_b64 runs at half the LDS rate)
+                    asm volatile("" : "+v"(oR1));
+                    asm volatile("" : "+v"(oT1));
+                }
+                const uint2 r00 = lds_texel(oR), r10 = lds_texel(oR1), r01 = lds_texel(oR + Wn.rPitchB), r11 = lds_texel(oR1 + Wn.rPitchB);
+                const uint2 t00 = lds_texel(oT), t10 = lds_texel(oT1), t01 = lds_texel(oT + Wn.tPitchB), t11 = lds_texel(oT1 + Wn.tPitchB);
+                h = hlerp3x4(r00, r10, r01, r11, t00, t10, t01, t11, wr, wt);
+            }
             const Lab3 &rt = h.rt, &tt = h.tt, &rb = h.rb, &tb = h.tb;
             const v2f L2 = v2f{rt.L, tt.L} * nb + v2f{rb.L, tb.L} * wb; // x 2^16
             const v2f a2 = v2f{rt.a, tt.a} * nb + v2f{rb.a, tb.a} * wb;
@@ -403,16 +473,17 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
     return sim;
 }
 
-__device__ __forceinline__ LdsWindows make_windows(const uint2* smem, int rcap, int rPitch, int rx0, int ry0, int tPitch, int tx0, int ty0)
+// recB = bytes per window record: 8 (one texel) or 16 (paired layout); rcap stays in 8-byte units
+__device__ __forceinline__ LdsWindows make_windows(const uint2* smem, int rcap, int rPitch, int rx0, int ry0, int tPitch, int tx0, int ty0, int recB)
 {
     LdsWindows W;
     const int base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem; // LDS byte address of the dynamic segment
-    W.rPitchB = (unsigned)rPitch * 8u;
-    W.tPitchB = (unsigned)tPitch * 8u;
-    W.rPitchBF = (float)(rPitch * 8);
-    W.tPitchBF = (float)(tPitch * 8);
-    W.rOffB = (float)(base - 8 * (ry0 * rPitch + rx0));
-    W.tOffB = (float)(base + 8 * (rcap - (ty0 * tPitch + tx0)));
+    W.rPitchB = (unsigned)(rPitch * recB);
+    W.tPitchB = (unsigned)(tPitch * recB);
+    W.rPitchBF = (float)(rPitch * recB);
+    W.tPitchBF = (float)(tPitch * recB);
+    W.rOffB = (float)(base - recB * (ry0 * rPitch + rx0));
+    W.tOffB = (float)(base + 8 * rcap - recB * (ty0 * tPitch + tx0));
     return W;
 }
 
@@ -440,7 +511,7 @@ struct RTile
 };
 
 // R footprint of the workgroup: stage pixels [bx, bx+15] x [by, by+15] of the ROI, patch halo wsh + 2 (the border-test margin)
-__device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int wsh, int stepXY, avdm_roi_t roi)
+__device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int wsh, int stepXY, avdm_roi_t roi, bool paired)
 {
     RTile T;
     const int roiW = (int)(roi.x.end - roi.x.begin), roiH = (int)(roi.y.end - roi.y.begin);
@@ -463,9 +534,14 @@ __device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int w
     T.w = x1 - x0 + 1;
     T.h = y1 - y0 + 1;
     T.pitch = lds_pitch_for(T.w);
-    T.ok = !A.forceGeneric && T.w > 1 && T.h > 1 && T.pitch * T.h <= A.rcap;
+    T.ok = !A.forceGeneric && T.w > 1 && T.h > 1 && T.pitch * T.h * (paired ? 2 : 1) <= A.rcap;
     if(T.ok)
-        stage_window(sR, T.pitch, A.rcL, T.x0, T.y0, T.w, T.h);
+    {
+        if(paired)
+            stage_window_paired((uint4*)sR, T.pitch, A.rcL, T.x0, T.y0, T.w, T.h);
+        else
+            stage_window(sR, T.pitch, A.rcL, T.x0, T.y0, T.w, T.h);
+    }
     return T;
 }
 
@@ -545,7 +621,7 @@ struct TWindow
 };
 
 // second half (after the barrier): decide — uniformly for the workgroup — whether plane k runs from LDS, and stage the T window
-__device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk)
+__device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk, bool paired)
 {
     TWindow Wd;
     const int mnx = sh.box[k][0], mny = sh.box[k][1], mxx = sh.box[k][2], mxy = sh.box[k][3];
@@ -563,12 +639,17 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
         Wd.w = x1 - Wd.x0 + 1;
         Wd.h = y1 - Wd.y0 + 1;
         Wd.pitch = lds_pitch_for(Wd.w);
-        const bool fits = Wd.w <= 4096 && Wd.h <= 4096 && Wd.pitch * Wd.h <= A.tcap;
+        const bool fits = Wd.w <= 4096 && Wd.h <= 4096 && Wd.pitch * Wd.h * (paired ? 2 : 1) <= A.tcap;
         Wd.ok = inImage && fits;
         reason = Wd.ok ? 0 : (inImage ? 3 : 2);
     }
     if(Wd.ok)
-        stage_window(sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
+    {
+        if(paired)
+            stage_window_paired((uint4*)sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
+        else
+            stage_window(sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
+    }
     if(A.stats != nullptr && threadIdx.x == 0)
         atomicAdd(A.stats + reason, 1u);
     return Wd;
@@ -585,7 +666,7 @@ __device__ __forceinline__ void init_shared(BlockShared& sh)
 // ---------------------------------------------------------------------------------------------
 // SGM similarity: best / second-best uint8 volumes, 4 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-template <bool FIXED8, int WSH>
+template <bool FIXED8, int WSH, bool PAIRED>
 __global__ void __launch_bounds__(256, 3)
   similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
                     avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
@@ -602,8 +683,10 @@ __global__ void __launch_bounds__(256, 3)
     const bool inRoi = vx < roi.x.end - roi.x.begin && vy < roi.y.end - roi.y.begin;
     const unsigned z0 = ((zBegin >> 2) + blockIdx.z) << 2;
 
+    // paired LDS records only feed the packed FIXED8 path (uniform)
+    const bool paired = PAIRED && FIXED8 && !A.noPacked;
     init_shared(sh);
-    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi);
+    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired);
     __syncthreads();
 
     const float x = (float)(roi.x.begin + vx) * (float)stepXY;
@@ -670,7 +753,7 @@ __global__ void __launch_bounds__(256, 3)
         }
         publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
         __syncthreads();
-        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok);
+        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok, paired);
         __syncthreads();
 
         float fsim = 255.0f;
@@ -678,7 +761,7 @@ __global__ void __launch_bounds__(256, 3)
         {
             float s;
             if(Wd.ok && FIXED8 && !A.noPacked)
-                s = ncc_accumulate_lds_fixed8<WSH, false>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0), rcCenter,
+                s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
                                                           tcCenter);
             else if(Wd.ok)
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
@@ -708,7 +791,7 @@ __global__ void __launch_bounds__(256, 3)
 // ---------------------------------------------------------------------------------------------
 // Refine similarity: fp16 volume += sigmoid-filtered NCC, 8 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-template <bool FIXED8, int WSH>
+template <bool FIXED8, int WSH, bool PAIRED>
 __global__ void __launch_bounds__(256, 3)
   refine_similarity_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize,
                            int map_pitch, const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A,
@@ -726,8 +809,10 @@ __global__ void __launch_bounds__(256, 3)
     const bool inRoi = vx < roi.x.end - roi.x.begin && vy < roi.y.end - roi.y.begin;
     const unsigned z0 = ((zBegin >> 3) + blockIdx.z) << 3;
 
+    // paired LDS records only feed the packed FIXED8 path (uniform)
+    const bool paired = PAIRED && FIXED8 && !A.noPacked;
     init_shared(sh);
-    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi);
+    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired);
     __syncthreads();
 
     float2 dps = make_float2(-1.f, 0.f);
@@ -805,14 +890,14 @@ __global__ void __launch_bounds__(256, 3)
         }
         publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
         __syncthreads();
-        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok);
+        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok, paired);
         __syncthreads();
 
         if(valid)
         {
             float s;
             if(Wd.ok && FIXED8 && !A.noPacked)
-                s = ncc_accumulate_lds_fixed8<WSH, true>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0), rcCenter,
+                s = ncc_accumulate_lds_fixed8<WSH, true, PAIRED>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
                                                          tcCenter);
             else if(Wd.ok)
                 s = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
@@ -840,8 +925,9 @@ __global__ void __launch_bounds__(256, 3)
 // ---------------------------------------------------------------------------------------------
 static unsigned* g_stats = nullptr; // device counters, allocated on first use when AVDM_SIM_STATS=1
 
+// paired: in = the caller would like the 16-byte paired records (FIXED8 pyramids only); out = whether the LDS budget allows them
 static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcPyr, const avdm_pyramid_t* tcPyr, int scale, int stepXY, int wsh,
-                          double gammaC, double gammaP)
+                          double gammaC, double gammaP, bool& paired)
 {
     int rl, tl;
     if(!lod_is_integral(rcPyr, scale, &rl) || !lod_is_integral(tcPyr, scale, &tl))
@@ -877,14 +963,22 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
     // LDS budget: R tile = 16 stage pixels * stepXY texels + halo; T window: the same footprint (a T view at a
     // markedly larger scale, or a depth edge inside the workgroup, overflows it and takes the generic path).  Row pitches are 8 (mod 16) texels.
     const int rw = 15 * stepXY + 2 * (wsh + 2) + 5;
-    A.rcap = lds_pitch_for(rw) * rw;
     const int tw = rw + 1;
-    A.tcap = lds_pitch_for(tw) * tw;
+    const int third = (160 * 1024) / 3 - 1024; // bytes per workgroup at 3 per CU, minus the static shared state and allocation granularity
+    {
+        const char* pe = getenv("AVDM_SIM_PAIRED");
+        if(pe && pe[0] == '0')
+            paired = false;
+        // the paired layout doubles the bytes per texel: only when the R tile and a T window of 1.5 x the R footprint still fit
+        if(paired && (lds_pitch_for(rw) * rw * 2 + lds_pitch_for(tw) * tw * 3) * 8 > third)
+            paired = false;
+    }
+    A.rcap = lds_pitch_for(rw) * rw * (paired ? 2 : 1);
+    A.tcap = lds_pitch_for(tw) * tw * (paired ? 2 : 1);
     // both kernels run 3 workgroups per CU (168 VGPRs): the T window may use what is left of a third of the 160 KiB — a T view at a
     // larger scale or a slanted surface then still runs from LDS (3 % of the plane-workgroups of cfg3 overflowed the R-sized window
     // and paid the ~4x slower generic path)
     {
-        const int third = (160 * 1024) / 3 - 1024; // minus the static shared state and allocation granularity
         const int room = third / 8 - A.rcap;
         if(room > A.tcap)
             A.tcap = room;
@@ -953,28 +1047,35 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
         return set_error_msg(1, "avdm_volume_compute_similarity: volume base / pitches must be multiples of 4 bytes");
     NccArgs A;
     PatchTable tab;
-    if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, sp->scale, sp->stepXY, sp->wsh, sp->gammaC, sp->gammaP))
+    const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
+    bool paired = fixed8;
+    if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, sp->scale, sp->stepXY, sp->wsh, sp->gammaC, sp->gammaP, paired))
         return set_error_msg(1, "avdm_volume_compute_similarity: non-integral mip level");
     const unsigned nchunks = ((dr.end + 3) >> 2) - (dr.begin >> 2);
     if(((dr.end + 3) & ~3u) > (unsigned)pitch_x)
         return set_error_msg(1, "avdm_volume_compute_similarity: pitch_x too small for the depth range (must cover the 4-aligned range)");
     dim3 grid(divUp(roi.x.end - roi.x.begin, 16), divUp(roi.y.end - roi.y.begin, 16), nchunks);
     const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
-    const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
-#define LAUNCH(F8, W)                                                                                                                                 \
-    hipLaunchKernelGGL((similarity_kernel<F8, W>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
+#define LAUNCH(F8, W, PR)                                                                                                                                 \
+    hipLaunchKernelGGL((similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
                        sp->stepXY, dr.begin, dr.end, roi)
-    if(fixed8)
+    if(fixed8 && paired)
     {
-        if(sp->wsh == 4) LAUNCH(true, 4);
-        else if(sp->wsh == 3) LAUNCH(true, 3);
-        else LAUNCH(true, 0);
+        if(sp->wsh == 4) LAUNCH(true, 4, true);
+        else if(sp->wsh == 3) LAUNCH(true, 3, true);
+        else LAUNCH(true, 0, true);
+    }
+    else if(fixed8)
+    {
+        if(sp->wsh == 4) LAUNCH(true, 4, false);
+        else if(sp->wsh == 3) LAUNCH(true, 3, false);
+        else LAUNCH(true, 0, false);
     }
     else
     {
-        if(sp->wsh == 4) LAUNCH(false, 4);
-        else if(sp->wsh == 3) LAUNCH(false, 3);
-        else LAUNCH(false, 0);
+        if(sp->wsh == 4) LAUNCH(false, 4, false);
+        else if(sp->wsh == 3) LAUNCH(false, 3, false);
+        else LAUNCH(false, 0, false);
     }
 #undef LAUNCH
     AVDM_LAUNCH_CHECK("avdm_volume_compute_similarity");
@@ -997,26 +1098,33 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
         return set_error_msg(1, "avdm_volume_refine_similarity: pitch_x too small (must cover the 8-aligned depth range)");
     NccArgs A;
     PatchTable tab;
-    if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->stepXY, rp->wsh, rp->gammaC, rp->gammaP))
+    const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
+    bool paired = fixed8;
+    if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->stepXY, rp->wsh, rp->gammaC, rp->gammaP, paired))
         return set_error_msg(1, "avdm_volume_refine_similarity: non-integral mip level");
     const unsigned nchunks = ((dr.end + 7) >> 3) - (dr.begin >> 3);
     dim3 grid(divUp(roi.x.end - roi.x.begin, 16), divUp(roi.y.end - roi.y.begin, 16), nchunks);
     const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
-    const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
-#define LAUNCH(F8, W)                                                                                                                              \
-    hipLaunchKernelGGL((refine_similarity_kernel<F8, W>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,       \
+#define LAUNCH(F8, W, PR)                                                                                                                          \
+    hipLaunchKernelGGL((refine_similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,   \
                        (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi)
-    if(fixed8)
+    if(fixed8 && paired)
     {
-        if(rp->wsh == 3) LAUNCH(true, 3);
-        else if(rp->wsh == 4) LAUNCH(true, 4);
-        else LAUNCH(true, 0);
+        if(rp->wsh == 3) LAUNCH(true, 3, true);
+        else if(rp->wsh == 4) LAUNCH(true, 4, true);
+        else LAUNCH(true, 0, true);
+    }
+    else if(fixed8)
+    {
+        if(rp->wsh == 3) LAUNCH(true, 3, false);
+        else if(rp->wsh == 4) LAUNCH(true, 4, false);
+        else LAUNCH(true, 0, false);
     }
     else
     {
-        if(rp->wsh == 3) LAUNCH(false, 3);
-        else if(rp->wsh == 4) LAUNCH(false, 4);
-        else LAUNCH(false, 0);
+        if(rp->wsh == 3) LAUNCH(false, 3, false);
+        else if(rp->wsh == 4) LAUNCH(false, 4, false);
+        else LAUNCH(false, 0, false);
     }
 #undef LAUNCH
     AVDM_LAUNCH_CHECK("avdm_volume_refine_similarity");
