@@ -421,7 +421,7 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
             const v2f fX = floor2(X), fY = floor2(Y);
             // quant8(): weights in units of 1/256
             const v2f wa = floor2((X - fX) * 256.0f + 0.5f), wb = floor2((Y - fY) * 256.0f + 0.5f);
-            const v2f na = 256.0f - wa, nb = 256.0f - wb;
+            const v2f na = 256.0f - wa, nnb = wb - 256.0f; // nnb = -(256 - B)
             // LDS byte address of the top-left tap, formed in fp32 (exact integers), then one conversion per image
             const v2f oidx = fY * pitch2 + (fX * (PAIRED ? 16.0f : 8.0f) + off2);
             const unsigned oR = (unsigned)(int)oidx.x, oT = (unsigned)(int)oidx.y;
@@ -445,11 +445,10 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
                 h = hlerp3x4(r00, r10, r01, r11, t00, t10, t01, t11, wr, wt);
             }
             const Lab3 &rt = h.rt, &tt = h.tt, &rb = h.rb, &tb = h.tb;
-            const v2f L2 = v2f{rt.L, tt.L} * nb + v2f{rb.L, tb.L} * wb; // x 2^16
-            const v2f a2 = v2f{rt.a, tt.a} * nb + v2f{rb.a, tb.a} * wb;
-            const v2f b2 = v2f{rt.b, tt.b} * nb + v2f{rb.b, tb.b} * wb;
-
-            const v2f dL = cL - L2, da = ca - a2, db = cb - b2;
+            // centre - bilinear value (x 2^16), the vertical lerp folded into the difference: two packed FMAs per channel
+            const v2f dL = (v2f{rt.L, tt.L} * nnb + cL) - v2f{rb.L, tb.L} * wb;
+            const v2f da = (v2f{rt.a, tt.a} * nnb + ca) - v2f{rb.a, tb.a} * wb;
+            const v2f db = (v2f{rt.b, tt.b} * nnb + cb) - v2f{rb.b, tb.b} * wb;
             const v2f sq = dL * dL + (da * da + db * db);
             const float dcs = __builtin_amdgcn_sqrtf(sq.x) + __builtin_amdgcn_sqrtf(sq.y);
             const float w = __builtin_amdgcn_exp2f(fmaf(dcs, kC, -trow[xp]));
