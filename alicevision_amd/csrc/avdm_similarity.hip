@@ -141,6 +141,31 @@ __device__ __forceinline__ void stage_window_paired(uint4* dst, int pitch, const
     }
 }
 
+// "Half-paired" 8-byte records for the packed FIXED8 path when the 16-byte records do not fit: {L(c) | L(c + 1)}, {a(c) | b(c)}.  The L
+// pair of a row tap is ready as stored; the a and b pairs still take one v_perm_b32 each from the second dwords of columns c and
+// c + 1 (8 instead of 12 permutes per sample), and the right-hand column is a ds_read_b32.
+#define AVDM_PERM_AB 0x05040302u // {hi16(src1), lo16(src0)}: (a | b) from {L | a}, {b | pad}
+__device__ __forceinline__ void stage_window_halfpaired(uint2* dst, int pitch, const TexLevel& L, int x0, int y0, int w, int h)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for(int r = wave; r < h; r += 4)
+    {
+        const uint2* src = L.base + (long long)(y0 + r) * L.pitch8 + x0;
+        uint2* d = dst + r * pitch;
+        for(int c0 = 0; c0 < w; c0 += 63)
+        {
+            const int c = c0 + lane;
+            const uint2 t0 = src[min(c, w - 1)];
+            const unsigned t1x = (unsigned)__builtin_amdgcn_update_dpp((int)t0.x, (int)t0.x, 0x130, 0xf, 0xf, false); // next lane's {L | a}
+            uint2 rec;
+            rec.x = __builtin_amdgcn_perm(t1x, t0.x, AVDM_PERM_LO);
+            rec.y = __builtin_amdgcn_perm(t0.y, t0.x, AVDM_PERM_AB);
+            if(lane < 63 && c < w)
+                d[c] = rec;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-voxel patch: homogeneous image coordinates of the centre and of the two scaled patch axes in R and T
 // ---------------------------------------------------------------------------------------------
@@ -277,6 +302,8 @@ __device__ __forceinline__ uint4 lds_record(unsigned byteAddr)
     const v4u32 v = *(lds_record_ptr)(size_t)byteAddr;
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+typedef __attribute__((address_space(3))) const unsigned* lds_u32_ptr; // one ds_read_b32
+__device__ __forceinline__ unsigned lds_u32(unsigned byteAddr) { return *(lds_u32_ptr)(size_t)byteAddr; }
 __device__ __forceinline__ uint2 lds_texel(unsigned byteAddr)
 {
     const unsigned long long v = *(lds_texel_ptr)(size_t)byteAddr;
@@ -382,6 +409,35 @@ __device__ __forceinline__ Lab3x4 hlerp3x4_paired(uint4 r0, uint4 r1, uint4 t0, 
     return o;
 }
 
+// half-paired records: r0 / r1 = top / bottom record of column c, r0n / r1n = second dword ({a | b}) of column c + 1
+__device__ __forceinline__ Lab3x4 hlerp3x4_halfpaired(uint2 r0, unsigned r0n, uint2 r1, unsigned r1n, uint2 t0, unsigned t0n, uint2 t1, unsigned t1n, v2h wr,
+                                                      v2h wt)
+{
+    Lab3x4 o;
+    const unsigned uwr = __builtin_bit_cast(unsigned, wr), uwt = __builtin_bit_cast(unsigned, wt);
+    const unsigned p1 = __builtin_amdgcn_perm(r0n, r0.y, AVDM_PERM_LO), p2 = __builtin_amdgcn_perm(r0n, r0.y, AVDM_PERM_HI);
+    const unsigned p4 = __builtin_amdgcn_perm(t0n, t0.y, AVDM_PERM_LO), p5 = __builtin_amdgcn_perm(t0n, t0.y, AVDM_PERM_HI);
+    const unsigned p7 = __builtin_amdgcn_perm(r1n, r1.y, AVDM_PERM_LO), p8 = __builtin_amdgcn_perm(r1n, r1.y, AVDM_PERM_HI);
+    const unsigned p10 = __builtin_amdgcn_perm(t1n, t1.y, AVDM_PERM_LO), p11 = __builtin_amdgcn_perm(t1n, t1.y, AVDM_PERM_HI);
+    asm("v_dot2_f32_f16 %0, %12, %24, 0\n\t"
+        "v_dot2_f32_f16 %1, %13, %24, 0\n\t"
+        "v_dot2_f32_f16 %2, %14, %24, 0\n\t"
+        "v_dot2_f32_f16 %3, %15, %25, 0\n\t"
+        "v_dot2_f32_f16 %4, %16, %25, 0\n\t"
+        "v_dot2_f32_f16 %5, %17, %25, 0\n\t"
+        "v_dot2_f32_f16 %6, %18, %24, 0\n\t"
+        "v_dot2_f32_f16 %7, %19, %24, 0\n\t"
+        "v_dot2_f32_f16 %8, %20, %24, 0\n\t"
+        "v_dot2_f32_f16 %9, %21, %25, 0\n\t"
+        "v_dot2_f32_f16 %10, %22, %25, 0\n\t"
+        "v_dot2_f32_f16 %11, %23, %25, 0\n\t"
+        "s_nop 2"
+        : "=&v"(o.rt.L), "=&v"(o.rt.a), "=&v"(o.rt.b), "=&v"(o.tt.L), "=&v"(o.tt.a), "=&v"(o.tt.b), "=&v"(o.rb.L), "=&v"(o.rb.a), "=&v"(o.rb.b),
+          "=&v"(o.tb.L), "=&v"(o.tb.a), "=&v"(o.tb.b)
+        : "v"(r0.x), "v"(p1), "v"(p2), "v"(t0.x), "v"(p4), "v"(p5), "v"(r1.x), "v"(p7), "v"(p8), "v"(t1.x), "v"(p10), "v"(p11), "v"(uwr), "v"(uwt));
+    return o;
+}
+
 template <int WSH, bool TInvert, bool PAIRED>
 __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const LdsWindows& Wn,
                                                            float4 rcCenter, float4 tcCenter)
@@ -434,15 +490,11 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
             }
             else
             {
-                unsigned oR1 = oR + 8u, oT1 = oT + 8u;
-                if(kLdsSplitReads)
-                { // keep the two horizontally adjacent taps as two ds_read_b64 (a fused ds_read2_b64 runs at half the LDS rate)
-                    asm volatile("" : "+v"(oR1));
-                    asm volatile("" : "+v"(oT1));
-                }
-                const uint2 r00 = lds_texel(oR), r10 = lds_texel(oR1), r01 = lds_texel(oR + Wn.rPitchB), r11 = lds_texel(oR1 + Wn.rPitchB);
-                const uint2 t00 = lds_texel(oT), t10 = lds_texel(oT1), t01 = lds_texel(oT + Wn.tPitchB), t11 = lds_texel(oT1 + Wn.tPitchB);
-                h = hlerp3x4(r00, r10, r01, r11, t00, t10, t01, t11, wr, wt);
+                // half-paired records: column c whole (ds_read_b64), of column c + 1 only the {a | b} dword (ds_read_b32 at +12)
+                const unsigned oRb = oR + Wn.rPitchB, oTb = oT + Wn.tPitchB;
+                const uint2 r0 = lds_texel(oR), r1 = lds_texel(oRb), t0 = lds_texel(oT), t1 = lds_texel(oTb);
+                const unsigned r0n = lds_u32(oR + 12u), r1n = lds_u32(oRb + 12u), t0n = lds_u32(oT + 12u), t1n = lds_u32(oTb + 12u);
+                h = hlerp3x4_halfpaired(r0, r0n, r1, r1n, t0, t0n, t1, t1n, wr, wt);
             }
             const Lab3 &rt = h.rt, &tt = h.tt, &rb = h.rb, &tb = h.tb;
             // centre - bilinear value (x 2^16), the vertical lerp folded into the difference: two packed FMAs per channel
@@ -510,15 +562,15 @@ struct RTile
 };
 
 // R footprint of the workgroup: stage pixels [bx, bx+15] x [by, by+15] of the ROI, patch halo wsh + 2 (the border-test margin)
-__device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int wsh, int stepXY, avdm_roi_t roi, bool paired)
+__device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int wsh, int stepXY, avdm_roi_t roi, bool paired, bool halfPaired, int bw = 16)
 {
     RTile T;
     const int roiW = (int)(roi.x.end - roi.x.begin), roiH = (int)(roi.y.end - roi.y.begin);
-    const int bx = blockIdx.x * 16, by = blockIdx.y * 16;
+    const int bx = blockIdx.x * bw, by = blockIdx.y * bw;
     const float pxMin = (float)((int)roi.x.begin + bx) * (float)stepXY;
-    const float pxMax = (float)((int)roi.x.begin + min(bx + 15, roiW - 1)) * (float)stepXY;
+    const float pxMax = (float)((int)roi.x.begin + min(bx + bw - 1, roiW - 1)) * (float)stepXY;
     const float pyMin = (float)((int)roi.y.begin + by) * (float)stepXY;
-    const float pyMax = (float)((int)roi.y.begin + min(by + 15, roiH - 1)) * (float)stepXY;
+    const float pyMax = (float)((int)roi.y.begin + min(by + bw - 1, roiH - 1)) * (float)stepXY;
     const float m = (float)wsh + 2.0f;
     int x0 = (int)floorf(fmaf(pxMin - m, A.rcSx, A.rcOx)) - 1;
     int x1 = (int)floorf(fmaf(pxMax + m, A.rcSx, A.rcOx)) + 2;
@@ -538,6 +590,8 @@ __device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int w
     {
         if(paired)
             stage_window_paired((uint4*)sR, T.pitch, A.rcL, T.x0, T.y0, T.w, T.h);
+        else if(halfPaired)
+            stage_window_halfpaired(sR, T.pitch, A.rcL, T.x0, T.y0, T.w, T.h);
         else
             stage_window(sR, T.pitch, A.rcL, T.x0, T.y0, T.w, T.h);
     }
@@ -620,7 +674,7 @@ struct TWindow
 };
 
 // second half (after the barrier): decide — uniformly for the workgroup — whether plane k runs from LDS, and stage the T window
-__device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk, bool paired)
+__device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk, bool paired, bool halfPaired)
 {
     TWindow Wd;
     const int mnx = sh.box[k][0], mny = sh.box[k][1], mxx = sh.box[k][2], mxy = sh.box[k][3];
@@ -646,6 +700,8 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
     {
         if(paired)
             stage_window_paired((uint4*)sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
+        else if(halfPaired)
+            stage_window_halfpaired(sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
         else
             stage_window(sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
     }
@@ -684,8 +740,9 @@ __global__ void __launch_bounds__(256, 3)
 
     // paired LDS records only feed the packed FIXED8 path (uniform)
     const bool paired = PAIRED && FIXED8 && !A.noPacked;
+    const bool halfPaired = !PAIRED && FIXED8 && !A.noPacked; // the packed path without room for 16-byte records
     init_shared(sh);
-    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired);
+    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired, halfPaired);
     __syncthreads();
 
     const float x = (float)(roi.x.begin + vx) * (float)stepXY;
@@ -752,7 +809,7 @@ __global__ void __launch_bounds__(256, 3)
         }
         publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
         __syncthreads();
-        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok, paired);
+        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired);
         __syncthreads();
 
         float fsim = 255.0f;
@@ -810,8 +867,9 @@ __global__ void __launch_bounds__(256, 3)
 
     // paired LDS records only feed the packed FIXED8 path (uniform)
     const bool paired = PAIRED && FIXED8 && !A.noPacked;
+    const bool halfPaired = !PAIRED && FIXED8 && !A.noPacked; // the packed path without room for 16-byte records
     init_shared(sh);
-    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired);
+    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired, halfPaired);
     __syncthreads();
 
     float2 dps = make_float2(-1.f, 0.f);
@@ -889,7 +947,7 @@ __global__ void __launch_bounds__(256, 3)
         }
         publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
         __syncthreads();
-        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok, paired);
+        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired);
         __syncthreads();
 
         if(valid)
