@@ -153,6 +153,82 @@ __global__ void __launch_bounds__(256)
     *o = make_float2(dps.x + sampleSizeOffset, bestSampleSim);
 }
 
+// Same computation with the Gaussian table as a kernel argument.  (sample, plane) is uniform over the wave: the weights of 8 consecutive
+// sub-samples of a plane are 8 consecutive entries of the mirrored table gm[j] = gauss[|j - off|], j = sample - zs + off, fetched with
+// scalar loads from the kernarg segment, and each term is a VALU multiply + add with an SGPR operand — no LDS traffic.  Every sample's
+// sum still runs over the planes in ascending order (same floats as the one-sample-at-a-time loop); planes past volDimZ carry a zero
+// weight-free term (x + 0 * g == x).  The table is filled on the host with the reference's expression (expf, kernels.cuh:566-570).
+#define RBD_TAB 640
+#define RBD_GROUP 8
+struct GaussTable
+{
+    float g[RBD_TAB];
+};
+template <int NZ>
+__global__ void __launch_bounds__(256)
+  refine_best_depth_ktab_kernel(float2* out, int out_pitch, const float2* __restrict__ sgmDepthPixSize, int map_pitch, const __half* __restrict__ vol,
+                                long long pitch_y, int pitch_x, int volDimZ, int samplesPerPixSize, int halfNbSamples, int halfNbDepths, int off,
+                                const GaussTable gm, avdm_roi_t roi)
+{
+    const unsigned vx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const unsigned vy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if(vx >= roi.x.end - roi.x.begin || vy >= roi.y.end - roi.y.begin)
+        return;
+    const float2 dps = *((const float2*)((const char*)sgmDepthPixSize + (long long)vy * map_pitch) + vx);
+    float2* o = (float2*)((char*)out + (long long)vy * out_pitch) + vx;
+    if(dps.x <= 0.0f)
+    {
+        *o = make_float2(dps.x, 1.0f);
+        return;
+    }
+    const __half* v = (const __half*)((const char*)vol + (long long)vy * pitch_y + (long long)vx * pitch_x);
+    float simSum[NZ];
+#pragma unroll
+    for(int c = 0; c < NZ / 8; ++c)
+    {
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if(8 * c < volDimZ)
+            q = *reinterpret_cast<const uint4*>(v + 8 * c);
+        const __half* hq = reinterpret_cast<const __half*>(&q);
+#pragma unroll
+        for(int j = 0; j < 8; ++j)
+            simSum[8 * c + j] = (8 * c + j < volDimZ) ? -__half2float(hq[j]) : 0.0f;
+    }
+
+    float bestSampleSim = 0.f;
+    int bestSampleOffsetIndex = 0;
+#pragma unroll 1
+    for(int s0 = -halfNbSamples; s0 <= halfNbSamples; s0 += RBD_GROUP)
+    {
+        float acc[RBD_GROUP];
+#pragma unroll
+        for(int t = 0; t < RBD_GROUP; ++t)
+            acc[t] = 0.f;
+#pragma unroll
+        for(int vz = 0; vz < NZ; ++vz)
+        {
+            // planes past the volume: any in-range index, their simSum is 0
+            const int zs = ((vz < volDimZ ? vz : 0) - halfNbDepths) * samplesPerPixSize;
+            const float* g = gm.g + (s0 - zs + off);
+#pragma unroll
+            for(int t = 0; t < RBD_GROUP; ++t)
+                acc[t] += simSum[vz] * g[t];
+        }
+#pragma unroll
+        for(int t = 0; t < RBD_GROUP; ++t)
+        {
+            if(s0 + t <= halfNbSamples && acc[t] < bestSampleSim)
+            {
+                bestSampleOffsetIndex = s0 + t;
+                bestSampleSim = acc[t];
+            }
+        }
+    }
+    const float sampleSize = dps.y / (float)samplesPerPixSize;
+    const float sampleSizeOffset = (float)bestSampleOffsetIndex * sampleSize;
+    *o = make_float2(dps.x + sampleSizeOffset, bestSampleSim);
+}
+
 // ---------------------------------------------------------------------------------------------
 // depth/sim map kernels
 // ---------------------------------------------------------------------------------------------
@@ -633,6 +709,26 @@ int avdm_volume_refine_best_depth(float* out_depth_sim, int out_pitch, const flo
     const size_t lds = (size_t)((tableSize * 4 + 15) & ~15);
     if(lds > 64 * 1024)
         return set_error_msg(1, "avdm_volume_refine_best_depth: Gaussian table too large");
+    // mirrored table gm[j] = gauss[|j - off|], padded for the last group of sub-samples
+    const int off = tableSize - 1;
+    if(2 * off + 1 + RBD_GROUP <= RBD_TAB)
+    {
+        GaussTable gt;
+        for(int j = 0; j < RBD_TAB; ++j)
+        {
+            const int d = j - off < 0 ? off - j : j - off;
+            gt.g[j] = d < tableSize ? expf(-(float)(d * d) / tt) : 0.0f;
+        }
+        if(dimZ <= 32)
+            hipLaunchKernelGGL(refine_best_depth_ktab_kernel<32>, map_grid(roiW, roiH), dim3(256), 0, (hipStream_t)stream, (float2*)out_depth_sim,
+                               out_pitch, (const float2*)sgm_depth_pixsize, map_pitch, (const __half*)vol_f16, pitch_y, pitch_x, dimZ, rp->nbSubsamples,
+                               halfNbSamples, rp->halfNbDepths, off, gt, roi);
+        else
+            hipLaunchKernelGGL(refine_best_depth_ktab_kernel<64>, map_grid(roiW, roiH), dim3(256), 0, (hipStream_t)stream, (float2*)out_depth_sim,
+                               out_pitch, (const float2*)sgm_depth_pixsize, map_pitch, (const __half*)vol_f16, pitch_y, pitch_x, dimZ, rp->nbSubsamples,
+                               halfNbSamples, rp->halfNbDepths, off, gt, roi);
+        AVDM_LAUNCH_CHECK("avdm_volume_refine_best_depth");
+    }
     if(dimZ <= 32)
         hipLaunchKernelGGL(refine_best_depth_kernel<32>, map_grid(roiW, roiH), dim3(256), lds, (hipStream_t)stream, (float2*)out_depth_sim, out_pitch,
                            (const float2*)sgm_depth_pixsize, map_pitch, (const __half*)vol_f16, pitch_y, pitch_x, dimZ, rp->nbSubsamples,
