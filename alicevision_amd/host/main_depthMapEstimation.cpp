@@ -211,12 +211,6 @@ int aliceVision_main(int argc, char* argv[])
         AVDM_LOG_ERROR("useConsistentScale is not built.");
         return EXIT_FAILURE;
     }
-    if(refineParams.interpolateMiddleDepth)
-    {
-        AVDM_LOG_ERROR("refineInterpolateMiddleDepth is not built.");
-        return EXIT_FAILURE;
-    }
-
     if(!dryRun)
     {
         // gpu::gpuInformationCUDA / gpuSupportCUDA (main_depthMapEstimation.cpp:246-255)

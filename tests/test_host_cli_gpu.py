@@ -195,3 +195,40 @@ def test_sweep_only_configuration(dataset):
     m[:4] = m[-4:] = False
     m[:, :4] = m[:, -4:] = False
     assert m.mean() > 0.5 and np.median(np.abs(depth - gt)[m] / gt[m]) < 2e-2
+
+
+def test_non_default_refine_switches(dataset):
+    """non-default Refine switches through the program: --refineInterpolateMiddleDepth 1 (bilinear upscale of the SGM depth,
+    deviceDepthSimilarityMapKernels.cuh:276-383), --colorOptimizationEnabled 0 (Refine.cpp:156-160: the refined + fused map is the
+    output) and --refineEnabled 0 (Refine.cpp:143-151: the upscaled SGM depth goes straight to the optimisation) — each must equal
+    the harness with the same switches"""
+    import torch
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    sc, sfm, img, d = dataset
+    torch.cuda.set_device(0)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(NVIEWS)]
+    results = {}
+    for name, extra, kw, run_kw in (("interp", ["--refineInterpolateMiddleDepth", 1], dict(interpolateMiddleDepth=1), {}),
+                                    ("noopt", ["--colorOptimizationEnabled", 0], {}, dict(optimize_enabled=False)),
+                                    ("norefine", ["--refineEnabled", 0], {}, dict(refine_enabled=False))):
+        out = os.path.join(d, "out_" + name)
+        args = common_args(sfm, img, out) + extra
+        plan = json.loads(run_cli(args + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
+        t0 = plan["tiles"][0]
+        run_cli(args)
+        depth, sim, _, _ = read_maps(out)
+        sgm = abi.SgmParams.default(scale=plan["sgmScale"], stepXY=plan["sgmStepXY"])
+        ref = abi.RefineParams.default(optimizationNbIterations=OPT_ITERS, **kw)
+        h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+        ranges = [(a, a + n) for a, n in t0["depthsTcLimits"]]
+        h.run_sgm(0, t0["sgmTCams"], np.asarray(t0["depths"], np.float32), tc_ranges=ranges)
+        got = h.run_refine(0, t0["refineTCams"], **run_kw).cpu().numpy()
+        assert np.array_equal(got[..., 0], depth), (name, float(np.abs(got[..., 0] - depth).max()))
+        assert np.array_equal(got[..., 1].astype(np.float16).astype(np.float32), sim), name
+        results[name] = depth
+    base = read_maps(os.path.join(d, "out_single"))[0] if os.path.exists(os.path.join(d, "out_single")) else None
+    if base is not None:  # the switches change the result, and not by much
+        for name, depth in results.items():
+            both = (base > 0) & (depth > 0)
+            assert both.mean() > 0.5 and not np.array_equal(base, depth)
+            assert np.median(np.abs(base - depth)[both] / base[both]) < 2e-2, name
