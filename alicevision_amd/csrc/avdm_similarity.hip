@@ -978,6 +978,204 @@ __global__ void __launch_bounds__(256, 3)
 }
 
 // ---------------------------------------------------------------------------------------------
+// useConsistentScale (Patch.cuh:250-308, :499-505): per voxel, the R and T images are sampled at fractional mip levels chosen so that a
+// pixel of either image covers the same surface area at the patch centre.  Off by default in the reference (SgmParams.hpp:50,
+// RefineParams.hpp:41); built for completeness as one plain kernel for both stages: one lane per pixel, trilinear taps through the
+// software texture unit straight from global memory (no LDS windows: the footprint changes with the level).
+// ---------------------------------------------------------------------------------------------
+struct LodTap
+{
+    Tex T;
+    float lod, invW, invH; // 1 / dims of the nominal level's texel grid: u = (X + 0.5) * invW with X in that level's texel space
+    template <bool FIXED8>
+    __device__ __forceinline__ float4 fetch(float x, float y) const
+    {
+        return tex2DLod(T, (x + 0.5f) * invW, (y + 0.5f) * invH, lod);
+    }
+};
+
+// Patch.cuh:250-308
+__device__ __forceinline__ void computeRcTcMipmapLevels(float& out_rcMipmapLevel, float& out_tcMipmapLevel, float mipmapLevel, const avdm_camera_t& rc,
+                                                        const avdm_camera_t& tc, float rp0x, float rp0y, float tp0x, float tp0y, f3 p0)
+{
+    const float rcDepth = size(ld3(rc.C) - p0);
+    const float tcDepth = size(ld3(tc.C) - p0);
+    const f3 prp1 = ld3(rc.C) + normalize(M3x3mulV2(rc.iP, rp0x + 1.f, rp0y + 0.f)) * rcDepth;
+    const f3 ptp1 = ld3(tc.C) + normalize(M3x3mulV2(tc.iP, tp0x + 1.f, tp0y + 0.f)) * tcDepth;
+    const float rcDist = size(p0 - prp1);
+    const float tcDist = size(p0 - ptp1);
+    const float distFactor = rcDist / tcDist;
+    if(distFactor < 1.f)
+    {
+        // T camera has a lower resolution (1 Rc pixSize < 1 Tc pixSize)
+        out_tcMipmapLevel = mipmapLevel - log2f(1.f / distFactor);
+        if(out_tcMipmapLevel < 0.f)
+        {
+            out_rcMipmapLevel = mipmapLevel + fabsf(out_tcMipmapLevel);
+            out_tcMipmapLevel = 0.f;
+        }
+    }
+    else
+    {
+        out_rcMipmapLevel = mipmapLevel;
+        out_tcMipmapLevel = mipmapLevel + log2f(distFactor);
+    }
+}
+
+struct CsArgs
+{
+    Tex rcT, tcT;
+    float mipmapLevel;
+};
+
+// REFINE = false: volume_computeSimilarity_kernel (kernels.cuh:109-233); REFINE = true: volume_refineSimilarity_kernel (:235-391)
+template <bool REFINE>
+__global__ void __launch_bounds__(256)
+  similarity_cs_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, __half* __restrict__ vol, int volDimZ,
+                       const float2* __restrict__ sgmDepthPixSize, int map_pitch, const float* __restrict__ sgmNormal, int normal_pitch,
+                       long long pitch_y, int pitch_x, const float* __restrict__ depths, avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab,
+                       CsArgs S, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
+{
+    constexpr int CH = REFINE ? 8 : 4; // planes per lane, written as one 16-byte / 4-byte word like the main kernels
+    const unsigned vx = blockIdx.x * 64 + (threadIdx.x & 63), vy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if(vx >= roi.x.end - roi.x.begin || vy >= roi.y.end - roi.y.begin)
+        return;
+    const unsigned z0 = ((zBegin / CH) + blockIdx.z) * CH;
+    const int wsh = A.wsh;
+    const float x = (float)(roi.x.begin + vx) * (float)stepXY;
+    const float y = (float)(roi.y.begin + vy) * (float)stepXY;
+    const f3 C = ld3(rc.C), Z = ld3(rc.ZVect);
+    const f3 v = normalize(M3x3mulV2(rc.iP, x, y));
+    const float dd = (float)wsh + 2.0f;
+    const bool rInside = !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd));
+
+    float2 dps = make_float2(-1.f, 0.f);
+    f3 pMid = C, dir = v;
+    bool pixActive = true;
+    if(REFINE)
+    {
+        dps = *((const float2*)((const char*)sgmDepthPixSize + (long long)vy * map_pitch) + vx);
+        pixActive = dps.x > 0.0f;
+        pMid = C + v * dps.x;
+        dir = normalize(pMid - C);
+    }
+    const float dnC = dot(Z, C), dnv = dot(Z, v);
+
+    unsigned wb = 0, ws = 0;
+    uint4 packed = make_uint4(0u, 0u, 0u, 0u);
+    uint8_t *pb = nullptr, *ps = nullptr;
+    __half* pv = nullptr;
+    if(REFINE)
+    {
+        pv = vol + ((long long)vy * pitch_y + (long long)vx * pitch_x) / 2 + z0;
+        if(pixActive)
+            packed = *reinterpret_cast<const uint4*>(pv);
+    }
+    else
+    {
+        pb = best + (long long)vy * pitch_y + (long long)vx * pitch_x + z0;
+        ps = second + (long long)vy * pitch_y + (long long)vx * pitch_x + z0;
+        wb = *reinterpret_cast<const unsigned*>(pb);
+        ws = *reinterpret_cast<const unsigned*>(ps);
+    }
+
+    const LodTap rtap0{S.rcT, 0.f, 1.0f / (float)A.rcL.W, 1.0f / (float)A.rcL.H}, ttap0{S.tcT, 0.f, 1.0f / (float)A.tcL.W, 1.0f / (float)A.tcL.H};
+#pragma unroll 1
+    for(int k = 0; k < CH; ++k)
+    {
+        const unsigned vz = z0 + k;
+        if(vz < zBegin || vz >= zEnd)
+            continue;
+        float s = INFINITY;
+        if(pixActive && rInside)
+        {
+            f3 p;
+            if(REFINE)
+            {
+                const int rel = (int)vz - ((volDimZ - 1) / 2);
+                p = rel != 0 ? pMid + dir * ((float)rel * dps.y) : pMid;
+            }
+            else
+            {
+                const f3 planep = C + Z * depths[vz];
+                p = C + v * ((dot(planep, Z) - dnC) / dnv);
+            }
+            const float pd = computePixSize(rc, p);
+            f3 ax, ay;
+            if(REFINE && sgmNormal != nullptr)
+            {
+                const f3 v1 = normalize(C - p), v2 = normalize(ld3(tc.C) - p);
+                ay = normalize(cross(v1, v2));
+                const float* nn = (const float*)((const char*)sgmNormal + (long long)vy * normal_pitch) + 3 * vx;
+                ax = normalize(cross(ay, f3{nn[0], nn[1], nn[2]}));
+            }
+            else
+                patch_axes(rc, tc, p, ax, ay);
+            const PatchProj Q = make_patch_proj(rc, tc, p, ax, ay, pd);
+            const float it0 = fast_rcp(Q.ht0.z);
+            const float tpx = Q.ht0.x * it0, tpy = Q.ht0.y * it0;
+            if(!((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd)))
+            {
+                float rcLevel = S.mipmapLevel, tcLevel = S.mipmapLevel;
+                computeRcTcMipmapLevels(rcLevel, tcLevel, S.mipmapLevel, rc, tc, x, y, tpx, tpy, p);
+                LodTap rt = rtap0, tt = ttap0;
+                rt.lod = rcLevel;
+                tt.lod = tcLevel;
+                const float4 rcCenter = rt.fetch<true>(fmaf(x, A.rcSx, A.rcOx), fmaf(y, A.rcSy, A.rcOy));
+                const float4 tcCenter = tt.fetch<true>(fmaf(tpx, A.tcSx, A.tcOx), fmaf(tpy, A.tcSy, A.tcOy));
+                if(!(rcCenter.w < (255.f * 0.9f) || tcCenter.w < (255.f * 0.4f)))
+                    s = ncc_accumulate<true, 0, REFINE>(Q, A, tab, rt, tt, rcCenter, tcCenter);
+            }
+        }
+        if(REFINE)
+        {
+            if(pixActive && s != INFINITY)
+            { // packed[k] += s (invalid patches add nothing, kernels.cuh:373-381)
+                const unsigned sel = (unsigned)k >> 1, hiHalf = (unsigned)k & 1u;
+                unsigned word = sel == 0 ? packed.x : (sel == 1 ? packed.y : (sel == 2 ? packed.z : packed.w));
+                const unsigned short hbits = (unsigned short)(hiHalf ? (word >> 16) : (word & 0xffffu));
+                const __half hs = __float2half(__half2float(__ushort_as_half(hbits)) + s);
+                const unsigned nb = (unsigned)__half_as_ushort(hs);
+                word = hiHalf ? ((word & 0x0000ffffu) | (nb << 16)) : ((word & 0xffff0000u) | nb);
+                packed.x = sel == 0 ? word : packed.x;
+                packed.y = sel == 1 ? word : packed.y;
+                packed.z = sel == 2 ? word : packed.z;
+                packed.w = sel == 3 ? word : packed.w;
+            }
+        }
+        else
+        {
+            float fsim = 255.0f;
+            if(s != INFINITY)
+            {
+                s = (s + 1.0f) * 0.5f;
+                s = fminf(1.0f, fmaxf(0.0f, s));
+                fsim = s * 254.0f;
+            }
+            const unsigned sh8 = 8u * k;
+            const unsigned b1 = (wb >> sh8) & 0xffu, b2 = (ws >> sh8) & 0xffu;
+            if(fsim < (float)b1)
+            {
+                ws = (ws & ~(0xffu << sh8)) | (b1 << sh8);
+                wb = (wb & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
+            }
+            else if(fsim < (float)b2)
+                ws = (ws & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
+        }
+    }
+    if(REFINE)
+    {
+        if(pixActive)
+            *reinterpret_cast<uint4*>(pv) = packed;
+    }
+    else
+    {
+        *reinterpret_cast<unsigned*>(pb) = wb;
+        *reinterpret_cast<unsigned*>(ps) = ws;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static unsigned* g_stats = nullptr; // device counters, allocated on first use when AVDM_SIM_STATS=1
@@ -1098,8 +1296,6 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
         return 0;
     if(sp->wsh < 1 || sp->wsh > 4)
         return set_error_msg(1, "avdm_volume_compute_similarity: wsh must be in [1, 4]");
-    if(sp->useConsistentScale)
-        return set_error_msg(1, "avdm_volume_compute_similarity: useConsistentScale is not supported yet (SURVEY §8f.4)");
     if((pitch_x & 3) || (pitch_y & 3) || ((uintptr_t)best & 3) || ((uintptr_t)second & 3))
         return set_error_msg(1, "avdm_volume_compute_similarity: volume base / pitches must be multiples of 4 bytes");
     NccArgs A;
@@ -1111,6 +1307,17 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
     const unsigned nchunks = ((dr.end + 3) >> 2) - (dr.begin >> 2);
     if(((dr.end + 3) & ~3u) > (unsigned)pitch_x)
         return set_error_msg(1, "avdm_volume_compute_similarity: pitch_x too small for the depth range (must cover the 4-aligned range)");
+    if(sp->useConsistentScale)
+    {
+        CsArgs S;
+        S.rcT = make_tex(rc_pyr);
+        S.tcT = make_tex(tc_pyr);
+        S.mipmapLevel = A.mipmapLevel;
+        hipLaunchKernelGGL((similarity_cs_kernel<false>), dim3(divUp(roi.x.end - roi.x.begin, 64), divUp(roi.y.end - roi.y.begin, 4), nchunks), dim3(256), 0,
+                           (hipStream_t)stream, best, second, (__half*)nullptr, 0, (const float2*)nullptr, 0, (const float*)nullptr, 0, pitch_y, pitch_x,
+                           depths, *rc, *tc, A, tab, S, sp->stepXY, dr.begin, dr.end, roi);
+        AVDM_LAUNCH_CHECK("avdm_volume_compute_similarity(consistent scale)");
+    }
     dim3 grid(divUp(roi.x.end - roi.x.begin, 16), divUp(roi.y.end - roi.y.begin, 16), nchunks);
     const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
 #define LAUNCH(F8, W, PR)                                                                                                                                 \
@@ -1147,8 +1354,6 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
         return 0;
     if(rp->wsh < 1 || rp->wsh > 4)
         return set_error_msg(1, "avdm_volume_refine_similarity: wsh must be in [1, 4]");
-    if(rp->useConsistentScale)
-        return set_error_msg(1, "avdm_volume_refine_similarity: useConsistentScale is not supported yet (SURVEY §8f.4)");
     if((pitch_x & 15) || (pitch_y & 15) || ((uintptr_t)vol_f16 & 15))
         return set_error_msg(1, "avdm_volume_refine_similarity: volume base / pitches must be multiples of 16 bytes");
     if((int)(((dr.end + 7) & ~7u) * 2) > pitch_x)
@@ -1160,6 +1365,17 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
     if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->stepXY, rp->wsh, rp->gammaC, rp->gammaP, paired))
         return set_error_msg(1, "avdm_volume_refine_similarity: non-integral mip level");
     const unsigned nchunks = ((dr.end + 7) >> 3) - (dr.begin >> 3);
+    if(rp->useConsistentScale)
+    {
+        CsArgs S;
+        S.rcT = make_tex(rc_pyr);
+        S.tcT = make_tex(tc_pyr);
+        S.mipmapLevel = A.mipmapLevel;
+        hipLaunchKernelGGL((similarity_cs_kernel<true>), dim3(divUp(roi.x.end - roi.x.begin, 64), divUp(roi.y.end - roi.y.begin, 4), nchunks), dim3(256), 0,
+                           (hipStream_t)stream, (uint8_t*)nullptr, (uint8_t*)nullptr, (__half*)vol_f16, dimZ, (const float2*)sgm_depth_pixsize, map_pitch,
+                           sgm_normal, normal_pitch, pitch_y, pitch_x, (const float*)nullptr, *rc, *tc, A, tab, S, rp->stepXY, dr.begin, dr.end, roi);
+        AVDM_LAUNCH_CHECK("avdm_volume_refine_similarity(consistent scale)");
+    }
     dim3 grid(divUp(roi.x.end - roi.x.begin, 16), divUp(roi.y.end - roi.y.begin, 16), nchunks);
     const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
 #define LAUNCH(F8, W, PR)                                                                                                                          \

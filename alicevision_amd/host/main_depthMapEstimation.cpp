@@ -206,11 +206,6 @@ int aliceVision_main(int argc, char* argv[])
         AVDM_LOG_ERROR("Custom patch patterns are not built.");
         return EXIT_FAILURE;
     }
-    if(sgmParams.useConsistentScale || refineParams.useConsistentScale)
-    {
-        AVDM_LOG_ERROR("useConsistentScale is not built.");
-        return EXIT_FAILURE;
-    }
     if(!dryRun)
     {
         // gpu::gpuInformationCUDA / gpuSupportCUDA (main_depthMapEstimation.cpp:246-255)

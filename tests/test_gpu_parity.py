@@ -387,3 +387,91 @@ def test_normal_map_parity(case):
     # indices): a few neighbourhoods are degenerate (collinear points, double smallest eigenvalue) and have no unique normal
     assert (cosang > 1.0 - 5e-7).mean() > 0.98, float((cosang > 1.0 - 5e-7).mean())
     assert np.allclose(np.linalg.norm(got[ok], axis=-1), 1.0, atol=1e-5)
+
+
+def test_consistent_scale_parity():
+    """useConsistentScale (Patch.cuh:250-308; off by default in the reference): fractional mip levels per voxel, trilinear taps — the
+    similarity and the Refine volumes against the oracle (tolerance classes of the default path, slightly wider: every tap is a
+    blend of two levels), with T cameras at other distances than R so that the levels really differ"""
+    torch = _torch()
+    from oracle import oracle
+    sc, sgm, ref, depths = small_case()
+    # pull one T camera towards the surface and push the other away: pixel footprints differ by ~ +-15 %
+    for i, f in ((1, 0.85), (2, 1.18)):
+        sc.C[i] = np.array([sc.C[i][0], sc.C[i][1], 4.0 * (1.0 - f)])
+    sc = _rerender(sc, sc)  # the same surface and texture seen from the moved cameras
+    sgm = abi.SgmParams.default(useConsistentScale=1)
+    ref = abi.RefineParams.default(useConsistentScale=1)
+    Z = len(depths)
+    o = make_oracle(sc, sgm, ref)
+    with oracle.well_posed():
+        o.run_sgm(0, [1, 2], depths, optimize=False)
+        best64, second64 = o.best_raw[..., :Z].copy(), o.second[..., :Z].copy()
+        o.run_sgm(0, [1, 2], depths)
+        o.run_refine(0, [1, 2], optimize_enabled=False)
+    h = make_hip_from_oracle(o, sc, sgm, ref)
+    h.run_sgm(0, [1, 2], depths, optimize=False, keep_raw=True)
+    torch.cuda.synchronize()
+    for got, want in ((h.best_raw.cpu().numpy()[..., :Z], best64), (h.second.cpu().numpy()[..., :Z], second64)):
+        frac, mx = level_mismatch(want, got)
+        d = np.abs(want.astype(np.int16) - got.astype(np.int16))
+        assert (want != 255).mean() > 0.3
+        assert frac <= 0.05, (frac, mx)
+        assert (d > 1).mean() <= 4e-3, (d > 1).mean()
+        assert ((want == 255) != (got == 255)).mean() <= 4e-3
+    # the levels matter: the same volumes without consistent scale differ clearly from these
+    o0 = make_oracle(sc, abi.SgmParams.default(), abi.RefineParams.default())
+    with oracle.well_posed():
+        o0.run_sgm(0, [1, 2], depths, optimize=False)
+    assert level_mismatch(o0.best_raw[..., :Z], best64)[0] > 0.2
+
+    h._alloc(Z)
+    h.sgm_depth_thickness.copy_(torch.from_numpy(o.sgm_depth_thickness))
+    h.run_refine(0, [1, 2], optimize_enabled=False)
+    torch.cuda.synchronize()
+    Zr = ref.halfNbDepths * 2 + 1
+    a = o.refine_volume[..., :Zr].astype(np.float32)
+    b = h.refine_volume.cpu().numpy()[..., :Zr].astype(np.float32)
+    diff = np.abs(a - b)
+    assert a.max() > 0.5
+    assert (diff > 4e-3).mean() <= 4e-3, (diff > 4e-3).mean()
+    assert (diff > 0.02).mean() <= 3e-4, ((diff > 0.02).mean(), diff.max())
+
+
+def _rerender(base, moved):
+    """images of the analytic scene for the cameras of `moved` (K, R, C), same surface and texture as `base`"""
+    import math
+    import torch as T
+    from alicevision_amd.synthetic import Scene, _surface, _texture, look_at_rotation
+    rng = np.random.RandomState(7)
+    sc = Scene()
+    sc.width, sc.height, sc.K = base.width, base.height, base.K
+    sc.C = [np.asarray(c, np.float64) for c in moved.C]
+    sc.R = [look_at_rotation(c, np.array([0.0, 0.0, 4.0])) for c in sc.C]
+    f = sc.K[0, 0]
+    px = 4.0 / f
+    waves = []
+    for lam_px, a in ((7.0, 0.10), (13.0, 0.12), (29.0, 0.14), (61.0, 0.10)):
+        for _ in range(3):
+            th = rng.uniform(0, math.pi)
+            kk = 2.0 * math.pi / (lam_px * px)
+            waves.append((kk * math.cos(th), kk * math.sin(th), rng.uniform(0, 2 * math.pi), a / 1.7, rng.uniform(0.3, 1.0)))
+    v, u = T.meshgrid(T.arange(sc.height, dtype=T.float64), T.arange(sc.width, dtype=T.float64), indexing="ij")
+    Kinv = np.linalg.inv(sc.K)
+    imgs = []
+    for i in range(len(sc.C)):
+        M = sc.R[i].T @ Kinv
+        dx = M[0, 0] * u + M[0, 1] * v + M[0, 2]
+        dy = M[1, 0] * u + M[1, 1] * v + M[1, 2]
+        dz = M[2, 0] * u + M[2, 1] * v + M[2, 2]
+        cx, cy, cz = [float(t) for t in sc.C[i]]
+        t = (4.0 - cz) / dz
+        for _ in range(12):
+            t = (_surface(cx + t * dx, cy + t * dy, 4.0, 0.2) - cz) / dz
+        r, g, b = _texture(cx + t * dx, cy + t * dy, waves)
+        imgs.append(T.stack([r, g, b, T.ones_like(r)], dim=-1).to(T.float32))
+        if i == 0:
+            sc.gt_depth = (t * T.sqrt(dx * dx + dy * dy + dz * dz)).to(T.float32)
+    sc.images = T.stack(imgs, dim=0).contiguous()
+    sc.z_range = base.z_range
+    return sc

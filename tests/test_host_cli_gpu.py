@@ -200,8 +200,8 @@ def test_sweep_only_configuration(dataset):
 def test_non_default_refine_switches(dataset):
     """non-default Refine switches through the program: --refineInterpolateMiddleDepth 1 (bilinear upscale of the SGM depth,
     deviceDepthSimilarityMapKernels.cuh:276-383), --colorOptimizationEnabled 0 (Refine.cpp:156-160: the refined + fused map is the
-    output) and --refineEnabled 0 (Refine.cpp:143-151: the upscaled SGM depth goes straight to the optimisation) — each must equal
-    the harness with the same switches"""
+    output), --refineEnabled 0 (Refine.cpp:143-151: the upscaled SGM depth goes straight to the optimisation) and
+    --sgmUseConsistentScale / --refineUseConsistentScale 1 (Patch.cuh:250-308) — each must equal the harness with the same switches"""
     import torch
     from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
     sc, sfm, img, d = dataset
@@ -210,14 +210,15 @@ def test_non_default_refine_switches(dataset):
     results = {}
     for name, extra, kw, run_kw in (("interp", ["--refineInterpolateMiddleDepth", 1], dict(interpolateMiddleDepth=1), {}),
                                     ("noopt", ["--colorOptimizationEnabled", 0], {}, dict(optimize_enabled=False)),
-                                    ("norefine", ["--refineEnabled", 0], {}, dict(refine_enabled=False))):
+                                    ("norefine", ["--refineEnabled", 0], {}, dict(refine_enabled=False)),
+                                    ("cscale", ["--sgmUseConsistentScale", 1, "--refineUseConsistentScale", 1], dict(useConsistentScale=1), {})):
         out = os.path.join(d, "out_" + name)
         args = common_args(sfm, img, out) + extra
         plan = json.loads(run_cli(args + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
         t0 = plan["tiles"][0]
         run_cli(args)
         depth, sim, _, _ = read_maps(out)
-        sgm = abi.SgmParams.default(scale=plan["sgmScale"], stepXY=plan["sgmStepXY"])
+        sgm = abi.SgmParams.default(scale=plan["sgmScale"], stepXY=plan["sgmStepXY"], useConsistentScale=kw.get("useConsistentScale", 0))
         ref = abi.RefineParams.default(optimizationNbIterations=OPT_ITERS, **kw)
         h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
         ranges = [(a, a + n) for a, n in t0["depthsTcLimits"]]
