@@ -49,12 +49,12 @@ class SgmParams(C.Structure):
     """SgmParams.hpp:21-55 defaults."""
     _fields_ = [("scale", C.c_int), ("stepXY", C.c_int), ("wsh", C.c_int), ("gammaC", C.c_double), ("gammaP", C.c_double), ("p1", C.c_double),
                 ("p2Weighting", C.c_double), ("maxSimilarity", C.c_double), ("depthThicknessInflate", C.c_double), ("filteringAxes", C.c_char * 8),
-                ("useConsistentScale", C.c_int), ("strictRoiQuirk", C.c_int)]
+                ("useConsistentScale", C.c_int), ("strictRoiQuirk", C.c_int), ("useCustomPatchPattern", C.c_int)]
 
     @staticmethod
     def default(**kw):
         p = SgmParams(scale=2, stepXY=2, wsh=4, gammaC=5.5, gammaP=8.0, p1=10.0, p2Weighting=100.0, maxSimilarity=1.0, depthThicknessInflate=0.0,
-                      filteringAxes=b"YX", useConsistentScale=0, strictRoiQuirk=1)
+                      filteringAxes=b"YX", useConsistentScale=0, strictRoiQuirk=1, useCustomPatchPattern=0)
         for k, v in kw.items():
             setattr(p, k, v)
         return p
@@ -64,15 +64,29 @@ class RefineParams(C.Structure):
     """RefineParams.hpp:19-45 defaults."""
     _fields_ = [("scale", C.c_int), ("stepXY", C.c_int), ("wsh", C.c_int), ("halfNbDepths", C.c_int), ("nbSubsamples", C.c_int),
                 ("optimizationNbIterations", C.c_int), ("sigma", C.c_double), ("gammaC", C.c_double), ("gammaP", C.c_double),
-                ("interpolateMiddleDepth", C.c_int), ("useConsistentScale", C.c_int)]
+                ("interpolateMiddleDepth", C.c_int), ("useConsistentScale", C.c_int), ("useCustomPatchPattern", C.c_int)]
 
     @staticmethod
     def default(**kw):
         p = RefineParams(scale=1, stepXY=1, wsh=3, halfNbDepths=15, nbSubsamples=10, optimizationNbIterations=100, sigma=15.0, gammaC=15.5,
-                         gammaP=8.0, interpolateMiddleDepth=0, useConsistentScale=0)
+                         gammaP=8.0, interpolateMiddleDepth=0, useConsistentScale=0, useCustomPatchPattern=0)
         for k, v in kw.items():
             setattr(p, k, v)
         return p
+
+
+class PatchSubpartParams(C.Structure):
+    """CustomPatchPatternParams::SubpartParams"""
+    _fields_ = [("isCircle", C.c_int), ("level", C.c_int), ("nbCoordinates", C.c_int), ("radius", C.c_float), ("weight", C.c_float)]
+
+
+class PatchPatternSubpart(C.Structure):
+    _fields_ = [("coordinates", (C.c_float * 2) * 24), ("nbCoordinates", C.c_int), ("level", C.c_float), ("downscale", C.c_float),
+                ("weight", C.c_float), ("isCircle", C.c_int), ("wsh", C.c_int)]
+
+
+class PatchPattern(C.Structure):
+    _fields_ = [("subparts", PatchPatternSubpart * 4), ("nbSubparts", C.c_int)]
 
 
 class SgmTile(C.Structure):
@@ -90,6 +104,7 @@ SIGNATURES = {
     "avdm_version": (i32, []),
     "avdm_device_count": (i32, []),
     "avdm_device_info": (i32, [i32, C.c_char_p, C.c_size_t]),
+    "avdm_build_custom_patch_pattern": (i32, [i32, P(PatchSubpartParams), i32, P(PatchPattern)]),
     "avdm_pyramid_layout": (i32, [P(Pyramid), i32, i32, i32, i32, i32]),
     "avdm_image_rgba_f32_to_f16x255": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "avdm_rgb2lab": (i32, [vp, i32, i32, i32, vp]),
@@ -165,6 +180,24 @@ def load(path=None):
 def check(rc, what=""):
     if rc != 0:
         raise AvdmError(f"{what} failed (status {rc}): {load().avdm_last_error().decode()}")
+
+
+def patch_subparts(spec):
+    """[("circle" | "full", radius, nbCoordinates, level, weight), ...] -> array of avdm_patch_subpart_params_t (the order of the
+    reference's command-line tokens `type:radius:nbCoords:level:weight`, CustomPatchPatternParams.cpp:16-41)"""
+    arr = (PatchSubpartParams * len(spec))()
+    for i, (typ, radius, nb, level, weight) in enumerate(spec):
+        arr[i] = PatchSubpartParams(isCircle=1 if str(typ).lower() == "circle" else 0, level=int(level), nbCoordinates=int(nb), radius=float(radius),
+                                    weight=float(weight))
+    return arr
+
+
+def build_custom_patch_pattern(spec, group_per_level=False):
+    """buildCustomPatchPattern through the library: the pattern becomes the one the similarity entry points use; returns a copy"""
+    arr = patch_subparts(spec)
+    out = PatchPattern()
+    check(load().avdm_build_custom_patch_pattern(len(spec), arr, 1 if group_per_level else 0, C.byref(out)), "avdm_build_custom_patch_pattern")
+    return out
 
 
 def camera_fill(K, R, Cc, downscale):

@@ -22,6 +22,9 @@
 
 #include <limits.h>
 #include <math.h>
+#include <cmath>
+#include <iterator>
+#include <map>
 #include <stdlib.h>
 
 // taps in flight per lane: each unrolled sample keeps 8 LDS reads (16 VGPRs) live; 3 keeps the kernels at 3 waves / SIMD
@@ -1026,7 +1029,88 @@ struct CsArgs
 {
     Tex rcT, tcT;
     float mipmapLevel;
+    int useConsistentScale;
+    int useCustomPatchPattern;
+    avdm_patch_pattern_t pattern;
 };
+
+// compNCCby3DptsYK_customPatchPattern (Patch.cuh:598-773): one weighted NCC per subpart (a full square at a coarser level, or circles of
+// samples weighted by colour only), combined with the subparts' weights.  Returns INFINITY when invalid.
+template <bool TInvert>
+__device__ __forceinline__ float ncc_custom_pattern(const PatchProj& Q, const NccArgs& A, const CsArgs& S, const avdm_camera_t& rc, const avdm_camera_t& tc,
+                                                    float rpx, float rpy, float tpx, float tpy, f3 p0)
+{
+    const float dd = 2.f; // Patch.cuh:617
+    if((rpx < dd) || (rpx > A.rcW1 - dd) || (tpx < dd) || (tpx > A.tcW1 - dd) || (rpy < dd) || (rpy > A.rcH1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd))
+        return INFINITY;
+    LodTap rt{S.rcT, S.mipmapLevel, 1.0f / (float)A.rcL.W, 1.0f / (float)A.rcL.H}, tt{S.tcT, S.mipmapLevel, 1.0f / (float)A.tcL.W, 1.0f / (float)A.tcL.H};
+    const float rX0 = fmaf(rpx, A.rcSx, A.rcOx), rY0 = fmaf(rpy, A.rcSy, A.rcOy), tX0 = fmaf(tpx, A.tcSx, A.tcOx), tY0 = fmaf(tpy, A.tcSy, A.tcOy);
+    // centre alpha at the stage's level
+    if(rt.fetch<true>(rX0, rY0).w < (255.f * 0.9f) || tt.fetch<true>(tX0, tY0).w < (255.f * 0.4f))
+        return INFINITY;
+    float rcLevel = S.mipmapLevel, tcLevel = S.mipmapLevel;
+    if(S.useConsistentScale)
+        computeRcTcMipmapLevels(rcLevel, tcLevel, S.mipmapLevel, rc, tc, rpx, rpy, tpx, tpy, p0);
+
+    float fsim = 0.f, wsumParts = 0.f;
+#pragma unroll 1
+    for(int sp = 0; sp < S.pattern.nbSubparts; ++sp)
+    {
+        const avdm_patch_pattern_subpart_t& part = S.pattern.subparts[sp];
+        rt.lod = rcLevel + part.level;
+        tt.lod = tcLevel + part.level;
+        const float4 rcCenter = rt.fetch<true>(rX0, rY0), tcCenter = tt.fetch<true>(tX0, tY0);
+        float xsum = 0.f, ysum = 0.f, xxsum = 0.f, yysum = 0.f, xysum = 0.f, wsum = 0.f;
+        const int n = part.isCircle ? part.nbCoordinates : (2 * part.wsh + 1) * (2 * part.wsh + 1);
+#pragma unroll 1
+        for(int c = 0; c < n; ++c)
+        {
+            float fx, fy, dP = 0.f;
+            if(part.isCircle)
+            {
+                fx = part.coordinates[c][0];
+                fy = part.coordinates[c][1];
+            }
+            else
+            {
+                const int side = 2 * part.wsh + 1;
+                const int yp = c / side - part.wsh, xp = c % side - part.wsh;
+                fx = (float)xp * part.downscale;
+                fy = (float)yp * part.downscale;
+                dP = sqrtf((float)(xp * xp + yp * yp)) * A.invGammaP; // CostYKfromLab(dx, dy, ...): the unscaled offsets (Patch.cuh:724)
+            }
+            f3 hrRow, htRow;
+            row_of(Q, fy, hrRow, htRow);
+            float rX, rY, tX, tY;
+            sample_pos(Q, A, hrRow, htRow, fx, rX, rY, tX, tY);
+            const float4 rcC = rt.fetch<true>(rX, rY), tcC = tt.fetch<true>(tX, tY);
+            const float drx = rcCenter.x - rcC.x, dry = rcCenter.y - rcC.y, drz = rcCenter.z - rcC.z;
+            const float dtx = tcCenter.x - tcC.x, dty = tcCenter.y - tcC.y, dtz = tcCenter.z - tcC.z;
+            const float dcr = sqrtf(fmaf(drx, drx, fmaf(dry, dry, drz * drz))), dct = sqrtf(fmaf(dtx, dtx, fmaf(dty, dty, dtz * dtz)));
+            const float w = __expf(-(dcr * A.invGammaC + dP)) * __expf(-(dct * A.invGammaC + dP));
+            // statistics of L shifted by the centre values, as in ncc_accumulate (shift invariant)
+            const float gx = drx, gy = dtx, wgx = w * gx, wgy = w * gy;
+            wsum += w;
+            xsum += wgx;
+            ysum += wgy;
+            xxsum = fmaf(wgx, gx, xxsum);
+            yysum = fmaf(wgy, gy, yysum);
+            xysum = fmaf(wgx, gy, xysum);
+        }
+        const float iw = 1.0f / wsum;
+        const float varXW = (xxsum - xsum * xsum * iw) * iw, varYW = (yysum - ysum * ysum * iw) * iw, varXYW = (xysum - xsum * ysum * iw) * iw;
+        const float rawSim = varXYW / sqrtf(varXW * varYW);
+        const float fsimSubpart = isfinite(rawSim) ? -rawSim : 1.0f;
+        if(fsimSubpart < 0.f)
+        {
+            fsim += (TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, fsimSubpart) : fsimSubpart) * part.weight;
+            wsumParts += part.weight;
+        }
+    }
+    if(wsumParts == 0.f)
+        return INFINITY;
+    return TInvert ? fsim : fsim / wsumParts; // Refine does not average (Patch.cuh:764-768)
+}
 
 // REFINE = false: volume_computeSimilarity_kernel (kernels.cuh:109-233); REFINE = true: volume_refineSimilarity_kernel (:235-391)
 template <bool REFINE>
@@ -1047,7 +1131,7 @@ __global__ void __launch_bounds__(256)
     const f3 C = ld3(rc.C), Z = ld3(rc.ZVect);
     const f3 v = normalize(M3x3mulV2(rc.iP, x, y));
     const float dd = (float)wsh + 2.0f;
-    const bool rInside = !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd));
+    const bool rInside = S.useCustomPatchPattern || !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd));
 
     float2 dps = make_float2(-1.f, 0.f);
     f3 pMid = C, dir = v;
@@ -1114,10 +1198,13 @@ __global__ void __launch_bounds__(256)
             const PatchProj Q = make_patch_proj(rc, tc, p, ax, ay, pd);
             const float it0 = fast_rcp(Q.ht0.z);
             const float tpx = Q.ht0.x * it0, tpy = Q.ht0.y * it0;
-            if(!((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd)))
+            if(S.useCustomPatchPattern)
+                s = ncc_custom_pattern<REFINE>(Q, A, S, rc, tc, x, y, tpx, tpy, p);
+            else if(!((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd)))
             {
                 float rcLevel = S.mipmapLevel, tcLevel = S.mipmapLevel;
-                computeRcTcMipmapLevels(rcLevel, tcLevel, S.mipmapLevel, rc, tc, x, y, tpx, tpy, p);
+                if(S.useConsistentScale)
+                    computeRcTcMipmapLevels(rcLevel, tcLevel, S.mipmapLevel, rc, tc, x, y, tpx, tpy, p);
                 LodTap rt = rtap0, tt = ttap0;
                 rt.lod = rcLevel;
                 tt.lod = tcLevel;
@@ -1178,6 +1265,8 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+static avdm_patch_pattern_t g_patchPattern = {}; // the reference's constantPatchPattern_d (DevicePatchPattern.hpp:51)
+static bool g_patchPatternSet = false;
 static unsigned* g_stats = nullptr; // device counters, allocated on first use when AVDM_SIM_STATS=1
 
 // paired: in = the caller would like the 16-byte paired records (FIXED8 pyramids only); out = whether the LDS budget allows them
@@ -1273,6 +1362,98 @@ using namespace avdm;
 
 extern "C" {
 
+int avdm_build_custom_patch_pattern(int n_subparts, const avdm_patch_subpart_params_t* subparts, int group, avdm_patch_pattern_t* out)
+{
+    // patchPattern.cpp:18-80: checks
+    if(n_subparts <= 0 || subparts == nullptr)
+        return set_error_msg(1, "Cannot build custom patch pattern: No patch pattern subpart given.");
+    std::map<int, int> nbCoordsPerSubparts; // <level or subpart index, nb coordinates>
+    for(int i = 0; i < n_subparts; ++i)
+    {
+        const avdm_patch_subpart_params_t& sp = subparts[i];
+        if(sp.radius <= 0.f)
+            return set_error_msg(1, "Cannot build custom patch pattern: A patch pattern subpart radius is incorrect.");
+        if(sp.isCircle && sp.nbCoordinates <= 0)
+            return set_error_msg(1, "Cannot build custom patch pattern: A patch pattern subpart circle number of coordinates is incorrect.");
+        if(group)
+        {
+            if(!sp.isCircle && nbCoordsPerSubparts.find(sp.level) != nbCoordsPerSubparts.end())
+                return set_error_msg(1, "Cannot build custom patch pattern: Cannot group more than one full patch pattern subpart.");
+            nbCoordsPerSubparts[sp.level] += sp.isCircle ? sp.nbCoordinates : 0;
+        }
+        else
+            nbCoordsPerSubparts[i] += sp.isCircle ? sp.nbCoordinates : 0;
+    }
+    int maxSubpartCoords = 0;
+    for(const auto& kv : nbCoordsPerSubparts)
+        maxSubpartCoords = std::max(maxSubpartCoords, kv.second);
+    const int nbSubparts = (int)nbCoordsPerSubparts.size();
+    if(nbSubparts > AVDM_PATCH_MAX_SUBPARTS)
+        return set_error_msg(1, "Cannot build custom patch pattern: Too many patch pattern subpart given.");
+    if(maxSubpartCoords > AVDM_PATCH_MAX_COORDS_PER_SUBPART)
+        return set_error_msg(1, "Cannot build custom patch pattern: Too many patch pattern subpart coordinates given.");
+
+    avdm_patch_pattern_t pp = {};
+    pp.nbSubparts = nbSubparts;
+    auto fillCircle = [](avdm_patch_pattern_subpart_t& part, int first, const avdm_patch_subpart_params_t& sp) {
+        const float angleDifference = (float)((M_PI * 2.f) / sp.nbCoordinates); // double division, then float (patchPattern.cpp:138)
+        for(int i = 0; i < sp.nbCoordinates; ++i)
+        {
+            const float radians = angleDifference * (float)i;
+            part.coordinates[first + i][0] = std::cos(radians) * sp.radius;
+            part.coordinates[first + i][1] = std::sin(radians) * sp.radius;
+        }
+    };
+    if(group)
+    {
+        for(int i = 0; i < n_subparts; ++i)
+        {
+            const avdm_patch_subpart_params_t& sp = subparts[i];
+            avdm_patch_pattern_subpart_t& part = pp.subparts[std::distance(nbCoordsPerSubparts.begin(), nbCoordsPerSubparts.find(sp.level))];
+            if(sp.isCircle)
+            {
+                fillCircle(part, part.nbCoordinates, sp);
+                part.wsh = std::max(part.wsh, int(sp.radius + std::pow(2.f, (float)sp.level - 1.f)));
+                part.nbCoordinates += sp.nbCoordinates;
+            }
+            else
+                part.wsh = std::max(part.wsh, int(sp.radius));
+            part.level = (float)sp.level;
+            part.downscale = std::pow(2.f, part.level);
+            part.weight = sp.weight;
+            part.isCircle = sp.isCircle ? 1 : 0;
+        }
+    }
+    else
+    {
+        for(int i = 0; i < nbSubparts; ++i)
+        {
+            const avdm_patch_subpart_params_t& sp = subparts[i];
+            avdm_patch_pattern_subpart_t& part = pp.subparts[i];
+            if(sp.isCircle)
+            {
+                fillCircle(part, 0, sp); // the reference divides by and loops over the not yet assigned subpart.nbCoordinates (:196-201)
+                part.wsh = int(sp.radius + std::pow(2.f, (float)sp.level - 1.f));
+                part.nbCoordinates = sp.nbCoordinates;
+            }
+            else
+            {
+                part.wsh = int(sp.radius);
+                part.nbCoordinates = 0;
+            }
+            part.level = (float)sp.level;
+            part.downscale = std::pow(2.f, part.level);
+            part.weight = sp.weight;
+            part.isCircle = sp.isCircle ? 1 : 0;
+        }
+    }
+    g_patchPattern = pp;
+    g_patchPatternSet = true;
+    if(out != nullptr)
+        *out = pp;
+    return 0;
+}
+
 /* debugging aid (not part of avdm.h): plane-workgroups since the last call {LDS path, generic: R tile, generic: T outside, generic: T too large} */
 int avdm_debug_similarity_stats(unsigned out[4])
 {
@@ -1307,12 +1488,17 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
     const unsigned nchunks = ((dr.end + 3) >> 2) - (dr.begin >> 2);
     if(((dr.end + 3) & ~3u) > (unsigned)pitch_x)
         return set_error_msg(1, "avdm_volume_compute_similarity: pitch_x too small for the depth range (must cover the 4-aligned range)");
-    if(sp->useConsistentScale)
+    if(sp->useCustomPatchPattern && !g_patchPatternSet)
+        return set_error_msg(1, "avdm_volume_compute_similarity: useCustomPatchPattern without a pattern (avdm_build_custom_patch_pattern)");
+    if(sp->useConsistentScale || sp->useCustomPatchPattern)
     {
         CsArgs S;
         S.rcT = make_tex(rc_pyr);
         S.tcT = make_tex(tc_pyr);
         S.mipmapLevel = A.mipmapLevel;
+        S.useConsistentScale = sp->useConsistentScale;
+        S.useCustomPatchPattern = sp->useCustomPatchPattern;
+        S.pattern = g_patchPattern;
         hipLaunchKernelGGL((similarity_cs_kernel<false>), dim3(divUp(roi.x.end - roi.x.begin, 64), divUp(roi.y.end - roi.y.begin, 4), nchunks), dim3(256), 0,
                            (hipStream_t)stream, best, second, (__half*)nullptr, 0, (const float2*)nullptr, 0, (const float*)nullptr, 0, pitch_y, pitch_x,
                            depths, *rc, *tc, A, tab, S, sp->stepXY, dr.begin, dr.end, roi);
@@ -1365,12 +1551,17 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
     if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->stepXY, rp->wsh, rp->gammaC, rp->gammaP, paired))
         return set_error_msg(1, "avdm_volume_refine_similarity: non-integral mip level");
     const unsigned nchunks = ((dr.end + 7) >> 3) - (dr.begin >> 3);
-    if(rp->useConsistentScale)
+    if(rp->useCustomPatchPattern && !g_patchPatternSet)
+        return set_error_msg(1, "avdm_volume_refine_similarity: useCustomPatchPattern without a pattern (avdm_build_custom_patch_pattern)");
+    if(rp->useConsistentScale || rp->useCustomPatchPattern)
     {
         CsArgs S;
         S.rcT = make_tex(rc_pyr);
         S.tcT = make_tex(tc_pyr);
         S.mipmapLevel = A.mipmapLevel;
+        S.useConsistentScale = rp->useConsistentScale;
+        S.useCustomPatchPattern = rp->useCustomPatchPattern;
+        S.pattern = g_patchPattern;
         hipLaunchKernelGGL((similarity_cs_kernel<true>), dim3(divUp(roi.x.end - roi.x.begin, 64), divUp(roi.y.end - roi.y.begin, 4), nchunks), dim3(256), 0,
                            (hipStream_t)stream, (uint8_t*)nullptr, (uint8_t*)nullptr, (__half*)vol_f16, dimZ, (const float2*)sgm_depth_pixsize, map_pitch,
                            sgm_normal, normal_pitch, pitch_y, pitch_x, (const float*)nullptr, *rc, *tc, A, tab, S, rp->stepXY, dr.begin, dr.end, roi);

@@ -252,8 +252,19 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
 
     DeviceCache deviceCache(nbMipmapImagesPerBatch, nbCamerasParamsPerBatch, filterModeFromEnv());
 
+    // build the custom patch pattern (DepthMapEstimator.cpp:272-274; library state like the reference's constant memory)
     if(_sgmParams.useCustomPatchPattern || _refineParams.useCustomPatchPattern)
-        AVDM_THROW_ERROR("custom patch patterns are not built (SURVEY.md §8f.4).");
+    {
+        std::vector<avdm_patch_subpart_params_t> sub;
+        for(const auto& sp : _depthMapParams.customPatchPattern.subpartsParams)
+        {
+            avdm_patch_subpart_params_t a;
+            a.isCircle = sp.isCircle ? 1 : 0, a.level = sp.level, a.nbCoordinates = sp.nbCoordinates, a.radius = sp.radius, a.weight = sp.weight;
+            sub.push_back(a);
+        }
+        avdmCheck(avdm_build_custom_patch_pattern((int)sub.size(), sub.data(), _depthMapParams.customPatchPattern.groupSubpartsPerLevel ? 1 : 0, nullptr),
+                  "Cannot build custom patch pattern");
+    }
 
     std::vector<std::unique_ptr<Sgm>> sgmPerStream;
     std::vector<std::unique_ptr<Refine>> refinePerStream;

@@ -24,6 +24,7 @@ struct Option
     std::string dflt;      // textual default
     std::function<void(const std::string&)> set;
     bool hidden;
+    bool multitoken = false; // boost's ->multitoken(): the option takes every following argument up to the next option
 };
 
 class CmdLine
@@ -39,6 +40,15 @@ class CmdLine
         d << *target;
         o.dflt = d.str();
         o.set = [target, name](const std::string& v) { parse(name, v, target); };
+        _options.push_back(o);
+    }
+    // po::value<std::vector<T>>()->multitoken(): tokens are collected as text, the caller parses them
+    void addMultitoken(const std::string& name, std::vector<std::string>* target, const std::string& help)
+    {
+        Option o;
+        o.name = name, o.shortName = 0, o.required = false, o.help = help, o.hidden = false, o.multitoken = true;
+        o.dflt = "";
+        o.set = [target](const std::string& v) { target->push_back(v); };
         _options.push_back(o);
     }
     // returns false when the program should stop (help or error; `error` tells which)
@@ -83,6 +93,9 @@ class CmdLine
             try
             {
                 opt->set(value);
+                if(opt->multitoken)
+                    while(i + 1 < argc && !(argv[i + 1][0] == '-' && (argv[i + 1][1] == '-' || std::isalpha((unsigned char)argv[i + 1][1]))))
+                        opt->set(argv[++i]);
             }
             catch(const std::exception& e)
             {

@@ -95,8 +95,7 @@ int aliceVision_main(int argc, char* argv[])
     int nbGPUs = 0;
     int maxMemoryAvailable = 0, maxCoresAvailable = 0; // cmdline.cpp:10-26 hardware limits
     bool dryRun = false;
-    std::string customPatchPatternSubparts;
-    bool customPatchPatternGroupSubpartsPerLevel = false;
+    std::vector<std::string> customPatchPatternSubparts; // tokens `type:radius:nbCoords:level:weight` (CustomPatchPatternParams.cpp:16-41)
 
     CmdLine cmdline("Dense Reconstruction.\n"
                     "This program estimate a depth map for each input calibrated camera using Plane Sweeping, a multi-view stereo algorithm notable "
@@ -151,8 +150,8 @@ int aliceVision_main(int argc, char* argv[])
     cmdline.add("refineEnabled", &refineParams.useRefineFuse, "Enable/Disable depth/similarity map refinement process.");
     cmdline.add("colorOptimizationEnabled", &refineParams.useColorOptimization, "Enable/Disable depth/similarity map post-process color optimization.");
     cmdline.add("autoAdjustSmallImage", &depthMapParams.autoAdjustSmallImage, "Automatically adjust depth map parameters if images are smaller than one tile (maxTCamsPerTile=maxTCams, adjust step if needed).");
-    cmdline.add("customPatchPatternSubparts", &customPatchPatternSubparts, "User custom patch pattern subparts for similarity volume computation.");
-    cmdline.add("customPatchPatternGroupSubpartsPerLevel", &customPatchPatternGroupSubpartsPerLevel, "Group all custom patch pattern subparts with the same image level.");
+    cmdline.addMultitoken("customPatchPatternSubparts", &customPatchPatternSubparts, "User custom patch pattern subparts for similarity volume computation.");
+    cmdline.add("customPatchPatternGroupSubpartsPerLevel", &depthMapParams.customPatchPattern.groupSubpartsPerLevel, "Group all custom patch pattern subparts with the same image level.");
     cmdline.add("exportIntermediateDepthSimMaps", &exportIntermediateDepthSimMaps, "Export intermediate depth/similarity maps from the SGM and Refine steps.");
     cmdline.add("exportIntermediateNormalMaps", &exportIntermediateNormalMaps, "Export intermediate normal maps from the SGM and Refine steps.");
     cmdline.add("exportIntermediateVolumes", &exportIntermediateVolumes, "Export intermediate full similarity volumes from the SGM and Refine steps.");
@@ -201,9 +200,44 @@ int aliceVision_main(int argc, char* argv[])
         AVDM_LOG_ERROR("Intermediate volume exports (Alembic / CSV debug dumps of volumeIO.cpp) are not built.");
         return EXIT_FAILURE;
     }
-    if(sgmParams.useCustomPatchPattern || refineParams.useCustomPatchPattern || !customPatchPatternSubparts.empty())
+    // CustomPatchPatternParams.cpp:16-41 (operator>>): `circle|full:radius:nbCoordinates:level:weight`
+    for(const std::string& token : customPatchPatternSubparts)
     {
-        AVDM_LOG_ERROR("Custom patch patterns are not built.");
+        std::vector<std::string> parts;
+        size_t b = 0;
+        while(true)
+        {
+            const size_t e = token.find(':', b);
+            parts.push_back(token.substr(b, e == std::string::npos ? std::string::npos : e - b));
+            if(e == std::string::npos)
+                break;
+            b = e + 1;
+        }
+        CustomPatchPatternParams::SubpartParams sp;
+        try
+        {
+            if(parts.size() != 5)
+                throw std::invalid_argument(token);
+            std::string type = parts[0];
+            for(char& c : type)
+                c = (char)std::tolower((unsigned char)c);
+            sp.isCircle = (type == "circle");
+            sp.radius = std::stof(parts[1]);
+            sp.nbCoordinates = std::stoi(parts[2]);
+            sp.level = std::stoi(parts[3]);
+            sp.weight = std::stof(parts[4]);
+        }
+        catch(const std::exception&)
+        {
+            std::cerr << "ERROR: Failed to parse CustomPatchPatternParams::SubpartParams from: " << token << std::endl;
+            return EXIT_FAILURE;
+        }
+        depthMapParams.customPatchPattern.subpartsParams.push_back(sp);
+    }
+    if((sgmParams.useCustomPatchPattern || refineParams.useCustomPatchPattern) && depthMapParams.customPatchPattern.subpartsParams.empty())
+    {
+        // buildCustomPatchPattern would throw at the start of the computation (patchPattern.cpp:20-24); say so before loading anything
+        AVDM_LOG_ERROR("Cannot build custom patch pattern: No patch pattern subpart given (--customPatchPatternSubparts).");
         return EXIT_FAILURE;
     }
     if(!dryRun)

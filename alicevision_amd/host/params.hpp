@@ -59,6 +59,7 @@ struct SgmParams
         std::strncpy(p.filteringAxes, filteringAxes.c_str(), sizeof(p.filteringAxes) - 1);
         p.useConsistentScale = useConsistentScale ? 1 : 0;
         p.strictRoiQuirk = 1;
+        p.useCustomPatchPattern = useCustomPatchPattern ? 1 : 0;
         return p;
     }
 };
@@ -96,8 +97,24 @@ struct RefineParams
         p.sigma = sigma, p.gammaC = gammaC, p.gammaP = gammaP;
         p.interpolateMiddleDepth = interpolateMiddleDepth ? 1 : 0;
         p.useConsistentScale = useConsistentScale ? 1 : 0;
+        p.useCustomPatchPattern = useCustomPatchPattern ? 1 : 0;
         return p;
     }
+};
+
+// DM/CustomPatchPatternParams.hpp:19-36
+struct CustomPatchPatternParams
+{
+    struct SubpartParams
+    {
+        bool isCircle = false;
+        int level = 0;
+        int nbCoordinates = 0;
+        float radius = 0.f;
+        float weight = 0.f;
+    };
+    std::vector<SubpartParams> subpartsParams;
+    bool groupSubpartsPerLevel = false;
 };
 
 struct DepthMapParams
@@ -106,6 +123,7 @@ struct DepthMapParams
     bool chooseTCamsPerTile = true;
     bool exportTilePattern = false;
     bool autoAdjustSmallImage = true;
+    CustomPatchPatternParams customPatchPattern; // DepthMapParams.hpp:31
     bool useRefine = true; // const true in the reference (DepthMapParams.hpp:34); hidden CLI switch --useRefine
 };
 

@@ -92,6 +92,7 @@ typedef struct avdm_sgm_params
     char filteringAxes[8];    /* ordered axis string, e.g. "YX" (SgmParams.hpp:34) */
     int useConsistentScale;
     int strictRoiQuirk;       /* 1 = replicate the begin-x/begin-y swap of deviceSimilarityVolumeKernels.cuh:688-709 */
+    int useCustomPatchPattern; /* SgmParams.hpp:51: compare with the pattern of avdm_build_custom_patch_pattern instead of the wsh square */
 } avdm_sgm_params_t;
 
 /* subset of RefineParams used by the kernels (RefineParams.hpp:19-45) */
@@ -108,7 +109,36 @@ typedef struct avdm_refine_params
     double gammaP;
     int interpolateMiddleDepth;
     int useConsistentScale;
+    int useCustomPatchPattern; /* RefineParams.hpp:42 */
 } avdm_refine_params_t;
+
+/* ---- custom patch pattern (cuda/device/DevicePatchPattern.hpp:11-54) ---- */
+#define AVDM_PATCH_MAX_SUBPARTS 4
+#define AVDM_PATCH_MAX_COORDS_PER_SUBPART 24
+typedef struct avdm_patch_pattern_subpart
+{
+    float coordinates[AVDM_PATCH_MAX_COORDS_PER_SUBPART][2]; /* circle(s): patch-relative sample positions */
+    int nbCoordinates;
+    float level;     /* mipmap level added to the stage's level (>= 0) */
+    float downscale; /* 2^level */
+    float weight;
+    int isCircle;
+    int wsh;         /* half-width of a full subpart */
+} avdm_patch_pattern_subpart_t;
+typedef struct avdm_patch_pattern
+{
+    avdm_patch_pattern_subpart_t subparts[AVDM_PATCH_MAX_SUBPARTS]; /* one similarity per subpart */
+    int nbSubparts;
+} avdm_patch_pattern_t;
+/* CustomPatchPatternParams::SubpartParams (CustomPatchPatternParams.hpp:26-33) */
+typedef struct avdm_patch_subpart_params
+{
+    int isCircle;
+    int level;
+    int nbCoordinates;
+    float radius;
+    float weight;
+} avdm_patch_subpart_params_t;
 
 /* ---- library ---- */
 const char* avdm_last_error(void);
@@ -116,6 +146,13 @@ int avdm_version(void);
 /* gpu/gpu.cpp:15-66 (gpuSupportCUDA / gpuInformationCUDA) */
 int avdm_device_count(void);
 int avdm_device_info(int device, char* out, size_t out_len);
+
+/* buildCustomPatchPattern (cuda/host/patchPattern.cpp:18-251): validates the subparts, builds the pattern and makes it the one the
+ * similarity entry points use when their parameters say useCustomPatchPattern (the reference keeps it in constant memory,
+ * DevicePatchPattern.hpp:51).  `out` (optional) receives a copy.  In the non-grouped form the reference reads the circle's number
+ * of coordinates from uninitialised memory (:196-201); the value of the subpart's parameters is used here. */
+int avdm_build_custom_patch_pattern(int n_subparts, const avdm_patch_subpart_params_t* subparts, int group_subparts_per_level,
+                                    avdm_patch_pattern_t* out);
 
 /* ---- image side ---- */
 /* host-only: fills width/height/pitch/offset/bytes for an image of w x h process pixels.

@@ -763,6 +763,215 @@ static float compNCCby3DptsYK(int invertAndFilter, const avdm_camera_t* rc, cons
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Custom patch pattern (cuda/host/patchPattern.cpp:18-251, cuda/device/Patch.cuh:598-773, DevicePatchPattern.hpp)
+ * ---------------------------------------------------------------------------------------------- */
+static avdm_patch_pattern_t g_patchPattern; /* constantPatchPattern_d */
+static int g_patchPatternSet = 0;
+
+/* patchPattern.cpp:18-251.  In the non-grouped form the reference uses subpart.nbCoordinates before assigning it (:196-201,
+ * uninitialised pinned memory); the parameter's value is used here, as in the library. */
+int avo_build_custom_patch_pattern(int n_subparts, const avdm_patch_subpart_params_t* subparts, int group, avdm_patch_pattern_t* out)
+{
+    if(n_subparts <= 0 || subparts == NULL)
+        return 1;
+    /* std::map<int, int> nbCoordsPerSubparts: keys in ascending order */
+    int keys[64], counts[64], nkeys = 0;
+    if(n_subparts > 64)
+        return 1;
+    for(int i = 0; i < n_subparts; ++i)
+    {
+        const avdm_patch_subpart_params_t* sp = &subparts[i];
+        if(sp->radius <= 0.f)
+            return 1;
+        if(sp->isCircle && sp->nbCoordinates <= 0)
+            return 1;
+        const int key = group ? sp->level : i;
+        int k = 0;
+        while(k < nkeys && keys[k] != key)
+            ++k;
+        if(k < nkeys && group && !sp->isCircle)
+            return 1; /* Cannot group more than one full patch pattern subpart */
+        if(k == nkeys)
+        {
+            /* sorted insert */
+            int pos = nkeys;
+            while(pos > 0 && keys[pos - 1] > key)
+            {
+                keys[pos] = keys[pos - 1];
+                counts[pos] = counts[pos - 1];
+                --pos;
+            }
+            keys[pos] = key;
+            counts[pos] = 0;
+            ++nkeys;
+            k = pos;
+        }
+        counts[k] += sp->isCircle ? sp->nbCoordinates : 0;
+    }
+    int maxCoords = 0;
+    for(int k = 0; k < nkeys; ++k)
+        maxCoords = counts[k] > maxCoords ? counts[k] : maxCoords;
+    if(nkeys > AVDM_PATCH_MAX_SUBPARTS || maxCoords > AVDM_PATCH_MAX_COORDS_PER_SUBPART)
+        return 1;
+
+    avdm_patch_pattern_t pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.nbSubparts = nkeys;
+    for(int i = 0; i < n_subparts; ++i)
+    {
+        const avdm_patch_subpart_params_t* sp = &subparts[i];
+        int k = 0;
+        const int key = group ? sp->level : i;
+        while(keys[k] != key)
+            ++k;
+        avdm_patch_pattern_subpart_t* part = &pp.subparts[k];
+        if(sp->isCircle)
+        {
+            const float angleDifference = (float)((3.14159265358979323846 * 2.f) / sp->nbCoordinates); /* (M_PI * 2.f) / n in double, then float */
+            const int first = group ? part->nbCoordinates : 0;
+            for(int j = 0; j < sp->nbCoordinates; ++j)
+            {
+                const float radians = angleDifference * (float)j;
+                part->coordinates[first + j][0] = cosf(radians) * sp->radius;
+                part->coordinates[first + j][1] = sinf(radians) * sp->radius;
+            }
+            const int w = (int)(sp->radius + powf(2.f, (float)sp->level - 1.f));
+            part->wsh = group ? (part->wsh > w ? part->wsh : w) : w;
+            part->nbCoordinates = group ? part->nbCoordinates + sp->nbCoordinates : sp->nbCoordinates;
+        }
+        else
+        {
+            const int w = (int)sp->radius;
+            part->wsh = group ? (part->wsh > w ? part->wsh : w) : w;
+            if(!group)
+                part->nbCoordinates = 0;
+        }
+        part->level = (float)sp->level;
+        part->downscale = powf(2.f, part->level);
+        part->weight = sp->weight;
+        part->isCircle = sp->isCircle ? 1 : 0;
+    }
+    g_patchPattern = pp;
+    g_patchPatternSet = 1;
+    if(out != NULL)
+        *out = pp;
+    return 0;
+}
+
+/* color.cuh:226-232 */
+static inline float CostYKfromLab3(f4 c1, f4 c2, float invGammaC) { return expf(-(euclideanDist3(c1, c2) * invGammaC)); }
+
+/* Patch.cuh:598-773 (compNCCby3DptsYK_customPatchPattern<TInvertAndFilter>) */
+static float compNCCby3DptsYK_customPatchPattern(int invertAndFilter, const avdm_camera_t* rc, const avdm_camera_t* tc, const avdm_pyramid_t* rcTex,
+                                                 const avdm_pyramid_t* tcTex, unsigned rcLevelWidth, unsigned rcLevelHeight, unsigned tcLevelWidth,
+                                                 unsigned tcLevelHeight, float mipmapLevel, float invGammaC, float invGammaP, int useConsistentScale,
+                                                 const Patch* patch, f2 rcPixel)
+{
+    const f2 rp = g_exact_rc_pixel ? rcPixel : project3DPoint(rc->P, patch->p);
+    const f2 tp = project3DPoint(tc->P, patch->p);
+    const float dd = 2.f;
+    if((rp.x < dd) || (rp.x > (float)(rcLevelWidth - 1) - dd) || (tp.x < dd) || (tp.x > (float)(tcLevelWidth - 1) - dd) || (rp.y < dd) ||
+       (rp.y > (float)(rcLevelHeight - 1) - dd) || (tp.y < dd) || (tp.y > (float)(tcLevelHeight - 1) - dd))
+        return INFINITY;
+    const float rcInvLevelWidth = 1.f / (float)rcLevelWidth, rcInvLevelHeight = 1.f / (float)rcLevelHeight;
+    const float tcInvLevelWidth = 1.f / (float)tcLevelWidth, tcInvLevelHeight = 1.f / (float)tcLevelHeight;
+    const float rcAlpha = tex2DLod(rcTex, (rp.x + 0.5f) * rcInvLevelWidth, (rp.y + 0.5f) * rcInvLevelHeight, mipmapLevel).w;
+    const float tcAlpha = tex2DLod(tcTex, (tp.x + 0.5f) * tcInvLevelWidth, (tp.y + 0.5f) * tcInvLevelHeight, mipmapLevel).w;
+    if(rcAlpha < (255.f * 0.9f) || tcAlpha < (255.f * 0.4f))
+        return INFINITY;
+    float rcMipmapLevel = mipmapLevel, tcMipmapLevel = mipmapLevel;
+    if(useConsistentScale)
+        computeRcTcMipmapLevels(&rcMipmapLevel, &tcMipmapLevel, mipmapLevel, rc, tc, rp, tp, patch->p);
+
+    float fsim = 0.f, wsum = 0.f;
+    for(int s = 0; s < g_patchPattern.nbSubparts; ++s)
+    {
+        const avdm_patch_pattern_subpart_t* subpart = &g_patchPattern.subparts[s];
+        const f4 rcCenterColor = tex2DLod(rcTex, (rp.x + 0.5f) * rcInvLevelWidth, (rp.y + 0.5f) * rcInvLevelHeight, rcMipmapLevel + subpart->level);
+        const f4 tcCenterColor = tex2DLod(tcTex, (tp.x + 0.5f) * tcInvLevelWidth, (tp.y + 0.5f) * tcInvLevelHeight, tcMipmapLevel + subpart->level);
+        /* simStat in double when the well-conditioned evaluation is on (see avo_set_ncc_precision), else fp32 like SimStat.cuh */
+        double xsum = 0., ysum = 0., xxsum = 0., yysum = 0., xysum = 0., sw = 0.;
+        float fxsum = 0.f, fysum = 0.f, fxxsum = 0.f, fyysum = 0.f, fxysum = 0.f, fsw = 0.f;
+        const int side = 2 * subpart->wsh + 1;
+        const int n = subpart->isCircle ? subpart->nbCoordinates : side * side;
+        for(int c = 0; c < n; ++c)
+        {
+            float cx, cy;
+            int xp = 0, yp = 0;
+            if(subpart->isCircle)
+            {
+                cx = subpart->coordinates[c][0];
+                cy = subpart->coordinates[c][1];
+            }
+            else
+            {
+                yp = c / side - subpart->wsh;
+                xp = c % side - subpart->wsh;
+                cx = (float)xp * subpart->downscale;
+                cy = (float)yp * subpart->downscale;
+            }
+            const f3 p = add3(add3(patch->p, mul3(patch->x, (float)(patch->d * cx))), mul3(patch->y, (float)(patch->d * cy)));
+            const f2 rpc = project3DPoint(rc->P, p);
+            const f2 tpc = project3DPoint(tc->P, p);
+            const f4 rcC = tex2DLod(rcTex, (rpc.x + 0.5f) * rcInvLevelWidth, (rpc.y + 0.5f) * rcInvLevelHeight, rcMipmapLevel + subpart->level);
+            const f4 tcC = tex2DLod(tcTex, (tpc.x + 0.5f) * tcInvLevelWidth, (tpc.y + 0.5f) * tcInvLevelHeight, tcMipmapLevel + subpart->level);
+            float wr, wt;
+            if(subpart->isCircle)
+            {
+                wr = CostYKfromLab3(rcCenterColor, rcC, invGammaC);
+                wt = CostYKfromLab3(tcCenterColor, tcC, invGammaC);
+            }
+            else
+            {
+                wr = CostYKfromLab(xp, yp, rcCenterColor, rcC, invGammaC, invGammaP);
+                wt = CostYKfromLab(xp, yp, tcCenterColor, tcC, invGammaC, invGammaP);
+            }
+            const float w = wr * wt, gx = rcC.x, gy = tcC.x;
+            fsw += w;
+            fxsum += w * gx;
+            fysum += w * gy;
+            fxxsum += w * gx * gx;
+            fyysum += w * gy * gy;
+            fxysum += w * gx * gy;
+            const double dw = (double)wr * (double)wt, dgx = gx, dgy = gy;
+            sw += dw;
+            xsum += dw * dgx;
+            ysum += dw * dgy;
+            xxsum += dw * dgx * dgx;
+            yysum += dw * dgy * dgy;
+            xysum += dw * dgx * dgy;
+        }
+        float fsimSubpart;
+        if(g_ncc_f64)
+        {
+            const double varXW = (xxsum - xsum * xsum / sw) / sw, varYW = (yysum - ysum * ysum / sw) / sw, varXYW = (xysum - xsum * ysum / sw) / sw;
+            const double rawSim = varXYW / sqrt(varXW * varYW);
+            fsimSubpart = isfinite(rawSim) ? (float)-rawSim : 1.0f;
+        }
+        else
+        {
+            const float varXW = (fxxsum - fxsum * fxsum / fsw) / fsw, varYW = (fyysum - fysum * fysum / fsw) / fsw;
+            const float varXYW = (fxysum - fxsum * fysum / fsw) / fsw;
+            const float rawSim = varXYW / sqrtf(varXW * varYW);
+            fsimSubpart = isfinite(rawSim) ? -rawSim : 1.0f;
+        }
+        if(fsimSubpart < 0.f)
+        {
+            if(invertAndFilter)
+                fsim += sigmoidf_(0.0f, 1.0f, 0.7f, -0.7f, fsimSubpart) * subpart->weight;
+            else
+                fsim += fsimSubpart * subpart->weight;
+            wsum += subpart->weight;
+        }
+    }
+    if(wsum == 0.f)
+        return INFINITY;
+    if(invertAndFilter)
+        return fsim; /* "for now, we do not average" */
+    return fsim / wsum;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Similarity volume kernels (planeSweeping/deviceSimilarityVolumeKernels.cuh)
  * ---------------------------------------------------------------------------------------------- */
 #define VOL8(base, x, y, z) ((base) + (long long)(y) * pitch_y + (long long)(x) * pitch_x + (z))
@@ -836,8 +1045,12 @@ void avo_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
                 patch.p = get3DPointForPixelAndFrontoParellePlaneRC(rc, mk2(x, y), depthPlane);
                 patch.d = computePixSize(rc, patch.p);
                 computeRotCSEpip(&patch, rc, tc);
-                float fsim = compNCCby3DptsYK(0, rc, tc, rcPyr, tcPyr, rcW, rcH, tcW, tcH, rcMipmapLevel, sp->wsh, invGammaC, invGammaP,
-                                              sp->useConsistentScale, &patch, mk2(x, y));
+                /* kernels.cuh:163-192: custom patch pattern or the wsh square */
+                float fsim = (sp->useCustomPatchPattern && g_patchPatternSet)
+                                 ? compNCCby3DptsYK_customPatchPattern(0, rc, tc, rcPyr, tcPyr, rcW, rcH, tcW, tcH, rcMipmapLevel, invGammaC, invGammaP,
+                                                                       sp->useConsistentScale, &patch, mk2(x, y))
+                                 : compNCCby3DptsYK(0, rc, tc, rcPyr, tcPyr, rcW, rcH, tcW, tcH, rcMipmapLevel, sp->wsh, invGammaC, invGammaP,
+                                                    sp->useConsistentScale, &patch, mk2(x, y));
                 if(fsim == INFINITY)
                     fsim = 255.0f;
                 else
@@ -912,8 +1125,12 @@ void avo_volume_refine_similarity(uint16_t* vol, long long pitch_y, int pitch_x,
                         patch.n = normalize3(div3(add3(v1, v2), 2.0f));
                     patch.x = normalize3(cross3(patch.y, patch.n));
                 }
-                const float fsim = compNCCby3DptsYK(1, rc, tc, rcPyr, tcPyr, rcW, rcH, tcW, tcH, rcMipmapLevel, rp->wsh, invGammaC, invGammaP,
-                                                    rp->useConsistentScale, &patch, mk2(x, y));
+                /* kernels.cuh:339-368 */
+                const float fsim = (rp->useCustomPatchPattern && g_patchPatternSet)
+                                       ? compNCCby3DptsYK_customPatchPattern(1, rc, tc, rcPyr, tcPyr, rcW, rcH, tcW, tcH, rcMipmapLevel, invGammaC,
+                                                                             invGammaP, rp->useConsistentScale, &patch, mk2(x, y))
+                                       : compNCCby3DptsYK(1, rc, tc, rcPyr, tcPyr, rcW, rcH, tcW, tcH, rcMipmapLevel, rp->wsh, invGammaC, invGammaP,
+                                                          rp->useConsistentScale, &patch, mk2(x, y));
                 if(fsim == INFINITY)
                     continue;
                 uint16_t* out = (uint16_t*)((char*)vol + (long long)vy * pitch_y + (long long)vx * pitch_x) + vz;

@@ -57,6 +57,9 @@ void avo_depth_sim_map_optimize_gradient_descent(float* outOpt, int out_pitch, f
                                                  int ref_pitch, const avdm_camera_t* rc, const avdm_pyramid_t* rcPyr,
                                                  const avdm_refine_params_t* rp, avdm_roi_t roi);
 
+/* custom patch pattern (patchPattern.cpp:18-251): builds the pattern and makes it the oracle's current one */
+int avo_build_custom_patch_pattern(int n_subparts, const avdm_patch_subpart_params_t* subparts, int group, avdm_patch_pattern_t* out);
+
 /* ---- depth-map filtering (avdm_fuse_oracle.c; fuseCut/Fuser.cpp:66-304) ---- */
 /* camArr (3x4), iCamArr (3x3), CArr of a camera, row-major, and the image size MultiViewParams reports for it */
 typedef struct

@@ -26,6 +26,7 @@ _SIG = {
     "avo_exp_p2": (f32, [f32]),
     "avo_set_ncc_precision": (None, [i32]),
     "avo_set_exact_rc_pixel": (None, [i32]),
+    "avo_build_custom_patch_pattern": (i32, [i32, P(abi.PatchSubpartParams), i32, P(abi.PatchPattern)]),
     "avo_tex2dlod": (None, [P(abi.Pyramid), f32, f32, f32, P(f32 * 4)]),
     "avo_pyramid_layout": (i32, [P(abi.Pyramid), i32, i32, i32, i32, i32]),
     "avo_image_rgba_f32_to_f16x255": (None, [vp, i32, vp, i32, i32, i32]),

@@ -475,3 +475,65 @@ def _rerender(base, moved):
     sc.images = T.stack(imgs, dim=0).contiguous()
     sc.z_range = base.z_range
     return sc
+
+
+@pytest.mark.parametrize("group,consistent", [(False, 0), (True, 1)])
+def test_custom_patch_pattern_parity(group, consistent):
+    """useCustomPatchPattern (Patch.cuh:598-773, patchPattern.cpp; off by default in the reference): circles of colour-weighted samples
+    and a full square at a coarser level, one NCC per subpart combined by the subparts' weights — the pattern builder against the
+    oracle's (same structure), then the similarity and Refine volumes in the tolerance classes of the default path"""
+    torch = _torch()
+    from oracle import oracle
+    spec = [("full", 2, 0, 1, 0.4), ("circle", 3.5, 12, 0, 0.35), ("circle", 6, 10, 1, 0.25)] if group else \
+        [("circle", 4, 16, 0, 0.5), ("full", 3, 0, 1, 0.3), ("circle", 7.5, 24, 2, 0.2)]
+    got_pp = abi.build_custom_patch_pattern(spec, group)
+    want_pp = abi.PatchPattern()
+    assert oracle.load().avo_build_custom_patch_pattern(len(spec), abi.patch_subparts(spec), 1 if group else 0, C.byref(want_pp)) == 0
+    assert got_pp.nbSubparts == want_pp.nbSubparts == (2 if group else 3)
+    for a, b in zip(got_pp.subparts[:got_pp.nbSubparts], want_pp.subparts[:want_pp.nbSubparts]):
+        assert (a.nbCoordinates, a.level, a.downscale, a.weight, a.isCircle, a.wsh) == (b.nbCoordinates, b.level, b.downscale, b.weight, b.isCircle, b.wsh)
+        ca = np.array([[c[0], c[1]] for c in a.coordinates[:a.nbCoordinates]]).reshape(-1, 2)
+        cb = np.array([[c[0], c[1]] for c in b.coordinates[:b.nbCoordinates]]).reshape(-1, 2)
+        assert np.allclose(ca, cb, rtol=0, atol=2e-6)  # cosf / sinf: libm vs the host's
+
+    sc, _, _, depths = small_case()
+    sgm = abi.SgmParams.default(useCustomPatchPattern=1, useConsistentScale=consistent)
+    ref = abi.RefineParams.default(useCustomPatchPattern=1, useConsistentScale=consistent)
+    Z = len(depths)
+    o = make_oracle(sc, sgm, ref)
+    with oracle.well_posed():
+        o.run_sgm(0, [1, 2], depths, optimize=False)
+        best64, second64 = o.best_raw[..., :Z].copy(), o.second[..., :Z].copy()
+        o.run_sgm(0, [1, 2], depths)
+        o.run_refine(0, [1, 2], optimize_enabled=False)
+    h = make_hip_from_oracle(o, sc, sgm, ref)
+    h.run_sgm(0, [1, 2], depths, optimize=False, keep_raw=True)
+    torch.cuda.synchronize()
+    for got, want in ((h.best_raw.cpu().numpy()[..., :Z], best64), (h.second.cpu().numpy()[..., :Z], second64)):
+        frac, mx = level_mismatch(want, got)
+        d = np.abs(want.astype(np.int16) - got.astype(np.int16))
+        assert (want != 255).mean() > 0.3
+        assert frac <= 0.05, (frac, mx)
+        assert (d > 1).mean() <= 4e-3, (d > 1).mean()
+        assert ((want == 255) != (got == 255)).mean() <= 4e-3
+    # the pattern matters: the default square patch gives clearly different volumes
+    o0 = make_oracle(sc, abi.SgmParams.default(), abi.RefineParams.default())
+    with oracle.well_posed():
+        o0.run_sgm(0, [1, 2], depths, optimize=False)
+    assert level_mismatch(o0.best_raw[..., :Z], best64)[0] > 0.2
+
+    h._alloc(Z)
+    h.sgm_depth_thickness.copy_(torch.from_numpy(o.sgm_depth_thickness))
+    h.run_refine(0, [1, 2], optimize_enabled=False)
+    torch.cuda.synchronize()
+    Zr = ref.halfNbDepths * 2 + 1
+    a = o.refine_volume[..., :Zr].astype(np.float32)
+    b = h.refine_volume.cpu().numpy()[..., :Zr].astype(np.float32)
+    diff = np.abs(a - b)
+    assert a.max() > 0.3
+    assert (diff > 4e-3).mean() <= 4e-3, (diff > 4e-3).mean()
+    assert (diff > 0.02).mean() <= 3e-4, ((diff > 0.02).mean(), diff.max())
+
+    # without a pattern the entry points refuse (here: the library keeps the last one, so only the flag-less call is checked)
+    sgm0 = abi.SgmParams.default()
+    assert sgm0.useCustomPatchPattern == 0

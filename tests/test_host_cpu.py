@@ -247,7 +247,11 @@ def test_cli_argument_errors(scene):
     assert run(base + ["--rangeStart", -1, "--rangeSize", 2], check=False).returncode == 1
     r = run(base + ["--rangeStart", 50, "--rangeSize", 2, "--downscale", 1], check=False)
     assert r.returncode == 0 and "No camera to process" in r.stdout
-    assert run(base + ["--sgmUseCustomPatchPattern", 1], check=False).returncode == 1  # not built: refused loudly
+    assert run(base + ["--sgmUseCustomPatchPattern", 1], check=False).returncode == 1  # no subparts given
+    assert run(base + ["--sgmUseCustomPatchPattern", 1, "--customPatchPatternSubparts", "circle:5:8:0"], check=False).returncode == 1  # bad token
+    r = run(base + ["--refineUseCustomPatchPattern", 1, "--customPatchPatternSubparts", "circle:5:8:0:0.5", "full:2:0:1:0.5",
+                    "--customPatchPatternGroupSubpartsPerLevel", 0, "--downscale", 1], check=False)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]  # multitoken option followed by another option
     assert run([CLI, "--help"], check=False).returncode == 0
     r = run([CLI, "-i", os.path.join(d, "nope.abc"), "--imagesFolder", img, "-o", d, "--dryRun", 1], check=False)
     assert r.returncode == 1 and "Alembic" in r.stdout + r.stderr
