@@ -283,7 +283,7 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
 //   * FIXED8 weights are k/256, k = 0..256; they are kept as integers (k, 256 - k), exactly representable in fp16, so every
 //     interpolated colour carries a factor 2^16, which is folded into the centre colours and into the gammaC factor (powers of
 //     two commute with fp32 rounding; the NCC itself is scale-free);
-//   * the horizontal half of each tap is one v_perm_b32 + one v_dot2_f32_f16 per channel on the fp16 texel pairs (no unpack);
+//   * the horizontal half of each tap is one v_dot2_f32_f16 per channel on fp16 texel pairs that were paired when the window was staged;
 //   * window-relative texel indices are formed in fp32 (exact integers) with one packed FMA for both images.
 // ---------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -316,76 +316,23 @@ __device__ __forceinline__ uint2 lds_texel(unsigned byteAddr)
     return r;
 }
 
-// Horizontal half of a bilinear tap for the three colour channels of one texel row: v_perm_b32 pairs the two taps' fp16
-// values of a channel, v_dot2_f32_f16 multiplies them with the fp16 weight pair {256 - A, A} (exact: k <= 256) and adds in fp32
-// — products of two fp16 values are exact in fp32, so the row lerp has a single rounding.
-// The builtin is used on purpose: written as inline asm the compiler no longer pads the DOT-result read hazard of gfx950 and
-// the kernel silently returns wrong similarities (measured; see DESIGN.md "dead ends").
+// Horizontal half of a bilinear tap: v_dot2_f32_f16 multiplies the fp16 pair {texel c, texel c + 1} of a channel with the fp16 weight
+// pair {256 - A, A} (exact: k <= 256) and adds in fp32 — products of two fp16 values are exact in fp32, so the row lerp has a single
+// rounding.  The pairs come paired from LDS (stage_window_paired / stage_window_halfpaired).
+// The four horizontal lerps of a sample (R / T image x top / bottom texel row, three channels each) are ONE asm block of twelve VOP3P
+// v_dot2_f32_f16 with the inline constant 0 as accumulator.  The builtin only ever selects the VOP2 form v_dot2c_f32_f16, which
+// accumulates into its destination and therefore costs a v_mov_b32 0 per product.  The compiler does not see the DOT inside an asm
+// statement and would not pad its result hazard (3 wait states before another VALU reads a DOT result on gfx94x/95x — what made an
+// earlier asm attempt return wrong similarities): the block ends with s_nop 2, and the twelve products are independent of each other.
 struct Lab3
 {
     float L, a, b;
 };
-__device__ __forceinline__ v2h pk_half_weights(float w0, float w1) { return __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(w0, w1)); }
-__device__ __forceinline__ float dot2_h(unsigned pair, v2h w) { return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, pair), w, 0.0f, false); }
-__device__ __forceinline__ Lab3 hlerp3(uint2 t0, uint2 t1, v2h w)
-{
-    Lab3 r;
-    r.L = dot2_h(__builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_LO), w);
-    r.a = dot2_h(__builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_HI), w);
-    r.b = dot2_h(__builtin_amdgcn_perm(t1.y, t0.y, AVDM_PERM_LO), w);
-    return r;
-}
-
-#ifndef AVDM_DOT2_ASM
-#define AVDM_DOT2_ASM 1
-#endif
-// The four horizontal lerps of a sample (R / T image x top / bottom texel row, three channels each) as ONE block of twelve
-// VOP3P v_dot2_f32_f16 with the inline constant 0 as accumulator.  The builtin only ever selects the VOP2 form v_dot2c_f32_f16,
-// which accumulates into its destination and therefore costs a v_mov_b32 0 per product (12 of the ~104 VALU instructions of a
-// sample).  The compiler does not see the DOT inside an asm statement and would not pad its result hazard (3 wait states before
-// another VALU reads a DOT result on gfx94x/95x — what made an earlier asm attempt return wrong similarities): the block ends
-// with s_nop 2, and the twelve products are independent of each other.
 struct Lab3x4
 {
     Lab3 rt, tt, rb, tb;
 };
-__device__ __forceinline__ Lab3x4 hlerp3x4(uint2 r00, uint2 r10, uint2 r01, uint2 r11, uint2 t00, uint2 t10, uint2 t01, uint2 t11, v2h wr, v2h wt)
-{
-    Lab3x4 o;
-#if AVDM_DOT2_ASM
-    const unsigned uwr = __builtin_bit_cast(unsigned, wr), uwt = __builtin_bit_cast(unsigned, wt);
-    const unsigned p0 = __builtin_amdgcn_perm(r10.x, r00.x, AVDM_PERM_LO), p1 = __builtin_amdgcn_perm(r10.x, r00.x, AVDM_PERM_HI),
-                   p2 = __builtin_amdgcn_perm(r10.y, r00.y, AVDM_PERM_LO);
-    const unsigned p3 = __builtin_amdgcn_perm(t10.x, t00.x, AVDM_PERM_LO), p4 = __builtin_amdgcn_perm(t10.x, t00.x, AVDM_PERM_HI),
-                   p5 = __builtin_amdgcn_perm(t10.y, t00.y, AVDM_PERM_LO);
-    const unsigned p6 = __builtin_amdgcn_perm(r11.x, r01.x, AVDM_PERM_LO), p7 = __builtin_amdgcn_perm(r11.x, r01.x, AVDM_PERM_HI),
-                   p8 = __builtin_amdgcn_perm(r11.y, r01.y, AVDM_PERM_LO);
-    const unsigned p9 = __builtin_amdgcn_perm(t11.x, t01.x, AVDM_PERM_LO), p10 = __builtin_amdgcn_perm(t11.x, t01.x, AVDM_PERM_HI),
-                   p11 = __builtin_amdgcn_perm(t11.y, t01.y, AVDM_PERM_LO);
-    asm("v_dot2_f32_f16 %0, %12, %24, 0\n\t"
-        "v_dot2_f32_f16 %1, %13, %24, 0\n\t"
-        "v_dot2_f32_f16 %2, %14, %24, 0\n\t"
-        "v_dot2_f32_f16 %3, %15, %25, 0\n\t"
-        "v_dot2_f32_f16 %4, %16, %25, 0\n\t"
-        "v_dot2_f32_f16 %5, %17, %25, 0\n\t"
-        "v_dot2_f32_f16 %6, %18, %24, 0\n\t"
-        "v_dot2_f32_f16 %7, %19, %24, 0\n\t"
-        "v_dot2_f32_f16 %8, %20, %24, 0\n\t"
-        "v_dot2_f32_f16 %9, %21, %25, 0\n\t"
-        "v_dot2_f32_f16 %10, %22, %25, 0\n\t"
-        "v_dot2_f32_f16 %11, %23, %25, 0\n\t"
-        "s_nop 2"
-        : "=&v"(o.rt.L), "=&v"(o.rt.a), "=&v"(o.rt.b), "=&v"(o.tt.L), "=&v"(o.tt.a), "=&v"(o.tt.b), "=&v"(o.rb.L), "=&v"(o.rb.a), "=&v"(o.rb.b),
-          "=&v"(o.tb.L), "=&v"(o.tb.a), "=&v"(o.tb.b)
-        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7), "v"(p8), "v"(p9), "v"(p10), "v"(p11), "v"(uwr), "v"(uwt));
-#else
-    o.rt = hlerp3(r00, r10, wr);
-    o.tt = hlerp3(t00, t10, wt);
-    o.rb = hlerp3(r01, r11, wr);
-    o.tb = hlerp3(t01, t11, wt);
-#endif
-    return o;
-}
+__device__ __forceinline__ v2h pk_half_weights(float w0, float w1) { return __builtin_bit_cast(v2h, __builtin_amdgcn_cvt_pkrtz(w0, w1)); }
 
 // the twelve products of a sample from paired records (see stage_window_paired): no v_perm_b32 per tap
 __device__ __forceinline__ Lab3x4 hlerp3x4_paired(uint4 r0, uint4 r1, uint4 t0, uint4 t1, v2h wr, v2h wt)
