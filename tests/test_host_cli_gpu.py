@@ -239,3 +239,26 @@ def test_non_default_refine_switches(dataset):
             both = (base > 0) & (depth > 0)
             assert both.mean() > 0.5 and not np.array_equal(base, depth)
             assert np.median(np.abs(base - depth)[both] / base[both]) < 3e-2, name
+
+
+def test_default_process_downscale(tmp_path):
+    """the program's default --downscale 2 (main_depthMapEstimation.cpp:75): images are halved on load (mvsUtils/fileIO.cpp:389-443), the
+    maps come out at half the image size with AliceVision:downscale = 2 and still find the surface"""
+    w, h = 1280, 960
+    sc = make_scene(4, w, h, seed=5, baseline=0.9, amp=0.6)
+    d = str(tmp_path)
+    sfm, img = scene_io.write_scene(sc, d, n_landmarks=10, compression=0)
+    with open(sfm, "w") as f:
+        json.dump(scene_io.sfm_dict(sc, scene_io.sample_landmarks(sc, 500, amp=0.6), img), f)
+    out = os.path.join(d, "out")
+    run_cli(["-i", sfm, "--imagesFolder", img, "-o", out, "--rangeStart", 0, "--rangeSize", 1, "--sgmMaxDepths", 96, "--colorOptimizationNbIterations",
+             OPT_ITERS, "-v", "warning"])
+    depth, sim, dinfo, _ = read_maps(out)
+    assert depth.shape == (h // 2, w // 2)
+    assert exr_io.attr_value(dinfo, "AliceVision:downscale") == 2
+    gt = sc.gt_depth.numpy()[::2, ::2]
+    m = depth > 0
+    m[:16] = m[-16:] = False
+    m[:, :16] = m[:, -16:] = False
+    assert m.mean() > 0.6
+    assert np.median(np.abs(depth - gt)[m] / gt[m]) < 3e-3
