@@ -537,3 +537,47 @@ def test_custom_patch_pattern_parity(group, consistent):
     # without a pattern the entry points refuse (here: the library keeps the last one, so only the flag-less call is checked)
     sgm0 = abi.SgmParams.default()
     assert sgm0.useCustomPatchPattern == 0
+
+
+@pytest.mark.parametrize("mode", [abi.FILTER_CUDA_FIXED8, abi.FILTER_EXACT])
+def test_odd_sizes_and_offset_roi_parity(mode):
+    """image sizes that are no multiple of anything, a tile ROI in the middle of the image that touches two image borders, ragged
+    plane ranges: the LDS windows (paired / half-paired records) are clipped at image borders and the last staged column pairs with
+    itself — the volumes must stay in the tolerance classes of the default case"""
+    torch = _torch()
+    from oracle import oracle
+    from alicevision_amd.synthetic import make_scene, plane_depths
+    sc = make_scene(3, 251, 189, seed=11)
+    sgm, ref = abi.SgmParams.default(), abi.RefineParams.default()
+    depths = plane_depths(sc, 27)
+    Z = len(depths)
+    roi = (100, 251, 0, 132)  # x to the right image border, y from the top border; multiples of scale * step at the open ends
+    rng_t = [(0, 27), (5, 22)]
+    o = make_oracle(sc, sgm, ref, filter_mode=mode, roi=roi)
+    with oracle.well_posed():
+        o.run_sgm(0, [1, 2], depths, tc_ranges=rng_t, optimize=False)
+        best64, second64 = o.best_raw[..., :Z].copy(), o.second[..., :Z].copy()
+        o.run_sgm(0, [1, 2], depths, tc_ranges=rng_t)
+        o.run_refine(0, [1, 2], optimize_enabled=False)
+    h = make_hip_from_oracle(o, sc, sgm, ref, roi=roi)
+    h.run_sgm(0, [1, 2], depths, tc_ranges=rng_t, optimize=False, keep_raw=True)
+    torch.cuda.synchronize()
+    for got, want in ((h.best_raw.cpu().numpy()[..., :Z], best64), (h.second.cpu().numpy()[..., :Z], second64)):
+        assert got.shape == want.shape
+        frac, mx = level_mismatch(want, got)
+        d = np.abs(want.astype(np.int16) - got.astype(np.int16))
+        assert (want != 255).mean() > 0.2
+        assert frac <= (0.035 if mode == abi.FILTER_CUDA_FIXED8 else 0.015), (frac, mx)
+        assert (d > 1).mean() <= 3e-3, (d > 1).mean()
+        assert ((want == 255) != (got == 255)).mean() <= 3e-3
+    h._alloc(Z)
+    h.sgm_depth_thickness.copy_(torch.from_numpy(o.sgm_depth_thickness))
+    h.run_refine(0, [1, 2], optimize_enabled=False)
+    torch.cuda.synchronize()
+    Zr = ref.halfNbDepths * 2 + 1
+    a = o.refine_volume[..., :Zr].astype(np.float32)
+    b = h.refine_volume.cpu().numpy()[..., :Zr].astype(np.float32)
+    assert a.shape == b.shape and a.max() > 0.5
+    diff = np.abs(a - b)
+    assert (diff > 2e-3).mean() <= 3e-3, (diff > 2e-3).mean()
+    assert (diff > 0.02).mean() <= 2e-4, ((diff > 0.02).mean(), diff.max())
