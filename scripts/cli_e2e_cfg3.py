@@ -34,6 +34,7 @@ print("scene written in %.1f s" % (time.time() - t0), flush=True)
 out = os.path.join(d, "out")
 args = [CLI, "-i", os.path.join(d, "scene.sfm"), "--imagesFolder", os.path.join(d, "images"), "-o", out, "--downscale", "1", "--rangeStart", "0", "--rangeSize", str(ncam),
         "--sgmMaxDepths", "256", "--maxTCams", "10", "--sgmMaxTCamsPerTile", "10", "--refineMaxTCamsPerTile", "10", "-v", "info"]
+args += os.environ.get("AVDM_E2E_ARGS", "").split()  # e.g. "--tileBufferWidth 4000 --tileBufferHeight 3000": one tile per camera
 t0 = time.time()
 r = subprocess.run(args, capture_output=True, text=True)
 wall = time.time() - t0
