@@ -344,6 +344,7 @@ std::string getFileNameFromViewId(const MultiViewParams& mp, IndexT viewId, EFil
         case EFileType::simMapFiltered: folder = mp.getDepthMapsFilterFolder(), suffix = "_simMap"; break;
         case EFileType::normalMapFiltered: folder = mp.getDepthMapsFilterFolder(), suffix = "_normalMap"; break;
         case EFileType::nmodMap: folder = mp.getDepthMapsFilterFolder(), suffix = "_nmodMap", ext = "png"; break;
+        case EFileType::stats9p: folder = mp.getDepthMapsFolder(), suffix = "_9p", ext = "csv"; break;
         case EFileType::none: break;
     }
     return folder + std::to_string(viewId) + suffix + customSuffix + tileSuffix + "." + ext;

@@ -29,6 +29,7 @@ enum class EFileType
     simMapFiltered,
     normalMapFiltered,
     nmodMap,
+    stats9p,
     P,
     D
 };

@@ -137,6 +137,13 @@ void Refine::refineAndFuseDepthSimMap(const Tile& tile)
     avdmCheck(avdm_volume_refine_best_depth(_refinedDepthSimMap.as<float>(), _mapPitch, _sgmDepthPixSizeMap.as<float>(), _mapPitch, _volumeRefineSim.ptr(),
                                             pitchY, _volPitchX, _volZ, &rp, roi, _stream),
               "avdm_volume_refine_best_depth");
+    if(_refineParams.exportIntermediateVolume9pCsv)
+    { // Refine.cpp:235, :340-349
+        const int tileBeginX = tile.nbTiles > 1 ? (int)tile.roi.x.begin : -1, tileBeginY = tile.nbTiles > 1 ? (int)tile.roi.y.begin : -1;
+        AVDM_LOG_INFO(tile << "Export similarity volume 9 points CSV (afterRefine).");
+        exportSimilaritySamplesCSV(_volumeRefineSim.ptr(), true, pitchY, _volPitchX, _volZ, X, Y, "afterRefine",
+                                   getFileNameFromIndex(_mp, tile.rc, EFileType::stats9p, "_refine", tileBeginX, tileBeginY), _stream);
+    }
     AVDM_LOG_INFO(tile << "Refine and fuse depth/sim map volume done.");
 }
 

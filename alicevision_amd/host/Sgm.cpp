@@ -139,6 +139,19 @@ void Sgm::computeVolumes(const Tile& tile, const SgmDepthList& tileDepthList)
                   "avdm_volume_update_uninitialized");
     }
     AVDM_LOG_INFO(tile << "SGM Compute similarity volume done.");
+    exportVolumeInformation(tile, tileDepthList, _volumeSecBestSim, "beforeFiltering"); // Sgm.cpp:139
+}
+
+void Sgm::exportVolumeInformation(const Tile& tile, const SgmDepthList& tileDepthList, const DeviceBuffer& volume, const std::string& name) const
+{
+    if(!_sgmParams.exportIntermediateVolume9pCsv)
+        return;
+    const int tileBeginX = tile.nbTiles > 1 ? (int)tile.roi.x.begin : -1, tileBeginY = tile.nbTiles > 1 ? (int)tile.roi.y.begin : -1;
+    AVDM_LOG_INFO(tile << "Export similarity volume 9 points CSV (" << name << ").");
+    const std::string stats9Path = getFileNameFromIndex(_mp, tile.rc, EFileType::stats9p, "_sgm", tileBeginX, tileBeginY);
+    const ROI r = downscaleROI(tile.roi, float(_sgmParams.scale * _sgmParams.stepXY));
+    exportSimilaritySamplesCSV(volume.ptr(), false, _pitchY, _pitchX, (int)tileDepthList.getDepths().size(), (int)r.width(), (int)r.height(), name, stats9Path,
+                               _stream);
 }
 
 avdm_sgm_tile_t Sgm::sgmTileDescriptor(const Tile& tile, const SgmDepthList& tileDepthList) const
@@ -168,6 +181,7 @@ void Sgm::optimizeDisabledCopy()
 
 void Sgm::finish(const Tile& tile, const SgmDepthList& tileDepthList)
 {
+    exportVolumeInformation(tile, tileDepthList, _volumeBestSim, "afterFiltering"); // Sgm.cpp:155
     AVDM_LOG_INFO(tile << "SGM Retrieve best depth in volume.");
     const ROI downscaledRoi = downscaleROI(tile.roi, float(_sgmParams.scale * _sgmParams.stepXY));
     const avdm_roi_t roi = {{downscaledRoi.x.begin, downscaledRoi.x.end}, {downscaledRoi.y.begin, downscaledRoi.y.end}};

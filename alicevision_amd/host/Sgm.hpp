@@ -40,6 +40,8 @@ class Sgm
     void computeVolumes(const Tile& tile, const SgmDepthList& tileDepthList);   // depth upload + Sgm.cpp:203-279
     avdm_sgm_tile_t sgmTileDescriptor(const Tile& tile, const SgmDepthList& tileDepthList) const; // arguments of Sgm.cpp:281-304 for a batched launch
     size_t optimizeScratchBytes(const Tile& tile, const SgmDepthList& tileDepthList) const;
+    // Sgm.cpp:327-396 (the 9-point CSV part; the Alembic exports are not built)
+    void exportVolumeInformation(const Tile& tile, const SgmDepthList& tileDepthList, const DeviceBuffer& volume, const std::string& name) const;
     void optimizeDisabledCopy();                                                // Sgm.cpp:147-151
     void finish(const Tile& tile, const SgmDepthList& tileDepthList);           // Sgm.cpp:306-329 + exports + normals
     // Sgm.cpp:190-201

@@ -9,6 +9,8 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <fstream>
+#include <sstream>
 #include <cstdio>
 #include <fstream>
 #include <limits>
@@ -341,6 +343,36 @@ void writeNormalMap(int rc, const MultiViewParams& mp, const TileParams& tilePar
     AVDM_HIP_CHECK(hipMemcpy2DAsync(rgb.data(), (size_t)w * 12, map_d, (size_t)pitch, (size_t)w * 12, (size_t)h, hipMemcpyDeviceToHost, stream));
     AVDM_HIP_CHECK(hipStreamSynchronize(stream));
     writeMap3(rc, mp, EFileType::normalMap, tileParams, roi, rgb, w, h, scale, step, name.empty() ? "" : "_" + name);
+}
+
+void exportSimilaritySamplesCSV(const void* volume_d, bool halfFloat, long long pitchY, int pitchX, int nbPlanes, int width, int height, const std::string& name,
+                                const std::string& filepath, hipStream_t stream)
+{
+    const int sampleSize = 3;
+    const int xOffset = (int)std::floor(width / (sampleSize + 1.0f));
+    const int yOffset = (int)std::floor(height / (sampleSize + 1.0f));
+    const size_t elem = halfFloat ? 2 : 1;
+    std::vector<unsigned char> column((size_t)nbPlanes * elem);
+    std::stringstream ss;
+    ss << name << "\n";
+    for(int iy = 0; iy < sampleSize; ++iy)
+        for(int ix = 0; ix < sampleSize; ++ix)
+        {
+            const int x = (ix + 1) * xOffset, y = (iy + 1) * yOffset;
+            AVDM_HIP_CHECK(hipMemcpyAsync(column.data(), (const char*)volume_d + (long long)y * pitchY + (long long)x * pitchX, column.size(), hipMemcpyDeviceToHost,
+                                          stream));
+            AVDM_HIP_CHECK(hipStreamSynchronize(stream));
+            ss << "p" << (iy * sampleSize + ix + 1) << " (x: " << x << ", y: " << y << ");";
+            for(int iz = 0; iz < nbPlanes; ++iz)
+            {
+                const float simValue = halfFloat ? halfToFloat(reinterpret_cast<const uint16_t*>(column.data())[iz]) : (float)column[iz];
+                ss << simValue << ";";
+            }
+            ss << "\n";
+        }
+    std::ofstream file(filepath, std::ios_base::app);
+    if(file.is_open())
+        file << ss.str();
 }
 
 void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileParams& tileParams, const std::vector<ROI>& tileRoiList,

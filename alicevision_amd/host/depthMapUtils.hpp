@@ -66,6 +66,11 @@ void writeDepthPixSizeMap(int rc, const MultiViewParams& mp, const TileParams& t
 void writeNormalMap(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, const float* map_d, int pitch, int scale, int step,
                     const std::string& name, hipStream_t stream);
 
+// volumeIO.cpp:28-146 (exportSimilaritySamplesCSV): the similarity over the planes at a 3 x 3 grid of pixels of the tile, appended to `filepath`.
+// The volume is z-fastest here: a sample is one contiguous run of nbPlanes elements (uint8 for the SGM volumes, fp16 for the Refine volume).
+void exportSimilaritySamplesCSV(const void* volume_d, bool halfFloat, long long pitchY, int pitchX, int nbPlanes, int width, int height, const std::string& name,
+                                const std::string& filepath, hipStream_t stream);
+
 // depthMapUtils.cpp:240-277
 void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileParams& tileParams, const std::vector<ROI>& tileRoiList,
                                   const std::vector<Float2Tile>& in_depthSimMapTiles, int scale, int step, const std::string& name = "");

@@ -123,7 +123,18 @@ def test_tiled_run_merges(dataset):
     args4 = common_args(sfm, img, out4) + ["--autoAdjustSmallImage", 0, "--tileBufferWidth", 416, "--tileBufferHeight", 352, "--tilePadding", 32]
     plan = json.loads(run_cli(args4 + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
     assert len(plan["tiles"]) == 4, [t["roi"] for t in plan["tiles"]]
-    run_cli(args4 + ["--exportIntermediateDepthSimMaps", 1, "--exportIntermediateNormalMaps", 1])
+    run_cli(args4 + ["--exportIntermediateDepthSimMaps", 1, "--exportIntermediateNormalMaps", 1, "--exportIntermediateVolume9pCsv", 1])
+    # 9-point CSV dumps of the volumes (volumeIO.cpp:28-146), one file per tile and stage: name line + p1..p9 with one value per plane
+    csvs = sorted(f for f in os.listdir(out4) if f.endswith(".csv"))
+    assert len([f for f in csvs if "_9p_sgm_" in f]) == 4 and len([f for f in csvs if "_9p_refine_" in f]) == 4, csvs
+    for f in csvs:
+        lines = open(os.path.join(out4, f)).read().strip().split("\n")
+        blocks = [ln for ln in lines if not ln.startswith("p")]
+        assert blocks == (["beforeFiltering", "afterFiltering"] if "_sgm_" in f else ["afterRefine"]), (f, blocks)
+        pts = [ln for ln in lines if ln.startswith("p")]
+        assert len(pts) == 9 * len(blocks)
+        vals = [float(v) for v in pts[0].split(";")[1:] if v]
+        assert len(vals) >= 12 and (all(0 <= v <= 255 for v in vals) if "_sgm_" in f else len(vals) == 31)
     # normal maps (SGM resolution, refined, final): merged from the tiles, unit vectors facing the camera where a depth exists
     vid = scene_io.view_id(0)
     for name, shape in (("normalMap_sgm", (H // 4, W // 4)), ("normalMap_refinedFused", (H, W)), ("normalMap", (H, W))):
@@ -140,7 +151,7 @@ def test_tiled_run_merges(dataset):
     assert d4.shape == d1.shape == (H, W)
     # the merged file is a whole image again and the tile files of the intermediate maps were merged and removed
     assert info4["data_window"] == (0, 0, W - 1, H - 1)
-    leftovers = [f for f in os.listdir(out4) if f.count("_") >= 3 and f.endswith(".exr") and f.split("_")[-1][0].isdigit()]
+    leftovers = [f for f in os.listdir(out4) if f.count("_") >= 3 and f.endswith(".exr") and f.split("_")[-1][0].isdigit()]  # (the CSVs stay per tile)
     assert not leftovers, leftovers
     assert os.path.exists(os.path.join(out4, "%d_depthMap_sgm.exr" % scene_io.view_id(0)))
     assert os.path.exists(os.path.join(out4, "%d_depthMap_refinedFused.exr" % scene_io.view_id(0)))
