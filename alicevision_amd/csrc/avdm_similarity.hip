@@ -25,6 +25,7 @@
 #include <cmath>
 #include <iterator>
 #include <map>
+#include <mutex>
 #include <stdlib.h>
 
 // taps in flight per lane: each unrolled sample keeps 8 LDS reads (16 VGPRs) live; 3 keeps the kernels at 3 waves / SIMD
@@ -1214,6 +1215,7 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------------------------
 static avdm_patch_pattern_t g_patchPattern = {}; // the reference's constantPatchPattern_d (DevicePatchPattern.hpp:51)
 static bool g_patchPatternSet = false;
+static std::mutex g_patchPatternMutex;           // one host thread per device may build / read it (computeOnMultiGPUs)
 static unsigned* g_stats = nullptr; // device counters, allocated on first use when AVDM_SIM_STATS=1
 
 // paired: in = the caller would like the 16-byte paired records (FIXED8 pyramids only); out = whether the LDS budget allows them
@@ -1394,8 +1396,11 @@ int avdm_build_custom_patch_pattern(int n_subparts, const avdm_patch_subpart_par
             part.isCircle = sp.isCircle ? 1 : 0;
         }
     }
-    g_patchPattern = pp;
-    g_patchPatternSet = true;
+    {
+        std::lock_guard<std::mutex> lock(g_patchPatternMutex);
+        g_patchPattern = pp;
+        g_patchPatternSet = true;
+    }
     if(out != nullptr)
         *out = pp;
     return 0;
@@ -1445,7 +1450,10 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
         S.mipmapLevel = A.mipmapLevel;
         S.useConsistentScale = sp->useConsistentScale;
         S.useCustomPatchPattern = sp->useCustomPatchPattern;
-        S.pattern = g_patchPattern;
+        {
+            std::lock_guard<std::mutex> lock(g_patchPatternMutex);
+            S.pattern = g_patchPattern;
+        }
         hipLaunchKernelGGL((similarity_cs_kernel<false>), dim3(divUp(roi.x.end - roi.x.begin, 64), divUp(roi.y.end - roi.y.begin, 4), nchunks), dim3(256), 0,
                            (hipStream_t)stream, best, second, (__half*)nullptr, 0, (const float2*)nullptr, 0, (const float*)nullptr, 0, pitch_y, pitch_x,
                            depths, *rc, *tc, A, tab, S, sp->stepXY, dr.begin, dr.end, roi);
@@ -1508,7 +1516,10 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
         S.mipmapLevel = A.mipmapLevel;
         S.useConsistentScale = rp->useConsistentScale;
         S.useCustomPatchPattern = rp->useCustomPatchPattern;
-        S.pattern = g_patchPattern;
+        {
+            std::lock_guard<std::mutex> lock(g_patchPatternMutex);
+            S.pattern = g_patchPattern;
+        }
         hipLaunchKernelGGL((similarity_cs_kernel<true>), dim3(divUp(roi.x.end - roi.x.begin, 64), divUp(roi.y.end - roi.y.begin, 4), nchunks), dim3(256), 0,
                            (hipStream_t)stream, (uint8_t*)nullptr, (uint8_t*)nullptr, (__half*)vol_f16, dimZ, (const float2*)sgm_depth_pixsize, map_pitch,
                            sgm_normal, normal_pitch, pitch_y, pitch_x, (const float*)nullptr, *rc, *tc, A, tab, S, rp->stepXY, dr.begin, dr.end, roi);
