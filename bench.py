@@ -186,6 +186,12 @@ def main():
                        "sgm": "scale 2 stepXY 2 wsh 4, 4 paths", "refine": "scale 1 stepXY 1 wsh 3, 31 planes, 100 opt iters",
                        "sharding": f"round-robin reference cameras over {world} rank(s)", "pyramid_exchange_s": t_ex},
             "roofline": roof,
+            # the similarity kernels are VALU-issue bound, HBM fraction is not their figure: voxel x T camera rates instead
+            # (a voxel-T is (2 wsh + 1)^2 patch samples: 81 for the SGM volume, 49 for the Refine volume)
+            "similarity": {"sgm_voxelT_per_s": X * Y * Z * T / (stages["sgm_similarity"] * 1e-3),
+                           "refine_voxelT_per_s": W * H * (2 * ref.halfNbDepths + 1) * T / (stages["refine_similarity"] * 1e-3),
+                           "sgm_samples_per_s": X * Y * Z * T * (2 * sgm.wsh + 1) ** 2 / (stages["sgm_similarity"] * 1e-3),
+                           "refine_samples_per_s": W * H * (2 * ref.halfNbDepths + 1) * T * (2 * ref.wsh + 1) ** 2 / (stages["refine_similarity"] * 1e-3)},
             "stages_ms": stages, "valid_fraction": valid,
         }
         if os.environ.get("AVDM_SIM_STATS") == "1":
