@@ -138,3 +138,30 @@ def test_estimation_then_filtering(tmp_path):
         inner = np.zeros_like(valid_b)
         inner[60:-60, 60:-60] = True
         assert (valid_a & inner).sum() > 0.6 * (valid_b & inner).sum(), (i, (valid_a & inner).sum(), (valid_b & inner).sum())
+
+
+def test_filtering_with_a_missing_neighbour_depth_map(oracle_lib, tmp_path):
+    """a neighbour camera without depth map files: readMap gives an all-zero map (mapIO.cpp:343-357), the camera contributes no point
+    but still takes its place in the ranking (and in the carried-over counters)"""
+    from oracle import fuse_oracle as fo
+    from png_util import read_png_gray8
+    n, w, h, nn = 4, 200, 150, 3
+    fs = make_fuse_scene(n, w, h, seed=17, noise=2e-4, outliers=0.05)
+    d = str(tmp_path)
+    sfm = os.path.join(d, "scene.sfm")
+    with open(sfm, "w") as f:
+        json.dump(scene_io.sfm_dict(fs, scene_io.sample_landmarks(fs, 400), os.path.join(d, "images")), f)
+    dm, flt = os.path.join(d, "depthMaps"), os.path.join(d, "filtered")
+    write_depth_maps(dm, fs, fs.depth, fs.sim)
+    info = json.loads(run([TOOL, "fuse-cameras", sfm, dm, flt, nn]).stdout)["cams"]  # cameras while every map is still there
+    missing = info[0]["tcams"][1]
+    for suffix in ("_depthMap.exr", "_simMap.exr"):
+        os.remove(os.path.join(dm, "%d%s" % (scene_io.view_id(missing), suffix)))
+    run([FILTER_CLI, "-i", sfm, "--depthMapsFolder", dm, "-o", flt, "--nNearestCams", nn, "--rangeStart", 0, "--rangeSize", 1, "-v", "error"])
+    cams = [fo.fuse_cam(np.array(c["P"]), np.array(c["iP"]), np.array(c["C"]), c["width"], c["height"]) for c in info]
+    tc = info[0]["tcams"]
+    sim0 = fs.sim[0].astype(np.float16).astype(np.float32)
+    depths = [np.zeros_like(fs.depth[t]) if t == missing else fs.depth[t] for t in tc]
+    want = fo.filter_groups_rc(fs.depth[0], sim0, cams[0], [cams[t] for t in tc], depths)
+    got = read_png_gray8(os.path.join(flt, "%d_nmodMap.png" % scene_io.view_id(0)))
+    assert want.max() == nn and np.array_equal(got, want)
