@@ -104,3 +104,44 @@ def test_missing_library_fails_loudly(tmp_path):
     import pytest
     with pytest.raises(abi.AvdmError):
         abi.load(str(tmp_path / "nope.so"))
+
+
+def test_custom_patch_pattern_builder_matches_oracle(oracle_lib):
+    """avdm_build_custom_patch_pattern is host code (patchPattern.cpp:18-251): same structure as the oracle's restatement for grouped and
+    ungrouped subparts, and the reference's refusals (no subpart, bad radius / count, two full subparts in a group, too many subparts
+    or coordinates) are reported as errors"""
+    lib = abi.load()
+    specs = [
+        ([("circle", 4, 16, 0, 0.5), ("full", 3, 0, 1, 0.3), ("circle", 7.5, 24, 2, 0.2)], False),
+        ([("full", 2, 0, 1, 0.4), ("circle", 3.5, 12, 0, 0.35), ("circle", 6, 10, 1, 0.25)], True),
+        ([("circle", 2, 8, 0, 0.5), ("circle", 4, 8, 0, 0.25), ("circle", 6, 8, 0, 0.25)], True),   # three circles grouped into one subpart
+        ([("full", 4, 0, 0, 1.0)], False),
+    ]
+    for spec, group in specs:
+        got, want = abi.PatchPattern(), abi.PatchPattern()
+        arr = abi.patch_subparts(spec)
+        assert lib.avdm_build_custom_patch_pattern(len(spec), arr, int(group), C.byref(got)) == 0, lib.avdm_last_error()
+        assert oracle_lib.avo_build_custom_patch_pattern(len(spec), arr, int(group), C.byref(want)) == 0
+        assert got.nbSubparts == want.nbSubparts
+        for a, b in zip(got.subparts[:got.nbSubparts], want.subparts[:want.nbSubparts]):
+            assert (a.nbCoordinates, a.level, a.downscale, a.weight, a.isCircle, a.wsh) == (b.nbCoordinates, b.level, b.downscale, b.weight, b.isCircle,
+                                                                                           b.wsh)
+            ca = np.array([[c[0], c[1]] for c in a.coordinates[:a.nbCoordinates]]).reshape(-1, 2)
+            cb = np.array([[c[0], c[1]] for c in b.coordinates[:b.nbCoordinates]]).reshape(-1, 2)
+            assert np.allclose(ca, cb, rtol=0, atol=2e-6)
+            if a.isCircle:
+                assert np.allclose(np.hypot(ca[:, 0], ca[:, 1]).reshape(-1, 1), np.hypot(cb[:, 0], cb[:, 1]).reshape(-1, 1), atol=1e-5)
+    bad = [
+        ([], False),
+        ([("circle", 0.0, 8, 0, 1.0)], False),
+        ([("circle", 3.0, 0, 0, 1.0)], False),
+        ([("full", 2, 0, 1, 0.5), ("full", 3, 0, 1, 0.5)], True),
+        ([("full", 1, 0, l, 0.2) for l in range(5)], False),
+        ([("circle", 3, 25, 0, 1.0)], False),
+        ([("circle", 3, 16, 0, 0.5), ("circle", 5, 16, 0, 0.5)], True),   # 32 coordinates in one group
+    ]
+    for spec, group in bad:
+        arr = abi.patch_subparts(spec) if spec else None
+        assert lib.avdm_build_custom_patch_pattern(len(spec), arr, int(group), None) != 0, spec
+        assert b"custom patch pattern" in lib.avdm_last_error()
+        assert oracle_lib.avo_build_custom_patch_pattern(len(spec), arr, int(group), None) != 0, spec
