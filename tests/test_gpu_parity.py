@@ -198,6 +198,92 @@ def test_sgm_aggregation_tiles_batch():
         assert torch.equal(a, b)
 
 
+@pytest.fixture(scope="module")
+def big_pyramid():
+    """one 1760x1320 R image (SGM stage 440x330 at scale 2 x stepXY 2): real colour steps for the adaptive P2 at the sizes below"""
+    sc, sgm, ref, _ = small_case(width=1760, height=1320, n_views=1, seed=5)
+    o = make_oracle(sc, sgm, ref)
+    return sc, o
+
+
+def _structured_volume(rng, Y, X, Zp):
+    """uint8 cost volume with a smooth minimum valley + noise + invalid (255) voxels: exercises every branch of the recurrence
+    (a uniformly random volume saturates at 255 after a few steps and hides errors of the steady state)"""
+    yy, xx, zz = np.meshgrid(np.arange(Y), np.arange(X), np.arange(Zp), indexing="ij")
+    valley = Zp * (0.5 + 0.3 * np.sin(xx / 37.0) * np.cos(yy / 23.0))
+    v = np.minimum(np.abs(zz - valley) * 3.0 + rng.randint(0, 40, size=(Y, X, Zp)), 254).astype(np.uint8)
+    v[rng.rand(Y, X, Zp) < 0.02] = 255
+    v[rng.rand(Y, X) < 0.03] = 255  # whole invalid pixels
+    return v
+
+
+@pytest.mark.parametrize("X,Y,Z,axes,x0,y0,quirk,p2w", [(300, 401, 256, b"YX", 0, 0, 0, 100.0), (401, 300, 256, b"XY", 0, 0, 0, 12.0),
+                                                      (401, 300, 300, b"YX", 0, 0, 0, 12.0), (300, 401, 300, b"XY", 0, 0, 0, 100.0),
+                                                      (401, 300, 256, b"YX", 21, 9, 0, 30.0), (300, 311, 256, b"YX", 33, 5, 1, 12.0),
+                                                      (401, 300, 300, b"YX", 7, 19, 1, 100.0)])
+def test_sgm_aggregation_at_scale_bit_exact(big_pyramid, X, Y, Z, axes, x0, y0, quirk, p2w):
+    """the register ring's steady state (whole spans of 4 slots x 8 slices, B >= 300) and the later 64-step chunks of the P2 map, both
+    axis orders, ROI offsets (also with the reference's begin-x / begin-y swap, kernels.cuh:688-709), adaptive P2 from a real pyramid:
+    HIP == avo_volume_optimize byte for byte.  Follows deviceSimilarityVolume.cu:262-425."""
+    torch = _torch()
+    from oracle import oracle
+    from alicevision_amd.pipeline import DevicePyramid, optimize_scratch
+    sc, o = big_pyramid
+    sgm = abi.SgmParams.default(filteringAxes=axes, strictRoiQuirk=quirk, p2Weighting=p2w)
+    lib, olib = abi.load(), oracle.load()
+    rng = np.random.RandomState(X * 7 + Z)
+    Zp = (Z + 3) // 4 * 4
+    roi = abi.ROI.make(x0, x0 + X, y0, y0 + Y)
+    vin = _structured_volume(rng, Y, X, Zp)
+    want = np.full_like(vin, 9)
+    olib.avo_volume_optimize(oracle.ptr(want), oracle.ptr(vin), X * Zp, Zp, X, Y, C.byref(o.pyr[0].desc), C.byref(sgm), Z, roi)
+    pyr = DevicePyramid.from_host_bytes(o.pyr[0].desc, o.pyr[0].buf)
+    tin = torch.from_numpy(vin).cuda()
+    tout = torch.full_like(tin, 9)
+    scratch = optimize_scratch(lib, X, Y, Z)
+    abi.check(lib.avdm_volume_optimize(_ptr(tout), _ptr(tin), X * Zp, Zp, _ptr(scratch), C.byref(pyr.desc), C.byref(sgm), Z, roi, _st()))
+    torch.cuda.synchronize()
+    got = tout.cpu().numpy()
+    assert np.array_equal(got, want), level_mismatch(got, want)
+    # the adaptive P2 really varies here (otherwise this is the fixed-P2 test again)
+    assert len(np.unique(want[2:-2, 2:-2, 1:Z - 1])) > 100
+
+
+def test_sgm_aggregation_tiles_batch_at_scale_bit_exact(big_pyramid):
+    """avdm_volume_optimize_tiles with three large tiles (different sizes / offsets / depth counts) in one launch per axis == the oracle
+    tile by tile"""
+    torch = _torch()
+    from oracle import oracle
+    from alicevision_amd.pipeline import DevicePyramid
+    sc, o = big_pyramid
+    sgm = abi.SgmParams.default()
+    lib, olib = abi.load(), oracle.load()
+    rng = np.random.RandomState(3)
+    pyr = DevicePyramid.from_host_bytes(o.pyr[0].desc, o.pyr[0].buf)
+    specs = [(401, 300, 256, 0, 0), (300, 320, 300, 130, 7), (333, 301, 256, 40, 25)]
+    tiles = (abi.SgmTile * len(specs))()
+    wants, outs, keep, total = [], [], [], 0
+    for i, (X, Y, Z, x0, y0) in enumerate(specs):
+        Zp = (Z + 3) // 4 * 4
+        roi = abi.ROI.make(x0, x0 + X, y0, y0 + Y)
+        vin = _structured_volume(rng, Y, X, Zp)
+        want = np.full_like(vin, 9)
+        olib.avo_volume_optimize(oracle.ptr(want), oracle.ptr(vin), X * Zp, Zp, X, Y, C.byref(o.pyr[0].desc), C.byref(sgm), Z, roi)
+        wants.append(want)
+        tin = torch.from_numpy(vin).cuda()
+        tout = torch.full_like(tin, 9)
+        keep.append(tin)
+        outs.append(tout)
+        tiles[i] = abi.SgmTile(tout.data_ptr(), tin.data_ptr(), X * Zp, Zp, Z, roi, C.pointer(pyr.desc))
+        total += int(lib.avdm_volume_optimize_scratch_bytes(X, Y, Z))
+    scratch = torch.empty(total, dtype=torch.uint8, device="cuda")
+    abi.check(lib.avdm_volume_optimize_tiles(len(specs), tiles, _ptr(scratch), C.byref(sgm), _st()))
+    torch.cuda.synchronize()
+    for want, tout in zip(wants, outs):
+        got = tout.cpu().numpy()
+        assert np.array_equal(got, want), level_mismatch(got, want)
+
+
 def test_retrieve_best_depth_bit_exact(case):
     torch = _torch()
     sc, sgm, ref, depths, o = case
