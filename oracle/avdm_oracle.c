@@ -219,6 +219,9 @@ float avo_exp_p2(float x)
  *   (cudaTextureDesc of deviceMipmappedArray.cu:329-351: normalized coords, linear + mip-linear, clamp)
  * ---------------------------------------------------------------------------------------------- */
 static inline float quant8(float a) { return floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f); }
+/* texel index of a (floored) filter coordinate: coordinates far outside the image (the wrapped unsigned taps of the pyramid kernels,
+ * see avo_pyramid_build_levels) must clamp to the edge they are beyond, not overflow the int conversion */
+static inline int tex_index(float f) { return f < -4.0f ? -4 : (f > 1.0e9f ? 1000000000 : (int)f); }
 
 static inline f4 texel(const avdm_pyramid_t* p, int level, int x, int y)
 {
@@ -241,7 +244,7 @@ static inline f4 tex_level(const avdm_pyramid_t* p, int level, float u, float v)
         a = quant8(a);
         b = quant8(b);
     }
-    const int i = (int)fx, j = (int)fy;
+    const int i = tex_index(fx), j = tex_index(fy);
     const f4 t00 = texel(p, level, i, j), t10 = texel(p, level, i + 1, j), t01 = texel(p, level, i, j + 1), t11 = texel(p, level, i + 1, j + 1);
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     f4 r;
@@ -402,7 +405,7 @@ static inline f4 tex2D_plain(const uint16_t* img, int pitch, int W, int H, int f
         a = quant8(a);
         b = quant8(b);
     }
-    const int i = (int)fx, j = (int)fy;
+    const int i = tex_index(fx), j = tex_index(fy);
     const f4 t00 = texel(&p, 0, i, j), t10 = texel(&p, 0, i + 1, j), t01 = texel(&p, 0, i, j + 1), t11 = texel(&p, 0, i + 1, j + 1);
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     f4 r;
@@ -427,7 +430,10 @@ void avo_downscale_with_gaussian_blur(uint16_t* out, int out_pitch, int out_w, i
             for(int i = -gaussRadius; i <= gaussRadius; i++)
                 for(int j = -gaussRadius; j <= gaussRadius; j++)
                 {
-                    const f4 c = tex2D_plain(in, in_pitch, in_w, in_h, filter_mode, (float)(x * downscale + j) + s, (float)(y * downscale + i) + s);
+                    /* `float(x * downscale + j)` with x UNSIGNED (deviceGaussianFilter.cu:54-55,65): taps left of / above the image wrap
+                     * to ~4.29e9 and clamp to the RIGHT / BOTTOM edge — found by oracle/_ref, restated as the reference computes it */
+                    const f4 c = tex2D_plain(in, in_pitch, in_w, in_h, filter_mode, (float)((unsigned)x * (unsigned)downscale + (unsigned)j) + s,
+                                             (float)((unsigned)y * (unsigned)downscale + (unsigned)i) + s);
                     const float factor = getGauss(downscale - 1, i + gaussRadius) * getGauss(downscale - 1, j + gaussRadius);
                     acc.x = acc.x + c.x * factor;
                     acc.y = acc.y + c.y * factor;
@@ -468,8 +474,11 @@ void avo_pyramid_build_levels(const avdm_pyramid_t* p)
                     for(int j = -2; j <= 2; j++)
                     {
                         const float factor = getGauss(1, i + 2) * getGauss(1, j + 2);
-                        const float u = ((float)(x + j) + 0.5f) * px; /* (x + j + 0.5f): unsigned+int promoted to float */
-                        const float v = ((float)(y + i) + 0.5f) * py;
+                        /* `(x + j + 0.5f)` with x UNSIGNED (deviceMipmappedArray.cu:28-29,52-53): x + j is evaluated in unsigned
+                         * arithmetic, so the taps left of / above the image wrap to ~4.29e9 and the clamp addressing sends them to the
+                         * RIGHT / BOTTOM edge texel — the two first rows and columns of every level carry that quirk (found by oracle/_ref) */
+                        const float u = ((float)((unsigned)x + (unsigned)j) + 0.5f) * px;
+                        const float v = ((float)((unsigned)y + (unsigned)i) + 0.5f) * py;
                         const f4 c = tex_level(&prev, 0, u, v);
                         sum.x = sum.x + c.x * factor;
                         sum.y = sum.y + c.y * factor;
