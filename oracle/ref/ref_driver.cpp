@@ -172,6 +172,8 @@ void avr_image_tex2dlod(void* h, const float* uvl, int n, float* out4)
 void avr_image_read_level(void* h, int level, int w, int h_, float* out4)
 {
     const cudaTextureObject_t t = ((DeviceMipmapImage*)h)->getTextureObject();
+    const bool keep = shim::g_fixed8;
+    shim::g_fixed8 = true; // fixed-point weights are exactly 0 at a texel centre; fp32 weights are only nearly so ((x + 0.5) / w * w)
     for(int y = 0; y < h_; ++y)
         for(int x = 0; x < w; ++x)
         {
@@ -179,6 +181,7 @@ void avr_image_read_level(void* h, int level, int w, int h_, float* out4)
             float* o = out4 + 4 * ((size_t)y * w + x);
             o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
         }
+    shim::g_fixed8 = keep;
 }
 float avr_image_level(void* h, int downscale) { return ((DeviceMipmapImage*)h)->getLevel(downscale); }
 void avr_image_dimensions(void* h, int downscale, int* w, int* h_)

@@ -231,7 +231,8 @@ def test_retrieve_best_depth_on_a_known_volume(oracle_lib):
 
 @pytest.mark.parametrize("name,mode", [("relief_192x144_fixed8", abi.FILTER_CUDA_FIXED8), ("relief_192x144_exact", abi.FILTER_EXACT)])
 def test_golden_fixture(oracle_lib, name, mode):
-    """the committed outputs (tests/golden/make_golden.py) are reproduced, and they match the analytic surface"""
+    """the committed outputs — produced by the REFERENCE's own kernels through oracle/_ref (tests/golden/make_golden.py) — are reproduced bit for
+    bit by the oracle, and they match the analytic surface"""
     from oracle import oracle
     g = np.load(os.path.join(HERE, "golden", name + ".npz"))
     sc = make_scene(3, 192, 144, seed=3)
@@ -245,7 +246,7 @@ def test_golden_fixture(oracle_lib, name, mode):
     assert np.array_equal(o.second[..., :24], g["second"])
     assert np.array_equal(o.filtered[..., :24], g["filtered"])
     assert np.array_equal(o.sgm_depth_thickness, g["sgm_depth_thickness"])
-    assert np.array_equal(o.refine_volume.view(np.uint16)[::4, ::4], g["refine_volume_s4"])
+    assert np.array_equal(o.refine_volume.view(np.uint16)[::4, ::4, :31], g["refine_volume_s4"])
     assert np.array_equal(o.refined, g["refined"])
     assert np.allclose(out, g["optimized"], rtol=0, atol=1e-6)
     # analytic check: the estimate follows the known surface (plane spacing here is ~0.03, relief amplitude 0.2)
