@@ -81,8 +81,13 @@ __global__ void __launch_bounds__(256)
     for(int i = -radius; i <= radius; i++)
         for(int j = -radius; j <= radius; j++)
         {
-            // unnormalised linear texture: texel-space coordinate = coord - 0.5
-            const float4 c = tex_bilinear_px<FIXED8>(in, ((float)(x * downscale + j) + s) - 0.5f, ((float)(y * downscale + i) + s) - 0.5f);
+            // unnormalised linear texture: texel-space coordinate = coord - 0.5.
+            // `float(x * downscale + j)` is evaluated in UNSIGNED arithmetic in the reference (deviceGaussianFilter.cu:54-55,65): the taps
+            // left of / above the image wrap to ~4.29e9 and the clamp addressing sends them to the RIGHT / BOTTOM edge (found by
+            // oracle/_ref).  min(., 1e9): any coordinate beyond the image reads the edge texel with weight 1, and the int conversion stays exact
+            const float cx = fminf((float)((unsigned)x * (unsigned)downscale + (unsigned)j), 1.0e9f);
+            const float cy = fminf((float)((unsigned)y * (unsigned)downscale + (unsigned)i), 1.0e9f);
+            const float4 c = tex_bilinear_px<FIXED8>(in, (cx + s) - 0.5f, (cy + s) - 0.5f);
             const float factor = taps.g[i + radius] * taps.g[j + radius];
             acc.x = acc.x + c.x * factor;
             acc.y = acc.y + c.y * factor;
@@ -116,9 +121,12 @@ __global__ void __launch_bounds__(256) mip_level_kernel(uint2* out, int out_pitc
         for(int j = -2; j <= 2; j++)
         {
             const float factor = taps.g[i + 2] * taps.g[j + 2];
-            const float u = ((float)(x + j) + 0.5f) * px;
-            const float v = ((float)(y + i) + 0.5f) * py;
-            const float4 c = tex2D_level<FIXED8>(prev, u, v);
+            // `(x + j + 0.5f)` with x unsigned in the reference (deviceMipmappedArray.cu:28-29,52-53): the taps left of / above the image wrap
+            // to ~4.29e9 and clamp to the RIGHT / BOTTOM edge texel — the first two rows / columns of every level carry that quirk
+            // (found by oracle/_ref).  min(., 1e4 image widths): same edge texel, and u * W stays inside the int range
+            const float u = fminf((float)((unsigned)(x + j)), 1.0e4f * (float)width) + 0.5f;
+            const float v = fminf((float)((unsigned)(y + i)), 1.0e4f * (float)height) + 0.5f;
+            const float4 c = tex2D_level<FIXED8>(prev, u * px, v * py);
             sum.x = sum.x + c.x * factor;
             sum.y = sum.y + c.y * factor;
             sum.z = sum.z + c.z * factor;

@@ -10,7 +10,7 @@
  * compiles UNCHANGED with g++ over the stand-in CUDA runtime of oracle/ref/shim (oracle/_ref, recipe oracle/ref/Makefile).  This
  * file follows the reference sources function by function (each function cites the file:line it restates, paths relative to
  * /root/reference/src/aliceVision/depthMap) and tests/test_oracle_ref.py holds it to that library BIT FOR BIT: whole tiles through
- * every stage in both filter modes, and the committed vectors tests/golden/*.npz that library produced (tests/golden/make_golden.py).
+ * every stage in both filter modes, and the committed vectors tests/golden/ that library produced (tests/golden/make_golden.py).
  * What remains restated on both sides — and is named "unpinned" in DESIGN.md — is NVIDIA's part: the texture unit's filtering
  * arithmetic and the fast-math intrinsics; plus fillHostCameraParameters (needs MultiViewParams), checked by projection identities.
  *

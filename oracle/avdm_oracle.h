@@ -1,5 +1,5 @@
 /*
- * avdm_oracle.h — CPU parity oracle (TEST INFRASTRUCTURE ONLY; parity unpinned — see avdm_oracle.c header).
+ * avdm_oracle.h — CPU parity oracle (TEST INFRASTRUCTURE ONLY; pinned to the reference's own code through oracle/_ref — see avdm_oracle.c header).
  * Types are shared with the product ABI (include/avdm.h); all pointers are HOST pointers here.
  */
 #ifndef AVDM_ORACLE_H
