@@ -708,10 +708,12 @@ __device__ __forceinline__ void sgm_lstep_u16(unsigned (&P)[2 * NW], const unsig
     }
 }
 
-// fp32 restatement of one step WITHOUT the output stage (same expression order as sgm_step_f32); q = min(trunc(L), 255)
+// fp32 restatement of one step WITHOUT the output stage (same expression order as sgm_step_f32).  lc = clamp(L, 0, 255) with its
+// FRACTION: the reference averages the un-truncated clamped cost into the output volume (kernels.cuh:733-743), and on the steps that
+// take this path (frac(P2) within 2^-13 of 1) that fraction can carry into the integer part of the average
 template <int NW, bool FULL>
 __device__ __forceinline__ void sgm_lstep_f32(unsigned (&prev)[4 * NW], const unsigned (&inw)[NW], float P2, float P1, const SgmLane<NW>& Ln,
-                                              unsigned (&q)[2 * NW])
+                                              float (&lc)[4 * NW])
 {
     constexpr int ZL = 4 * NW;
     unsigned m = prev[0];
@@ -742,15 +744,25 @@ __device__ __forceinline__ void sgm_lstep_f32(unsigned (&prev)[4 * NW], const un
             pathCost = ((Ln.z0 + i == 0) || (Ln.z0 + i >= Ln.Z - 1)) ? 255.0f : pathCost;
         const float tr = truncf(pathCost);
         nprev[i] = (FULL || ((Ln.vmask[w] >> (8 * j)) & 1u)) ? fbits(tr) : fbits(SGM_BIG);
-        const unsigned c = (unsigned)__builtin_amdgcn_fmed3f(tr, 0.0f, 255.0f);
-        if(i & 1)
-            q[i >> 1] |= c << 16;
-        else
-            q[i >> 1] = c;
+        lc[i] = __builtin_amdgcn_fmed3f(pathCost, 0.0f, 255.0f);
     }
 #pragma unroll
     for(int i = 0; i < ZL; ++i)
         prev[i] = nprev[i];
+}
+// (uint8)((o * K + lc) / (K + 1)) of the reference (kernels.cuh:741-743) as an integer-valued float; o, K integers, lc in [0, 255] with a
+// fraction.  Same expressions as sgm_step_f32 (o * K is exact; the n / 3 form is checked exhaustively)
+template <int K>
+__device__ __forceinline__ float avg_f32(float o, float lc)
+{
+    if(K == 0)
+        return truncf(lc);
+    const float n = fmaf(o, (float)K, lc);
+    if(K == 1)
+        return truncf(n * 0.5f);
+    if(K == 3)
+        return truncf(n * 0.25f);
+    return truncf(truncf(n) * 0.33333334f);
 }
 
 #define AVDM_SGM_PAIR_WPB 4 // columns per workgroup: 2 * WPB waves
@@ -791,6 +803,10 @@ __device__ __forceinline__ void st_slice(unsigned v, __amdgpu_buffer_rsrc_t rsrc
         *p = v;
 #endif
 }
+#define AVDM_SGM_STASH_SLOTS 4
+// dynamic LDS of the pair kernel: the stash of the reverse wave's FRACTIONAL clamped costs on its (rare) fp32 steps of phase 1
+static size_t pair_kernel_lds_bytes(int NW) { return (size_t)AVDM_SGM_PAIR_WPB * AVDM_SGM_STASH_SLOTS * (256 * NW * sizeof(float) + sizeof(int)); }
+
 template <int NW, int K, bool FULL>
 __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPathBatch S)
 {
@@ -798,6 +814,15 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
     constexpr int NR = 2 * NW;
     constexpr int PF = NW == 1 ? 8 : (NW == 2 ? 4 : 2);
     constexpr int NSETS = 4;
+    // Stash (LDS): on a step whose P2 fraction is within 2^-13 of 1 the reference's running average sees the un-truncated clamped cost
+    // (kernels.cuh:733-743) and its fraction can carry.  Three of the four roles have that cost in registers when they average; the
+    // reverse wave of phase 1 only STORES a byte that the forward wave averages in phase 2 — so on such a step it also leaves the 256 * NW
+    // floats here, keyed by slice, and the forward wave looks them up when its P2 map says the reverse path's step at that slice was one
+    // of those (probability ~1e-4 per step; 4 slots per column: an overflow — 5 such steps in one half column, ~1e-9 — degrades to the
+    // integer average of the stored bytes).
+    extern __shared__ float pairLds[];
+    float* const stashF = pairLds;
+    int* const stashSlice = reinterpret_cast<int*>(pairLds + AVDM_SGM_PAIR_WPB * AVDM_SGM_STASH_SLOTS * 256 * NW);
 
     int ti = 0;
     while(ti < AVDM_SGM_MAX_TILES - 1 && (int)blockIdx.x >= S.t[ti].colEnd)
@@ -809,6 +834,12 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
     const bool active = a < T.A; // inactive waves only take part in the barrier
     const int B = T.B;
     const long long strideB = T.strideB;
+    const int colInWg = wv - rev * AVDM_SGM_PAIR_WPB;
+    float* const myStashF = stashF + colInWg * (AVDM_SGM_STASH_SLOTS * 256 * NW);
+    int* const myStashSlice = stashSlice + colInWg * AVDM_SGM_STASH_SLOTS;
+    int nStashed = 0; // reverse wave, phase 1
+    if(rev && (threadIdx.x & 63) < AVDM_SGM_STASH_SLOTS)
+        myStashSlice[threadIdx.x & 63] = -1;
 
     SgmLane<NW> Ln;
     Ln.lane = threadIdx.x & 63;
@@ -940,81 +971,173 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
             __builtin_amdgcn_sched_barrier(0);
         };
         // adaptive P2 of 64 consecutive steps of this walk, one per lane
+        int curBlk = 0; // which 64-step block of the map p2vec / the masks describe
         auto load_p2 = [&](int blk) __attribute__((always_inline)) -> float {
             const int ib = min(ib0 + blk * 64 + Ln.lane, ib1 - 1);
             return p2col[rev ? B - ib : ib];
         };
         float p2vec = 0.f;
         unsigned ip2vec = 0;
-        unsigned long long riskyMask = 0;
+        unsigned long long riskyMask = 0, revRiskyMask = 0, ownRiskyMask = 0;
+        auto is_risky = [](float v) __attribute__((always_inline)) -> bool {
+            return !((v - floorf(v)) < (1.0f - 1.0f / 8192.0f)) || !(v >= 0.0f) || !(v < 8192.0f);
+        };
         auto set_p2_block = [&](float v) __attribute__((always_inline)) {
             p2vec = v;
             const float fl = floorf(v);
             ip2vec = (unsigned)(int)fl * 0x00010001u;
-            riskyMask = __ballot(!((v - fl) < (1.0f - 1.0f / 8192.0f)) || !(v >= 0.0f) || !(v < 8192.0f));
+            ownRiskyMask = __ballot(is_risky(v));
+            riskyMask = ownRiskyMask;
+            if(ROLE == SGM_SECOND_FWD)
+            {
+                // the reverse path's step at my slice uses the NEXT entry of the map (its colour step is mine shifted by one): when that
+                // one took the fp32 step, phase 1 left fractional costs in the stash and this step must average in fp32 too
+                const int ib = min(ib0 + curBlk * 64 + Ln.lane, ib1 - 1);
+                revRiskyMask = __ballot(is_risky(p2col[min(ib + 1, B - 1)]));
+                riskyMask |= revRiskyMask;
+            }
         };
 
         auto step = [&](auto fastTag, int i, const unsigned (&inw)[NW], const unsigned (&ow)[NW], const unsigned (&tw)[NW]) __attribute__((always_inline)) {
             constexpr bool FAST = decltype(fastTag)::value;
             const int idx = i & 63;
-            unsigned q[NR];
             if(FAST)
             {
+                unsigned q[NR];
                 const unsigned iP2Pair = (unsigned)__builtin_amdgcn_readlane((int)ip2vec, idx);
                 sgm_lstep_u16<NW>(P, inw, iP2Pair, P1Pair, keepM, forceV, q);
+                // output stage (integers)
+#pragma unroll
+                for(int w = 0; w < NW; ++w)
+                {
+                    unsigned res[2];
+#pragma unroll
+                    for(int h = 0; h < 2; ++h)
+                    {
+                        const unsigned c = q[2 * w + h];
+                        const unsigned o = LOAD_OUT ? __builtin_amdgcn_perm(0u, ow[w], h ? 0x0c030c02u : 0x0c010c00u) : 0u;
+                        if(ROLE == SGM_FIRST_FWD)
+                            res[h] = pk_avg<K>(o, c);
+                        else if(ROLE == SGM_FIRST_REV)
+                            res[h] = c;
+                        else if(ROLE == SGM_SECOND_REV)
+                            res[h] = pk_avg<K + 1>(o, c);
+                        else if(K == 0)
+                            res[h] = pk_avg<1>(o, c); // o = L of the reverse path
+                        else
+                        {
+                            const unsigned t = __builtin_amdgcn_perm(0u, tw[w], h ? 0x0c030c02u : 0x0c010c00u);
+                            res[h] = pk_avg<K + 1>(pk_avg<K>(o, c), t);
+                        }
+                    }
+                    const unsigned neww = __builtin_amdgcn_perm(res[1], res[0], 0x06040200u);
+                    if(FULL)
+                        st_slice(neww, STORE_TMP ? rsrcTmp : rsrcOut, STORE_TMP ? tmpCol : outCol, Ln.offw[w], outStore);
+                    else if(Ln.wAny[w])
+                    {
+                        if(STORE_TMP)
+                            st_slice(neww, rsrcTmp, tmpCol, Ln.offw[w], outStore); // scratch padding is free
+                        else
+                            st_slice((neww & Ln.vmask[w]) | (ow[w] & ~Ln.vmask[w]), rsrcOut, outCol, Ln.offw[w], outStore);
+                    }
+                }
             }
             else
             {
+                // the literal fp32 step, and the running average on the un-truncated clamped costs like the reference (kernels.cuh:733-743)
+                const bool ownRisky = (ownRiskyMask >> idx) & 1ull;
                 const float P2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p2vec), idx));
-#pragma unroll
-                for(int r = 0; r < NR; ++r)
+                float lc[ZL];
+                if(ownRisky || ROLE != SGM_SECOND_FWD)
                 {
-                    const unsigned lo = P[r] & 0xffffu, hi = P[r] >> 16;
-                    prevF[2 * r] = lo >= SGM_BIG16 ? fbits(SGM_BIG) : fbits((float)lo);
-                    prevF[2 * r + 1] = hi >= SGM_BIG16 ? fbits(SGM_BIG) : fbits((float)hi);
-                }
-                sgm_lstep_f32<NW, FULL>(prevF, inw, P2, P1f, Ln, q);
 #pragma unroll
-                for(int r = 0; r < NR; ++r)
-                {
-                    const float lo = bitsf(prevF[2 * r]), hi = bitsf(prevF[2 * r + 1]);
-                    const unsigned ulo = lo > 60000.0f ? SGM_BIG16 : (unsigned)lo, uhi = hi > 60000.0f ? SGM_BIG16 : (unsigned)hi;
-                    P[r] = ulo | (uhi << 16);
-                }
-            }
-            // output stage
-#pragma unroll
-            for(int w = 0; w < NW; ++w)
-            {
-                unsigned res[2];
-#pragma unroll
-                for(int h = 0; h < 2; ++h)
-                {
-                    const unsigned c = q[2 * w + h];
-                    const unsigned o = LOAD_OUT ? __builtin_amdgcn_perm(0u, ow[w], h ? 0x0c030c02u : 0x0c010c00u) : 0u;
-                    if(ROLE == SGM_FIRST_FWD)
-                        res[h] = pk_avg<K>(o, c);
-                    else if(ROLE == SGM_FIRST_REV)
-                        res[h] = c;
-                    else if(ROLE == SGM_SECOND_REV)
-                        res[h] = pk_avg<K + 1>(o, c);
-                    else if(K == 0)
-                        res[h] = pk_avg<1>(o, c); // o = L of the reverse path
-                    else
+                    for(int r = 0; r < NR; ++r)
                     {
-                        const unsigned t = __builtin_amdgcn_perm(0u, tw[w], h ? 0x0c030c02u : 0x0c010c00u);
-                        res[h] = pk_avg<K + 1>(pk_avg<K>(o, c), t);
+                        const unsigned lo = P[r] & 0xffffu, hi = P[r] >> 16;
+                        prevF[2 * r] = lo >= SGM_BIG16 ? fbits(SGM_BIG) : fbits((float)lo);
+                        prevF[2 * r + 1] = hi >= SGM_BIG16 ? fbits(SGM_BIG) : fbits((float)hi);
+                    }
+                    sgm_lstep_f32<NW, FULL>(prevF, inw, P2, P1f, Ln, lc);
+#pragma unroll
+                    for(int r = 0; r < NR; ++r)
+                    {
+                        const float lo = bitsf(prevF[2 * r]), hi = bitsf(prevF[2 * r + 1]);
+                        const unsigned ulo = lo > 60000.0f ? SGM_BIG16 : (unsigned)lo, uhi = hi > 60000.0f ? SGM_BIG16 : (unsigned)hi;
+                        P[r] = ulo | (uhi << 16);
                     }
                 }
-                const unsigned neww = __builtin_amdgcn_perm(res[1], res[0], 0x06040200u);
-                if(FULL)
-                    st_slice(neww, STORE_TMP ? rsrcTmp : rsrcOut, STORE_TMP ? tmpCol : outCol, Ln.offw[w], outStore);
-                else if(Ln.wAny[w])
+                else
                 {
-                    if(STORE_TMP)
-                        st_slice(neww, rsrcTmp, tmpCol, Ln.offw[w], outStore); // scratch padding is free
-                    else
-                        st_slice((neww & Ln.vmask[w]) | (ow[w] & ~Ln.vmask[w]), rsrcOut, outCol, Ln.offw[w], outStore);
+                    // only the reverse path's step at this slice was an fp32 step: mine is the integer step, its costs have no fraction
+                    unsigned q[NR];
+                    const unsigned iP2Pair = (unsigned)__builtin_amdgcn_readlane((int)ip2vec, idx);
+                    sgm_lstep_u16<NW>(P, inw, iP2Pair, P1Pair, keepM, forceV, q);
+#pragma unroll
+                    for(int r = 0; r < NR; ++r)
+                    {
+                        lc[2 * r] = (float)(q[r] & 0xffffu);
+                        lc[2 * r + 1] = (float)(q[r] >> 16);
+                    }
+                }
+                const int slice = rev ? (B - 1 - (ib0 + i)) : (ib0 + i);
+                // FIRST_REV: leave the fractional costs for the forward wave (phase 2)
+                if(ROLE == SGM_FIRST_REV)
+                {
+                    if(nStashed < AVDM_SGM_STASH_SLOTS)
+                    {
+                        float* dst = myStashF + nStashed * (256 * NW) + Ln.z0;
+#pragma unroll
+                        for(int z = 0; z < ZL; ++z)
+                            dst[z] = lc[z];
+                        if(Ln.lane == 0)
+                            myStashSlice[nStashed] = slice;
+                    }
+                    ++nStashed;
+                }
+                // SECOND_FWD: the reverse path's costs of this slice — from the stash when its step was an fp32 step, else the stored bytes
+                int slot = -1;
+                if(ROLE == SGM_SECOND_FWD && ((revRiskyMask >> idx) & 1ull))
+                {
+#pragma unroll
+                    for(int k = 0; k < AVDM_SGM_STASH_SLOTS; ++k)
+                        slot = (myStashSlice[k] == slice) ? k : slot;
+                }
+#pragma unroll
+                for(int w = 0; w < NW; ++w)
+                {
+                    unsigned neww = 0;
+#pragma unroll
+                    for(int j = 0; j < 4; ++j)
+                    {
+                        const int z = 4 * w + j;
+                        const float o = LOAD_OUT ? ubyte_f32(ow[w], j) : 0.0f;
+                        float q;
+                        if(ROLE == SGM_FIRST_FWD)
+                            q = avg_f32<K>(o, lc[z]);
+                        else if(ROLE == SGM_FIRST_REV)
+                            q = truncf(lc[z]);
+                        else if(ROLE == SGM_SECOND_REV)
+                            q = avg_f32<K + 1>(o, lc[z]);
+                        else
+                        {
+                            // K == 0: `out` holds the reverse path's byte, tmp is unused; K > 0: `out` holds out_{K-1}, tmp the reverse byte
+                            float pr = (K == 0) ? o : ubyte_f32(tw[w], j);
+                            if(slot >= 0)
+                                pr = myStashF[slot * (256 * NW) + Ln.z0 + z];
+                            const float first = (K == 0) ? truncf(lc[z]) : avg_f32<K>(o, lc[z]);
+                            q = avg_f32<K + 1>(first, pr);
+                        }
+                        neww = __builtin_amdgcn_cvt_pk_u8_f32(q, j, neww);
+                    }
+                    if(FULL)
+                        st_slice(neww, STORE_TMP ? rsrcTmp : rsrcOut, STORE_TMP ? tmpCol : outCol, Ln.offw[w], outStore);
+                    else if(Ln.wAny[w])
+                    {
+                        if(STORE_TMP)
+                            st_slice(neww, rsrcTmp, tmpCol, Ln.offw[w], outStore);
+                        else
+                            st_slice((neww & Ln.vmask[w]) | (ow[w] & ~Ln.vmask[w]), rsrcOut, outCol, Ln.offw[w], outStore);
+                    }
                 }
             }
             outStore += storeStride;
@@ -1066,6 +1189,7 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
         {
             if(G > 0 && ((G * PF) & 63) == 0)
             {
+                curBlk = (G * PF) / 64;
                 set_p2_block(p2next);
                 p2next = load_p2((G * PF) / 64 + 1);
             }
@@ -1076,7 +1200,10 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
         if(G < nGroups) // last, partial span
         {
             if(G > 0 && ((G * PF) & 63) == 0)
+            {
+                curBlk = (G * PF) / 64;
                 set_p2_block(p2next);
+            }
 #pragma unroll
             for(int s = 0; s < NS - 1; ++s)
                 if(G + s < nGroups)
@@ -1152,20 +1279,29 @@ template <int NW>
 static void launch_pair(const SgmPathBatch& S, int nWorkgroups, int K, bool full, hipStream_t st)
 {
     dim3 grid(nWorkgroups), block(128 * AVDM_SGM_PAIR_WPB);
+    const size_t lds = pair_kernel_lds_bytes(NW);
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        // the stash of the widest instantiations exceeds the 64 KB a kernel gets without asking
+        (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
     SgmKernelTimerScope timing(st);
     if(K == 0)
     {
         if(full)
-            hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, true>), grid, block, 0, st, S);
+            hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, true>), grid, block, lds, st, S);
         else
-            hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, false>), grid, block, 0, st, S);
+            hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, false>), grid, block, lds, st, S);
     }
     else
     {
         if(full)
-            hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, true>), grid, block, 0, st, S);
+            hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, true>), grid, block, lds, st, S);
         else
-            hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, false>), grid, block, 0, st, S);
+            hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, false>), grid, block, lds, st, S);
     }
 }
 
@@ -1212,6 +1348,14 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
         int16 = false;
     // forward + reverse path of an axis in one launch (two waves per column); AVDM_SGM_PAIR=0 selects the sequential kernels
     bool pair = int16;
+    // a FIXED P2 (p2Weighting < 0) whose fraction is within 2^-13 of 1 makes EVERY step an fp32 step: the pair kernel's stash (sized
+    // for the ~1e-4 of the steps an adaptive P2 sends there) cannot hold that; the sequential kernels average in fp32 in place
+    if(sp->p2Weighting < 0)
+    {
+        const float v = fabsf((float)sp->p2Weighting);
+        if(!((v - floorf(v)) < (1.0f - 1.0f / 8192.0f)) || !(v < 8192.0f))
+            pair = false;
+    }
     const char* ep = getenv("AVDM_SGM_PAIR");
     if(ep && ep[0] == '0')
         pair = false;

@@ -35,6 +35,9 @@ namespace avdm {
 #define AVDM_NCC_UNROLL 3
 #endif
 constexpr int kNccUnroll = AVDM_NCC_UNROLL;
+#ifndef AVDM_NCC_W3_MODE
+#define AVDM_NCC_W3_MODE 2 // 7-tap rows (wsh 3, the Refine default): 0 = plain `unroll 3` (spills), 1 = no unroll, 2 = 3 + 3 + 1 with fences
+#endif
 constexpr bool kLdsSplitReads = true;
 
 struct PatchTable
@@ -237,7 +240,9 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
         f3 hrRow, htRow;
         row_of(Q, (float)yp, hrRow, htRow);
         const float* trow = tab.c + (yp + wsh) * n + wsh;
-#pragma unroll kNccUnroll
+// (the generic paths run on ~5 % of the plane-workgroups: no unrolling here — unrolled, their taps raise the register demand of the whole
+        // kernel and the compiler spills values that are live across the packed path's loop)
+#pragma unroll 1
         for(int xp = -wsh; xp <= wsh; ++xp)
         {
             float rX, rY, tX, tY;
@@ -416,51 +421,77 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
         // == row_of(), with the texel-space scale folded into the numerators: X = ((fx*ax + rowx) * Sx) / hz + Ox
         const v2f rowx = (fy * bx + h0x) * Sx, rowy = (fy * by + h0y) * Sy, rowz = fy * bz + h0z;
         const float* trow = tab.c + (yp + wsh) * n + wsh;
-#pragma unroll kNccUnroll
-        for(int xp = -wsh; xp <= wsh; ++xp)
-        {
-            const float fx = (float)xp;
-            // == sample_pos(): homogeneous coordinates, one v_rcp per image, texel-space transform
-            const v2f hz = fx * az + rowz;
-            const v2f inv = {fast_rcp(hz.x), fast_rcp(hz.y)};
-            const v2f X = (fx * axS + rowx) * inv + Ox;
-            const v2f Y = (fx * ayS + rowy) * inv + Oy;
-            const v2f fX = floor2(X), fY = floor2(Y);
-            // quant8(): weights in units of 1/256
-            const v2f wa = floor2((X - fX) * 256.0f + 0.5f), wb = floor2((Y - fY) * 256.0f + 0.5f);
-            const v2f na = 256.0f - wa, nnb = wb - 256.0f; // nnb = -(256 - B)
-            // LDS byte address of the top-left tap, formed in fp32 (exact integers), then one conversion per image
-            const v2f oidx = fY * pitch2 + (fX * (PAIRED ? 16.0f : 8.0f) + off2);
-            const unsigned oR = (unsigned)(int)oidx.x, oT = (unsigned)(int)oidx.y;
-            const v2h wr = pk_half_weights(na.x, wa.x), wt = pk_half_weights(na.y, wa.y);
-            Lab3x4 h;
-            if(PAIRED)
-            {
-                const uint4 r0 = lds_record(oR), r1 = lds_record(oR + Wn.rPitchB), t0 = lds_record(oT), t1 = lds_record(oT + Wn.tPitchB);
-                h = hlerp3x4_paired(r0, r1, t0, t1, wr, wt);
-            }
-            else
-            {
-                // half-paired records: column c whole (ds_read_b64), of column c + 1 only the {a | b} dword (ds_read_b32 at +12)
-                const unsigned oRb = oR + Wn.rPitchB, oTb = oT + Wn.tPitchB;
-                const uint2 r0 = lds_texel(oR), r1 = lds_texel(oRb), t0 = lds_texel(oT), t1 = lds_texel(oTb);
-                const unsigned r0n = lds_u32(oR + 12u), r1n = lds_u32(oRb + 12u), t0n = lds_u32(oT + 12u), t1n = lds_u32(oTb + 12u);
-                h = hlerp3x4_halfpaired(r0, r0n, r1, r1n, t0, t0n, t1, t1n, wr, wt);
-            }
-            const Lab3 &rt = h.rt, &tt = h.tt, &rb = h.rb, &tb = h.tb;
-            // centre - bilinear value (x 2^16), the vertical lerp folded into the difference: two packed FMAs per channel
-            const v2f dL = (v2f{rt.L, tt.L} * nnb + cL) - v2f{rb.L, tb.L} * wb;
-            const v2f da = (v2f{rt.a, tt.a} * nnb + ca) - v2f{rb.a, tb.a} * wb;
-            const v2f db = (v2f{rt.b, tt.b} * nnb + cb) - v2f{rb.b, tb.b} * wb;
-            const v2f sq = dL * dL + (da * da + db * db);
-            const float dcs = __builtin_amdgcn_sqrtf(sq.x) + __builtin_amdgcn_sqrtf(sq.y);
-            const float w = __builtin_amdgcn_exp2f(fmaf(dcs, kC, -trow[xp]));
+        auto sample = [&](int xp) __attribute__((always_inline)) {
+                const float fx = (float)xp;
+                // == sample_pos(): homogeneous coordinates, one v_rcp per image, texel-space transform
+                const v2f hz = fx * az + rowz;
+                const v2f inv = {fast_rcp(hz.x), fast_rcp(hz.y)};
+                const v2f X = (fx * axS + rowx) * inv + Ox;
+                const v2f Y = (fx * ayS + rowy) * inv + Oy;
+                const v2f fX = floor2(X), fY = floor2(Y);
+                // quant8(): weights in units of 1/256
+                const v2f wa = floor2((X - fX) * 256.0f + 0.5f), wb = floor2((Y - fY) * 256.0f + 0.5f);
+                const v2f na = 256.0f - wa, nnb = wb - 256.0f; // nnb = -(256 - B)
+                // LDS byte address of the top-left tap, formed in fp32 (exact integers), then one conversion per image
+                const v2f oidx = fY * pitch2 + (fX * (PAIRED ? 16.0f : 8.0f) + off2);
+                const unsigned oR = (unsigned)(int)oidx.x, oT = (unsigned)(int)oidx.y;
+                const v2h wr = pk_half_weights(na.x, wa.x), wt = pk_half_weights(na.y, wa.y);
+                Lab3x4 h;
+                if(PAIRED)
+                {
+                    const uint4 r0 = lds_record(oR), r1 = lds_record(oR + Wn.rPitchB), t0 = lds_record(oT), t1 = lds_record(oT + Wn.tPitchB);
+                    h = hlerp3x4_paired(r0, r1, t0, t1, wr, wt);
+                }
+                else
+                {
+                    // half-paired records: column c whole (ds_read_b64), of column c + 1 only the {a | b} dword (ds_read_b32 at +12)
+                    const unsigned oRb = oR + Wn.rPitchB, oTb = oT + Wn.tPitchB;
+                    const uint2 r0 = lds_texel(oR), r1 = lds_texel(oRb), t0 = lds_texel(oT), t1 = lds_texel(oTb);
+                    const unsigned r0n = lds_u32(oR + 12u), r1n = lds_u32(oRb + 12u), t0n = lds_u32(oT + 12u), t1n = lds_u32(oTb + 12u);
+                    h = hlerp3x4_halfpaired(r0, r0n, r1, r1n, t0, t0n, t1, t1n, wr, wt);
+                }
+                const Lab3 &rt = h.rt, &tt = h.tt, &rb = h.rb, &tb = h.tb;
+                // centre - bilinear value (x 2^16), the vertical lerp folded into the difference: two packed FMAs per channel
+                const v2f dL = (v2f{rt.L, tt.L} * nnb + cL) - v2f{rb.L, tb.L} * wb;
+                const v2f da = (v2f{rt.a, tt.a} * nnb + ca) - v2f{rb.a, tb.a} * wb;
+                const v2f db = (v2f{rt.b, tt.b} * nnb + cb) - v2f{rb.b, tb.b} * wb;
+                const v2f sq = dL * dL + (da * da + db * db);
+                const float dcs = __builtin_amdgcn_sqrtf(sq.x) + __builtin_amdgcn_sqrtf(sq.y);
+                const float w = __builtin_amdgcn_exp2f(fmaf(dcs, kC, -trow[xp]));
 
-            const v2f wg = dL * w;
-            wsum += w;
-            sum1 += wg;
-            sum2 = wg * dL + sum2;
-            xysum = fmaf(wg.x, dL.y, xysum);
+                const v2f wg = dL * w;
+                wsum += w;
+                sum1 += wg;
+                sum2 = wg * dL + sum2;
+                xysum = fmaf(wg.x, dL.y, xysum);
+        };
+        if(WSH == 3 && AVDM_NCC_W3_MODE == 2)
+        {
+            // 7 taps per row do not divide by the 3 samples in flight the register budget allows (8 LDS reads = 16 VGPRs each): any
+            // `#pragma unroll k` with a remainder makes the compiler unroll the whole row and spill 20-40 VGPRs to scratch inside the
+            // hottest loop of the program.  3 + 3 + 1 with scheduling fences keeps three samples in flight and nothing in scratch.
+#pragma unroll
+            for(int xp = -3; xp < 0; ++xp)
+                sample(xp);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for(int xp = 0; xp < 3; ++xp)
+                sample(xp);
+            __builtin_amdgcn_sched_barrier(0);
+            sample(3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        else if(WSH == 3 && AVDM_NCC_W3_MODE == 1)
+        {
+#pragma unroll 1
+            for(int xp = -wsh; xp <= wsh; ++xp)
+                sample(xp);
+        }
+        else
+        {
+#pragma unroll kNccUnroll
+            for(int xp = -wsh; xp <= wsh; ++xp)
+                sample(xp);
         }
     }
 

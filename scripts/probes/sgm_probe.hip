@@ -104,7 +104,7 @@ struct Vol
     const float* p2; // [A][B]
     long long strideA, strideB;
     int A, B;
-    unsigned long long* clk; // [4]: clock64 / wall_clock64 at the start of block 0 and at the end of the last block
+    unsigned long long* clk; // [4]: clock64 / wall_clock64 at the start and at the end of block 0 (the counters are per XCD: same block)
 };
 
 template <int ROLE, int K>
@@ -144,7 +144,7 @@ __device__ __forceinline__ void clk_begin(const Vol& V)
 }
 __device__ __forceinline__ void clk_end(const Vol& V)
 {
-    if(V.clk && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    if(V.clk && blockIdx.x == 0 && threadIdx.x == 0)
     {
         V.clk[2] = clock64();
         V.clk[3] = wall_clock64();
