@@ -982,7 +982,13 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
         auto is_risky = [](float v) __attribute__((always_inline)) -> bool {
             return !((v - floorf(v)) < (1.0f - 1.0f / 8192.0f)) || !(v >= 0.0f) || !(v < 8192.0f);
         };
-        auto set_p2_block = [&](float v) __attribute__((always_inline)) {
+        // the reverse path's step at my slice uses the NEXT entry of the map (its colour step is mine shifted by one): a second vector,
+        // prefetched one block ahead like the first (a load consumed at once would drain the prefetch ring every 64 steps)
+        auto load_p2_shifted = [&](int blk) __attribute__((always_inline)) -> float {
+            const int ib = min(ib0 + blk * 64 + Ln.lane, ib1 - 1);
+            return p2col[min(ib + 1, B - 1)];
+        };
+        auto set_p2_block = [&](float v, float vShifted) __attribute__((always_inline)) {
             p2vec = v;
             const float fl = floorf(v);
             ip2vec = (unsigned)(int)fl * 0x00010001u;
@@ -990,10 +996,9 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
             riskyMask = ownRiskyMask;
             if(ROLE == SGM_SECOND_FWD)
             {
-                // the reverse path's step at my slice uses the NEXT entry of the map (its colour step is mine shifted by one): when that
-                // one took the fp32 step, phase 1 left fractional costs in the stash and this step must average in fp32 too
-                const int ib = min(ib0 + curBlk * 64 + Ln.lane, ib1 - 1);
-                revRiskyMask = __ballot(is_risky(p2col[min(ib + 1, B - 1)]));
+                // when the reverse path's step at a slice took the fp32 step, phase 1 left fractional costs in the stash and this step
+                // must average in fp32 too
+                revRiskyMask = __ballot(is_risky(vShifted));
                 riskyMask |= revRiskyMask;
             }
         };
@@ -1173,8 +1178,9 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
 #pragma unroll
         for(int s = 0; s < NS; ++s)
             load_group(rin[s], rout[s], rtmp[s]);
-        set_p2_block(load_p2(0));
+        set_p2_block(load_p2(0), ROLE == SGM_SECOND_FWD ? load_p2_shifted(0) : 0.0f);
         float p2next = load_p2(1);
+        float p2nextShifted = ROLE == SGM_SECOND_FWD ? load_p2_shifted(1) : 0.0f;
 #if AVDM_SGM_PROLOGUE_DRAIN
         // every prologue load has landed before the loop: the loop-header state of the wait counter is then the back edge's alone
         // (slot loaded 3 groups + 7 loads ago -> vmcnt(55)); without this the prologue path (slot loaded 31 ops ago) caps every
@@ -1190,8 +1196,10 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
             if(G > 0 && ((G * PF) & 63) == 0)
             {
                 curBlk = (G * PF) / 64;
-                set_p2_block(p2next);
+                set_p2_block(p2next, p2nextShifted);
                 p2next = load_p2((G * PF) / 64 + 1);
+                if(ROLE == SGM_SECOND_FWD)
+                    p2nextShifted = load_p2_shifted((G * PF) / 64 + 1);
             }
 #pragma unroll
             for(int s = 0; s < NS; ++s)
@@ -1202,7 +1210,7 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
             if(G > 0 && ((G * PF) & 63) == 0)
             {
                 curBlk = (G * PF) / 64;
-                set_p2_block(p2next);
+                set_p2_block(p2next, p2nextShifted);
             }
 #pragma unroll
             for(int s = 0; s < NS - 1; ++s)

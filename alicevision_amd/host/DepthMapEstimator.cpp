@@ -232,14 +232,94 @@ void DepthMapEstimator::plan(const std::vector<int>& cams, std::vector<TilePlan>
         std::rethrow_exception(error);
 }
 
-void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
+std::vector<int> DepthMapEstimator::viewsNeeded(const std::vector<int>& cams) const
+{
+    std::vector<Tile> tiles;
+    getTilesList(cams, tiles);
+    std::vector<int> views;
+    for(const Tile& t : tiles)
+    {
+        if(t.roi.isEmpty())
+            continue;
+        views.push_back(t.rc);
+        views.insert(views.end(), t.sgmTCams.begin(), t.sgmTCams.end());
+        views.insert(views.end(), t.refineTCams.begin(), t.refineTCams.end());
+    }
+    std::sort(views.begin(), views.end());
+    views.erase(std::unique(views.begin(), views.end()), views.end());
+    return views;
+}
+
+void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams) { computeImpl(deviceId, cams, 0, nullptr, nullptr); }
+
+void DepthMapEstimator::computeShared(int worker, int deviceId, const std::vector<int>& cams, const std::vector<int>& allViews, PyramidExchange& exchange)
+{
+    computeImpl(deviceId, cams, worker, &allViews, &exchange);
+}
+
+void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, int worker, const std::vector<int>* allViews, PyramidExchange* exchange)
 {
     AVDM_HIP_CHECK(hipSetDevice(deviceId));
 
     ImagesCache ic(_mp);
 
+    const int minMipmapDownscale = std::min(_refineParams.scale, _sgmParams.scale);
+    const int maxMipmapDownscale = std::max(_refineParams.scale, _sgmParams.scale) * (int)std::pow(2, 6); // 6 more levels
+
+    // multi-GPU pre-pass: decode, convert and publish the views of the job this worker owns, before anything can wait for them (no
+    // worker waits inside its own pre-pass, so the exchange cannot deadlock); a worker without R cameras still serves its views
+    if(exchange != nullptr && allViews != nullptr)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<int> mine;
+        for(const int v : *allViews)
+            if(exchange->ownerOf(v) == worker)
+                mine.push_back(v);
+        DeviceCache publisher(1, 1, filterModeFromEnv());
+        publisher.setExchange(exchange, worker);
+        hipStream_t s0;
+        AVDM_HIP_CHECK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+        try
+        {
+            // decode a few images ahead on the host cores, then convert them in order
+            const int chunk = 8;
+            for(size_t i0 = 0; i0 < mine.size(); i0 += chunk)
+            {
+                const int n = (int)std::min(mine.size() - i0, (size_t)chunk);
+                std::exception_ptr loadError;
+#pragma omp parallel for schedule(dynamic, 1)
+                for(int k = 0; k < n; ++k)
+                {
+                    try
+                    {
+                        ic.getImg_sync(mine[i0 + k]);
+                    }
+                    catch(...)
+                    {
+#pragma omp critical
+                        loadError = std::current_exception();
+                    }
+                }
+                if(loadError)
+                    std::rethrow_exception(loadError);
+                for(int k = 0; k < n; ++k)
+                    publisher.buildOwnedView(mine[i0 + k], minMipmapDownscale, maxMipmapDownscale, ic, _mp, s0);
+            }
+        }
+        catch(...)
+        {
+            (void)hipStreamDestroy(s0);
+            throw;
+        }
+        (void)hipStreamDestroy(s0);
+        AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): published " << mine.size() << " of the job's " << allViews->size()
+                                << " views in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s.");
+    }
+
     std::vector<Tile> tiles;
     getTilesList(cams, tiles);
+    if(tiles.empty())
+        return;
 
     const int nbStreams = std::min({getNbSimultaneousTiles(), static_cast<int>(tiles.size()), maxStreamsFromEnv()});
     DeviceStreamManager deviceStreamManager(nbStreams);
@@ -251,6 +331,7 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
     const int nbCamerasParamsPerBatch = nbMipmapImagesPerBatch * 3;
 
     DeviceCache deviceCache(nbMipmapImagesPerBatch, nbCamerasParamsPerBatch, filterModeFromEnv());
+    deviceCache.setExchange(exchange, worker);
 
     // build the custom patch pattern (DepthMapEstimator.cpp:272-274; library state like the reference's constant memory)
     if(_sgmParams.useCustomPatchPattern || _refineParams.useCustomPatchPattern)
@@ -320,8 +401,6 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
     logDeviceMemoryInfo();
 
     const int nbBatches = divideRoundUp(static_cast<int>(tiles.size()), nbTilesPerBatch);
-    const int minMipmapDownscale = std::min(_refineParams.scale, _sgmParams.scale);
-    const int maxMipmapDownscale = std::max(_refineParams.scale, _sgmParams.scale) * (int)std::pow(2, 6); // 6 more levels
     const int finalScaleStep = _depthMapParams.useRefine ? _refineParams.scale * _refineParams.stepXY : _sgmParams.scale * _sgmParams.stepXY;
 
     // camera index inside a batch: the reference uses rc % nbRcPerBatch (:390), which only separates the cameras of a batch
@@ -337,7 +416,9 @@ void DepthMapEstimator::compute(int deviceId, const std::vector<int>& cams)
 
         const auto tBatch0 = std::chrono::steady_clock::now();
         auto secondsSince = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
-        // decode the images of the batch on the host cores first (the reference reads them one by one inside addMipmapImage)
+        // decode the images of the batch on the host cores first (the reference reads them one by one inside addMipmapImage);
+        // with the multi-GPU exchange nothing is decoded here: own views were published by the pre-pass, the others arrive as pyramids
+        if(exchange == nullptr)
         {
             std::vector<int> camsOfBatch;
             for(int i = firstTileIndex; i < lastTileIndex; ++i)

@@ -11,10 +11,21 @@
 
 namespace avdm_host {
 
-// computeOnMultiGPUs.hpp:18-27
+class PyramidExchange;
+
+// computeOnMultiGPUs.hpp:18-27, plus the hooks of the multi-GPU pyramid exchange (device.hpp: PyramidExchange); a job that does not
+// override them runs exactly like the reference's (every worker loads what it needs by itself)
 struct IGPUJob
 {
     virtual void compute(int deviceId, const std::vector<int>& cams) = 0;
+    // the views (camera indices) the job reads for these R cameras; empty = the job does not take part in the exchange
+    virtual std::vector<int> viewsNeeded(const std::vector<int>& cams) const { return {}; }
+    // worker `worker` of exchange.nbWorkers(): compute `cams` on `deviceId`, sharing pyramids through `exchange`;
+    // `allViews` = viewsNeeded(every camera of the job)
+    virtual void computeShared(int worker, int deviceId, const std::vector<int>& cams, const std::vector<int>& allViews, PyramidExchange& exchange)
+    {
+        compute(deviceId, cams);
+    }
     virtual ~IGPUJob() = default;
 };
 
@@ -39,12 +50,17 @@ class DepthMapEstimator : public IGPUJob
     void getTilesList(const std::vector<int>& cams, std::vector<Tile>& tiles) const;
     // DepthMapEstimator.cpp:224-512
     void compute(int deviceId, const std::vector<int>& cams) override;
+    // multi-GPU form (see IGPUJob): R, SGM-T and Refine-T cameras of every tile of `cams`
+    std::vector<int> viewsNeeded(const std::vector<int>& cams) const override;
+    void computeShared(int worker, int deviceId, const std::vector<int>& cams, const std::vector<int>& allViews, PyramidExchange& exchange) override;
 
     // CPU-only part of compute(): tiles, T cameras and depth lists, no device needed (hidden CLI switch --dryRun)
     void plan(const std::vector<int>& cams, std::vector<TilePlan>& out) const;
     const std::vector<ROI>& tileRoiList() const { return _tileRoiList; }
 
   private:
+    void computeImpl(int deviceId, const std::vector<int>& cams, int worker, const std::vector<int>* allViews, PyramidExchange* exchange);
+
     const MultiViewParams& _mp;
     const TileParams& _tileParams;
     const DepthMapParams& _depthMapParams;
@@ -53,7 +69,8 @@ class DepthMapEstimator : public IGPUJob
     std::vector<ROI> _tileRoiList;
 };
 
-// computeOnMultiGPUs.cpp:15-69: one host thread per device, contiguous chunks of the camera list
+// computeOnMultiGPUs.cpp:15-69 re-designed: one host thread per device, R cameras dealt round-robin, pyramids shared through a
+// PyramidExchange when the job takes part in it (computeOnMultiGPUs.cpp of this directory)
 void computeOnMultiGPUs(const std::vector<int>& cams, IGPUJob& gpujob, int nbGPUsToUse);
 
 } // namespace avdm_host

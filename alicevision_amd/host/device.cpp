@@ -36,6 +36,52 @@ void DeviceMipmapImage::fill(const HostImage& img, int minDownscale, int maxDown
     AVDM_HIP_CHECK(hipStreamSynchronize(stream)); // the temporaries die here
 }
 
+void DeviceMipmapImage::copyFromPeer(const DeviceMipmapImage& src, int srcDevice, int dstDevice, hipStream_t stream)
+{
+    if(_buf.bytes() != src.bytes())
+        _buf.allocate(src.bytes());
+    _pyr = src.pyramid();
+    _pyr.base = _buf.ptr();
+    AVDM_HIP_CHECK(hipMemcpyPeerAsync(_buf.ptr(), dstDevice, src.pyramid().base, srcDevice, src.bytes(), stream));
+}
+
+void PyramidExchange::publish(int camId, std::shared_ptr<const DeviceMipmapImage> img)
+{
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        _resident[camId] = std::move(img);
+    }
+    ++nbBuilt;
+    _published.notify_all();
+}
+
+std::shared_ptr<const DeviceMipmapImage> PyramidExchange::find(int camId)
+{
+    std::lock_guard<std::mutex> lock(_mutex);
+    const auto it = _resident.find(camId);
+    return it == _resident.end() ? nullptr : it->second;
+}
+
+std::shared_ptr<const DeviceMipmapImage> PyramidExchange::await(int camId)
+{
+    std::unique_lock<std::mutex> lock(_mutex);
+    _published.wait(lock, [&] { return _failure || _resident.count(camId) != 0; });
+    const auto it = _resident.find(camId);
+    if(it != _resident.end())
+        return it->second;
+    std::rethrow_exception(_failure);
+}
+
+void PyramidExchange::fail(std::exception_ptr e)
+{
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        if(!_failure)
+            _failure = e;
+    }
+    _published.notify_all();
+}
+
 DeviceCache::DeviceCache(int maxMipmapImages, int maxCameraParams, int filterMode)
   : _filterMode(filterMode),
     _mipmapCache(maxMipmapImages),
@@ -46,9 +92,7 @@ DeviceCache::DeviceCache(int maxMipmapImages, int maxCameraParams, int filterMod
     AVDM_LOG_TRACE("Initialize device cache (device id: " << dev << "):" << std::endl
                                                           << "\t - # mipmap images: " << maxMipmapImages << std::endl
                                                           << "\t - # cameras parameters: " << maxCameraParams);
-    _mipmaps.reserve(maxMipmapImages);
-    for(int i = 0; i < maxMipmapImages; ++i)
-        _mipmaps.push_back(std::make_unique<DeviceMipmapImage>());
+    _mipmaps.resize(maxMipmapImages);
     _cameraParams.resize(maxCameraParams);
 }
 
@@ -61,8 +105,42 @@ void DeviceCache::addMipmapImage(int camId, int minDownscale, int maxDownscale, 
         return;
     }
     AVDM_LOG_TRACE("Add mipmap image on device cache (id: " << camId << ", view id: " << mp.getViewId(camId) << ").");
+    if(_exchange != nullptr)
+    {
+        const int owner = _exchange->ownerOf(camId);
+        if(owner == _worker)
+        {
+            // mine: built once (normally by the pre-pass of DepthMapEstimator::compute), resident for the whole job; the slot aliases it
+            if(!_exchange->find(camId))
+                buildOwnedView(camId, minDownscale, maxDownscale, imageCache, mp, stream);
+            _mipmaps.at(slot) = _exchange->find(camId);
+            return;
+        }
+        // another worker's: wait for its pyramid and copy it over the fabric
+        const std::shared_ptr<const DeviceMipmapImage> src = _exchange->await(camId);
+        auto copy = std::make_shared<DeviceMipmapImage>();
+        copy->copyFromPeer(*src, _exchange->deviceOf(owner), _exchange->deviceOf(_worker), stream);
+        AVDM_HIP_CHECK(hipStreamSynchronize(stream)); // `src` may be released by its owner's exchange only after the copy has read it
+        ++_exchange->nbCopied;
+        _exchange->bytesCopied += (long long)src->bytes();
+        _mipmaps.at(slot) = copy;
+        return;
+    }
     const std::shared_ptr<const HostImage> img = imageCache.getImg_sync(camId);
-    _mipmaps.at(slot)->fill(*img, minDownscale, maxDownscale, _filterMode, stream);
+    auto own = std::make_shared<DeviceMipmapImage>();
+    own->fill(*img, minDownscale, maxDownscale, _filterMode, stream);
+    _mipmaps.at(slot) = own;
+}
+
+void DeviceCache::buildOwnedView(int camId, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp, hipStream_t stream)
+{
+    if(_exchange == nullptr || _exchange->find(camId))
+        return;
+    AVDM_LOG_TRACE("Build the pyramid of an owned view for the exchange (id: " << camId << ", view id: " << mp.getViewId(camId) << ").");
+    const std::shared_ptr<const HostImage> img = imageCache.getImg_sync(camId);
+    auto own = std::make_shared<DeviceMipmapImage>();
+    own->fill(*img, minDownscale, maxDownscale, _filterMode, stream);
+    _exchange->publish(camId, own);
 }
 
 void DeviceCache::addCameraParams(int camId, int downscale, const MultiViewParams& mp)

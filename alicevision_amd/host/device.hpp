@@ -12,9 +12,13 @@
 #include <avdm.h>
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <exception>
 #include <list>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -132,6 +136,8 @@ class DeviceMipmapImage
   public:
     // DeviceMipmapImage.cpp:28-90 via avdm_pyramid_layout + avdm_pyramid_fill (x255 -> fp16 -> Gaussian downscale -> Lab -> levels)
     void fill(const HostImage& img, int minDownscale, int maxDownscale, int filterMode, hipStream_t stream);
+    // a copy of a pyramid that lives on another device (or on this one): hipMemcpyPeerAsync over xGMI, same bytes, own descriptor
+    void copyFromPeer(const DeviceMipmapImage& src, int srcDevice, int dstDevice, hipStream_t stream);
     const avdm_pyramid_t& pyramid() const { return _pyr; }
     size_t bytes() const { return _buf.bytes(); }
 
@@ -186,11 +192,48 @@ class LRUCache
     std::map<Key, std::pair<int, typename std::list<Key>::iterator>> _map;
 };
 
+// PyramidExchange — the multi-GPU design of this stage (BASELINE north_star; no counterpart in the reference, where every device
+// thread decodes, uploads and converts every image it needs by itself, DepthMapEstimator.cpp:224-232 + DeviceCache.cpp:222-281).
+// The workers of one process (one host thread per GPU) share it: the views the job needs are partitioned over the workers
+// (view index modulo the number of workers); the OWNER of a view decodes it, builds its Lab pyramid once and keeps it resident;
+// every other worker that needs the view copies the finished pyramid device-to-device (hipMemcpyPeerAsync: xGMI between the GPUs of
+// a node) into its own LRU cache.  A 12 MP pyramid is 128 MB = ~1 ms over one xGMI link against ~50 ms of EXR decode + 3 ms of PCIe
+// upload + conversion, and each image is decoded once per node instead of once per device that uses it.
+class PyramidExchange
+{
+  public:
+    // devices[w] = physical device of worker w (the same device may appear several times: that is how the one-GPU tests run two workers)
+    explicit PyramidExchange(std::vector<int> devices) : _devices(std::move(devices)) {}
+    int nbWorkers() const { return (int)_devices.size(); }
+    int deviceOf(int worker) const { return _devices.at(worker); }
+    int ownerOf(int camId) const { return camId % nbWorkers(); }
+    // owner side: hand over a finished pyramid; it stays resident until the exchange dies
+    void publish(int camId, std::shared_ptr<const DeviceMipmapImage> img);
+    // the owner's resident pyramid, waiting until it is published; rethrows the failure of a worker that died before publishing
+    std::shared_ptr<const DeviceMipmapImage> await(int camId);
+    std::shared_ptr<const DeviceMipmapImage> find(int camId);
+    void fail(std::exception_ptr e);
+    // statistics for the log: pyramids built by their owners / copied between workers, bytes copied
+    std::atomic<long> nbBuilt{0}, nbCopied{0};
+    std::atomic<long long> bytesCopied{0};
+
+  private:
+    std::vector<int> _devices;
+    std::mutex _mutex;
+    std::condition_variable _published;
+    std::map<int, std::shared_ptr<const DeviceMipmapImage>> _resident;
+    std::exception_ptr _failure;
+};
+
 // DeviceCache.{hpp,cpp}: one instance per device (owned by the DepthMapEstimator::compute call of that device)
 class DeviceCache
 {
   public:
     DeviceCache(int maxMipmapImages, int maxCameraParams, int filterMode);
+    // multi-GPU: views owned by other workers are copied from their owners instead of decoded again (see PyramidExchange)
+    void setExchange(PyramidExchange* exchange, int worker) { _exchange = exchange, _worker = worker; }
+    // owner side of the exchange: decode + build + publish a view this worker owns (no LRU slot is taken: the pyramid stays resident)
+    void buildOwnedView(int camId, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp, hipStream_t stream);
     // DeviceCache.cpp:222-281
     void addMipmapImage(int camId, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp, hipStream_t stream);
     // DeviceCache.cpp:283-323 (+ fillHostCameraParameters :41-134 through avdm_camera_fill)
@@ -203,8 +246,10 @@ class DeviceCache
     int _filterMode;
     LRUCache<int> _mipmapCache;
     LRUCache<std::pair<int, int>> _cameraParamCache;
-    std::vector<std::unique_ptr<DeviceMipmapImage>> _mipmaps;
+    std::vector<std::shared_ptr<const DeviceMipmapImage>> _mipmaps; // a slot owns its pyramid, or aliases one this worker published
     std::vector<avdm_camera_t> _cameraParams;
+    PyramidExchange* _exchange = nullptr;
+    int _worker = 0;
 };
 
 void logDeviceMemoryInfo();

@@ -45,8 +45,10 @@ def look_at_rotation(C, target):
     return np.stack([x, y, z], axis=0)
 
 
-def make_scene(n_views=3, width=640, height=480, seed=1, device="cpu", z0=4.0, amp=0.2, baseline=0.3, focal=None, dtype=torch.float32):
-    """Render `n_views` images of size width x height.  View 0 is the reference camera (centre of the arc)."""
+def make_scene(n_views=3, width=640, height=480, seed=1, device="cpu", z0=4.0, amp=0.2, baseline=0.3, focal=None, dtype=torch.float32, render=None):
+    """Render `n_views` images of size width x height.  View 0 is the reference camera (centre of the arc).
+    render = list of view indices: only those are rendered and `images` is a dict {view: (H, W, 4)} (a rank of a multi-GPU job renders
+    the views it owns; the cameras of all views are always set)."""
     rng = np.random.RandomState(seed)
     sc = Scene()
     sc.width, sc.height = width, height
@@ -77,7 +79,7 @@ def make_scene(n_views=3, width=640, height=480, seed=1, device="cpu", z0=4.0, a
     v, u = torch.meshgrid(torch.arange(height, device=dev, dtype=torch.float64), torch.arange(width, device=dev, dtype=torch.float64), indexing="ij")
     Kinv = np.linalg.inv(sc.K)
     imgs = []
-    for i in range(n_views):
+    for i in (range(n_views) if render is None else render):
         M = sc.R[i].T @ Kinv  # pixel -> world ray direction
         dx = M[0, 0] * u + M[0, 1] * v + M[0, 2]
         dy = M[1, 0] * u + M[1, 1] * v + M[1, 2]
@@ -95,7 +97,7 @@ def make_scene(n_views=3, width=640, height=480, seed=1, device="cpu", z0=4.0, a
         imgs.append(img)
         if i == 0:
             sc.gt_depth = (t * torch.sqrt(dx * dx + dy * dy + dz * dz)).to(torch.float32)
-    sc.images = torch.stack(imgs, dim=0).contiguous()
+    sc.images = torch.stack(imgs, dim=0).contiguous() if render is None else dict(zip(render, imgs))
     sc.z_range = (z0 - amp - 0.02, z0 + amp + 0.02)
     return sc
 

@@ -4,13 +4,19 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (config.workload = "cfg3"): synthetic 11-view scene at 12 MP (4000x3000), 1 reference camera + 10 neighbours,
-256 depth planes, full path per step = R-image pyramid build (+ all-gather of it across ranks when N > 1) ->
-similarity volume x10 -> 4-path SGM aggregation -> WTA -> thickness smoothing -> upscale -> Refine volume x10 ->
-sub-sample arg-min -> 100 optimisation iterations.  One step = one depth map; every rank computes K depth maps of
-different reference cameras (weak scaling), value = N*K / max-over-ranks time.  Images are resident in HBM before the
-timed region.  All compute goes through the C ABI of alicevision_amd/csrc/libavdm.so (hand-written HIP); the oracle is only
-used for the `cpu_baseline` leg on rank 0 at N = 1.
+Workloads (BASELINE.json configs; config.workload names the one that ran):
+  cfg3 (default at N = 1)  11 views at 12 MP (4000x3000), 1 reference camera + 10 neighbours, 256 depth planes — the metric's configuration;
+  cfg4 (default at N > 1)  20 views at 12 MP sharded round-robin over the ranks, 10 neighbours each, 256 planes — the same work per depth map;
+  cfg5                     100 views at 24 MP (6000x4000), each depth map computed as 4 x 4 tiles (tile buffer 1664 x 1152, padding 64);
+  cfg2 / cfg1              the smaller parity configurations.
+One step = one depth map of one reference camera: R-image pyramid build -> similarity volume x10 -> 4-path SGM aggregation -> WTA ->
+thickness smoothing -> upscale -> Refine volume x10 -> sub-sample arg-min -> 100 optimisation iterations.  Every rank computes K depth
+maps of reference cameras it owns (weak scaling); value = N*K / max-over-ranks time.  Images are resident in HBM before the timed
+region.  Multi-GPU: a view's pyramid is built ONLY by the rank that owns the view; set-up broadcasts every pyramid once from its owner,
+and in the timed region each step's freshly rebuilt R pyramids travel by one all-gather INTO the other ranks' pyramid stores — the
+neighbour pyramids a rank sweeps against are the bytes it received (alicevision_amd/sharding.py: ViewExchange).
+All compute goes through the C ABI of alicevision_amd/csrc/libavdm.so (hand-written HIP); the oracle is only used for the
+`cpu_baseline` leg on rank 0 at N = 1.
 """
 import argparse
 import ctypes
@@ -28,15 +34,31 @@ import torch
 
 from alicevision_amd import abi
 from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
-from alicevision_amd.sharding import cameras_of_rank, exchange_pyramid
+from alicevision_amd.sharding import ViewExchange, cameras_of_rank, owner_of_view
 from alicevision_amd.synthetic import make_scene, plane_depths
 
 WORKLOADS = {
-    # name: (views, width, height, planes, tcams)
-    "cfg3": (11, 4000, 3000, 256, 10),
-    "cfg2": (5, 1920, 1080, 128, 4),
-    "cfg1": (3, 640, 480, 64, 2),
+    # name: (views, width, height, planes, tcams, tiles per side)
+    "cfg3": (11, 4000, 3000, 256, 10, 1),
+    "cfg4": (20, 4000, 3000, 256, 10, 1),
+    "cfg5": (100, 6000, 4000, 256, 10, 4),
+    "cfg2": (5, 1920, 1080, 128, 4, 1),
+    "cfg1": (3, 640, 480, 64, 2, 1),
 }
+
+
+def tile_rois(W, H, n_side, buffer_w=1664, buffer_h=1152, padding=64):
+    """getTileRoiList (mvsUtils/TileParams.cpp:15-61) for the cfg5 geometry: effective tile = buffer - 2 * padding, tiles start every
+    effective width / height and extend by the padding on both sides, clipped to the image"""
+    if n_side == 1:
+        return [None]
+    ew, eh = buffer_w - 2 * padding, buffer_h - 2 * padding
+    out = []
+    for j in range((H + eh - 1) // eh):
+        for i in range((W + ew - 1) // ew):
+            x0, y0 = i * ew, j * eh
+            out.append((max(x0 - padding, 0), min(x0 + ew + padding, W), max(y0 - padding, 0), min(y0 + eh + padding, H)))
+    return out
 
 
 def cpu_baseline(sc_small, sgm, ref, n_planes, full_px, full_t):
@@ -70,7 +92,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,45 +109,56 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    V, W, H, Z, T = WORKLOADS[args.workload]
+    if args.workload is None:
+        args.workload = "cfg3" if world == 1 else "cfg4"
+    V, W, H, Z, T, n_side = WORKLOADS[args.workload]
     sgm, ref = abi.SgmParams.default(), abi.RefineParams.default()
 
-    # ---- scene: every rank renders the views it owns, builds their pyramids, then the pyramids are exchanged over RCCL ----
-    sc = make_scene(V, W, H, seed=3, device=dev)  # deterministic: identical on every rank (cameras needed everywhere)
-    images = sc.images  # (V, H, W, 4) fp32, resident in HBM
+    # ---- scene: cameras everywhere; a rank renders and converts ONLY the views it owns ----
+    sc = make_scene(V, W, H, seed=3, device=dev, render=[v for v in range(V) if owner_of_view(v, world) == rank])
+    images = sc.images  # {view: (H, W, 4) fp32 in HBM} for the owned views
     min_ds, max_ds = min(sgm.scale, ref.scale), max(sgm.scale, ref.scale) * 64
     pyr = []
     for v in range(V):
-        if world > 1 and v % world != rank:
-            pyr.append(DevicePyramid.allocate(W, H, min_ds, max_ds, abi.FILTER_CUDA_FIXED8, device=dev))  # received below
-        else:
+        if v in images:
             pyr.append(DevicePyramid(images[v], min_ds, max_ds, abi.FILTER_CUDA_FIXED8, device=dev))
+        else:
+            pyr.append(DevicePyramid.allocate(W, H, min_ds, max_ds, abi.FILTER_CUDA_FIXED8, device=dev))  # received, never built here
     torch.cuda.synchronize()
+    exchange = ViewExchange([p.buf for p in pyr], rank, world, dist)
     t_ex = 0.0
     if world > 1:
         dist.barrier()
         t0 = time.time()
-        for v in range(V):
-            exchange_pyramid(pyr[v].buf, src=v % world, dist=dist)  # broadcast from the owner over xGMI
+        exchange.setup()  # every view's pyramid broadcast once from its owner over xGMI
         torch.cuda.synchronize()
         t_ex = time.time() - t0
     depths = plane_depths(sc, Z)
-    tile = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, device=dev)
+    rois = tile_rois(W, H, n_side)
+    tiles = [DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=r, device=dev) for r in rois]
+    for t in tiles:
+        t.timers = tiles[0].timers
+    tile = tiles[0]
     tile.enable_timers(True)
     lib = abi.load()
     lib.avdm_debug_sgm_kernel_timing.argtypes = [ctypes.c_int]
     lib.avdm_debug_sgm_kernel_timing_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long), ctypes.c_int]
-    my_cams = cameras_of_rank(list(range(V)), rank, world)  # reference cameras of this rank (round-robin), cycled over steps
+    cams_of = [cameras_of_rank(list(range(V)), r, world) for r in range(world)]  # reference cameras per rank (round-robin = the views it owns)
+    my_cams = cams_of[rank]
 
     def step(i):
         rc = my_cams[i % len(my_cams)]
-        tcs = [v for v in range(V) if v != rc][:T]
+        tcs = [(rc + 1 + k) % V for k in range(T)]  # the T following views of the ring: owned by other ranks when N > 1
         with tile.timers.range("image_pyramid"):
-            pyr[rc].fill(images[rc])              # image -> Lab pyramid (DeviceCache::addMipmapImage)
+            pyr[rc].fill(images[rc])              # image -> Lab pyramid (DeviceCache::addMipmapImage): only ever for a view I own
         if world > 1:
-            exchange_pyramid(pyr[rc].buf, src=rank, dist=dist, all_ranks=True)
-        tile.run_sgm(rc, tcs, depths)
-        return tile.run_refine(rc, tcs)
+            with tile.timers.range("pyramid_exchange"):
+                exchange.publish_round([cams_of[r][i % len(cams_of[r])] for r in range(world)])
+        out = None
+        for t in tiles:
+            t.run_sgm(rc, tcs, depths)
+            out = t.run_refine(rc, tcs)
+        return out
 
     for i in range(args.warmup):
         step(i)
@@ -146,7 +179,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    stages = tile.stage_ms()  # mean ms per step and stage (HIP events on the launch stream)
+    stages = tile.timers.mean_ms(per=args.steps)  # ms per step and stage (HIP events on the launch stream; summed over the tiles of a step)
     k_ms, k_n = ctypes.c_double(0.0), ctypes.c_long(0)
     abi.check(lib.avdm_debug_sgm_kernel_timing_read(ctypes.byref(k_ms), ctypes.byref(k_n), 1), "avdm_debug_sgm_kernel_timing_read")
     lib.avdm_debug_sgm_kernel_timing(0)
@@ -157,41 +190,61 @@ def main():
         value = world * args.steps / elapsed
         # roofline of the SGM path-aggregation kernel (BASELINE.json: "SGM HBM GB/s vs roofline")
         ds = sgm.scale * sgm.stepXY
-        X, Y = (W + ds - 1) // ds, (H + ds - 1) // ds
+        vols = []  # (X, Y) of the SGM volume of every tile of a depth map
+        for r in rois:
+            x0, x1, y0, y1 = r if r is not None else (0, W, 0, H)
+            vols.append(((x1 + ds - 1) // ds - x0 // ds, (y1 + ds - 1) // ds - y0 // ds))
         # 11 B/voxel + 64 B/pixel for the four paths = two launches of sgm_pair_kernel (forward + reverse path of one
         # axis per launch); AVDM_SGM_PAIR=0 runs the four sequential sgm_path_kernel launches instead
         n_launches = 4 if os.environ.get("AVDM_SGM_PAIR") == "0" else 2
-        alg_bytes_per_launch = (11.0 * X * Y * Z + 64.0 * X * Y) / n_launches
-        # average duration of one path-aggregation kernel launch (events around the launches alone); stages["sgm_optimize"] is the
-        # whole avdm_volume_optimize call, i.e. these launches + the adaptive-P2 map kernel
-        if k_n.value != n_launches * args.steps:
-            raise SystemExit(f"expected {n_launches * args.steps} path-kernel launches in the timed region, the library timed {k_n.value}")
+        alg_bytes_per_volume = sum(11.0 * x * y * Z + 64.0 * x * y for x, y in vols) / len(vols)
+        alg_bytes_per_launch = alg_bytes_per_volume / n_launches
+        # average duration of one path-aggregation kernel launch (HIP events around the launches alone, on their stream);
+        # stages["sgm_optimize"] is the whole avdm_volume_optimize call, i.e. these launches + the adaptive-P2 map kernel
+        if k_n.value != n_launches * args.steps * len(vols):
+            raise SystemExit(f"expected {n_launches * args.steps * len(vols)} path-kernel launches in the timed region, the library timed {k_n.value}")
         sgm_ms_per_launch = k_ms.value / k_n.value
         achieved = alg_bytes_per_launch / (sgm_ms_per_launch * 1e-3) / 1e9
+        whole_call_ms = stages["sgm_optimize"] / len(vols)
         roof = {"bound": "hbm", "kernel": "sgm_pair_kernel" if n_launches == 2 else "sgm_path_kernel", "achieved": achieved, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "alg_bytes_per_launch": alg_bytes_per_launch,
                 "ms_per_launch": sgm_ms_per_launch, "launches_per_volume": n_launches,
-                "ms_whole_call_per_volume": stages["sgm_optimize"]}
-        pmc = os.path.join(ROOT, "profiles", "r01_sgm_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+                # the same bytes over the whole avdm_volume_optimize call (path launches + sgm_p2_map_kernel, whose 64 B/pixel are in the numerator)
+                "ms_whole_call_per_volume": whole_call_ms, "frac_whole_call": alg_bytes_per_volume / (whole_call_ms * 1e-3) / 1e9 / 8000.0,
+                "frac_kernels_only": achieved / 8000.0}
+        # HBM bytes per launch from the PMC counters: NOT measured by this run (counters need their own rocprofv3 --pmc passes); the value
+        # is the committed summary of the latest counter session of the SAME kernel and volume size, named here with its provenance
+        for pmc in ("r02_sgm_pmc.json", "r01_sgm_pmc.json"):
+            path = os.path.join(ROOT, "profiles", pmc)
+            if os.path.exists(path) and n_side == 1 and (W, H, Z) == (4000, 3000, 256):
+                try:
+                    roof["traffic"] = json.load(open(path)).get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = f"profiles/{pmc}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/sgm_microbench.py (2 x FETCH + WRITE, KiB), not this run"
+                except Exception:
+                    pass
+                break
+        # the similarity kernels are VALU / LDS-gather bound, HBM fraction is not their figure.  Work units: a voxel-T is
+        # (2 wsh + 1)^2 patch samples (81 SGM, 49 Refine); flops per voxel-T from SURVEY §8(a) (8.1 k / 4.9 k); LDS bytes per sample as the
+        # kernels read them (SGM: half-paired 8-byte records, 4 x 8 + 4 x 4 B; Refine: paired 16-byte records, 4 x 16 B)
+        px_sgm = sum(x * y for x, y in vols)
+        px_ref = sum(((r[1] - r[0]) * (r[3] - r[2])) if r is not None else W * H for r in rois)
+        nz_ref = 2 * ref.halfNbDepths + 1
+        t_sgm, t_ref = stages["sgm_similarity"] * 1e-3, stages["refine_similarity"] * 1e-3
+        vt_sgm, vt_ref = px_sgm * Z * T / t_sgm, px_ref * nz_ref * T / t_ref
+        s_sgm, s_ref = vt_sgm * (2 * sgm.wsh + 1) ** 2, vt_ref * (2 * ref.wsh + 1) ** 2
         line = {
             "metric": "depth-maps/sec (12 MP, 256 depth hyp, 10 neighbours)", "value": value, "unit": "depth-maps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (fp16 texels, u8 cost volume)", "data": "synthetic",
-            "config": {"workload": args.workload, "views": V, "width": W, "height": H, "depth_planes": Z, "t_cams": T,
+            "config": {"workload": args.workload, "views": V, "width": W, "height": H, "depth_planes": Z, "t_cams": T, "tiles_per_depth_map": len(rois),
                        "sgm": "scale 2 stepXY 2 wsh 4, 4 paths", "refine": "scale 1 stepXY 1 wsh 3, 31 planes, 100 opt iters",
-                       "sharding": f"round-robin reference cameras over {world} rank(s)", "pyramid_exchange_s": t_ex},
+                       "sharding": f"round-robin reference cameras over {world} rank(s); a view's pyramid is built by its owner only",
+                       "pyramid_setup_broadcast_s": t_ex, "pyramid_bytes_received_per_rank": exchange.bytes_received},
             "roofline": roof,
-            # the similarity kernels are VALU-issue bound, HBM fraction is not their figure: voxel x T camera rates instead
-            # (a voxel-T is (2 wsh + 1)^2 patch samples: 81 for the SGM volume, 49 for the Refine volume)
-            "similarity": {"sgm_voxelT_per_s": X * Y * Z * T / (stages["sgm_similarity"] * 1e-3),
-                           "refine_voxelT_per_s": W * H * (2 * ref.halfNbDepths + 1) * T / (stages["refine_similarity"] * 1e-3),
-                           "sgm_samples_per_s": X * Y * Z * T * (2 * sgm.wsh + 1) ** 2 / (stages["sgm_similarity"] * 1e-3),
-                           "refine_samples_per_s": W * H * (2 * ref.halfNbDepths + 1) * T * (2 * ref.wsh + 1) ** 2 / (stages["refine_similarity"] * 1e-3)},
+            "similarity": {"sgm_voxelT_per_s": vt_sgm, "refine_voxelT_per_s": vt_ref, "sgm_samples_per_s": s_sgm, "refine_samples_per_s": s_ref,
+                           "sgm_lds_GBps": s_sgm * 48.0 / 1e9, "refine_lds_GBps": s_ref * 64.0 / 1e9, "lds_peak_GBps": 150000.0,
+                           "sgm_fp32_TFLOPs": vt_sgm * 8.1e3 / 1e12, "refine_fp32_TFLOPs": vt_ref * 4.9e3 / 1e12,
+                           "sgm_fp32_frac": vt_sgm * 8.1e3 / 157.3e12, "refine_fp32_frac": vt_ref * 4.9e3 / 157.3e12, "fp32_vector_peak_TFLOPs": 157.3},
             "stages_ms": stages, "valid_fraction": valid,
         }
         if os.environ.get("AVDM_SIM_STATS") == "1":

@@ -116,6 +116,17 @@ class HostPyramid:
         rgba = np.ascontiguousarray(rgba, dtype=np.float32)
         assert lib.avo_pyramid_fill(C.byref(self.desc), ptr(rgba), w * 16) == 0
 
+    @classmethod
+    def from_bytes(cls, width, height, min_downscale, max_downscale, filter_mode, raw):
+        """a pyramid whose bytes were built elsewhere (e.g. received from the rank that owns the view)"""
+        self = cls.__new__(cls)
+        self.desc = abi.Pyramid()
+        assert load().avo_pyramid_layout(C.byref(self.desc), width, height, min_downscale, max_downscale, filter_mode) == 0
+        self.buf = np.ascontiguousarray(raw, dtype=np.uint8)
+        assert self.buf.size == self.desc.bytes
+        self.desc.base = self.buf.ctypes.data
+        return self
+
     def level(self, l):
         d = self.desc
         raw = self.buf[d.offset[l]:d.offset[l] + d.pitch[l] * d.height[l]].reshape(d.height[l], d.pitch[l])
@@ -129,14 +140,18 @@ def ceil_div(a, b):
 class OracleDepthMap:
     """One tile of one R camera through SGM + Refine on the CPU.  roi = full-resolution (process) pixel ROI."""
 
-    def __init__(self, images, K, Rs, Cs, sgm, refine, filter_mode=abi.FILTER_CUDA_FIXED8, roi=None):
+    def __init__(self, images, K, Rs, Cs, sgm, refine, filter_mode=abi.FILTER_CUDA_FIXED8, roi=None, pyramids=None):
         self.lib = load()
         self.sgm, self.refine = sgm, refine
-        n, H, W = images.shape[:3]
+        if pyramids is not None:  # prebuilt (or received) pyramids instead of images
+            self.pyr = list(pyramids)
+            W, H = self.pyr[0].desc.width0, self.pyr[0].desc.height0
+        else:
+            n, H, W = images.shape[:3]
+            min_ds = min(sgm.scale, refine.scale)
+            max_ds = max(sgm.scale, refine.scale) * 64  # DepthMapEstimator.cpp:324-325
+            self.pyr = [HostPyramid(images[i], min_ds, max_ds, filter_mode) for i in range(n)]
         self.W, self.H = W, H
-        min_ds = min(sgm.scale, refine.scale)
-        max_ds = max(sgm.scale, refine.scale) * 64  # DepthMapEstimator.cpp:324-325
-        self.pyr = [HostPyramid(images[i], min_ds, max_ds, filter_mode) for i in range(n)]
         self.K, self.Rs, self.Cs = K, Rs, Cs
         self.roi = roi if roi is not None else (0, W, 0, H)
 

@@ -51,7 +51,7 @@ def depth_stats(got, want, pix=None):
     return out
 
 
-def run_case(name, spec, filter_mode):
+def run_case(name, spec, filter_mode, with_ref=False):
     import torch
     from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
     from oracle import oracle
@@ -106,7 +106,22 @@ def run_case(name, spec, filter_mode):
                                            "oracle": float(np.median(np.abs(want[..., 0] - gt)[both]))}
         r["t_oracle_s"] = time.time() - t1
         res[mode] = r
-    # the oracle's two modes against each other: the noise floor of the reference's own fp32 arithmetic
+    # the REFERENCE'S OWN kernels (oracle/_ref, prebuilt library travelling with the snapshot): the literal oracle must equal them bit for
+    # bit, which makes the "literal" block above GPU-vs-reference-code numbers
+    from oracle import ref as refmod
+    if with_ref and refmod.available():
+        t1 = time.time()
+        r = refmod.RefDepthMap(sc.images.numpy(), sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi)
+        r.run_sgm(0, tcs, depths)
+        want_ref = r.run_refine(0, tcs)
+        o.run_sgm(0, tcs, depths)
+        want_lit = o.run_refine(0, tcs)
+        res["reference_code"] = {
+            "oracle_literal_equals_reference": bool(np.array_equal(o.second[..., :Z], r.second[..., :Z]) and np.array_equal(o.filtered[..., :Z], r.filtered[..., :Z])
+                                                    and np.array_equal(o.refined, r.refined) and np.array_equal(want_lit, want_ref)),
+            "final_depth_gpu_vs_reference": depth_stats(g_final, want_ref, r.sgm_upscaled[..., 1]),
+            "similarity_volume_levels_gpu_vs_reference": level_hist(r.second[..., :Z], g_second),
+            "t_reference_s": time.time() - t1}
     return res
 
 
@@ -115,12 +130,13 @@ def main():
     ap.add_argument("--cases", default="cfg1,crop2,crop3")
     ap.add_argument("--filters", default="fixed8")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--ref-cases", default="cfg1", help="cases also run through oracle/_ref (the reference's own kernels on the CPU)")
     a = ap.parse_args()
     out = []
     for name in a.cases.split(","):
         for f in a.filters.split(","):
             mode = abi.FILTER_CUDA_FIXED8 if f == "fixed8" else abi.FILTER_EXACT
-            r = run_case(name, CASES[name], mode)
+            r = run_case(name, CASES[name], mode, with_ref=name in a.ref_cases.split(","))
             out.append(r)
             print(json.dumps(r), flush=True)
     if a.out:

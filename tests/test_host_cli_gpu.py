@@ -273,3 +273,29 @@ def test_default_process_downscale(tmp_path):
     m[:, :16] = m[:, -16:] = False
     assert m.mean() > 0.6
     assert np.median(np.abs(depth - gt)[m] / gt[m]) < 3e-3
+
+
+def test_multi_worker_exchange_equals_single_worker(dataset):
+    """the in-process multi-GPU path (computeOnMultiGPUs.cpp: one thread per device, R cameras dealt round-robin, every view decoded and
+    converted by ONE worker and copied device-to-device to the others through PyramidExchange): with AVDM_FAKE_DEVICES=2 the two workers
+    share the box's one GPU, so the whole path runs here, peer copies included.  The maps of every camera must be byte-identical to the
+    single-worker run — each worker computed from pyramids it RECEIVED for the views it does not own."""
+    sc, sfm, img, d = dataset
+    base = ["-i", sfm, "--imagesFolder", img, "--downscale", 1, "--rangeStart", 0, "--rangeSize", 4, "--sgmMaxDepths", 64,
+            "--colorOptimizationNbIterations", 5, "--tileBufferWidth", 400, "--tileBufferHeight", 300, "--tilePadding", 32, "-v", "info"]
+    out1, out2 = os.path.join(d, "out_w1"), os.path.join(d, "out_w2")
+    run_cli(base + ["-o", out1, "--nbGPUs", 1])
+    env = dict(os.environ, AVDM_FAKE_DEVICES="2")
+    r = subprocess.run([CLI] + [str(a) for a in base + ["-o", out2, "--nbGPUs", 2]], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    log = r.stdout + r.stderr
+    assert "workers: 2" in log and "Pyramid exchange:" in log, log[-2000:]
+    import re
+    m = re.search(r"Pyramid exchange: (\d+) views converted once, (\d+) peer copies", log)
+    assert m and int(m.group(1)) == NVIEWS and int(m.group(2)) >= 2, log[-2000:]  # every view decoded once; the others travelled
+    for i in range(4):
+        vid = scene_io.view_id(i)
+        for name in ("%d_depthMap.exr" % vid, "%d_simMap.exr" % vid):
+            a = open(os.path.join(out1, name), "rb").read()
+            b = open(os.path.join(out2, name), "rb").read()
+            assert a == b, name

@@ -24,31 +24,67 @@ def test_shards_partition_the_camera_list(n, world):
 
 
 def _worker(rank, world, port, q):
+    """rank-local part of the world-2 test.  The compute stand-in on CPU is the oracle (tests may use it); what is under test is the
+    sharding: a view is built ONLY by its owner, every other rank computes from the bytes it RECEIVED."""
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
-    from alicevision_amd.sharding import exchange_pyramid
+    from alicevision_amd import abi
+    from alicevision_amd.sharding import ViewExchange, cameras_of_rank, exchange_pyramid, owner_of_view
+    from alicevision_amd.synthetic import make_scene, plane_depths
+    from oracle import oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ok = True
-        # set-up phase: every view's pyramid is broadcast from its owner
-        for v in range(5):
-            want = torch.arange(1000, dtype=torch.uint8) * (v + 1)
-            buf = want.clone() if v % world == rank else torch.zeros(1000, dtype=torch.uint8)
-            exchange_pyramid(buf, src=v % world, dist=dist)
-            ok &= bool(torch.equal(buf, want))
-        # steady state: every rank has rebuilt one pyramid; all-gather
-        mine = torch.full((64,), rank + 7, dtype=torch.uint8)
-        got = exchange_pyramid(mine, src=rank, dist=dist, all_ranks=True)
+        V, W, H = 3, 96, 64
+        sc = make_scene(V, W, H, seed=4)
+        imgs = sc.images.numpy()
+        sgm, rp = abi.SgmParams.default(), abi.RefineParams.default(optimizationNbIterations=2)
+        mode = abi.FILTER_CUDA_FIXED8
+
+        def build(img):
+            return oracle.HostPyramid(img, 1, 128, mode)
+
+        # every rank builds ONLY the views it owns; the others start as zeros of the right size
+        nbytes = build(imgs[0]).desc.bytes
+        bufs = [torch.from_numpy(build(imgs[v]).buf.copy()) if owner_of_view(v, world) == rank else torch.zeros(nbytes, dtype=torch.uint8)
+                for v in range(V)]
+        ex = ViewExchange(bufs, rank, world, dist)
+        ex.setup()
+        ok &= ex.bytes_received == nbytes * sum(1 for v in range(V) if owner_of_view(v, world) != rank)
+
+        def depth_map(buffers, rc):
+            pyr = [oracle.HostPyramid.from_bytes(W, H, 1, 128, mode, b.numpy()) for b in buffers]
+            o = oracle.OracleDepthMap(None, sc.K, sc.R, sc.C, sgm, rp, filter_mode=mode, pyramids=pyr)
+            o.run_sgm(rc, [v for v in range(V) if v != rc], plane_depths(sc, 8))
+            return o.run_refine(rc, [v for v in range(V) if v != rc])
+
+        # a depth map of one of MY reference cameras from received neighbour pyramids == the same from locally built ones
+        rc = cameras_of_rank(list(range(V)), rank, world)[0]
+        got = depth_map(bufs, rc)
+        want = depth_map([torch.from_numpy(build(imgs[v]).buf.copy()) for v in range(V)], rc)
+        ok &= bool(np.array_equal(got, want)) and bool((want[..., 0] > 0).mean() > 0.3)
+
+        # steady state: every rank rebuilds the pyramid of a view it owns (a changed image); one all-gather hands it to the others
+        mine = cameras_of_rank(list(range(V)), rank, world)[0]
+        bufs[mine].copy_(torch.from_numpy(build(imgs[mine] * np.float32(0.8)).buf))
+        views = [cameras_of_rank(list(range(V)), r, world)[0] for r in range(world)]
+        ex.publish_round(views)
+        for r, v in enumerate(views):
+            ok &= bool(torch.equal(bufs[v], torch.from_numpy(build(imgs[v] * np.float32(0.8)).buf)))
+        # the one-shot helpers
+        one = torch.full((64,), rank + 7, dtype=torch.uint8)
+        got = exchange_pyramid(one, src=rank, dist=dist, all_ranks=True)
         ok &= len(got) == world and all(bool((g == r + 7).all()) for r, g in enumerate(got))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
 
 
-def test_pyramid_exchange_gloo_world2():
+def test_depth_map_from_received_pyramids_gloo_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -56,7 +92,7 @@ def test_pyramid_exchange_gloo_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
