@@ -110,6 +110,7 @@ SIGNATURES = {
     "avdm_rgb2lab": (i32, [vp, i32, i32, i32, vp]),
     "avdm_downscale_with_gaussian_blur": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "avdm_pyramid_build_levels": (i32, [P(Pyramid), vp]),
+    "avdm_image_resize": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, vp]),
     "avdm_pyramid_fill": (i32, [P(Pyramid), vp, i32, vp, vp]),
     "avdm_tex2dlod": (i32, [vp, P(Pyramid), vp, i32, vp]),
     "avdm_volume_initialize_u8": (i32, [vp, i64, i32, i32, i32, i32, u8, vp]),

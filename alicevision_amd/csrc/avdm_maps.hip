@@ -6,6 +6,11 @@
 #include "avdm_device.h"
 
 #include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace avdm {
 
@@ -632,6 +637,228 @@ __global__ void __launch_bounds__(256)
     *op = outDS;
 }
 
+// ---- the same iteration over a POINT map ----------------------------------------------------------------------------------------
+// optimize_step_kernel evaluates five pixel rays (3x3 product, IEEE square root and division) per pixel and iteration to turn its own
+// depth and its four neighbours' depths into 3-D points.  A pixel's point only depends on its own ray and depth, and every neighbour
+// computes it with the very same expression — so each pixel keeps {p.x, p.y, p.z, depth} in a float4 map: the owner evaluates its ray
+// ONCE per iteration (for the depth it has just stepped to) and the four neighbours read the finished point.  Same operations on the same
+// operands, hence the same bits as the depth-map form; the copy of the depth map per iteration (kernel 19 of the reference) becomes the
+// ping-pong of two point maps, and the (depth, sim) map is only written by the last iteration (sim is recomputed from scratch by every
+// iteration, mapKernels.cuh:596-604).  Neighbours outside the tile keep the reference's clamp semantics: the CLAMPED cell's depth on the
+// UNCLAMPED pixel's ray (mapKernels.cuh:41-51 sample the depth texture with clamp addressing but build the point from the cell index).
+__device__ __forceinline__ float4 opt_point(const avdm_camera_t& rc, float px, float py, float depth)
+{
+    const f3 p = point_at_depth(rc, px, py, depth);
+    return make_float4(p.x, p.y, p.z, depth);
+}
+
+__global__ void __launch_bounds__(256)
+  optimize_init_points_kernel(float4* __restrict__ pts, int pts_pitch, const float2* __restrict__ sgmDepthPixSize, int sgm_pitch, avdm_camera_t rc, avdm_roi_t roi)
+{
+    MAP_XY();
+    if(roiX >= roi.x.end - roi.x.begin || roiY >= roi.y.end - roi.y.begin)
+        return;
+    const float d = ((const float2*)((const char*)sgmDepthPixSize + (long long)roiY * sgm_pitch) + roiX)->x;
+    *((float4*)((char*)pts + (long long)roiY * pts_pitch) + roiX) = opt_point(rc, (float)roiX + (float)roi.x.begin, (float)roiY + (float)roi.y.begin, d);
+}
+
+template <bool LAST>
+__global__ void __launch_bounds__(256)
+  optimize_step_points_kernel(float4* __restrict__ ptsOut, const float4* __restrict__ ptsIn, int pts_pitch, float2* __restrict__ outOpt, int out_pitch,
+                              const float2* __restrict__ sgmDepthPixSize, int sgm_pitch, const float2* __restrict__ refineDepthSim, int ref_pitch,
+                              const float* __restrict__ imgVariance, int var_pitch, int texW, int texH, avdm_camera_t rc, avdm_roi_t roi)
+{
+    MAP_XY();
+    if(roiX >= roi.x.end - roi.x.begin || roiY >= roi.y.end - roi.y.begin)
+        return;
+    const float2 sgm = *((const float2*)((const char*)sgmDepthPixSize + (long long)roiY * sgm_pitch) + roiX);
+    const float sgmDepth = sgm.x, sgmPixSize = sgm.y;
+    const float2 rf = *((const float2*)((const char*)refineDepthSim + (long long)roiY * ref_pitch) + roiX);
+    const float refineDepth = rf.x, refineSim = rf.y;
+    const int cx = (int)roiX, cy = (int)roiY;
+    auto cell = [&](int x, int y) __attribute__((always_inline)) -> float4 {
+        return *((const float4*)((const char*)ptsIn + (long long)y * pts_pitch) + x);
+    };
+    const float fx = (float)roiX, fy = (float)roiY;
+    const float offx = (float)roi.x.begin, offy = (float)roi.y.begin;
+    // a neighbour cell: its finished point, or — outside the depth texture — the clamped cell's depth on the unclamped pixel's ray
+    auto neighbour = [&](int dx, int dy, f3& pt, float& d) __attribute__((always_inline)) {
+        const int x = cx + dx, y = cy + dy;
+        const int xc = min(max(x, 0), texW - 1), yc = min(max(y, 0), texH - 1);
+        const float4 c = cell(xc, yc);
+        d = c.w;
+        if(xc == x && yc == y)
+            pt = f3{c.x, c.y, c.z};
+        else
+            pt = point_at_depth(rc, (fx + (float)dx) + offx, (fy + (float)dy) + offy, d);
+    };
+    // my own state; the reference reads its own cell of the depth texture with clamp addressing too (a tile larger than the texture is
+    // not a case the callers produce, but the semantics are kept)
+    const float4 own = cell(cx, cy);
+    float4 c0 = own;
+    if(cx >= texW || cy >= texH)
+        c0 = opt_point(rc, fx + offx, fy + offy, cell(min(cx, texW - 1), min(cy, texH - 1)).w);
+    const float depthOpt = own.w;
+    float2 outDS = make_float2(depthOpt, refineSim); // pixels that never move keep (sgmDepth, refineSim) of iteration 0
+    float4 outPt = own;
+    if(depthOpt > 0.0f)
+    {
+        float smoothStep = 0.0f, energy = 180.0f;
+        const float d0 = c0.w;
+        if(d0 > 0.0f)
+        {
+            const f3 p0 = f3{c0.x, c0.y, c0.z};
+            f3 pL, pR, pU, pB;
+            float dL, dR, dU, dB;
+            neighbour(0, -1, pL, dL);
+            neighbour(0, 1, pR, dR);
+            neighbour(-1, 0, pU, dU);
+            neighbour(1, 0, pB, dB);
+            f3 cg = f3{0.f, 0.f, 0.f};
+            float n = 0.0f;
+            if(dL > 0.0f) { cg = cg + pL; n++; }
+            if(dR > 0.0f) { cg = cg + pR; n++; }
+            if(dU > 0.0f) { cg = cg + pU; n++; }
+            if(dB > 0.0f) { cg = cg + pB; n++; }
+            if(n > 1.0f)
+            {
+                cg = f3{cg.x / n, cg.y / n, cg.z / n};
+                const f3 vcn = normalize_exact(ld3(rc.C) - p0);
+                const f3 pS = closestPointToLine3D(cg, p0, vcn);
+                smoothStep = size(ld3(rc.C) - pS) - d0;
+            }
+            float e = 0.0f;
+            n = 0.0f;
+            if(dL > 0.0f && dR > 0.0f)
+            {
+                e = fmaxf(e, (180.0f - angleBetwABandAC(p0, pL, pR)));
+                n++;
+            }
+            if(dU > 0.0f && dB > 0.0f)
+            {
+                e = fmaxf(e, (180.0f - angleBetwABandAC(p0, pU, pB)));
+                n++;
+            }
+            if(n > 0.0f)
+                energy = e;
+        }
+        float stepToSmoothDepth = smoothStep;
+        stepToSmoothDepth = copysignf(fminf(fabsf(stepToSmoothDepth), sgmPixSize / 10.0f), stepToSmoothDepth);
+        const float depthEnergy = energy;
+        float stepToFineDM = refineDepth - depthOpt;
+        stepToFineDM = copysignf(fminf(fabsf(stepToFineDM), sgmPixSize / 10.0f), stepToFineDM);
+        const float stepToRoughDM = sgmDepth - depthOpt;
+        const float imgColorVariance = *((const float*)((const char*)imgVariance + (long long)roiY * var_pitch) + roiX);
+        const float weightedColorVariance = sigmoid2(5.0f, 30.0f, 40.0f, 20.0f, imgColorVariance);
+        const float fineSimWeight = sigmoid(0.0f, 1.0f, 0.7f, -0.7f, refineSim);
+        const float energyLowerThanVarianceWeight = sigmoid(0.0f, 1.0f, 30.0f, weightedColorVariance, depthEnergy);
+        const float closeToRoughWeight = 1.0f - sigmoid(0.0f, 1.0f, 10.0f, 17.0f, fabsf(stepToRoughDM / sgmPixSize));
+        const float depthOptStep = closeToRoughWeight * stepToRoughDM +
+                                   (1.0f - closeToRoughWeight) * (energyLowerThanVarianceWeight * fineSimWeight * stepToFineDM +
+                                                                  (1.0f - energyLowerThanVarianceWeight) * stepToSmoothDepth);
+        outDS.x = depthOpt + depthOptStep;
+        outDS.y = (1.0f - closeToRoughWeight) *
+                  (energyLowerThanVarianceWeight * fineSimWeight * refineSim + (1.0f - energyLowerThanVarianceWeight) * (depthEnergy / 20.0f));
+        if(!LAST)
+            outPt = opt_point(rc, fx + offx, fy + offy, outDS.x);
+    }
+    if(LAST)
+        *((float2*)((char*)outOpt + (long long)roiY * out_pitch) + roiX) = outDS;
+    else
+        *((float4*)((char*)ptsOut + (long long)roiY * pts_pitch) + roiX) = outPt;
+}
+
+// ---- the --downscale resize of the input images (imageAlgo::resizeImage -> OpenImageIO's ImageBufAlgo::resize, default filter) ----------
+// One lane per destination pixel, float4 = RGBA.  The tap tables (one row of normalised weights per destination column / row) are built on
+// the host by avdm_image_resize below; the double loop keeps OpenImageIO's order — rows outer, columns inner, the product wy * wx formed
+// first, zero products skipped — and this file is compiled without FMA contraction, so the sums round like the scalar code.
+__global__ void __launch_bounds__(256)
+  image_resize_kernel(float4* __restrict__ dst, int dst_pitch, int dstW, int dstH, const float4* __restrict__ src, int src_pitch, int srcW, int srcH,
+                      const float* __restrict__ wx, const int* __restrict__ fx, int xtaps, const float* __restrict__ wy, const int* __restrict__ fy, int ytaps)
+{
+    MAP_XY();
+    if(roiX >= (unsigned)dstW || roiY >= (unsigned)dstH)
+        return;
+    const float* xw = wx + (size_t)roiX * xtaps;
+    const float* yw = wy + (size_t)roiY * ytaps;
+    const int x0 = fx[roiX], y0 = fy[roiY];
+    float4 pel = make_float4(0.f, 0.f, 0.f, 0.f);
+    float totalx = 0.0f;
+    for(int i = 0; i < xtaps; ++i)
+        totalx += xw[i];
+    if(totalx != 0.0f)
+        for(int j = 0; j < ytaps; ++j)
+        {
+            const float wyj = yw[j];
+            if(wyj == 0.0f)
+                continue;
+            const int sy = min(max(y0 + j, 0), srcH - 1);
+            const float4* srow = (const float4*)((const char*)src + (long long)sy * src_pitch);
+            for(int i = 0; i < xtaps; ++i)
+            {
+                const float w = wyj * xw[i];
+                if(w != 0.0f)
+                {
+                    const float4 p = srow[min(max(x0 + i, 0), srcW - 1)];
+                    pel.x += w * p.x;
+                    pel.y += w * p.y;
+                    pel.z += w * p.z;
+                    pel.w += w * p.w;
+                }
+            }
+        }
+    *((float4*)((char*)dst + (long long)roiY * dst_pitch) + roiX) = pel;
+}
+
+// libutil/filter.cpp, FilterLanczos3_1D::lanczos3 (OpenImageIO 2.x): one sinf, sin(pi x) through the triple-angle identity
+static float oiio_lanczos3(float x)
+{
+    const float a = 3.0f;
+    const float ainv = 1.0f / a;
+    const float m_pi = (float)3.14159265358979323846;
+    x = fabsf(x);
+    if(x > a)
+        return 0.0f;
+    if(x < 0.0001f)
+        return 1.0f;
+    const float s1 = sinf(x * ainv * m_pi);
+    const float s3 = (-4.0f * s1 * s1 + 3.0f) * s1;
+    return a / (x * x * (m_pi * m_pi)) * s3 * s1;
+}
+// imagebufalgo_xform.cpp, resize_(): the normalised tap weights of every destination pixel of one axis, and the source index of tap 0
+static int oiio_resize_taps(int dstN, int srcN, std::vector<float>& weights, std::vector<int>& first)
+{
+    const float srcf = (float)srcN, dstf = (float)dstN;
+    const float ratio = dstf / srcf;
+    const float dstpixel = 1.0f / dstf;
+    const float width = 6.0f * std::max(1.0f, ratio); // get_resize_filter(): fd.width * max(1, ratio)
+    const float filterrad = width / 2.0f;
+    const float wscale = 6.0f / width;                // FilterLanczos3_2D::m_wscale
+    const int rad = (int)ceilf(filterrad / ratio);
+    const int taps = 2 * rad + 1;
+    weights.resize((size_t)taps * dstN);
+    first.resize(dstN);
+    for(int d = 0; d < dstN; ++d)
+    {
+        const float s = ((float)d - 0.0f + 0.5f) * dstpixel;
+        const float src_f = 0.0f + s * srcf;
+        const float fl = floorf(src_f);
+        const float frac = src_f - fl;
+        float total = 0.0f;
+        float* w = weights.data() + (size_t)d * taps;
+        for(int i = 0; i < taps; ++i)
+        {
+            w[i] = oiio_lanczos3((ratio * ((float)(i - rad) - (frac - 0.5f))) * wscale);
+            total += w[i];
+        }
+        if(total != 0.0f)
+            for(int i = 0; i < taps; ++i)
+                w[i] /= total;
+        first[d] = (int)fl - rad;
+    }
+    return taps;
+}
+
 static inline dim3 map_grid(unsigned w, unsigned h) { return dim3(divUp(w, 64), divUp(h, 4)); }
 static inline int stream_blocks(long long total)
 {
@@ -801,6 +1028,41 @@ int avdm_compute_sgm_upscaled_depth_pixsize_map(float* out_map, int out_pitch, c
     AVDM_LAUNCH_CHECK("avdm_compute_sgm_upscaled_depth_pixsize_map");
 }
 
+int avdm_image_resize(float* dst_rgba, int dst_pitch, int dst_w, int dst_h, const float* src_rgba, int src_pitch, int src_w, int src_h, void* stream)
+{
+    if(dst_w <= 0 || dst_h <= 0 || src_w <= 0 || src_h <= 0)
+        return set_error_msg(1, "avdm_image_resize: empty image");
+    if(dst_w > src_w || dst_h > src_h)
+        return set_error_msg(1, "avdm_image_resize: enlarging is not supported (OpenImageIO would select blackman-harris)");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> wx, wy;
+    std::vector<int> fx, fy;
+    const int xtaps = oiio_resize_taps(dst_w, src_w, wx, fx), ytaps = oiio_resize_taps(dst_h, src_h, wy, fy);
+    const size_t bwx = (wx.size() * sizeof(float) + 255) & ~(size_t)255, bwy = (wy.size() * sizeof(float) + 255) & ~(size_t)255;
+    const size_t bfx = (fx.size() * sizeof(int) + 255) & ~(size_t)255, bfy = (fy.size() * sizeof(int) + 255) & ~(size_t)255;
+    char* tab = nullptr;
+    if(hipMallocAsync((void**)&tab, bwx + bwy + bfx + bfy, st) != hipSuccess || tab == nullptr)
+        return set_error_msg(2, "avdm_image_resize: scratch allocation failed");
+    hipError_t e = hipMemcpyAsync(tab, wx.data(), wx.size() * sizeof(float), hipMemcpyHostToDevice, st);
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(tab + bwx, wy.data(), wy.size() * sizeof(float), hipMemcpyHostToDevice, st);
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(tab + bwx + bwy, fx.data(), fx.size() * sizeof(int), hipMemcpyHostToDevice, st);
+    if(e == hipSuccess)
+        e = hipMemcpyAsync(tab + bwx + bwy + bfx, fy.data(), fy.size() * sizeof(int), hipMemcpyHostToDevice, st);
+    if(e == hipSuccess)
+    {
+        hipLaunchKernelGGL(image_resize_kernel, map_grid((unsigned)dst_w, (unsigned)dst_h), dim3(256), 0, st, (float4*)dst_rgba, dst_pitch, dst_w, dst_h,
+                           (const float4*)src_rgba, src_pitch, src_w, src_h, (const float*)tab, (const int*)(tab + bwx + bwy), xtaps,
+                           (const float*)(tab + bwx), (const int*)(tab + bwx + bwy + bfx), ytaps);
+        e = hipGetLastError();
+    }
+    (void)hipFreeAsync(tab, st);
+    // the tap tables live in pageable host memory: they must outlive the copies
+    const hipError_t es = hipStreamSynchronize(st);
+    return ::avdm::set_error(e != hipSuccess ? e : es, "avdm_image_resize");
+}
+
 int avdm_depth_sim_map_compute_normal(float* out_normal, int out_pitch, const float* in_depth_sim, int in_pitch, const avdm_camera_t* rc, int stepXY,
                                       avdm_roi_t roi, void* stream)
 {
@@ -835,14 +1097,59 @@ int avdm_depth_sim_map_optimize_gradient_descent(float* out_opt_depth_sim, int o
     else
         hipLaunchKernelGGL(var_L_kernel<false>, grid, dim3(256), 0, st, img_variance, var_pitch, t.lv[level], wN, hN, rp->stepXY, roi);
 
-    for(int iter = 0; iter < rp->optimizationNbIterations; ++iter)
+    const int nIter = rp->optimizationNbIterations;
+    const char* legacy = getenv("AVDM_OPT_DEPTH_MAP_FORM"); // A/B: the two-launches-per-iteration depth-map form
+    if(legacy && legacy[0] == '1')
     {
-        hipLaunchKernelGGL(extract_depth_kernel, grid, dim3(256), 0, st, tmp_depth, tmp_pitch, (const float2*)out_opt_depth_sim, out_pitch, roi);
-        hipLaunchKernelGGL(optimize_step_kernel, grid, dim3(256), 0, st, (float2*)out_opt_depth_sim, out_pitch, (const float2*)sgm_depth_pixsize,
-                           sgm_pitch, (const float2*)refine_depth_sim, ref_pitch, img_variance, var_pitch, tmp_depth, tmp_pitch, tmp_w, tmp_h, *rc, iter,
-                           roi);
+        for(int iter = 0; iter < nIter; ++iter)
+        {
+            hipLaunchKernelGGL(extract_depth_kernel, grid, dim3(256), 0, st, tmp_depth, tmp_pitch, (const float2*)out_opt_depth_sim, out_pitch, roi);
+            hipLaunchKernelGGL(optimize_step_kernel, grid, dim3(256), 0, st, (float2*)out_opt_depth_sim, out_pitch, (const float2*)sgm_depth_pixsize,
+                               sgm_pitch, (const float2*)refine_depth_sim, ref_pitch, img_variance, var_pitch, tmp_depth, tmp_pitch, tmp_w, tmp_h, *rc,
+                               iter, roi);
+        }
+        AVDM_LAUNCH_CHECK("avdm_depth_sim_map_optimize_gradient_descent");
     }
-    AVDM_LAUNCH_CHECK("avdm_depth_sim_map_optimize_gradient_descent");
+    if(nIter <= 0)
+        return 0;
+    // point-map form (see optimize_step_points_kernel): two float4 maps of the tile, stream-ordered scratch (several tiles may be in
+    // flight on different streams); `tmp_depth` — the reference's copy of the depth map — is not needed.  The depth texture is the tile
+    // itself (the reference binds the whole allocated buffer and reads cells no kernel of the tile wrote).
+    const int texW = std::min<int>(tmp_w, (int)roiW), texH = std::min<int>(tmp_h, (int)roiH);
+    const int ptsPitch = (int)(((size_t)roiW * sizeof(float4) + 255) & ~(size_t)255);
+    const size_t mapBytes = (size_t)ptsPitch * roiH;
+    char* scratch = nullptr;
+    {
+        static std::once_flag once[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::call_once(once[dev & 63], [&] {
+            hipMemPool_t pool;
+            if(hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
+            {
+                uint64_t keep = UINT64_MAX; // keep freed blocks in the pool: one allocation per tile size, not one per call
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            }
+        });
+    }
+    if(hipMallocAsync((void**)&scratch, 2 * mapBytes, st) != hipSuccess || scratch == nullptr)
+        return set_error_msg(2, "avdm_depth_sim_map_optimize_gradient_descent: scratch allocation failed");
+    float4* pts[2] = {(float4*)scratch, (float4*)(scratch + mapBytes)};
+    hipLaunchKernelGGL(optimize_init_points_kernel, grid, dim3(256), 0, st, pts[0], ptsPitch, (const float2*)sgm_depth_pixsize, sgm_pitch, *rc, roi);
+    for(int iter = 0; iter < nIter; ++iter)
+    {
+        if(iter == nIter - 1)
+            hipLaunchKernelGGL(optimize_step_points_kernel<true>, grid, dim3(256), 0, st, pts[(iter + 1) & 1], pts[iter & 1], ptsPitch,
+                               (float2*)out_opt_depth_sim, out_pitch, (const float2*)sgm_depth_pixsize, sgm_pitch, (const float2*)refine_depth_sim,
+                               ref_pitch, img_variance, var_pitch, texW, texH, *rc, roi);
+        else
+            hipLaunchKernelGGL(optimize_step_points_kernel<false>, grid, dim3(256), 0, st, pts[(iter + 1) & 1], pts[iter & 1], ptsPitch,
+                               (float2*)out_opt_depth_sim, out_pitch, (const float2*)sgm_depth_pixsize, sgm_pitch, (const float2*)refine_depth_sim,
+                               ref_pitch, img_variance, var_pitch, texW, texH, *rc, roi);
+    }
+    const hipError_t launchErr = hipGetLastError();
+    (void)hipFreeAsync(scratch, st);
+    return ::avdm::set_error(launchErr, "avdm_depth_sim_map_optimize_gradient_descent");
 }
 
 } // extern "C"

@@ -659,8 +659,13 @@ __device__ __forceinline__ unsigned pk_div(unsigned n)
         return as_u32(as_pk(n) >> (unsigned short)1);
     if(KP1 == 4)
         return as_u32(as_pk(n) >> (unsigned short)2);
-    const unsigned lo = ((n & 0xffffu) * 683u) >> 11, hi = ((n >> 16) * 683u) >> 11; // n div 3, exhaustively checked for n <= 1020
-    return lo | (hi << 16);
+    // n div 3 == (n * 683) >> 11 == (n * 21856) >> 16 for n <= 1020 (exhaustively checked, tests/test_host_cpu.py): the two 32-bit
+    // products by SDWA word selects, the two quotients (bits 16..25 of each product) gathered by one v_perm_b32 — 3 instructions per pair
+    unsigned lo, hi;
+    const unsigned mul = 21856u;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(lo) : "v"(n), "v"(mul));
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(hi) : "v"(n), "v"(mul));
+    return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
 }
 // (o * K + c) div (K + 1)
 template <int K>
@@ -781,13 +786,26 @@ __device__ __forceinline__ float avg_f32(float o, float lc)
 #ifndef AVDM_SGM_USE_BUFFER
 #define AVDM_SGM_USE_BUFFER 0 // 1: raw buffer instructions (descriptor + SGPR slice offset), 0: global_load / global_store
 #endif
+// A copy of a 32-bit lane offset that the optimizer cannot trace back to its definition.  col + sliceOff is wave-uniform (SGPRs); when the
+// zero extension of the lane offset stays in the basic block of the access, instruction selection sees (uniform base + zext(i32)) and emits
+// global_load_dword v, v_off, s[base:base+1]  — otherwise the extension is hoisted out of the loop and every access pays a 64-bit VALU add
+// (v_lshl_add_u64: 3-4 of the ~40 VALU instructions of a step).  One copy (v_mov_b32) per basic block: per ring reload, per group of steps.
+__device__ __forceinline__ unsigned opaque_lane_offset(unsigned laneOff)
+{
+    asm volatile("" : "+v"(laneOff));
+    return laneOff;
+}
 // one dword of slice `sliceOff` (bytes from the column base) at lane offset `laneOff`
 __device__ __forceinline__ unsigned ld_slice(__amdgpu_buffer_rsrc_t rsrc, const uint8_t* col, unsigned laneOff, unsigned sliceOff)
 {
 #if AVDM_SGM_USE_BUFFER
     return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)laneOff, (int)sliceOff, AVDM_SGM_AUX_LD);
 #else
-    const unsigned* p = reinterpret_cast<const unsigned*>(col + (size_t)sliceOff + laneOff);
+    const uint8_t* base = col + (size_t)sliceOff; // wave-uniform
+    asm volatile("" : "+s"(base));                // ... and kept apart from the lane offset (no re-association into (col + lane) + slice)
+    // (the asm hides that the pointer is a global one: say so again, or the access becomes a flat_load)
+    typedef const __attribute__((address_space(1))) unsigned* gptr_t;
+    gptr_t p = (gptr_t)(base + laneOff);
     return AVDM_SGM_AUX_LD ? __builtin_nontemporal_load(p) : *p;
 #endif
 }
@@ -796,7 +814,10 @@ __device__ __forceinline__ void st_slice(unsigned v, __amdgpu_buffer_rsrc_t rsrc
 #if AVDM_SGM_USE_BUFFER
     __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, (int)laneOff, (int)sliceOff, AVDM_SGM_AUX_ST);
 #else
-    unsigned* p = reinterpret_cast<unsigned*>(col + (size_t)sliceOff + laneOff);
+    uint8_t* base = col + (size_t)sliceOff;
+    asm volatile("" : "+s"(base));
+    typedef __attribute__((address_space(1))) unsigned* gptr_t;
+    gptr_t p = (gptr_t)(base + laneOff);
     if(AVDM_SGM_AUX_ST)
         __builtin_nontemporal_store(v, p);
     else
@@ -949,24 +970,31 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
 
         unsigned rin[NS][PF][NW], rout[NS][PF][NW], rtmp[NS][PF][NW];
         auto load_group = [&](unsigned (&ri)[PF][NW], unsigned (&ro)[PF][NW], unsigned (&rt)[PF][NW]) __attribute__((always_inline)) {
+            unsigned lo[NW];
+#pragma unroll
+            for(int w = 0; w < NW; ++w)
+                lo[w] = opaque_lane_offset(Ln.offw[w]);
 #pragma unroll
             for(int t = 0; t < PF; ++t)
             {
 #pragma unroll
                 for(int w = 0; w < NW; ++w)
                 {
-                    ri[t][w] = ld_slice(rsrcIn, inCol, Ln.offw[w], inLoad);
+                    ri[t][w] = ld_slice(rsrcIn, inCol, lo[w], inLoad);
                     if(LOAD_OUT)
-                        ro[t][w] = ld_slice(rsrcOut, outCol, Ln.offw[w], inLoad);
+                        ro[t][w] = ld_slice(rsrcOut, outCol, lo[w], inLoad);
                     if(LOAD_TMP)
-                        rt[t][w] = ld_slice(rsrcTmp, tmpCol, Ln.offw[w], tmpLoad);
+                        rt[t][w] = ld_slice(rsrcTmp, tmpCol, lo[w], tmpLoad);
                 }
                 // past the end: keep re-reading the last slice of the walk (harmless).  Written as selects: a branch here splits
                 // the loads over basic blocks and makes the waitcnt insertion fall back to vmcnt(0) at the joins
-                const bool more = nLoaded + 1 < nSteps;
-                inLoad += more ? (unsigned)dirStride : 0u;
-                tmpLoad += more ? (unsigned)tDirStride : 0u;
-                nLoaded += more ? 1 : 0;
+                // scalar min / multiply: a conditional increment (nLoaded += more ? 1 : 0) goes through v_cndmask + v_readfirstlane, and a plain
+                // counter lets the optimizer thread the "past the end" case into branches between the loads
+                const int nxt = min(nLoaded + 1, nSteps - 1);
+                const unsigned adv = (unsigned)(nxt - nLoaded); // 1, or 0 past the end
+                inLoad += adv * (unsigned)dirStride;
+                tmpLoad += adv * (unsigned)tDirStride;
+                nLoaded = nxt;
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -1003,9 +1031,11 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
             }
         };
 
-        auto step = [&](auto fastTag, int i, const unsigned (&inw)[NW], const unsigned (&ow)[NW], const unsigned (&tw)[NW]) __attribute__((always_inline)) {
+        auto step = [&](auto fastTag, int i, const unsigned (&inw)[NW], const unsigned (&ow)[NW], const unsigned (&tw)[NW],
+                        const unsigned (&stLo)[NW]) __attribute__((always_inline)) {
             constexpr bool FAST = decltype(fastTag)::value;
             const int idx = i & 63;
+            unsigned newWords[NW];
             if(FAST)
             {
                 unsigned q[NR];
@@ -1035,16 +1065,7 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
                             res[h] = pk_avg<K + 1>(pk_avg<K>(o, c), t);
                         }
                     }
-                    const unsigned neww = __builtin_amdgcn_perm(res[1], res[0], 0x06040200u);
-                    if(FULL)
-                        st_slice(neww, STORE_TMP ? rsrcTmp : rsrcOut, STORE_TMP ? tmpCol : outCol, Ln.offw[w], outStore);
-                    else if(Ln.wAny[w])
-                    {
-                        if(STORE_TMP)
-                            st_slice(neww, rsrcTmp, tmpCol, Ln.offw[w], outStore); // scratch padding is free
-                        else
-                            st_slice((neww & Ln.vmask[w]) | (ow[w] & ~Ln.vmask[w]), rsrcOut, outCol, Ln.offw[w], outStore);
-                    }
+                    newWords[w] = __builtin_amdgcn_perm(res[1], res[0], 0x06040200u);
                 }
             }
             else
@@ -1134,15 +1155,22 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
                         }
                         neww = __builtin_amdgcn_cvt_pk_u8_f32(q, j, neww);
                     }
-                    if(FULL)
-                        st_slice(neww, STORE_TMP ? rsrcTmp : rsrcOut, STORE_TMP ? tmpCol : outCol, Ln.offw[w], outStore);
-                    else if(Ln.wAny[w])
-                    {
-                        if(STORE_TMP)
-                            st_slice(neww, rsrcTmp, tmpCol, Ln.offw[w], outStore);
-                        else
-                            st_slice((neww & Ln.vmask[w]) | (ow[w] & ~Ln.vmask[w]), rsrcOut, outCol, Ln.offw[w], outStore);
-                    }
+                    newWords[w] = neww;
+                }
+            }
+            // the stores are COMMON code after the integer / fp32 alternatives (like the ring reloads): memory operations inside the
+            // alternatives give the wait-counter insertion two histories to merge at the join, and it then waits for the older one
+#pragma unroll
+            for(int w = 0; w < NW; ++w)
+            {
+                if(FULL)
+                    st_slice(newWords[w], STORE_TMP ? rsrcTmp : rsrcOut, STORE_TMP ? tmpCol : outCol, stLo[w], outStore);
+                else if(Ln.wAny[w])
+                {
+                    if(STORE_TMP)
+                        st_slice(newWords[w], rsrcTmp, tmpCol, stLo[w], outStore); // scratch padding is free
+                    else
+                        st_slice((newWords[w] & Ln.vmask[w]) | (ow[w] & ~Ln.vmask[w]), rsrcOut, outCol, stLo[w], outStore);
                 }
             }
             outStore += storeStride;
@@ -1153,24 +1181,35 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
         // One group = PF consecutive steps on ring slot s, then the reload of that slot.  The reload is COMMON code after the
         // fast / generic alternatives: the ring registers then have a single definition site per slot, so no copies of just-issued
         // loads appear at control-flow joins (such copies force the wait counter to zero and drain the prefetch ring).
-        auto group = [&](int g, unsigned (&ri)[PF][NW], unsigned (&ro)[PF][NW], unsigned (&rt)[PF][NW]) __attribute__((always_inline)) {
-            const unsigned risky = (unsigned)(riskyMask >> ((g * PF) & 63)) & ((1u << PF) - 1u);
-            if(g * PF + PF <= nSteps && risky == 0u)
+        // MODE 0: all PF steps exist and none takes the fp32 alternative (the hot code: nothing but integer steps and the reload);
+        // MODE 1: all PF steps exist, some may take the fp32 alternative; MODE 2: the last, possibly partial groups of a walk.
+        // The main loop picks MODE 0 / MODE 1 per SPAN of NS groups, so the hot loop body is one contiguous run of integer steps: with the
+        // choice made per group, the (almost never executed) fp32 alternatives sat between every two groups of the hot path and the kernel
+        // ran 2.4 x slower than without them (profiles/README.md, r02_e).  In MODE 1 / 2 every path through a step still consumes its ring
+        // registers: a path that skipped one would leave a load pending at the join, and the reload below would have to wait for it.
+        auto group = [&](auto modeTag, int g, unsigned (&ri)[PF][NW], unsigned (&ro)[PF][NW], unsigned (&rt)[PF][NW]) __attribute__((always_inline)) {
+            constexpr int MODE = decltype(modeTag)::value;
+            if(MODE == 0)
             {
+                unsigned stLo[NW]; // the PF stores of the group are in this one basic block
+#pragma unroll
+                for(int w = 0; w < NW; ++w)
+                    stLo[w] = opaque_lane_offset(Ln.offw[w]);
 #pragma unroll
                 for(int t = 0; t < PF; ++t)
-                    step(std::true_type{}, g * PF + t, ri[t], ro[t], rt[t]);
+                    step(std::true_type{}, g * PF + t, ri[t], ro[t], rt[t], stLo);
             }
             else
             {
+                const unsigned risky = (unsigned)(riskyMask >> ((g * PF) & 63)) & ((1u << PF) - 1u);
 #pragma unroll
                 for(int t = 0; t < PF; ++t)
-                    if(g * PF + t < nSteps)
+                    if(MODE == 1 || g * PF + t < nSteps)
                     {
                         if((risky >> t) & 1u)
-                            step(std::false_type{}, g * PF + t, ri[t], ro[t], rt[t]);
+                            step(std::false_type{}, g * PF + t, ri[t], ro[t], rt[t], Ln.offw);
                         else
-                            step(std::true_type{}, g * PF + t, ri[t], ro[t], rt[t]);
+                            step(std::true_type{}, g * PF + t, ri[t], ro[t], rt[t], Ln.offw);
                     }
             }
             load_group(ri, ro, rt);
@@ -1190,8 +1229,9 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
         // main loop: whole spans of NS groups with NO per-group guards — every control-flow path that cannot happen at run
         // time but exists in the CFG (e.g. group 0 -> skip 1..3 -> group 0) makes the waitcnt insertion assume the ring slot was
         // reloaded one group ago and wait for it with vmcnt(7), which drains the ring
+        const int nWholeGroups = nSteps / PF;
         int G = 0;
-        for(; G + NS <= nGroups; G += NS)
+        for(; G + NS <= nWholeGroups; G += NS)
         {
             if(G > 0 && ((G * PF) & 63) == 0)
             {
@@ -1201,11 +1241,21 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
                 if(ROLE == SGM_SECOND_FWD)
                     p2nextShifted = load_p2_shifted((G * PF) / 64 + 1);
             }
+            const unsigned long long spanBits = (NS * PF >= 64) ? ~0ull : ((1ull << (NS * PF)) - 1ull);
+            if(((riskyMask >> ((G * PF) & 63)) & spanBits) == 0ull)
+            {
 #pragma unroll
-            for(int s = 0; s < NS; ++s)
-                group(G + s, rin[s], rout[s], rtmp[s]);
+                for(int s = 0; s < NS; ++s)
+                    group(std::integral_constant<int, 0>{}, G + s, rin[s], rout[s], rtmp[s]);
+            }
+            else
+            {
+#pragma unroll
+                for(int s = 0; s < NS; ++s)
+                    group(std::integral_constant<int, 1>{}, G + s, rin[s], rout[s], rtmp[s]);
+            }
         }
-        if(G < nGroups) // last, partial span
+        if(G < nGroups) // last span: up to NS - 1 whole groups and a partial one (within one 64-step block of the P2 map: G * PF is a multiple of 32)
         {
             if(G > 0 && ((G * PF) & 63) == 0)
             {
@@ -1213,9 +1263,9 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
                 set_p2_block(p2next, p2nextShifted);
             }
 #pragma unroll
-            for(int s = 0; s < NS - 1; ++s)
+            for(int s = 0; s < NS; ++s)
                 if(G + s < nGroups)
-                    group(G + s, rin[s], rout[s], rtmp[s]);
+                    group(std::integral_constant<int, 2>{}, G + s, rin[s], rout[s], rtmp[s]);
         }
     };
 
@@ -1378,10 +1428,11 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
     int nAxes = 0;
     for(const char* ax = sp->filteringAxes; *ax; ++ax)
     {
+        // the reference looks every character up in a {X, Y} table (std::map::at throws otherwise, deviceSimilarityVolume.cu:393-405)
         if(*ax != 'X' && *ax != 'Y')
-            continue;
+            return set_error_msg(1, "avdm_volume_optimize: filteringAxes may only contain 'X' and 'Y'");
         if(nAxes >= 2)
-            return set_error_msg(1, "avdm_volume_optimize: at most 2 filtering axes");
+            return set_error_msg(1, "avdm_volume_optimize: at most 2 filtering axes (the reference runs two paths per character for any length)");
         axisIsX[nAxes++] = (*ax == 'X');
     }
     // pass 1: the adaptive-P2 map of every (axis, tile) — ONE launch for all of them when they fit the kernel-argument table

@@ -424,6 +424,8 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
         auto sample = [&](int xp) __attribute__((always_inline)) {
                 const float fx = (float)xp;
                 // == sample_pos(): homogeneous coordinates, one v_rcp per image, texel-space transform
+                // (replacing the two v_rcp_f32 by a packed third-order series in the patch's depth extent was measured, r02_e: no change —
+                // the transcendental pipe runs beside the packed FMAs, it is not what the loop waits for)
                 const v2f hz = fx * az + rowz;
                 const v2f inv = {fast_rcp(hz.x), fast_rcp(hz.y)};
                 const v2f X = (fx * axS + rowx) * inv + Ox;

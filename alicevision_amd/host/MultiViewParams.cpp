@@ -401,8 +401,7 @@ bool triangulateMatch(Point3d& out, const Point2d& refpix, const Point2d& tarpix
     return lineLineIntersect(out, mp.CArr[refCam], refpoint, mp.CArr[tarCam], tarpoint);
 }
 
-// mvsUtils/fileIO.cpp:389-443.  Decoding is OpenEXR only; the --downscale resize is a box filter (the reference calls
-// OpenImageIO's resize, whose filter is not restated: DESIGN.md "out of scope").
+// mvsUtils/fileIO.cpp:389-443.  Decoding is OpenEXR only; the --downscale resize happens on the device (see below).
 std::shared_ptr<const HostImage> ImagesCache::getImg_sync(int camId)
 {
     {
@@ -427,8 +426,6 @@ std::shared_ptr<const HostImage> ImagesCache::getImg_sync(int camId)
         throw std::runtime_error("image '" + path + "' has neither R,G,B nor Y channels");
     const size_t n = (size_t)exr.width * exr.height;
     auto full = std::make_shared<HostImage>();
-    full->width = exr.width;
-    full->height = exr.height;
     full->rgba.resize(n * 4);
     const float* r = exr.channels[iR >= 0 ? iR : iY].data();
     const float* g = exr.channels[iG >= 0 ? iG : iY].data();
@@ -442,29 +439,16 @@ std::shared_ptr<const HostImage> ImagesCache::getImg_sync(int camId)
         full->rgba[4 * i + 2] = b[i];
         full->rgba[4 * i + 3] = a ? a[i] : 1.0f;
     }
-    std::shared_ptr<const HostImage> result = full;
+    // --downscale: the image stays at its decoded size here; DeviceMipmapImage::fill resizes it on the device with OpenImageIO's default
+    // filter restated (avdm_image_resize <-> imageAlgo::resizeImage, fileIO.cpp:432-441) instead of a host loop over 12-24 M pixels
     const int s = _mp.getProcessDownscale();
+    full->srcWidth = exr.width;
+    full->srcHeight = exr.height;
+    full->width = s > 1 ? exr.width / s : exr.width;
+    full->height = s > 1 ? exr.height / s : exr.height;
     if(s > 1)
-    {
         AVDM_LOG_DEBUG("Downscale (x" << s << ") image: " << _mp.getViewId(camId) << ".");
-        auto small = std::make_shared<HostImage>();
-        small->width = exr.width / s;
-        small->height = exr.height / s;
-        small->rgba.resize((size_t)small->width * small->height * 4);
-        const float inv = 1.0f / float(s * s);
-#pragma omp parallel for
-        for(int y = 0; y < small->height; ++y)
-            for(int x = 0; x < small->width; ++x)
-                for(int c = 0; c < 4; ++c)
-                {
-                    float acc = 0.f;
-                    for(int dy = 0; dy < s; ++dy)
-                        for(int dx = 0; dx < s; ++dx)
-                            acc += full->rgba[((size_t)(y * s + dy) * exr.width + (x * s + dx)) * 4 + c];
-                    small->rgba[((size_t)y * small->width + x) * 4 + c] = acc * inv;
-                }
-        result = small;
-    }
+    std::shared_ptr<const HostImage> result = full;
     std::lock_guard<std::mutex> lock(_mutex);
     if(_cache.size() >= _max)
     {

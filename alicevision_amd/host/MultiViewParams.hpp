@@ -125,7 +125,8 @@ bool triangulateMatch(Point3d& out, const Point2d& refpix, const Point2d& tarpix
 // linear RGBA float image at process resolution (image::Image<RGBAfColor>), interleaved
 struct HostImage
 {
-    int width = 0, height = 0;
+    int width = 0, height = 0;       // size the process works at: source size / --downscale (integer division, imageAlgo.cpp:326-368)
+    int srcWidth = 0, srcHeight = 0; // size of `rgba` as decoded; the --downscale resize runs on the device (avdm_image_resize)
     std::vector<float> rgba;
 };
 // mvsUtils/fileIO.cpp:389-443 loadImage + mvsUtils/ImagesCache.hpp: a small thread-safe RAM cache keyed by camera index

@@ -27,12 +27,22 @@ void DeviceMipmapImage::fill(const HostImage& img, int minDownscale, int maxDown
         _buf.allocate((size_t)p.bytes);
     p.base = _buf.ptr();
     _pyr = p;
-    const size_t imgBytes = (size_t)img.width * img.height * 16;
-    DeviceBuffer rgba(imgBytes), scratch;
+    const int srcW = img.srcWidth > 0 ? img.srcWidth : img.width, srcH = img.srcHeight > 0 ? img.srcHeight : img.height;
+    const size_t srcBytes = (size_t)srcW * srcH * 16, imgBytes = (size_t)img.width * img.height * 16;
+    DeviceBuffer rgba(srcBytes), resized, scratch;
     if(minDownscale > 1)
         scratch.allocate((size_t)img.width * img.height * 8);
-    AVDM_HIP_CHECK(hipMemcpyAsync(rgba.ptr(), img.rgba.data(), imgBytes, hipMemcpyHostToDevice, stream));
-    avdmCheck(avdm_pyramid_fill(&_pyr, rgba.as<float>(), img.width * 16, scratch.ptr(), stream), "avdm_pyramid_fill");
+    AVDM_HIP_CHECK(hipMemcpyAsync(rgba.ptr(), img.rgba.data(), srcBytes, hipMemcpyHostToDevice, stream));
+    const float* processImage = rgba.as<float>();
+    if(srcW != img.width || srcH != img.height)
+    {
+        // --downscale (fileIO.cpp:432-441): OpenImageIO's default resize, on the device
+        resized.allocate(imgBytes);
+        avdmCheck(avdm_image_resize(resized.as<float>(), img.width * 16, img.width, img.height, rgba.as<float>(), srcW * 16, srcW, srcH, stream),
+                  "avdm_image_resize");
+        processImage = resized.as<float>();
+    }
+    avdmCheck(avdm_pyramid_fill(&_pyr, processImage, img.width * 16, scratch.ptr(), stream), "avdm_pyramid_fill");
     AVDM_HIP_CHECK(hipStreamSynchronize(stream)); // the temporaries die here
 }
 

@@ -21,6 +21,7 @@
 #include <iostream>
 #include <map>
 #include <sstream>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -273,6 +274,32 @@ int aliceVision_main(int argc, char* argv[])
         if(sgmScaleStep % refineScaleStep != 0)
         {
             AVDM_LOG_ERROR("SGM downscale (scale x step) should be a multiple of the Refine downscale (scale x step).");
+            return EXIT_FAILURE;
+        }
+    }
+    // Mip levels.  The reference samples its images at the fractional level log2(scale / min(sgmScale, refineScale)) with a mip-linear texture
+    // (deviceMipmappedArray.cu:348, DeviceMipmapImage::getLevel); the default-path kernels of this implementation stage ONE level in LDS, so
+    // the two scales must be a power-of-two multiple of each other (every combination Meshroom's defaults produce).  Said here, at parse
+    // time, instead of failing in the middle of the first tile (out of scope).
+    if(sgmParams.scale > 0 && refineParams.scale > 0)
+    {
+        const int lo = std::min(sgmParams.scale, refineParams.scale), hi = std::max(sgmParams.scale, refineParams.scale);
+        const int ratio = (hi % lo == 0) ? hi / lo : 0;
+        if(ratio == 0 || (ratio & (ratio - 1)) != 0)
+        {
+            AVDM_LOG_ERROR("sgmScale (" << sgmParams.scale << ") and refineScale (" << refineParams.scale
+                                        << ") must be a power-of-two multiple of each other: fractional mip levels (e.g. --sgmScale 3 --refineScale 1) "
+                                           "are not supported by this implementation.");
+            return EXIT_FAILURE;
+        }
+    }
+    // filtering axes: the reference maps every character through a table of {X, Y} (std::map::at throws on anything else) and runs two
+    // paths per character; this implementation runs one or two axes.
+    {
+        const std::string& axes = sgmParams.filteringAxes;
+        if(axes.empty() || axes.size() > 2 || axes.find_first_not_of("XY") != std::string::npos)
+        {
+            AVDM_LOG_ERROR("Invalid value for sgmFilteringAxes ('" << axes << "'): one or two characters out of 'X' and 'Y' (e.g. \"YX\").");
             return EXIT_FAILURE;
         }
     }

@@ -170,6 +170,12 @@ int avdm_pyramid_build_levels(const avdm_pyramid_t* pyr, void* stream);
 /* probe of the software texture unit: out[i] = tex2DLod<float4>(pyr, uvl[3i], uvl[3i+1], uvl[3i+2]) for n device-resident samples.
  * Restates the texture object of deviceMipmappedArray.cu:329-351 (normalised coords, linear + mip-linear, clamp). */
 int avdm_tex2dlod(float* out4, const avdm_pyramid_t* pyr, const float* uvl, int n, void* stream);
+/* The --downscale resize of the input images (first slice of the GPU image ingest):
+ * imageAlgo::resizeImage(downscale, in, out) (image/imageAlgo.cpp:220-235, 357-368) as mvsUtils/fileIO.cpp:432-441 (loadImage) calls it,
+ * i.e. oiio::ImageBufAlgo::resize(out, in, "", 0) — OpenImageIO's default filter: a separable 6-pixel lanczos3 when shrinking.  Float
+ * RGBA, device memory, dst no larger than src (enlarging would select blackman-harris: refused).  dst_w = src_w / downscale and
+ * dst_h = src_h / downscale (integer division) are the caller's, like in the reference. */
+int avdm_image_resize(float* dst_rgba, int dst_pitch, int dst_w, int dst_h, const float* src_rgba, int src_pitch, int src_w, int src_h, void* stream);
 /* convenience: the whole of DeviceCache::addMipmapImage (cuda/host/DeviceCache.cpp:222-281) + DeviceMipmapImage::fill
  * (cuda/host/DeviceMipmapImage.cpp:28-90) for an image already on the device.
  * `scratch_h4` must hold width*height fp16x4 texels when min_downscale > 1 (may be NULL otherwise). */

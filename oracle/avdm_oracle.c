@@ -520,6 +520,129 @@ int avo_pyramid_fill(const avdm_pyramid_t* p, const float* rgba, int in_pitch)
     return 0;
 }
 
+/* ---- image ingest: the --downscale resize ---------------------------------------------------------------------------------------------
+ * Reference call site: mvsUtils/fileIO.cpp:432-441 (loadImage: `imageAlgo::resizeImage(processScale, img, bmpr)`), which is
+ * image/imageAlgo.cpp:220-235, 326-368: out = in.width / downscale x in.height / downscale (integer division) and
+ * `oiio::ImageBufAlgo::resize(outBuf, inBuf, filter = "", filterSize = 0, ROI::All())`.
+ *
+ * THIRD-PARTY ALGORITHM, NOT IN /root/reference: OpenImageIO (pinned only by the CI image alicevision/alicevision-deps:2024.10.22,
+ * i.e. OpenImageIO 2.5.x).  Restated from its published source (libOpenImageIO/imagebufalgo_xform.cpp `resize_` / `get_resize_filter`,
+ * libutil/filter.cpp `FilterLanczos3_2D`); parity for this function is UNPINNED (no OpenImageIO here to generate vectors):
+ *   - an empty filter name selects "lanczos3" when shrinking (and "blackman-harris" when enlarging, which this path never does), with
+ *     the filter's own width (6 destination pixels) when filterSize is 0;
+ *   - destination pixel x samples the source at  src_xf = (x + 0.5) / dst_w * src_w,  split into src_x = floor and frac; the taps are the
+ *     source pixels src_x - rad .. src_x + rad with  rad = ceil(3 / ratio),  ratio = dst_w / src_w,  weights
+ *     lanczos3(ratio * (i - rad - (frac - 0.5))), normalised by their sum (a zero sum leaves the pixel black); rows likewise;
+ *   - the filter is separable: pel += (wy * wx) * src over j (rows) outer, i (columns) inner, zero products skipped, source
+ *     coordinates clamped to the image (ImageBuf::WrapClamp);
+ *   - lanczos3(x): 0 beyond 3, 1 below 1e-4, else 3 / (x^2 pi^2) * sin(x pi / 3)-based product with sin(pi x) obtained from
+ *     sin(pi x / 3) through the triple-angle identity (filter.cpp: "full-precision sin(), but use the trig identity"). */
+static float avo_lanczos3(float x)
+{
+    const float a = 3.0f;
+    const float ainv = 1.0f / a;
+    const float m_pi = (float)3.14159265358979323846; /* float(M_PI) */
+    x = fabsf(x);
+    if(x > a)
+        return 0.0f;
+    if(x < 0.0001f)
+        return 1.0f;
+    const float s1 = sinf(x * ainv * m_pi);
+    const float s3 = (-4.0f * s1 * s1 + 3.0f) * s1;
+    return a / (x * x * (m_pi * m_pi)) * s3 * s1;
+}
+
+/* tap table of one axis: returns the number of taps per destination pixel; weights[d * taps + i] (normalised), first[d] = source index
+ * of tap 0 (may be negative / past the end: the caller clamps) */
+int avo_image_resize_taps(int dst_n, int src_n, float* weights, int* first)
+{
+    const float srcf = (float)src_n, dstf = (float)dst_n;
+    const float ratio = dstf / srcf;
+    const float dstpixel = 1.0f / dstf;
+    const float filterrad = 6.0f * fmaxf(1.0f, ratio) / 2.0f; /* get_resize_filter: width = fd.width * max(1, ratio) */
+    const float wscale = 6.0f / (6.0f * fmaxf(1.0f, ratio));  /* FilterLanczos3_2D: m_wscale = 6 / width */
+    const int rad = (int)ceilf(filterrad / ratio);
+    const int taps = 2 * rad + 1;
+    if(weights == NULL || first == NULL)
+        return taps;
+    for(int d = 0; d < dst_n; ++d)
+    {
+        const float s = ((float)d - 0.0f + 0.5f) * dstpixel;
+        const float src_f = 0.0f + s * srcf;
+        const float fl = floorf(src_f);
+        const int src_i = (int)fl;
+        const float frac = src_f - fl;
+        float total = 0.0f;
+        float* w = weights + (size_t)d * taps;
+        for(int i = 0; i < taps; ++i)
+        {
+            w[i] = avo_lanczos3((ratio * ((float)(i - rad) - (frac - 0.5f))) * wscale);
+            total += w[i];
+        }
+        if(total != 0.0f)
+            for(int i = 0; i < taps; ++i)
+                w[i] /= total;
+        first[d] = src_i - rad;
+    }
+    return taps;
+}
+
+int avo_image_resize(float* dst, int dst_pitch, int dst_w, int dst_h, const float* src, int src_pitch, int src_w, int src_h, int nchannels)
+{
+    if(dst_w <= 0 || dst_h <= 0 || src_w <= 0 || src_h <= 0 || nchannels < 1 || nchannels > 4 || dst_w > src_w || dst_h > src_h)
+        return 1;
+    const int xtaps = avo_image_resize_taps(dst_w, src_w, NULL, NULL), ytaps = avo_image_resize_taps(dst_h, src_h, NULL, NULL);
+    float* wx = (float*)malloc(sizeof(float) * (size_t)xtaps * dst_w);
+    float* wy = (float*)malloc(sizeof(float) * (size_t)ytaps * dst_h);
+    int* fx = (int*)malloc(sizeof(int) * dst_w);
+    int* fy = (int*)malloc(sizeof(int) * dst_h);
+    avo_image_resize_taps(dst_w, src_w, wx, fx);
+    avo_image_resize_taps(dst_h, src_h, wy, fy);
+#pragma omp parallel for schedule(dynamic, 4)
+    for(int y = 0; y < dst_h; ++y)
+    {
+        const float* yw = wy + (size_t)y * ytaps;
+        float* drow = (float*)((char*)dst + (size_t)y * dst_pitch);
+        for(int x = 0; x < dst_w; ++x)
+        {
+            const float* xw = wx + (size_t)x * xtaps;
+            float pel[4] = {0.f, 0.f, 0.f, 0.f};
+            float totalx = 0.0f;
+            for(int i = 0; i < xtaps; ++i)
+                totalx += xw[i];
+            if(totalx != 0.0f)
+                for(int j = 0; j < ytaps; ++j)
+                {
+                    const float wyj = yw[j];
+                    if(wyj == 0.0f)
+                        continue;
+                    int sy = fy[y] + j;
+                    sy = sy < 0 ? 0 : (sy > src_h - 1 ? src_h - 1 : sy);
+                    const float* srow = (const float*)((const char*)src + (size_t)sy * src_pitch);
+                    for(int i = 0; i < xtaps; ++i)
+                    {
+                        const float w = wyj * xw[i];
+                        if(w != 0.0f)
+                        {
+                            int sx = fx[x] + i;
+                            sx = sx < 0 ? 0 : (sx > src_w - 1 ? src_w - 1 : sx);
+                            for(int c = 0; c < nchannels; ++c)
+                                pel[c] += w * srow[(size_t)sx * nchannels + c];
+                        }
+                    }
+                }
+            for(int c = 0; c < nchannels; ++c)
+                drow[(size_t)x * nchannels + c] = pel[c];
+        }
+    }
+    free(wx);
+    free(wy);
+    free(fx);
+    free(fy);
+    return 0;
+}
+
+
 /* DeviceCache.cpp:41-134 (fillHostCameraParameters), mvsData/Matrix3x3.hpp:268-287 (inverse) */
 static void inv3(const double* m, double* o) /* row-major */
 {

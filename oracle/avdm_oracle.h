@@ -25,6 +25,9 @@ void avo_downscale_with_gaussian_blur(uint16_t* out, int out_pitch, int out_w, i
                                       int downscale, int gaussRadius, int filter_mode);
 void avo_pyramid_build_levels(const avdm_pyramid_t* p);
 int avo_pyramid_fill(const avdm_pyramid_t* p, const float* rgba, int in_pitch);
+/* imageAlgo::resizeImage(downscale, in, out) -> oiio::ImageBufAlgo::resize with the default filter (see avdm_oracle.c) */
+int avo_image_resize(float* dst, int dst_pitch, int dst_w, int dst_h, const float* src, int src_pitch, int src_w, int src_h, int nchannels);
+int avo_image_resize_taps(int dst_n, int src_n, float* weights /* [dst_n][taps] or NULL */, int* first /* [dst_n] or NULL */);
 void avo_camera_fill(avdm_camera_t* out, const double K[9], const double R[9], const double C[3], int downscale);
 
 void avo_volume_initialize_u8(uint8_t* vol, long long pitch_y, int pitch_x, int dimX, int dimY, int dimZ, uint8_t value);

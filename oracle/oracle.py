@@ -30,6 +30,8 @@ _SIG = {
     "avo_tex2dlod": (None, [P(abi.Pyramid), f32, f32, f32, P(f32 * 4)]),
     "avo_pyramid_layout": (i32, [P(abi.Pyramid), i32, i32, i32, i32, i32]),
     "avo_image_rgba_f32_to_f16x255": (None, [vp, i32, vp, i32, i32, i32]),
+    "avo_image_resize": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, i32]),
+    "avo_image_resize_taps": (i32, [i32, i32, vp, vp]),
     "avo_rgb2lab": (None, [vp, i32, i32, i32]),
     "avo_downscale_with_gaussian_blur": (None, [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32]),
     "avo_pyramid_build_levels": (None, [P(abi.Pyramid)]),

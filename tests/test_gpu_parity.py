@@ -74,6 +74,33 @@ def test_pyramid_parity(mode):
         assert (diff > 0).mean() <= 5e-2, (l, (diff > 0).mean())
 
 
+@pytest.mark.parametrize("w,h,s", [(64, 48, 2), (67, 45, 2), (101, 77, 3), (256, 192, 4), (33, 21, 1)])
+def test_image_resize_bit_exact(w, h, s):
+    """--downscale resize (imageAlgo::resizeImage -> OpenImageIO's default lanczos3): the device kernel against the oracle's restatement,
+    even and odd sizes (non-integral ratios: per-column tap tables), clamp addressing at the borders; identical floats"""
+    torch = _torch()
+    from oracle import oracle
+    lib, olib = abi.load(), oracle.load()
+    rng = np.random.default_rng(w * 1000 + h)
+    src = rng.random((h, w, 4), dtype=np.float32)
+    src[..., 3] = (rng.random((h, w)) > 0.1).astype(np.float32)
+    dw, dh = w // s, h // s
+    want = np.zeros((dh, dw, 4), np.float32)
+    assert olib.avo_image_resize(oracle.ptr(want), dw * 16, dw, dh, oracle.ptr(src), w * 16, w, h, 4) == 0
+    tsrc = torch.from_numpy(src).cuda()
+    tdst = torch.full((dh, dw, 4), -1.0, dtype=torch.float32, device="cuda")
+    abi.check(lib.avdm_image_resize(_ptr(tdst), dw * 16, dw, dh, _ptr(tsrc), w * 16, w, h, _st()))
+    torch.cuda.synchronize()
+    got = tdst.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), float(np.abs(got - want).max())
+    # a constant image stays constant to rounding, and enlarging is refused
+    one = torch.full((h, w, 4), 0.75, dtype=torch.float32, device="cuda")
+    abi.check(lib.avdm_image_resize(_ptr(tdst), dw * 16, dw, dh, _ptr(one), w * 16, w, h, _st()))
+    torch.cuda.synchronize()
+    assert float((tdst - 0.75).abs().max()) < 4e-6  # 13 x 13 normalised taps summed in fp32
+    assert lib.avdm_image_resize(_ptr(one), w * 16, w, h, _ptr(tdst), dw * 16, dw, dh, _st()) != 0 or s == 1
+
+
 @pytest.mark.parametrize("mode", [abi.FILTER_CUDA_FIXED8, abi.FILTER_EXACT])
 def test_similarity_volume_parity(mode):
     """Weighted NCC is ill-conditioned in fp32 the way the reference accumulates it (DESIGN.md "NCC conditioning"): the
@@ -388,6 +415,50 @@ def test_optimize_parity(case):
     rel = np.abs(got[..., 0] - want[..., 0])[valid] / pix
     assert np.sqrt(np.mean(rel ** 2)) < 1e-3, np.sqrt(np.mean(rel ** 2))
     assert np.abs(got[..., 1] - want[..., 1])[valid].max() < 1e-2
+
+
+def test_optimize_point_map_form_is_bit_identical_to_depth_map_form(case):
+    """The production form of the colour optimisation keeps {point, depth} per pixel (one ray evaluation per pixel and iteration, no copy of
+    the depth map); the reference-shaped form (kernel 19 + kernel 20 per iteration, AVDM_OPT_DEPTH_MAP_FORM=1) must give the same bits —
+    with holes in the SGM map (pixels that never move, neighbours without depth) and for 1, 2, 7 and 100 iterations."""
+    import os
+    torch = _torch()
+    sc, sgm, ref, depths, o = case
+    lib = abi.load()
+    h = make_hip_from_oracle(o, sc, sgm, ref)
+    roiR = o.droi(ref.scale * ref.stepXY)
+    X, Y = roiR.width, roiR.height
+    up_np = o.sgm_upscaled.copy()
+    rng = np.random.default_rng(5)
+    holes = rng.random((Y, X)) < 0.03
+    up_np[holes, 0] = -1.0
+    up_np[Y // 3: Y // 3 + 4, X // 4: X // 2, 0] = -2.0
+    up = torch.from_numpy(up_np).cuda()
+    refined = torch.from_numpy(o.refined).cuda()
+    rc = abi.camera_fill(sc.K, sc.R[0], sc.C[0], ref.scale)
+
+    def run(n_iter, legacy):
+        rp = abi.RefineParams.default(optimizationNbIterations=n_iter)
+        for f, _t in ref._fields_:
+            if f != "optimizationNbIterations":
+                setattr(rp, f, getattr(ref, f))
+        opt = torch.full((Y, X, 2), 7.0, dtype=torch.float32, device="cuda")
+        var = torch.empty((Y, X), dtype=torch.float32, device="cuda")
+        tmp = torch.empty((Y, X), dtype=torch.float32, device="cuda")
+        if legacy:
+            os.environ["AVDM_OPT_DEPTH_MAP_FORM"] = "1"
+        try:
+            abi.check(lib.avdm_depth_sim_map_optimize_gradient_descent(_ptr(opt), X * 8, _ptr(var), X * 4, _ptr(tmp), X * 4, X, Y, _ptr(up), X * 8,
+                                                                       _ptr(refined), X * 8, C.byref(rc), C.byref(h.pyr[0].desc), C.byref(rp), roiR, _st()))
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("AVDM_OPT_DEPTH_MAP_FORM", None)
+        return opt.cpu().numpy()
+
+    for n_iter in (1, 2, 7, 100):
+        a, b = run(n_iter, False), run(n_iter, True)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n_iter, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+    assert (run(7, False)[..., 0] > 0).mean() > 0.5
 
 
 @pytest.mark.parametrize("mode", [abi.FILTER_CUDA_FIXED8, abi.FILTER_EXACT])
@@ -752,3 +823,30 @@ def test_full_size_cfg2_sweep_only_properties():
     zplane = depth * cosang
     nearest = np.abs(zplane[..., None][m][:200000] - depths[None, :]).min(axis=-1)
     assert np.percentile(nearest / zplane[m][:200000], 99) < 2e-5
+
+
+def test_parity_table_cfg1():
+    """The measured parity table of DESIGN.md section 2, asserted (scripts/parity_report.py; SURVEY 8d.1's cfg1: 3 views 640 x 480, 64 planes,
+    single tile): everything on the GPU against everything in the oracle, NO trimming of the depth error —
+      * well-posed oracle (double-precision NCC sums, exact R pixel): untrimmed final depth RMSE < 1e-3 (BASELINE.json's bar), similarity
+        volume within one uint8 level except on < 0.1 % of the voxels;
+      * LITERAL oracle (the reference's fp32 arithmetic as written; equal, bit for bit, to the reference's own kernels compiled for the CPU,
+        tests/test_oracle_ref.py): the fp32 NCC sums of the reference are themselves several levels away from their exact value on ~40 % of
+        the voxels, so the volumes differ accordingly; the depth map still agrees to RMSE < 1e-3 over the best 99.5 % of the pixels and to
+        < 5e-3 untrimmed, and the GPU result is as close to the analytic ground truth as the literal one."""
+    _torch()
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import parity_report
+    r = parity_report.run_case("cfg1", parity_report.CASES["cfg1"], abi.FILTER_CUDA_FIXED8, with_ref=False)
+    wp, lit = r["well_posed"], r["literal"]
+    assert wp["final_depth"]["rmse_untrimmed"] < 1e-3, wp["final_depth"]
+    assert wp["final_depth"]["validity_differs"] < 1e-3
+    lv = wp["similarity_volume_levels"]
+    assert lv["2"] + lv["3+"] < 1e-3 and lv["1"] < 0.03 and lv["validity_differs"] < 1e-3, lv
+    assert lit["final_depth"]["rmse_best_99.5pct"] < 1e-3, lit["final_depth"]
+    assert lit["final_depth"]["rmse_untrimmed"] < 5e-3, lit["final_depth"]
+    assert lit["final_depth"]["validity_differs"] < 2e-3
+    g = lit["median_abs_vs_ground_truth"]
+    assert g["gpu"] <= 1.02 * g["oracle"] + 1e-6, g

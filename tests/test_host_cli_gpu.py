@@ -274,6 +274,37 @@ def test_default_process_downscale(tmp_path):
     assert m.mean() > 0.6
     assert np.median(np.abs(depth - gt)[m] / gt[m]) < 3e-3
 
+    # the same plan through the harness on images resized by the ORACLE's restatement of OpenImageIO's default filter (fileIO.cpp:432-441):
+    # the program resizes on the device (avdm_image_resize, bit-exact against that restatement), so the maps must agree bit for bit
+    import ctypes as C
+    import torch
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    from oracle import oracle
+    args = ["-i", sfm, "--imagesFolder", img, "-o", out, "--rangeStart", 0, "--rangeSize", 1, "--sgmMaxDepths", 96, "--colorOptimizationNbIterations",
+            OPT_ITERS, "-v", "warning"]
+    plan = json.loads(run_cli(args + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
+    t0 = plan["tiles"][0]
+    assert t0["nbTiles"] == 1
+    olib = oracle.load()
+    small = []
+    for i in range(4):
+        src = np.ascontiguousarray(sc.images[i].numpy())
+        dst = np.zeros((h // 2, w // 2, 4), np.float32)
+        assert olib.avo_image_resize(oracle.ptr(dst), (w // 2) * 16, w // 2, h // 2, oracle.ptr(src), w * 16, w, h, 4) == 0
+        small.append(torch.from_numpy(dst))
+    K2 = sc.K.copy()
+    K2[:2] /= 2.0  # MultiViewParams.cpp:288-291: P rows 0-1 divided by the process downscale
+    sgm = abi.SgmParams.default(scale=plan["sgmScale"], stepXY=plan["sgmStepXY"])
+    ref = abi.RefineParams.default(optimizationNbIterations=OPT_ITERS)
+    depths = np.asarray(t0["depths"], np.float32)
+    ranges = [(a, a + n) for a, n in t0["depthsTcLimits"]]
+    torch.cuda.set_device(0)
+    pyr = [DevicePyramid(small[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(4)]
+    hn = DepthMapTile(pyr, K2, sc.R, sc.C, sgm, ref)
+    hn.run_sgm(0, t0["sgmTCams"], depths, tc_ranges=ranges)
+    got = hn.run_refine(0, t0["refineTCams"]).cpu().numpy()
+    assert np.array_equal(got[..., 0], depth), float(np.abs(got[..., 0] - depth).max())
+
 
 def test_multi_worker_exchange_equals_single_worker(dataset):
     """the in-process multi-GPU path (computeOnMultiGPUs.cpp: one thread per device, R cameras dealt round-robin, every view decoded and

@@ -241,6 +241,14 @@ def test_cli_argument_errors(scene):
     assert run(base + ["--downscale", 0], check=False).returncode == 1
     assert run(base + ["--sgmScale", 1, "--sgmStepXY", 1, "--refineScale", 2], check=False).returncode == 1  # SGM scale step < Refine scale step
     assert run(base + ["--sgmScale", 3, "--sgmStepXY", 1, "--refineScale", 2], check=False).returncode == 1  # not a multiple
+    # fractional mip level (log2(3 / 1)): the reference blends two levels, this implementation says so at parse time
+    r = run(base + ["--sgmScale", 3, "--sgmStepXY", 1, "--refineScale", 1, "--refineStepXY", 1], check=False)
+    assert r.returncode == 1 and "power-of-two" in r.stdout + r.stderr
+    assert run(base + ["--sgmScale", 4, "--sgmStepXY", 1, "--refineScale", 1, "--refineStepXY", 2, "--downscale", 1], check=False).returncode == 0
+    # filtering axes: anything but one or two of 'X' / 'Y' is refused (the reference throws on unknown characters)
+    assert run(base + ["--sgmFilteringAxes", "YZ"], check=False).returncode == 1
+    assert run(base + ["--sgmFilteringAxes", "YXY"], check=False).returncode == 1
+    assert run(base + ["--sgmFilteringAxes", "X", "--downscale", 1], check=False).returncode == 0
     assert run(base + ["--minViewAngle", 80, "--maxViewAngle", 70], check=False).returncode == 1
     assert run(base + ["--nosuchflag", 1], check=False).returncode == 1
     assert run(base + ["--sgmWSH", "abc"], check=False).returncode == 1

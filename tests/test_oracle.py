@@ -301,3 +301,61 @@ def test_normal_map_oracle_matches_numpy_pca_and_analytic_plane(oracle_lib):
         pts = P2[max(y - 3, 0):y + 4, max(x - 3, 0):x + 4].reshape(-1, 3)
         w_, vecs = np.linalg.eigh(np.cov(pts.T, bias=True))
         assert abs(out[y, x] @ vecs[:, 0]) > 1.0 - 1e-4, (y, x)
+
+
+# ------------------------------------------------------------------------------------------------ image ingest: --downscale resize
+def _np_lanczos3(x):
+    x = np.abs(np.asarray(x, np.float64))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        v = 3.0 * np.sin(np.pi * x) * np.sin(np.pi * x / 3.0) / (np.pi * np.pi * x * x)
+    return np.where(x > 3.0, 0.0, np.where(x < 1e-4, 1.0, v))
+
+
+@pytest.mark.parametrize("dst,src", [(32, 64), (33, 67), (25, 77), (48, 192), (21, 21)])
+def test_resize_taps_follow_the_published_filter(dst, src):
+    """imageAlgo::resizeImage -> OpenImageIO resize with its default filter (lanczos3 when shrinking): the oracle's tap tables against an
+    independent double-precision numpy evaluation of the published formula (src_xf = (x + 0.5) * src / dst, radius ceil(3 / ratio) source
+    pixels, weights lanczos3(ratio * (i - rad - (frac - 0.5))) normalised to 1)."""
+    from oracle import oracle
+    lib = oracle.load()
+    taps = lib.avo_image_resize_taps(dst, src, None, None)
+    ratio = dst / src
+    rad = int(np.ceil(3.0 / ratio))
+    assert taps == 2 * rad + 1
+    w = np.zeros((dst, taps), np.float32)
+    first = np.zeros(dst, np.int32)
+    lib.avo_image_resize_taps(dst, src, oracle.ptr(w), oracle.ptr(first))
+    for d in range(dst):
+        xf = (d + 0.5) / dst * src
+        xi = int(np.floor(xf))
+        frac = xf - xi
+        ref = _np_lanczos3(ratio * (np.arange(taps) - rad - (frac - 0.5)))
+        ref = ref / ref.sum()
+        assert first[d] == xi - rad
+        assert np.abs(w[d] - ref).max() < 2e-6, (d, np.abs(w[d] - ref).max())
+    assert np.abs(w.sum(1) - 1.0).max() < 1e-6
+
+
+def test_resize_properties():
+    from oracle import oracle
+    lib = oracle.load()
+    rng = np.random.default_rng(3)
+    h, w = 61, 83
+    # a constant stays constant; an affine ramp stays the same affine function of the continuous coordinate away from the (clamped) borders
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    src = np.stack([np.full((h, w), 0.3, np.float32), 0.01 * xx + 0.02 * yy, rng.random((h, w), dtype=np.float32), np.ones((h, w), np.float32)], -1)
+    src = np.ascontiguousarray(src)
+    dw, dh = w // 2, h // 2
+    dst = np.zeros((dh, dw, 4), np.float32)
+    assert lib.avo_image_resize(oracle.ptr(dst), dw * 16, dw, dh, oracle.ptr(src), w * 16, w, h, 4) == 0
+    assert np.abs(dst[..., 0] - 0.3).max() < 1e-6 and np.abs(dst[..., 3] - 1.0).max() < 1e-6
+    cy, cx = np.mgrid[0:dh, 0:dw].astype(np.float64)
+    sx, sy = (cx + 0.5) * w / dw - 0.5, (cy + 0.5) * h / dh - 0.5  # continuous source coordinate of a destination pixel centre
+    want = 0.01 * sx + 0.02 * sy
+    inner = (slice(4, dh - 4), slice(4, dw - 4))
+    assert np.abs(dst[..., 1] - want)[inner].max() < 3e-4  # discrete lanczos taps only preserve the mean exactly
+    # low-pass: the noise channel loses variance
+    assert dst[..., 2].std() < 0.6 * src[..., 2].std()
+    # enlarging is not this path
+    big = np.zeros((h * 2, w * 2, 4), np.float32)
+    assert lib.avo_image_resize(oracle.ptr(big), w * 2 * 16, w * 2, h * 2, oracle.ptr(src), w * 16, w, h, 4) != 0
