@@ -13,6 +13,8 @@
  * every stage in both filter modes, and the committed vectors tests/golden/ that library produced (tests/golden/make_golden.py).
  * What remains restated on both sides — and is named "unpinned" in DESIGN.md — is NVIDIA's part: the texture unit's filtering
  * arithmetic and the fast-math intrinsics; plus fillHostCameraParameters (needs MultiViewParams), checked by projection identities.
+ * PARITY UNPINNED for one function: avo_image_resize restates OpenImageIO's default resize filter (a third-party dependency that is not
+ * under /root/reference and not installed here) from its published source; see the comment above it.
  *
  * Arithmetic conventions (see DESIGN.md §"Texture unit restatement" and §"Fast-math intrinsics"):
  *   - compiled with -ffp-contract=off: every fp32 operation is the IEEE operation written;
