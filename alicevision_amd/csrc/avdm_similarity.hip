@@ -58,6 +58,7 @@ struct NccArgs
     int rcap, tcap;   // LDS capacities in texels (R tile, T window)
     int forceGeneric; // debugging / A-B switch: never use the LDS path
     int noPacked;     // debugging / A-B switch: LDS path with the plain fp32 tap arithmetic
+    int chunkWindow;  // packed path: ONE T window for the planes of a chunk (0: one window per plane, the A/B reference)
     unsigned* stats;  // optional device counters per plane-workgroup: {LDS path, R tile unusable, T taps leave the image, T window too large}
 };
 
@@ -117,7 +118,8 @@ __device__ __forceinline__ void stage_window(uint2* dst, int pitch, const TexLev
 }
 
 // "Paired" window layout for the FIXED8 LDS path: one 16-byte record per texel position holding, per colour channel, the fp16 pair
-// {texel c, texel c + 1} of the row — exactly the operand v_dot2_f32_f16 multiplies with the weight pair {256 - A, A}.  The pairing
+// {texel c, texel c + 1} of the row (L, a, b and — for the centre fetch of the chunk-window path — alpha) — exactly the operand
+// v_dot2_f32_f16 multiplies with the weight pair {256 - A, A}.  The pairing
 // (three v_perm_b32) is then done once per staged texel instead of once per tap (12 of the ~92 VALU instructions of a sample), and a
 // row tap is ONE ds_read_b128 instead of two ds_read_b64.  Costs twice the LDS per texel: used where the windows are small enough.
 #define AVDM_PERM_LO 0x05040100u // {lo16(src1), lo16(src0)}
@@ -141,7 +143,7 @@ __device__ __forceinline__ void stage_window_paired(uint4* dst, int pitch, const
             rec.x = __builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_LO);
             rec.y = __builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_HI);
             rec.z = __builtin_amdgcn_perm(t1.y, t0.y, AVDM_PERM_LO);
-            rec.w = 0u;
+            rec.w = __builtin_amdgcn_perm(t1.y, t0.y, AVDM_PERM_HI); // {alpha(c) | alpha(c + 1)}: only the centre fetch reads it
             if(lane < 63 && c < w)
                 d[c] = rec;
         }
@@ -522,6 +524,24 @@ __device__ __forceinline__ LdsWindows make_windows(const uint2* smem, int rcap, 
     return W;
 }
 
+// tex_bilinear_px<true>() from a staged window of PAIRED records (stage_window_paired): the same fp16 texels, the same quantised weights,
+// the same blend — four texels out of two 16-byte records instead of four global loads behind 64-bit address arithmetic.  (x, y) are
+// texel-space coordinates whose taps lie inside the window (never its last column: that record pairs the texel with itself).
+__device__ __forceinline__ float4 lds_center_paired(const uint2* win, int pitch, int x0, int y0, float x, float y)
+{
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = quant8(x - fx), b = quant8(y - fy);
+    const int i = (int)fx - x0, j = (int)fy - y0;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)win;
+    const unsigned addr = base + (unsigned)(j * pitch + i) * 16u;
+    const uint4 r0 = lds_record(addr), r1 = lds_record(addr + (unsigned)pitch * 16u);
+    auto lo = [](unsigned v) __attribute__((always_inline)) { return __half2float(__ushort_as_half((unsigned short)(v & 0xffffu))); };
+    auto hi = [](unsigned v) __attribute__((always_inline)) { return __half2float(__ushort_as_half((unsigned short)(v >> 16))); };
+    const float4 t00 = make_float4(lo(r0.x), lo(r0.y), lo(r0.z), lo(r0.w)), t10 = make_float4(hi(r0.x), hi(r0.y), hi(r0.z), hi(r0.w));
+    const float4 t01 = make_float4(lo(r1.x), lo(r1.y), lo(r1.z), lo(r1.w)), t11 = make_float4(hi(r1.x), hi(r1.y), hi(r1.z), hi(r1.w));
+    return bilinear_blend(t00, t10, t01, t11, a, b);
+}
+
 __device__ __forceinline__ void pixel_of_lane(int& tx, int& ty)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -533,10 +553,11 @@ __device__ __forceinline__ void pixel_of_lane(int& tx, int& ty)
 // workgroup state shared by the two kernels
 // ---------------------------------------------------------------------------------------------
 #define AVDM_MAX_CHUNK 8
+#define AVDM_CHUNK_BOX AVDM_MAX_CHUNK // entry of the window shared by all planes of a chunk
 struct BlockShared
 {
-    int box[AVDM_MAX_CHUNK][4]; // per plane of the chunk: min x, min y, max x, max y (floor of the texel-space tap positions in T)
-    int bad[AVDM_MAX_CHUNK];    // per plane: some lane's R taps leave the staged R tile
+    int box[AVDM_MAX_CHUNK + 1][4]; // per plane of the chunk (+ the chunk itself): min x, min y, max x, max y (floor of the texel-space tap positions in T)
+    int bad[AVDM_MAX_CHUNK + 1];    // per plane: some lane's R taps leave the staged R tile
 };
 
 struct RTile
@@ -696,9 +717,9 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
 
 __device__ __forceinline__ void init_shared(BlockShared& sh)
 {
-    if(threadIdx.x < AVDM_MAX_CHUNK * 4)
+    if(threadIdx.x < (AVDM_MAX_CHUNK + 1) * 4)
         sh.box[threadIdx.x >> 2][threadIdx.x & 3] = (threadIdx.x & 2) ? INT_MIN : INT_MAX;
-    if(threadIdx.x < AVDM_MAX_CHUNK)
+    if(threadIdx.x < AVDM_MAX_CHUNK + 1)
         sh.bad[threadIdx.x] = 0;
 }
 
@@ -758,6 +779,67 @@ __global__ void __launch_bounds__(256, 3)
         ws = *reinterpret_cast<const unsigned*>(ps);
     }
 
+    // geometry of my patch on plane vz (see the Refine kernel): false when the patch centre fails the border test in T
+    auto plane_geometry = [&](unsigned vz, PatchProj& Q, float& tpx, float& tpy) __attribute__((always_inline)) -> bool {
+        const float depthPlane = depths[vz];
+        const f3 planep = C + Z * depthPlane;
+        const float kk = (dot(planep, Z) - dnC) / dnv;
+        const f3 p = C + v * kk;
+        const float pd = computePixSize(rc, p);
+        f3 ax, ay;
+        patch_axes(rc, tc, p, ax, ay);
+        Q = make_patch_proj(rc, tc, p, ax, ay, pd);
+        const float it0 = fast_rcp(Q.ht0.z);
+        tpx = Q.ht0.x * it0;
+        tpy = Q.ht0.y * it0;
+        return !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+    };
+
+    // ONE T window for the 4 planes of the chunk (see the Refine kernel; here for both record layouts of the packed path, the centre
+    // colour still comes from global memory — the half-paired records carry no alpha — but no longer decides who contributes to the box)
+    bool chunkWin = false;
+    TWindow Wc;
+    Wc.ok = false;
+    Wc.x0 = Wc.y0 = Wc.w = Wc.h = Wc.pitch = 0;
+    float extX = 0.f, extY = 0.f;
+    if(FIXED8 && (paired || halfPaired) && A.chunkWindow)
+    {
+        const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + 4u < zEnd) ? z0 + 4u : zEnd;
+        if(ka < kbEnd) // uniform
+        {
+            float bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+            bool part = false, rIn = true;
+#pragma unroll 1
+            for(int e = 0; e < 2; ++e)
+            {
+                const unsigned vz = e == 0 ? ka : kbEnd - 1u;
+                if(e == 1 && vz == ka)
+                    break;
+                PatchProj Q;
+                float tpx, tpy;
+                if(rValid && plane_geometry(vz, Q, tpx, tpy))
+                {
+                    float cx0, cy0, cx1, cy1;
+                    bool ri;
+                    corner_boxes(Q, A, wsh, R, cx0, cy0, cx1, cy1, ri);
+                    bx0 = fminf(bx0, cx0);
+                    by0 = fminf(by0, cy0);
+                    bx1 = fmaxf(bx1, cx1);
+                    by1 = fmaxf(by1, cy1);
+                    extX = fmaxf(extX, 0.5f * (cx1 - cx0));
+                    extY = fmaxf(extY, 0.5f * (cy1 - cy0));
+                    rIn = rIn && ri;
+                    part = true;
+                }
+            }
+            publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
+            __syncthreads();
+            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired);
+            __syncthreads();
+            chunkWin = Wc.ok;
+        }
+    }
+
 #pragma unroll 1
     for(int k = 0; k < 4; ++k)
     {
@@ -768,42 +850,46 @@ __global__ void __launch_bounds__(256, 3)
         bool valid = rValid;
         PatchProj Q;
         float4 tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
-        float bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f;
-        bool rInside = false;
+        float tpx = 0.f, tpy = 0.f;
+        if(valid)
+            valid = plane_geometry(vz, Q, tpx, tpy);
         if(valid)
         {
-            const float depthPlane = depths[vz];
-            const f3 planep = C + Z * depthPlane;
-            const float kk = (dot(planep, Z) - dnC) / dnv;
-            const f3 p = C + v * kk;
-            const float pd = computePixSize(rc, p);
-            f3 ax, ay;
-            patch_axes(rc, tc, p, ax, ay);
-            Q = make_patch_proj(rc, tc, p, ax, ay, pd);
-            const float it0 = fast_rcp(Q.ht0.z);
-            const float tpx = Q.ht0.x * it0, tpy = Q.ht0.y * it0;
-            valid = !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+            tcCenter = tex_bilinear_px<FIXED8>(A.tcL, fmaf(tpx, A.tcSx, A.tcOx), fmaf(tpy, A.tcSy, A.tcOy));
+            valid = !(tcCenter.w < (255.f * 0.4f));
+        }
+        TWindow Wd = Wc;
+        bool laneLds = true; // my taps of this plane lie inside the staged window
+        if(chunkWin)
+        {
             if(valid)
             {
-                tcCenter = tex_bilinear_px<FIXED8>(A.tcL, fmaf(tpx, A.tcSx, A.tcOx), fmaf(tpy, A.tcSy, A.tcOy));
-                valid = !(tcCenter.w < (255.f * 0.4f));
+                const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
+                laneLds = (cxT - extX - 1.0f >= (float)Wd.x0) && (cxT + extX + 2.0f <= (float)(Wd.x0 + Wd.w - 1)) &&
+                          (cyT - extY - 1.0f >= (float)Wd.y0) && (cyT + extY + 2.0f <= (float)(Wd.y0 + Wd.h - 1));
             }
+            laneLds = __ballot(valid && !laneLds) == 0ull; // wave-uniform choice of the tap source (see the Refine kernel)
+        }
+        else
+        {
+            float bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f;
+            bool rInside = false;
             if(valid)
                 corner_boxes(Q, A, wsh, R, bx0, by0, bx1, by1, rInside);
+            publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
+            __syncthreads();
+            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired);
+            __syncthreads();
         }
-        publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
-        __syncthreads();
-        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired);
-        __syncthreads();
 
         float fsim = 255.0f;
         if(valid)
         {
             float s;
-            if(Wd.ok && FIXED8 && !A.noPacked)
+            if(Wd.ok && laneLds && FIXED8 && !A.noPacked)
                 s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
                                                           tcCenter);
-            else if(Wd.ok)
+            else if(Wd.ok && laneLds)
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
             else
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
@@ -883,6 +969,89 @@ __global__ void __launch_bounds__(256, 3)
     if(pixActive)
         packed = *reinterpret_cast<const uint4*>(pv);
 
+    // geometry of my patch on plane vz: the 3-D point, the patch axes and their projections; false when the patch centre fails the border
+    // test in T (Patch.cuh:486-496).  (tpx, tpy) = the centre's pixel in T.
+    auto plane_geometry = [&](unsigned vz, PatchProj& Q, float& tpx, float& tpy) __attribute__((always_inline)) -> bool {
+        const int rel = (int)vz - ((volDimZ - 1) / 2);
+        f3 p = pMid;
+        if(rel != 0)
+            p = pMid + dir * ((float)rel * dps.y);
+        const float pd = computePixSize(rc, p);
+        f3 ax, ay;
+        {
+            const f3 v1 = normalize(C - p);
+            const f3 v2 = normalize(ld3(tc.C) - p);
+            ay = normalize(cross(v1, v2));
+            f3 n;
+            if(sgmNormal != nullptr)
+            {
+                const float* nn = (const float*)((const char*)sgmNormal + (long long)vy * normal_pitch) + 3 * vx;
+                n = f3{nn[0], nn[1], nn[2]};
+            }
+            else
+                n = normalize((v1 + v2) * 0.5f);
+            ax = normalize(cross(ay, n));
+        }
+        Q = make_patch_proj(rc, tc, p, ax, ay, pd);
+        const float it0 = fast_rcp(Q.ht0.z);
+        tpx = Q.ht0.x * it0;
+        tpy = Q.ht0.y * it0;
+        return !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+    };
+
+    // ---- ONE T window for all planes of the chunk (paired records) -----------------------------------------------------------------
+    // The planes of a Refine chunk are one pixel size apart along the ray: the projected patch moves by about a texel per plane, so the
+    // union of the windows of 8 planes is barely larger than one of them — and building a window is the expensive part of a plane outside
+    // the sample loop (four corner projections and four wave reductions for the box, a cooperative copy, two barriers, and the centre colour
+    // fetched from global memory before the box is even known).  Each lane projects its patch corners on the FIRST and the LAST plane of
+    // the chunk; a point moving along a ray projects to a monotone path in T, so the hull of the two extreme quads bounds the planes in
+    // between (one more texel of slack, and every lane re-checks its own centre against the staged window per plane: a lane that does
+    // not fit takes the global-memory taps for that plane).  The alpha test of the centre no longer decides who contributes to the box
+    // (alpha is only known once the window is staged: the centre is read from it).
+    constexpr bool CHUNK_CAPABLE = PAIRED && FIXED8;
+    bool chunkWin = false;
+    TWindow Wc;
+    Wc.ok = false;
+    Wc.x0 = Wc.y0 = Wc.w = Wc.h = Wc.pitch = 0;
+    float extX = 0.f, extY = 0.f; // half extent of my projected patch in T texels (the larger of the two extreme planes)
+    if(CHUNK_CAPABLE && paired && A.chunkWindow)
+    {
+        const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + 8u < zEnd) ? z0 + 8u : zEnd;
+        if(ka < kbEnd) // uniform
+        {
+            float bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+            bool part = false, rIn = true;
+#pragma unroll 1
+            for(int e = 0; e < 2; ++e)
+            {
+                const unsigned vz = e == 0 ? ka : kbEnd - 1u;
+                if(e == 1 && vz == ka)
+                    break;
+                PatchProj Q;
+                float tpx, tpy;
+                if(rValid && plane_geometry(vz, Q, tpx, tpy))
+                {
+                    float cx0, cy0, cx1, cy1;
+                    bool ri;
+                    corner_boxes(Q, A, wsh, R, cx0, cy0, cx1, cy1, ri);
+                    bx0 = fminf(bx0, cx0);
+                    by0 = fminf(by0, cy0);
+                    bx1 = fmaxf(bx1, cx1);
+                    by1 = fmaxf(by1, cy1);
+                    extX = fmaxf(extX, 0.5f * (cx1 - cx0));
+                    extY = fmaxf(extY, 0.5f * (cy1 - cy0));
+                    rIn = rIn && ri;
+                    part = true;
+                }
+            }
+            publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
+            __syncthreads();
+            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired);
+            __syncthreads();
+            chunkWin = Wc.ok;
+        }
+    }
+
 #pragma unroll 1
     for(int k = 0; k < 8; ++k)
     {
@@ -893,34 +1062,33 @@ __global__ void __launch_bounds__(256, 3)
         bool valid = rValid;
         PatchProj Q;
         float4 tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
-        float bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f;
-        bool rInside = false;
+        float tpx = 0.f, tpy = 0.f;
         if(valid)
+            valid = plane_geometry(vz, Q, tpx, tpy);
+        TWindow Wd = Wc;
+        bool laneLds = true; // my taps of this plane lie inside the staged window
+        if(chunkWin)
         {
-            const int rel = (int)vz - ((volDimZ - 1) / 2);
-            f3 p = pMid;
-            if(rel != 0)
-                p = pMid + dir * ((float)rel * dps.y);
-            const float pd = computePixSize(rc, p);
-            f3 ax, ay;
+            if(valid)
             {
-                const f3 v1 = normalize(C - p);
-                const f3 v2 = normalize(ld3(tc.C) - p);
-                ay = normalize(cross(v1, v2));
-                f3 n;
-                if(sgmNormal != nullptr)
-                {
-                    const float* nn = (const float*)((const char*)sgmNormal + (long long)vy * normal_pitch) + 3 * vx;
-                    n = f3{nn[0], nn[1], nn[2]};
-                }
+                const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
+                // taps = texels floor(.) and floor(.) + 1 of positions within +- ext of the centre; one more texel for rounding
+                laneLds = (cxT - extX - 1.0f >= (float)Wd.x0) && (cxT + extX + 2.0f <= (float)(Wd.x0 + Wd.w - 1)) &&
+                          (cyT - extY - 1.0f >= (float)Wd.y0) && (cyT + extY + 2.0f <= (float)(Wd.y0 + Wd.h - 1));
+                if(laneLds)
+                    tcCenter = lds_center_paired(sT, Wd.pitch, Wd.x0, Wd.y0, cxT, cyT);
                 else
-                    n = normalize((v1 + v2) * 0.5f);
-                ax = normalize(cross(ay, n));
+                    tcCenter = tex_bilinear_px<FIXED8>(A.tcL, cxT, cyT);
+                valid = !(tcCenter.w < (255.f * 0.4f));
             }
-            Q = make_patch_proj(rc, tc, p, ax, ay, pd);
-            const float it0 = fast_rcp(Q.ht0.z);
-            const float tpx = Q.ht0.x * it0, tpy = Q.ht0.y * it0;
-            valid = !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+            // the choice of the tap source stays WAVE-uniform (a scalar branch around the sample loop, as with one window per plane): if one
+            // lane does not fit, its whole wave takes the global-memory taps for this plane
+            laneLds = __ballot(valid && !laneLds) == 0ull;
+        }
+        else
+        {
+            float bx0 = 0.f, by0 = 0.f, bx1 = 0.f, by1 = 0.f;
+            bool rInside = false;
             if(valid)
             {
                 tcCenter = tex_bilinear_px<FIXED8>(A.tcL, fmaf(tpx, A.tcSx, A.tcOx), fmaf(tpy, A.tcSy, A.tcOy));
@@ -928,19 +1096,19 @@ __global__ void __launch_bounds__(256, 3)
             }
             if(valid)
                 corner_boxes(Q, A, wsh, R, bx0, by0, bx1, by1, rInside);
+            publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
+            __syncthreads();
+            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired);
+            __syncthreads();
         }
-        publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
-        __syncthreads();
-        const TWindow Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired);
-        __syncthreads();
 
         if(valid)
         {
             float s;
-            if(Wd.ok && FIXED8 && !A.noPacked)
+            if(Wd.ok && laneLds && FIXED8 && !A.noPacked)
                 s = ncc_accumulate_lds_fixed8<WSH, true, PAIRED>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
                                                          tcCenter);
-            else if(Wd.ok)
+            else if(Wd.ok && laneLds)
                 s = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
             else
                 s = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
@@ -1290,7 +1458,11 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
     // markedly larger scale, or a depth edge inside the workgroup, overflows it and takes the generic path).  Row pitches are 8 (mod 16) texels.
     const int rw = 15 * stepXY + 2 * (wsh + 2) + 5;
     const int tw = rw + 1;
-    const int third = (160 * 1024) / 3 - 1024; // bytes per workgroup at 3 per CU, minus the static shared state and allocation granularity
+    // bytes of dynamic LDS per workgroup at 3 workgroups per CU.  LDS is allocated in granules (1280 B on gfx950, 160 KiB / 128): 42 granules
+    // per workgroup = 53 760 B, three of them 161 280 of the 163 840 B.  The static shared state (BlockShared, < 256 B) must fit in the same
+    // 42 granules: when it grew by 20 B (round 2: one more box for the chunk window) the old budget (160 KiB / 3 - 1 KiB = 53 589 B) tipped
+    // into a 43rd granule, only TWO workgroups fitted a CU and both kernels ran 20 % slower with identical sample loops.
+    const int third = 42 * 1280 - 256;
     {
         const char* pe = getenv("AVDM_SIM_PAIRED");
         if(pe && pe[0] == '0')
@@ -1322,6 +1494,8 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
         A.forceGeneric = 1;
     const char* pk = getenv("AVDM_SIM_PACKED");
     A.noPacked = (pk && pk[0] == '0') ? 1 : 0;
+    const char* cw = getenv("AVDM_SIM_CHUNK_WINDOW"); // 0: one T window per plane (the A/B reference of the chunk window)
+    A.chunkWindow = (cw && cw[0] == '0') ? 0 : 1;
     A.stats = nullptr;
     const char* st = getenv("AVDM_SIM_STATS");
     if(st && st[0] == '1')

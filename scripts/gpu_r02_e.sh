@@ -8,6 +8,9 @@ export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 ROOT=$(pwd)
 python -c "from alicevision_amd import abi; abi.load(); print('libavdm ok')" > $OUT/log.txt 2>&1
+# a box whose GPU does not complete a trivial job and the SGM micro-benchmark is not worth the session (r02_f: a faulty box cost 15 minutes)
+timeout 120 python -c "import torch; x = torch.ones(1 << 24, device='cuda'); print('gpu sanity', float(x.sum()))" || { echo "GPU sanity check failed"; exit 1; }
+timeout 120 python scripts/sgm_microbench.py 1 2>&1 | grep -q tiles || { echo "SGM micro-benchmark failed on this box"; exit 1; }
 echo "== SGM microbench" | tee -a $OUT/log.txt
 timeout 300 python scripts/sgm_microbench.py 1 8 2>&1 | grep tiles | tee $OUT/microbench.txt
 echo "== pytest -m gpu" | tee -a $OUT/log.txt

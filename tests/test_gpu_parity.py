@@ -374,6 +374,38 @@ def test_refine_volume_parity(case):
     assert (diff > 0.02).mean() <= 1e-4, ((diff > 0.02).mean(), diff.max())
 
 
+def test_refine_chunk_window_equals_per_plane_windows(case):
+    """The Refine kernel stages ONE T window for the 8 planes of a chunk (the hull of the projected patch on the first and the last plane,
+    the centre colour read from the staged records); AVDM_SIM_CHUNK_WINDOW=0 keeps one window per plane with the centre from global memory.
+    Same texels, same weights, same sums: the two volumes must be identical except where the two forms of the centre fetch round
+    differently (the alpha / colour of the centre enters every sample weight) — held to a handful of fp16 quanta on a vanishing
+    fraction of the voxels — and with a depth discontinuity and masked T texels in the scene."""
+    import os
+    torch = _torch()
+    sc, sgm, ref, depths, o = case
+    vols = []
+    for flag in ("1", "0"):
+        os.environ["AVDM_SIM_CHUNK_WINDOW"] = flag
+        try:
+            h = make_hip_from_oracle(o, sc, sgm, ref)
+            h._alloc(len(depths))
+            dt = o.sgm_depth_thickness.copy()
+            Yh, Xh = dt.shape[:2]
+            dt[Yh // 3:, Xh // 2:, 0] *= 1.04  # a depth step inside workgroups: windows of neighbouring lanes part
+            dt[:5, :7, 0] = -1.0
+            h.sgm_depth_thickness.copy_(torch.from_numpy(dt))
+            h.run_refine(0, [1, 2], optimize_enabled=False)
+            torch.cuda.synchronize()
+            vols.append(h.refine_volume.cpu().numpy().astype(np.float32))
+        finally:
+            os.environ.pop("AVDM_SIM_CHUNK_WINDOW", None)
+    a, b = vols
+    diff = np.abs(a - b)
+    assert (diff > 0).mean() < 2e-3, (diff > 0).mean()
+    assert diff.max() <= 4e-3, diff.max()
+    assert (a != 0).mean() > 0.3
+
+
 def test_refine_best_depth_bit_exact(case):
     torch = _torch()
     sc, sgm, ref, depths, o = case
