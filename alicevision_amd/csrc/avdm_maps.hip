@@ -547,10 +547,22 @@ __device__ __forceinline__ float angleBetwABandAC(f3 A, f3 B, f3 C)
 {
     const f3 V1 = normalize_exact(B - A);
     const f3 V2 = normalize_exact(C - A);
-    const double x = (double)(V1.x * V2.x + V1.y * V2.y + V1.z * V2.z);
-    double a = acos(x);
+    // The reference evaluates acos in double precision (matrix.cuh:306-322: the fp32 dot product converted, `acos`, then back to float).
+    // Two fp64 acos per pixel and iteration were ~60 % of this kernel's instruction slots (fp64 runs at half rate); the single-precision
+    // acos of the device library is within 2 ulp of the same value — 4e-5 degrees at 180 — which moves the energy of a flat neighbourhood
+    // (180 - angle, a fraction of a degree) by 1e-4 relative and the optimised depth by far less than the parity class of this stage
+    // allows (tests/test_gpu_parity.py::test_optimize_parity: depth RMSE < 1e-3 pixSize and |d sim| < 1e-2 against the double-precision
+    // oracle).  AVDM_OPT_ACOS_F64 restores the double evaluation for A/B.
+    const float xf = V1.x * V2.x + V1.y * V2.y + V1.z * V2.z;
+#ifdef AVDM_OPT_ACOS_F64
+    double a = acos((double)xf);
     a = isinf(a) ? 0.0 : a;
     return (float)(fabs(a) / (3.14159265358979323846 / 180.0));
+#else
+    float a = acosf(xf);
+    a = isinf(a) ? 0.0f : a;
+    return fabsf(a) * 57.29577951308232f;
+#endif
 }
 
 __global__ void __launch_bounds__(256)

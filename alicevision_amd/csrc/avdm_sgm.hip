@@ -1338,26 +1338,35 @@ static void launch_pair(const SgmPathBatch& S, int nWorkgroups, int K, bool full
 {
     dim3 grid(nWorkgroups), block(128 * AVDM_SGM_PAIR_WPB);
     const size_t lds = pair_kernel_lds_bytes(NW);
+    // the whole-dword form (FULL: Z == 256 * NW exactly) only exists for NW = 1, the shape of the headline configuration: for more than 256
+    // planes an exact multiple is a coincidence, the byte-masked form costs it a few percent, and every instantiation of this kernel takes
+    // ~30 s to compile
+    constexpr bool HAS_FULL = NW == 1;
+    if(!HAS_FULL)
+        full = false;
     static std::once_flag once;
     std::call_once(once, [&] {
         // the stash of the widest instantiations exceeds the 64 KB a kernel gets without asking
-        (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if(HAS_FULL)
+        {
+            (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 0, HAS_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 2, HAS_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
         (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     SgmKernelTimerScope timing(st);
     if(K == 0)
     {
         if(full)
-            hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, true>), grid, block, lds, st, S);
+            hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, HAS_FULL>), grid, block, lds, st, S);
         else
             hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, false>), grid, block, lds, st, S);
     }
     else
     {
         if(full)
-            hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, true>), grid, block, lds, st, S);
+            hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, HAS_FULL>), grid, block, lds, st, S);
         else
             hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, false>), grid, block, lds, st, S);
     }

@@ -207,6 +207,44 @@ __device__ __forceinline__ PatchProj make_patch_proj(const avdm_camera_t& rc, co
     return Q;
 }
 
+// the same with the centre's homogeneous coordinates given: a point on a fixed ray, p = C + v * t, projects to  P * (C, 1) + t * (M * v)  —
+// two vectors per (lane, camera) instead of a 3 x 4 product per plane
+__device__ __forceinline__ PatchProj make_patch_proj_on_ray(const avdm_camera_t& rc, const avdm_camera_t& tc, f3 hr0, f3 ht0, f3 px, f3 py, float pd)
+{
+    PatchProj Q;
+    Q.hr0 = hr0;
+    Q.ht0 = ht0;
+    const f3 ax = px * pd, ay = py * pd;
+    Q.rax = M3x3mulV3(rc.P, ax);
+    Q.ray = M3x3mulV3(rc.P, ay);
+    Q.tax = M3x3mulV3(tc.P, ax);
+    Q.tay = M3x3mulV3(tc.P, ay);
+    return Q;
+}
+// Per-lane constants of a pixel ray C + v * t for the plane loop: the pixel size is proportional to t (computePixSize is the distance of p to
+// the ray of the next pixel: t * |v' x v|), and the homogeneous coordinates in both cameras are affine in t.
+struct RayConsts
+{
+    float pixK;  // pixel size per unit distance
+    float hrW;   // M_R * v = hrW * (x, y, 1): my own pixel's ray projects onto my own pixel
+    f3 htB;      // M_T * v
+    f3 hrA, htA; // P_R * (C, 1), P_T * (C, 1): wave-uniform (kept in SGPRs; the first is zero up to the rounding of P's last column)
+};
+__device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ RayConsts make_ray_consts(const avdm_camera_t& rc, const avdm_camera_t& tc, f3 C, f3 v, float x, float y)
+{
+    RayConsts K;
+    const f3 vNext = normalize(M3x3mulV2(rc.iP, x + 1.0f, y));
+    K.pixK = size(cross(vNext, v));
+    K.hrW = M3x3mulV3(rc.P, v).z;
+    K.htB = M3x3mulV3(tc.P, v);
+    const f3 a = M3x4mulV3(rc.P, C), b = M3x4mulV3(tc.P, C);
+    K.hrA = f3{uniform_f32(a.x), uniform_f32(a.y), uniform_f32(a.z)};
+    K.htA = f3{uniform_f32(b.x), uniform_f32(b.y), uniform_f32(b.z)};
+    return K;
+}
+__device__ __forceinline__ f3 fma3(float t, f3 b, f3 a) { return f3{fmaf(t, b.x, a.x), fmaf(t, b.y, a.y), fmaf(t, b.z, a.z)}; }
+
 // texel-space tap positions of patch sample (fx, fy) in R and T — the ONE expression used by the sample loop and by the
 // window bounding boxes (so the boxes bound exactly what the loop will fetch)
 __device__ __forceinline__ void sample_pos(const PatchProj& Q, const NccArgs& A, f3 hrRow, f3 htRow, float fx, float& rX, float& rY, float& tX,
@@ -779,16 +817,25 @@ __global__ void __launch_bounds__(256, 3)
         ws = *reinterpret_cast<const unsigned*>(ps);
     }
 
+    const RayConsts RK = make_ray_consts(rc, tc, C, v, x, y);
     // geometry of my patch on plane vz (see the Refine kernel): false when the patch centre fails the border test in T
     auto plane_geometry = [&](unsigned vz, PatchProj& Q, float& tpx, float& tpy) __attribute__((always_inline)) -> bool {
         const float depthPlane = depths[vz];
         const f3 planep = C + Z * depthPlane;
         const float kk = (dot(planep, Z) - dnC) / dnv;
         const f3 p = C + v * kk;
-        const float pd = computePixSize(rc, p);
+        // on my pixel's ray: pixel size, view direction and centre projections from the per-lane constants (make_ray_consts)
+        const float pd = RK.pixK * kk;
         f3 ax, ay;
-        patch_axes(rc, tc, p, ax, ay);
-        Q = make_patch_proj(rc, tc, p, ax, ay, pd);
+        {
+            const f3 v1 = f3{-v.x, -v.y, -v.z}; // normalize(C - p)
+            const f3 v2 = normalize(ld3(tc.C) - p);
+            ay = normalize(cross(v1, v2));
+            const f3 n = normalize((v1 + v2) * 0.5f);
+            ax = normalize(cross(ay, n));
+        }
+        const float tw = kk * RK.hrW;
+        Q = make_patch_proj_on_ray(rc, tc, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, fma3(kk, RK.htB, RK.htA), ax, ay, pd);
         const float it0 = fast_rcp(Q.ht0.z);
         tpx = Q.ht0.x * it0;
         tpy = Q.ht0.y * it0;
@@ -969,17 +1016,18 @@ __global__ void __launch_bounds__(256, 3)
     if(pixActive)
         packed = *reinterpret_cast<const uint4*>(pv);
 
+    const RayConsts RK = make_ray_consts(rc, tc, C, dir, x, y);
     // geometry of my patch on plane vz: the 3-D point, the patch axes and their projections; false when the patch centre fails the border
     // test in T (Patch.cuh:486-496).  (tpx, tpy) = the centre's pixel in T.
     auto plane_geometry = [&](unsigned vz, PatchProj& Q, float& tpx, float& tpy) __attribute__((always_inline)) -> bool {
         const int rel = (int)vz - ((volDimZ - 1) / 2);
-        f3 p = pMid;
-        if(rel != 0)
-            p = pMid + dir * ((float)rel * dps.y);
-        const float pd = computePixSize(rc, p);
+        // p = pMid + dir * (rel * pixSize) (move3DPointByRcPixSize) = C + dir * t: on my pixel's ray
+        const float t = fmaf((float)rel, dps.y, dps.x);
+        const f3 p = C + dir * t;
+        const float pd = RK.pixK * t;
         f3 ax, ay;
         {
-            const f3 v1 = normalize(C - p);
+            const f3 v1 = f3{-dir.x, -dir.y, -dir.z}; // normalize(C - p)
             const f3 v2 = normalize(ld3(tc.C) - p);
             ay = normalize(cross(v1, v2));
             f3 n;
@@ -992,7 +1040,8 @@ __global__ void __launch_bounds__(256, 3)
                 n = normalize((v1 + v2) * 0.5f);
             ax = normalize(cross(ay, n));
         }
-        Q = make_patch_proj(rc, tc, p, ax, ay, pd);
+        const float tw = t * RK.hrW;
+        Q = make_patch_proj_on_ray(rc, tc, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, fma3(t, RK.htB, RK.htA), ax, ay, pd);
         const float it0 = fast_rcp(Q.ht0.z);
         tpx = Q.ht0.x * it0;
         tpy = Q.ht0.y * it0;
