@@ -212,6 +212,24 @@ def main():
                 # the same bytes over the whole avdm_volume_optimize call (path launches + sgm_p2_map_kernel, whose 64 B/pixel are in the numerator)
                 "ms_whole_call_per_volume": whole_call_ms, "frac_whole_call": alg_bytes_per_volume / (whole_call_ms * 1e-3) / 1e9 / 8000.0,
                 "frac_kernels_only": achieved / 8000.0}
+        # what this box's HBM delivers to a plain device-to-device copy (1 GiB read + 1 GiB written, measured here, after the timed region):
+        # the practical ceiling next to the 8 TB/s nominal peak the fraction is quoted against (profiles/README.md: box-to-box variance)
+        try:
+            src_t = torch.empty(1 << 28, dtype=torch.float32, device=dev).fill_(1.0)
+            dst_t = torch.empty_like(src_t)
+            dst_t.copy_(src_t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst_t.copy_(src_t)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbps = 5 * 2.0 * src_t.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            roof["box_copy_GBps"] = copy_gbps
+            roof["achieved_over_box_copy"] = achieved / copy_gbps
+            del src_t, dst_t
+        except Exception:
+            pass
         # HBM bytes per launch from the PMC counters: NOT measured by this run (counters need their own rocprofv3 --pmc passes); the value
         # is the committed summary of the latest counter session of the SAME kernel and volume size, named here with its provenance
         for pmc in ("r02_sgm_pmc.json", "r01_sgm_pmc.json"):
