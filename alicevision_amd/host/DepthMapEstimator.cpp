@@ -364,12 +364,48 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
     if(_sgmParams.doSgmOptimizeVolume)
         groupScratch.allocate((size_t)nbStreams * avdm_volume_optimize_scratch_bytes(sgmPerStream.front()->getMapWidth(), sgmPerStream.front()->getMapHeight(),
                                                                                      std::max(_sgmParams.maxDepths, 1)));
-    // one event per stream (group fan-in) + one for the aggregation (fan-out)
-    std::vector<hipEvent_t> volumeDone(nbStreams);
-    for(auto& e : volumeDone)
-        AVDM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipEvent_t aggregationDone;
-    AVDM_HIP_CHECK(hipEventCreateWithFlags(&aggregationDone, hipEventDisableTiming));
+    // one event per stream (group fan-in) + one for the aggregation (fan-out); RAII holders: an exception anywhere below (a tile that does
+    // not fit, a decoding error, a failed launch) must not leak events or free page-locked vectors while they are still registered
+    struct EventSet
+    {
+        std::vector<hipEvent_t> ev;
+        explicit EventSet(size_t n)
+        {
+            ev.reserve(n);
+            for(size_t i = 0; i < n; ++i)
+            {
+                hipEvent_t e = nullptr;
+                AVDM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ev.push_back(e);
+            }
+        }
+        ~EventSet()
+        {
+            for(hipEvent_t e : ev)
+                (void)hipEventDestroy(e);
+        }
+        EventSet(const EventSet&) = delete;
+        EventSet& operator=(const EventSet&) = delete;
+    };
+    struct PinnedRegistrations
+    {
+        std::vector<void*> ptrs;
+        void add(void* p, size_t bytes)
+        {
+            if(hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) // unpinned tiles still work (synchronous copies)
+                ptrs.push_back(p);
+            else
+                (void)hipGetLastError();
+        }
+        ~PinnedRegistrations()
+        {
+            for(void* p : ptrs)
+                (void)hipHostUnregister(p);
+        }
+    };
+    EventSet events((size_t)nbStreams + 1);
+    std::vector<hipEvent_t> volumeDone(events.ev.begin(), events.ev.begin() + nbStreams);
+    const hipEvent_t aggregationDone = events.ev.back();
 
     // final depth/similarity map tiles in host memory, per camera of a batch
     const int finalMapW = _depthMapParams.useRefine ? refinePerStream.front()->getMapWidth() : sgmPerStream.front()->getMapWidth();
@@ -378,6 +414,7 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
     // (the reference merges and writes between the batches, DepthMapEstimator.cpp:446-466, with the device idle)
     const int nbHostSets = 2;
     std::vector<std::vector<Float2Tile>> depthSimMapTileSets[nbHostSets];
+    PinnedRegistrations pinned; // declared after the tile sets: unregistered before the vectors are freed
     std::vector<std::vector<std::pair<float, float>>> depthMinMaxTileSets[nbHostSets];
     for(int s = 0; s < nbHostSets; ++s)
     {
@@ -393,11 +430,30 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
                 // page-lock the result tiles (CudaHostMemoryHeap is pinned memory in the reference): the device-to-host copies of a
                 // group then run asynchronously on the tile streams instead of blocking the host thread that feeds them
                 std::vector<float>& v = depthSimMapTileSets[s][i][j].data;
-                (void)hipHostRegister(v.data(), v.size() * sizeof(float), hipHostRegisterDefault);
+                pinned.add(v.data(), v.size() * sizeof(float));
             }
         }
     }
     std::future<void> pendingWrite;
+    // the background writer reads the host tile sets: on unwinding it must have finished before they go away (its own exception, if any, is
+    // dropped then — the one in flight is reported)
+    struct WriterGuard
+    {
+        std::future<void>& f;
+        ~WriterGuard()
+        {
+            if(f.valid())
+            {
+                try
+                {
+                    f.get();
+                }
+                catch(...)
+                {
+                }
+            }
+        }
+    } writerGuard{pendingWrite};
     logDeviceMemoryInfo();
 
     const int nbBatches = divideRoundUp(static_cast<int>(tiles.size()), nbTilesPerBatch);
@@ -634,13 +690,6 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
             }
         }
 
-    for(auto& set : depthSimMapTileSets)
-        for(auto& perCam : set)
-            for(auto& t : perCam)
-                (void)hipHostUnregister(t.data.data());
-    for(auto& e : volumeDone)
-        (void)hipEventDestroy(e);
-    (void)hipEventDestroy(aggregationDone);
 }
 
 } // namespace avdm_host

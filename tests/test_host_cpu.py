@@ -369,3 +369,16 @@ def test_filtering_cli_argument_errors(scene, tmp_path):
     assert r.returncode == 0 and "No camera to process" in r.stdout
     assert run([FILTER_CLI, "-i", sfm, "--depthMapsFolder", d, "-o", str(tmp_path), "--rangeStart", -1, "--rangeSize", 2], check=False).returncode == 1
     assert run([FILTER_CLI, "-i", sfm, "--depthMapsFolder", d, "-o", str(tmp_path), "--pixSizeBall", -1], check=False).returncode == 1
+
+
+def test_sgm_running_average_integer_forms():
+    """csrc/avdm_sgm.hip replaces the reference's (uint8)((out * K + clamp(L)) / (K + 1)) (kernels.cuh:741-743) by integer forms on packed
+    uint16 pairs: n >> 1, n >> 2 and, for K = 2, (n * 21856) >> 16 (two v_mul_u32_u24_sdwa + one v_perm_b32) == (n * 683) >> 11 — exact
+    for every n = out * K + clamp(L) <= 1020; and the fp32 expression of the reference truncates to the same integer."""
+    n = np.arange(0, 1021, dtype=np.int64)
+    assert np.array_equal((n * 21856) >> 16, n // 3)
+    assert np.array_equal((n * 683) >> 11, n // 3)
+    for K in (1, 2, 3):
+        o, c = np.meshgrid(np.arange(256, dtype=np.float32), np.arange(256, dtype=np.float32), indexing="ij")
+        ref = ((o * np.float32(K) + c) / np.float32(K + 1)).astype(np.uint8)  # fp32 division, truncating cast
+        assert np.array_equal(ref, ((o.astype(np.int64) * K + c.astype(np.int64)) // (K + 1)).astype(np.uint8)), K
