@@ -849,6 +849,7 @@ __global__ void __launch_bounds__(256, 3)
     Wc.ok = false;
     Wc.x0 = Wc.y0 = Wc.w = Wc.h = Wc.pitch = 0;
     float extX = 0.f, extY = 0.f;
+    bool lanePart = false;
     if(FIXED8 && (paired || halfPaired) && A.chunkWindow)
     {
         const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + 4u < zEnd) ? z0 + 4u : zEnd;
@@ -884,6 +885,7 @@ __global__ void __launch_bounds__(256, 3)
             Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired);
             __syncthreads();
             chunkWin = Wc.ok;
+            lanePart = part;
         }
     }
 
@@ -912,7 +914,8 @@ __global__ void __launch_bounds__(256, 3)
             if(valid)
             {
                 const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
-                laneLds = (cxT - extX - 1.0f >= (float)Wd.x0) && (cxT + extX + 2.0f <= (float)(Wd.x0 + Wd.w - 1)) &&
+                // (a lane that was valid on neither extreme plane has no extent on record: it never reads the window)
+                laneLds = lanePart && (cxT - extX - 1.0f >= (float)Wd.x0) && (cxT + extX + 2.0f <= (float)(Wd.x0 + Wd.w - 1)) &&
                           (cyT - extY - 1.0f >= (float)Wd.y0) && (cyT + extY + 2.0f <= (float)(Wd.y0 + Wd.h - 1));
             }
             laneLds = __ballot(valid && !laneLds) == 0ull; // wave-uniform choice of the tap source (see the Refine kernel)
@@ -1063,6 +1066,7 @@ __global__ void __launch_bounds__(256, 3)
     Wc.ok = false;
     Wc.x0 = Wc.y0 = Wc.w = Wc.h = Wc.pitch = 0;
     float extX = 0.f, extY = 0.f; // half extent of my projected patch in T texels (the larger of the two extreme planes)
+    bool lanePart = false;        // my patch was part of the hull (valid on the first or the last plane of the chunk)
     if(CHUNK_CAPABLE && paired && A.chunkWindow)
     {
         const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + 8u < zEnd) ? z0 + 8u : zEnd;
@@ -1098,6 +1102,7 @@ __global__ void __launch_bounds__(256, 3)
             Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired);
             __syncthreads();
             chunkWin = Wc.ok;
+            lanePart = part;
         }
     }
 
@@ -1122,7 +1127,8 @@ __global__ void __launch_bounds__(256, 3)
             {
                 const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
                 // taps = texels floor(.) and floor(.) + 1 of positions within +- ext of the centre; one more texel for rounding
-                laneLds = (cxT - extX - 1.0f >= (float)Wd.x0) && (cxT + extX + 2.0f <= (float)(Wd.x0 + Wd.w - 1)) &&
+                // (a lane that was valid on neither extreme plane has no extent on record: it never reads the window)
+                laneLds = lanePart && (cxT - extX - 1.0f >= (float)Wd.x0) && (cxT + extX + 2.0f <= (float)(Wd.x0 + Wd.w - 1)) &&
                           (cyT - extY - 1.0f >= (float)Wd.y0) && (cyT + extY + 2.0f <= (float)(Wd.y0 + Wd.h - 1));
                 if(laneLds)
                     tcCenter = lds_center_paired(sT, Wd.pitch, Wd.x0, Wd.y0, cxT, cyT);
