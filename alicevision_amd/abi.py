@@ -75,6 +75,15 @@ class RefineParams(C.Structure):
         return p
 
 
+class Intrinsic(C.Structure):
+    """avdm_intrinsic_t"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("scale_x", C.c_double), ("scale_y", C.c_double), ("offset_x", C.c_double),
+                ("offset_y", C.c_double), ("distortion_model", C.c_int), ("k", C.c_double * 3)]
+
+
+DISTORTION_NONE, DISTORTION_RADIALK1, DISTORTION_RADIALK3, DISTORTION_RADIALK3PT = 0, 1, 2, 3
+
+
 class PatchSubpartParams(C.Structure):
     """CustomPatchPatternParams::SubpartParams"""
     _fields_ = [("isCircle", C.c_int), ("level", C.c_int), ("nbCoordinates", C.c_int), ("radius", C.c_float), ("weight", C.c_float)]
@@ -111,6 +120,7 @@ SIGNATURES = {
     "avdm_downscale_with_gaussian_blur": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "avdm_pyramid_build_levels": (i32, [P(Pyramid), vp]),
     "avdm_image_resize": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, vp]),
+    "avdm_image_undistort": (i32, [vp, i32, vp, i32, P(Intrinsic), P(C.c_float * 4), vp]),
     "avdm_pyramid_fill": (i32, [P(Pyramid), vp, i32, vp, vp]),
     "avdm_tex2dlod": (i32, [vp, P(Pyramid), vp, i32, vp]),
     "avdm_volume_initialize_u8": (i32, [vp, i64, i32, i32, i32, i32, u8, vp]),

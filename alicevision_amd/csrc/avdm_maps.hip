@@ -822,6 +822,98 @@ __global__ void __launch_bounds__(256)
     *((float4*)((char*)dst + (long long)roiY * dst_pitch) + roiX) = pel;
 }
 
+// ---- undistortion of an input image (camera::UndistortImage, camera/cameraUndistortImage.hpp:81-139) -------------------------------------
+// One lane per pixel of the undistorted image; the geometry in double like the reference (this file is compiled without contraction), the
+// sample position converted to float before the sampler like its `operator()(src, float y, float x)`, the sampler's accumulation in double.
+__device__ __forceinline__ void add_distortion(const avdm_intrinsic_t& c, double& x, double& y)
+{
+    // DistortionRadialK1 / K3 / K3PT::addDistortion (camera/DistortionRadial.cpp:18-24, 110-124, 262-277)
+    double coeff = 1.0;
+    if(c.distortion_model == AVDM_DISTORTION_RADIALK1)
+    {
+        const double r2 = x * x + y * y;
+        coeff = (1. + c.k[0] * r2);
+    }
+    else if(c.distortion_model == AVDM_DISTORTION_RADIALK3 || c.distortion_model == AVDM_DISTORTION_RADIALK3PT)
+    {
+        const double r = sqrt(x * x + y * y);
+        const double r2 = r * r;
+        const double r4 = r2 * r2;
+        const double r6 = r4 * r2;
+        coeff = (1. + c.k[0] * r2 + c.k[1] * r4 + c.k[2] * r6);
+        if(c.distortion_model == AVDM_DISTORTION_RADIALK3PT)
+            coeff = coeff / (1.0 + c.k[0] + c.k[1] + c.k[2]);
+    }
+    x = x * coeff;
+    y = y * coeff;
+}
+
+__global__ void __launch_bounds__(256)
+  image_undistort_kernel(float4* __restrict__ dst, int dst_pitch, const float4* __restrict__ src, int src_pitch, avdm_intrinsic_t cam, float4 fill)
+{
+    MAP_XY();
+    const int W = cam.width, H = cam.height;
+    if(roiX >= (unsigned)W || roiY >= (unsigned)H)
+        return;
+    // getDistortedPixel(p) = cam2ima(addDistortion(ima2cam(p))) (IntrinsicScaleOffsetDisto.cpp:80; IntrinsicScaleOffset.cpp:31, 55-66)
+    const double ppx = cam.offset_x + (double)W * 0.5, ppy = cam.offset_y + (double)H * 0.5;
+    double cx = ((double)roiX - ppx) / cam.scale_x, cy = ((double)roiY - ppy) / cam.scale_y;
+    add_distortion(cam, cx, cy);
+    const double dxp = cx * cam.scale_x + ppx, dyp = cy * cam.scale_y + ppy;
+    float4 out = fill;
+    // imageIn.contains(disto_pix(1), disto_pix(0)): the doubles convert to int by truncation (image/Image.hpp:178)
+    const int ix = (int)dxp, iy = (int)dyp;
+    if(0 <= ix && ix < W && 0 <= iy && iy < H)
+    {
+        // Sampler2d<SamplerLinear>::operator()(src, float y, float x) (image/Sampler.hpp:391-474)
+        const float x = (float)dxp, y = (float)dyp;
+        const double fxl = floor((double)x), fyl = floor((double)y);
+        const double dx = (double)x - fxl, dy = (double)y - fyl;
+        const double coefsX[2] = {1.0 - dx, dx}, coefsY[2] = {1.0 - dy, dy};
+        const int gridX = (int)fxl, gridY = (int)fyl;
+        double r = 0.0, g = 0.0, b = 0.0, a = 0.0, totalWeight = 0.0;
+        for(int i = 0; i < 2; ++i)
+        {
+            const int iCurrent = gridY + 1 + i - 1;
+            if(iCurrent < 0 || iCurrent >= H)
+                continue;
+            const float4* row = (const float4*)((const char*)src + (long long)iCurrent * src_pitch);
+            for(int j = 0; j < 2; ++j)
+            {
+                const int jCurrent = gridX + 1 + j - 1;
+                if(jCurrent < 0 || jCurrent >= W)
+                    continue;
+                const double w = coefsX[j] * coefsY[i];
+                const float4 p = row[jCurrent];
+                r += (double)p.x * w;
+                g += (double)p.y * w;
+                b += (double)p.z * w;
+                a += (double)p.w * w;
+                totalWeight += w;
+            }
+        }
+        if(totalWeight <= 0.2)
+        {
+            int row = (int)floor((double)y), col = (int)floor((double)x);
+            row = row < 0 ? 0 : (row >= H ? H - 1 : row);
+            col = col < 0 ? 0 : (col >= W ? W - 1 : col);
+            out = *((const float4*)((const char*)src + (long long)row * src_pitch) + col);
+        }
+        else
+        {
+            if(totalWeight != 1.0)
+            {
+                r /= totalWeight;
+                g /= totalWeight;
+                b /= totalWeight;
+                a /= totalWeight;
+            }
+            out = make_float4((float)r, (float)g, (float)b, (float)a);
+        }
+    }
+    *((float4*)((char*)dst + (long long)roiY * dst_pitch) + roiX) = out;
+}
+
 // libutil/filter.cpp, FilterLanczos3_1D::lanczos3 (OpenImageIO 2.x): one sinf, sin(pi x) through the triple-angle identity
 static float oiio_lanczos3(float x)
 {
@@ -1038,6 +1130,27 @@ int avdm_compute_sgm_upscaled_depth_pixsize_map(float* out_map, int out_pitch, c
                            (const float2*)in_sgm_depth_thickness, in_pitch, t.lv[level], wN, hN, rp->stepXY, rp->halfNbDepths, ratio,
                            rp->interpolateMiddleDepth, roi);
     AVDM_LAUNCH_CHECK("avdm_compute_sgm_upscaled_depth_pixsize_map");
+}
+
+int avdm_image_undistort(float* dst_rgba, int dst_pitch, const float* src_rgba, int src_pitch, const avdm_intrinsic_t* cam, const float fill_rgba[4],
+                         void* stream)
+{
+    if(cam == nullptr || cam->width <= 0 || cam->height <= 0)
+        return set_error_msg(1, "avdm_image_undistort: empty image");
+    if(cam->distortion_model < AVDM_DISTORTION_NONE || cam->distortion_model > AVDM_DISTORTION_RADIALK3PT)
+        return set_error_msg(1, "avdm_image_undistort: unknown distortion model");
+    hipStream_t st = (hipStream_t)stream;
+    const bool hasDistortion = cam->distortion_model != AVDM_DISTORTION_NONE; // IntrinsicScaleOffsetDisto::hasDistortion(): a distortion object exists
+    if(!hasDistortion)
+    { // cameraUndistortImage.hpp:89-93: no distortion, a direct copy
+        const hipError_t e = hipMemcpy2DAsync(dst_rgba, (size_t)dst_pitch, src_rgba, (size_t)src_pitch, (size_t)cam->width * 16, (size_t)cam->height,
+                                              hipMemcpyDeviceToDevice, st);
+        return ::avdm::set_error(e, "avdm_image_undistort");
+    }
+    const float4 fill = make_float4(fill_rgba[0], fill_rgba[1], fill_rgba[2], fill_rgba[3]);
+    hipLaunchKernelGGL(image_undistort_kernel, map_grid((unsigned)cam->width, (unsigned)cam->height), dim3(256), 0, st, (float4*)dst_rgba, dst_pitch,
+                       (const float4*)src_rgba, src_pitch, *cam, fill);
+    AVDM_LAUNCH_CHECK("avdm_image_undistort");
 }
 
 int avdm_image_resize(float* dst_rgba, int dst_pitch, int dst_w, int dst_h, const float* src_rgba, int src_pitch, int src_w, int src_h, void* stream)

@@ -770,7 +770,9 @@ __device__ __forceinline__ float avg_f32(float o, float lc)
     return truncf(truncf(n) * 0.33333334f);
 }
 
+#ifndef AVDM_SGM_PAIR_WPB
 #define AVDM_SGM_PAIR_WPB 4 // columns per workgroup: 2 * WPB waves
+#endif
 #ifndef AVDM_SGM_AUX_LD
 #define AVDM_SGM_AUX_LD 2 // cache policy of the ring loads / the stores: 0 = default, 2 = non-temporal (gfx94x/95x aux bit 1)
 #endif

@@ -176,6 +176,26 @@ int avdm_tex2dlod(float* out4, const avdm_pyramid_t* pyr, const float* uvl, int 
  * RGBA, device memory, dst no larger than src (enlarging would select blackman-harris: refused).  dst_w = src_w / downscale and
  * dst_h = src_h / downscale (integer division) are the caller's, like in the reference. */
 int avdm_image_resize(float* dst_rgba, int dst_pitch, int dst_w, int dst_h, const float* src_rgba, int src_pitch, int src_w, int src_h, void* stream);
+/* Undistortion of an input image (second slice of the image ingest): camera::UndistortImage(imageIn, intrinsic, image_ud,
+ * fillcolor) (camera/cameraUndistortImage.hpp:81-139) as software/pipeline/main_prepareDenseScene.cpp:71-79 calls it — for every pixel of
+ * the undistorted image the distorted position  cam2ima(addDistortion(ima2cam(p)))  (camera/IntrinsicScaleOffsetDisto.cpp:80,
+ * IntrinsicScaleOffset.cpp:31-66, DistortionRadial.cpp:18-24, 110-124, 262-277) in double precision, then the bilinear sampler of
+ * image/Sampler.hpp:377-477 (out-of-range neighbours dropped and the weights renormalised, nearest pixel when less than 0.2 of the weight is
+ * left) if the position lies in the image, else the fill colour.  Float RGBA, device memory, same size in and out. */
+#define AVDM_DISTORTION_NONE 0
+#define AVDM_DISTORTION_RADIALK1 1
+#define AVDM_DISTORTION_RADIALK3 2
+#define AVDM_DISTORTION_RADIALK3PT 3
+typedef struct avdm_intrinsic
+{
+    int width, height;          /* camera::IntrinsicBase::_w, _h                                            */
+    double scale_x, scale_y;    /* IntrinsicScaleOffset::_scale: focal length in pixels                      */
+    double offset_x, offset_y;  /* IntrinsicScaleOffset::_offset: principal point - image centre             */
+    int distortion_model;       /* AVDM_DISTORTION_*                                                          */
+    double k[3];                /* distortion parameters                                                      */
+} avdm_intrinsic_t;
+int avdm_image_undistort(float* dst_rgba, int dst_pitch, const float* src_rgba, int src_pitch, const avdm_intrinsic_t* cam, const float fill_rgba[4],
+                         void* stream);
 /* convenience: the whole of DeviceCache::addMipmapImage (cuda/host/DeviceCache.cpp:222-281) + DeviceMipmapImage::fill
  * (cuda/host/DeviceMipmapImage.cpp:28-90) for an image already on the device.
  * `scratch_h4` must hold width*height fp16x4 texels when min_downscale > 1 (may be NULL otherwise). */

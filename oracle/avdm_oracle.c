@@ -645,6 +645,103 @@ int avo_image_resize(float* dst, int dst_pitch, int dst_w, int dst_h, const floa
 }
 
 
+/* ---- image ingest: undistortion ------------------------------------------------------------------------------------------------------
+ * camera::UndistortImage(imageIn, intrinsicPtr, image_ud, fillcolor) (camera/cameraUndistortImage.hpp:81-139), the call of
+ * software/pipeline/main_prepareDenseScene.cpp:71-79.  Everything it uses is in the reference tree:
+ *   getDistortedPixel = cam2ima(addDistortion(ima2cam(p)))      camera/IntrinsicScaleOffsetDisto.cpp:80
+ *   ima2cam / cam2ima / principal point = offset + size / 2      camera/IntrinsicScaleOffset.cpp:31, 55-66
+ *   addDistortion for radialk1 / radialk3 / radialk3pt            camera/DistortionRadial.cpp:18-24, 110-124, 262-277
+ *   Image::contains(int y, int x) on the (truncated) doubles      image/Image.hpp:178
+ *   Sampler2d<SamplerLinear>::operator()(src, float y, float x)   image/Sampler.hpp:57-75, 377-477 */
+static void avo_add_distortion(const avdm_intrinsic_t* c, double* x, double* y)
+{
+    double coeff = 1.0;
+    if(c->distortion_model == AVDM_DISTORTION_RADIALK1)
+    {
+        const double r2 = (*x) * (*x) + (*y) * (*y);
+        coeff = (1. + c->k[0] * r2);
+    }
+    else if(c->distortion_model == AVDM_DISTORTION_RADIALK3 || c->distortion_model == AVDM_DISTORTION_RADIALK3PT)
+    {
+        const double r = sqrt((*x) * (*x) + (*y) * (*y));
+        const double r2 = r * r;
+        const double r4 = r2 * r2;
+        const double r6 = r4 * r2;
+        coeff = (1. + c->k[0] * r2 + c->k[1] * r4 + c->k[2] * r6);
+        if(c->distortion_model == AVDM_DISTORTION_RADIALK3PT)
+            coeff = coeff / (1.0 + c->k[0] + c->k[1] + c->k[2]);
+    }
+    *x = (*x) * coeff;
+    *y = (*y) * coeff;
+}
+
+int avo_image_undistort(float* dst, int dst_pitch, const float* src, int src_pitch, const avdm_intrinsic_t* cam, const float fill[4])
+{
+    const int W = cam->width, H = cam->height;
+    if(W <= 0 || H <= 0 || cam->distortion_model < AVDM_DISTORTION_NONE || cam->distortion_model > AVDM_DISTORTION_RADIALK3PT)
+        return 1;
+    if(cam->distortion_model == AVDM_DISTORTION_NONE)
+    { /* hasDistortion() false: a direct copy (cameraUndistortImage.hpp:89-93) */
+        for(int y = 0; y < H; ++y)
+            memcpy((char*)dst + (size_t)y * dst_pitch, (const char*)src + (size_t)y * src_pitch, (size_t)W * 16);
+        return 0;
+    }
+    const double ppx = cam->offset_x + (double)W * 0.5, ppy = cam->offset_y + (double)H * 0.5;
+#pragma omp parallel for schedule(dynamic, 8)
+    for(int py = 0; py < H; ++py)
+        for(int px = 0; px < W; ++px)
+        {
+            double cx = ((double)px - ppx) / cam->scale_x, cy = ((double)py - ppy) / cam->scale_y;
+            avo_add_distortion(cam, &cx, &cy);
+            const double dxp = cx * cam->scale_x + ppx, dyp = cy * cam->scale_y + ppy;
+            float* o = (float*)((char*)dst + (size_t)py * dst_pitch) + 4 * (size_t)px;
+            o[0] = fill[0], o[1] = fill[1], o[2] = fill[2], o[3] = fill[3];
+            const int ix = (int)dxp, iy = (int)dyp;
+            if(!(0 <= ix && ix < W && 0 <= iy && iy < H))
+                continue;
+            const float x = (float)dxp, y = (float)dyp;
+            const double fxl = floor((double)x), fyl = floor((double)y);
+            const double dx = (double)x - fxl, dy = (double)y - fyl;
+            const double coefsX[2] = {1.0 - dx, dx}, coefsY[2] = {1.0 - dy, dy};
+            const int gridX = (int)fxl, gridY = (int)fyl;
+            double res[4] = {0.0, 0.0, 0.0, 0.0}, totalWeight = 0.0;
+            for(int i = 0; i < 2; ++i)
+            {
+                const int iCurrent = gridY + 1 + i - 1;
+                if(iCurrent < 0 || iCurrent >= H)
+                    continue;
+                const float* row = (const float*)((const char*)src + (size_t)iCurrent * src_pitch);
+                for(int j = 0; j < 2; ++j)
+                {
+                    const int jCurrent = gridX + 1 + j - 1;
+                    if(jCurrent < 0 || jCurrent >= W)
+                        continue;
+                    const double w = coefsX[j] * coefsY[i];
+                    for(int c = 0; c < 4; ++c)
+                        res[c] += (double)row[4 * (size_t)jCurrent + c] * w;
+                    totalWeight += w;
+                }
+            }
+            if(totalWeight <= 0.2)
+            {
+                int row = (int)floor((double)y), col = (int)floor((double)x);
+                row = row < 0 ? 0 : (row >= H ? H - 1 : row);
+                col = col < 0 ? 0 : (col >= W ? W - 1 : col);
+                const float* p = (const float*)((const char*)src + (size_t)row * src_pitch) + 4 * (size_t)col;
+                o[0] = p[0], o[1] = p[1], o[2] = p[2], o[3] = p[3];
+                continue;
+            }
+            for(int c = 0; c < 4; ++c)
+            {
+                if(totalWeight != 1.0)
+                    res[c] /= totalWeight;
+                o[c] = (float)res[c];
+            }
+        }
+    return 0;
+}
+
+
 /* DeviceCache.cpp:41-134 (fillHostCameraParameters), mvsData/Matrix3x3.hpp:268-287 (inverse) */
 static void inv3(const double* m, double* o) /* row-major */
 {

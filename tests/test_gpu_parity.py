@@ -101,6 +101,31 @@ def test_image_resize_bit_exact(w, h, s):
     assert lib.avdm_image_resize(_ptr(one), w * 16, w, h, _ptr(tdst), dw * 16, dw, dh, _st()) != 0 or s == 1
 
 
+@pytest.mark.parametrize("model,k", [(0, (0.0, 0.0, 0.0)), (1, (0.08, 0.0, 0.0)), (2, (0.1, -0.05, 0.01)), (2, (-0.3, 0.1, 0.0)), (3, (0.05, 0.02, -0.01))])
+def test_image_undistort_bit_exact(model, k):
+    """camera::UndistortImage (PrepareDenseScene): the device kernel against the oracle — double-precision geometry, float sample position,
+    double accumulation in the sampler: identical floats, fill colour where the distorted position leaves the image, pitched rows"""
+    torch = _torch()
+    from oracle import oracle
+    lib, olib = abi.load(), oracle.load()
+    rng = np.random.default_rng(11 + model)
+    H, W = 123, 187
+    src = rng.random((H, W, 4), dtype=np.float32)
+    cam = abi.Intrinsic(width=W, height=H, scale_x=150.0, scale_y=148.5, offset_x=3.25, offset_y=-2.5, distortion_model=model, k=(C.c_double * 3)(*k))
+    fill = (C.c_float * 4)(0.1, 0.2, 0.3, 0.0)
+    want = np.zeros_like(src)
+    assert olib.avo_image_undistort(oracle.ptr(want), W * 16, oracle.ptr(src), W * 16, C.byref(cam), C.byref(fill)) == 0
+    pitch = (W + 5) * 16
+    tsrc = torch.zeros((H, W + 5, 4), dtype=torch.float32, device="cuda")
+    tsrc[:, :W] = torch.from_numpy(src).cuda()
+    tdst = torch.full((H, W + 5, 4), -1.0, dtype=torch.float32, device="cuda")
+    abi.check(lib.avdm_image_undistort(_ptr(tdst), pitch, _ptr(tsrc), pitch, C.byref(cam), C.byref(fill), _st()))
+    torch.cuda.synchronize()
+    got = tdst.cpu().numpy()
+    assert np.array_equal(got[:, :W].view(np.uint32), want.view(np.uint32)), float(np.abs(got[:, :W] - want).max())
+    assert np.all(got[:, W:] == -1.0)  # padding untouched
+
+
 @pytest.mark.parametrize("mode", [abi.FILTER_CUDA_FIXED8, abi.FILTER_EXACT])
 def test_similarity_volume_parity(mode):
     """Weighted NCC is ill-conditioned in fp32 the way the reference accumulates it (DESIGN.md "NCC conditioning"): the

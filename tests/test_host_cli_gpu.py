@@ -330,3 +330,52 @@ def test_multi_worker_exchange_equals_single_worker(dataset):
             a = open(os.path.join(out1, name), "rb").read()
             b = open(os.path.join(out2, name), "rb").read()
             assert a == b, name
+
+
+def test_prepare_dense_scene_undistorts_and_feeds_the_estimation(tmp_path):
+    """aliceVision_prepareDenseScene (the program before this stage): views of a camera with radial distortion come out undistorted —
+    bit for bit the oracle's camera::UndistortImage — with the camera in the image metadata, and aliceVision_depthMapEstimation plans
+    from those files exactly as from the SfMData."""
+    import ctypes as C
+    from oracle import oracle
+    exe = os.path.join(ROOT, "alicevision_amd", "bin", "aliceVision_prepareDenseScene")
+    w, h = 320, 240
+    sc = make_scene(4, w, h, seed=9, baseline=0.9, amp=0.6)
+    d = str(tmp_path)
+    sfm, img = scene_io.write_scene(sc, d, n_landmarks=10, compression=0)
+    sd = scene_io.sfm_dict(sc, scene_io.sample_landmarks(sc, 300, amp=0.6), img)
+    k = (0.09, -0.04, 0.012)
+    sd["intrinsics"][0]["distortionType"] = "radialk3"
+    sd["intrinsics"][0]["distortionParams"] = ["%.17g" % v for v in k]
+    with open(sfm, "w") as f:
+        json.dump(sd, f)
+    out = os.path.join(d, "prepared")
+    r = subprocess.run([exe, "-i", sfm, "-o", out, "--saveMatricesTxtFiles", "1", "-v", "info"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    olib = oracle.load()
+    fx = float(sc.K[0, 0])
+    cam = abi.Intrinsic(width=w, height=h, scale_x=fx, scale_y=fx, offset_x=float(sc.K[0, 2]) - w / 2.0, offset_y=float(sc.K[1, 2]) - h / 2.0,
+                        distortion_model=abi.DISTORTION_RADIALK3, k=(C.c_double * 3)(*k))
+    fill = (C.c_float * 4)(0, 0, 0, 0)
+    for i in range(4):
+        vid = scene_io.view_id(i)
+        ch, info = exr_io.read_exr(os.path.join(out, "%d.exr" % vid))
+        got = np.stack([ch["R"], ch["G"], ch["B"], ch["A"]], -1)
+        src = np.ascontiguousarray(sc.images[i].numpy())
+        want = np.zeros_like(src)
+        assert olib.avo_image_undistort(oracle.ptr(want), w * 16, oracle.ptr(src), w * 16, C.byref(cam), C.byref(fill)) == 0
+        assert np.array_equal(got, want), (i, float(np.abs(got - want).max()))
+        assert not np.array_equal(got, src)
+        P = exr_io.attr_value(info, "AliceVision:P").reshape(4, 4)[:3]
+        Pref = sc.K @ np.concatenate([sc.R[i], (-sc.R[i] @ sc.C[i])[:, None]], axis=1)
+        assert np.allclose(P, Pref, atol=1e-6)
+        assert exr_io.attr_value(info, "AliceVision:downscale") == 1
+        Ptxt = np.loadtxt(os.path.join(out, "%d_P.txt" % vid))
+        assert np.allclose(Ptxt, Pref, rtol=1e-8, atol=1e-8)
+    # the estimation program on the prepared folder: same plan as from the SfMData with the original images
+    a = ["-i", sfm, "--imagesFolder", out, "-o", os.path.join(d, "o1"), "--downscale", 1, "--rangeStart", 0, "--rangeSize", 1, "--sgmMaxDepths", 48, "--dryRun", 1]
+    b = ["-i", sfm, "--imagesFolder", img, "-o", os.path.join(d, "o2"), "--downscale", 1, "--rangeStart", 0, "--rangeSize", 1, "--sgmMaxDepths", 48, "--dryRun", 1]
+    pa = json.loads(run_cli(a).stdout.strip().splitlines()[-1])
+    pb = json.loads(run_cli(b).stdout.strip().splitlines()[-1])
+    assert pa["tiles"][0]["sgmTCams"] == pb["tiles"][0]["sgmTCams"]
+    assert np.allclose(pa["tiles"][0]["depths"], pb["tiles"][0]["depths"], rtol=1e-5)

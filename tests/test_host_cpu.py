@@ -382,3 +382,19 @@ def test_sgm_running_average_integer_forms():
         o, c = np.meshgrid(np.arange(256, dtype=np.float32), np.arange(256, dtype=np.float32), indexing="ij")
         ref = ((o * np.float32(K) + c) / np.float32(K + 1)).astype(np.uint8)  # fp32 division, truncating cast
         assert np.array_equal(ref, ((o.astype(np.int64) * K + c.astype(np.int64)) // (K + 1)).astype(np.uint8)), K
+
+
+def test_prepare_dense_scene_cli_argument_errors(scene, tmp_path):
+    """aliceVision_prepareDenseScene: the reference's flags; what this implementation does not build is refused, not ignored"""
+    sc, lms, sfm, img, d = scene
+    exe = os.path.join(ROOT, "alicevision_amd", "bin", "aliceVision_prepareDenseScene")
+    assert os.path.exists(exe)
+    base = [exe, "-i", sfm, "-o", str(tmp_path / "prep")]
+    assert run([exe, "--help"], check=False).returncode == 0
+    assert run([exe, "-i", sfm], check=False).returncode == 1                                  # --output is required
+    assert run(base + ["--outputFileType", "jpg"], check=False).returncode == 1               # exr only
+    assert run(base + ["--masksFolders", str(tmp_path)], check=False).returncode == 1
+    assert run(base + ["--evCorrection", 1], check=False).returncode == 1
+    assert run(base + ["--rangeStart", 2, "--rangeSize", -1], check=False).returncode == 1   # Range is incorrect
+    r = run([exe, "-i", str(tmp_path / "nope.sfm"), "-o", str(tmp_path / "prep")], check=False)
+    assert r.returncode == 1 and "cannot be read" in r.stdout + r.stderr

@@ -359,3 +359,70 @@ def test_resize_properties():
     # enlarging is not this path
     big = np.zeros((h * 2, w * 2, 4), np.float32)
     assert lib.avo_image_resize(oracle.ptr(big), w * 2 * 16, w * 2, h * 2, oracle.ptr(src), w * 16, w, h, 4) != 0
+
+
+# ------------------------------------------------------------------------------------------------ image ingest: undistortion
+def _np_undistort(src, W, H, fx, fy, ox, oy, model, k, fill):
+    """camera::UndistortImage restated independently in numpy (vectorised, double): distorted position of every pixel, the
+    truncating `contains`, the float-converted sample position, the 2 x 2 sampler with dropped out-of-range neighbours."""
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    ppx, ppy = ox + W * 0.5, oy + H * 0.5
+    cx, cy = (xx - ppx) / fx, (yy - ppy) / fy
+    if model == 1:
+        coeff = 1.0 + k[0] * (cx * cx + cy * cy)
+    else:
+        r = np.sqrt(cx * cx + cy * cy)
+        r2 = r * r
+        r4 = r2 * r2
+        r6 = r4 * r2
+        coeff = 1.0 + k[0] * r2 + k[1] * r4 + k[2] * r6
+        if model == 3:
+            coeff = coeff / (1.0 + k[0] + k[1] + k[2])
+    dx, dy = cx * coeff * fx + ppx, cy * coeff * fy + ppy
+    inside = (np.trunc(dx) >= 0) & (np.trunc(dx) < W) & (np.trunc(dy) >= 0) & (np.trunc(dy) < H)
+    xf, yf = dx.astype(np.float32).astype(np.float64), dy.astype(np.float32).astype(np.float64)
+    gx, gy = np.floor(xf), np.floor(yf)
+    ax, ay = xf - gx, yf - gy
+    out = np.zeros((H, W, 4), np.float64)
+    tw = np.zeros((H, W), np.float64)
+    for i, wy in ((0, 1.0 - ay), (1, ay)):
+        for j, wx in ((0, 1.0 - ax), (1, ax)):
+            ic, jc = (gy + i).astype(np.int64), (gx + j).astype(np.int64)
+            ok = (ic >= 0) & (ic < H) & (jc >= 0) & (jc < W)
+            wgt = np.where(ok, wx * wy, 0.0)
+            out += src[np.clip(ic, 0, H - 1), np.clip(jc, 0, W - 1)].astype(np.float64) * wgt[..., None]
+            tw += wgt
+    near = src[np.clip(gy.astype(np.int64), 0, H - 1), np.clip(gx.astype(np.int64), 0, W - 1)]
+    res = np.where((tw != 1.0)[..., None], out / np.where(tw == 0, 1.0, tw)[..., None], out)
+    res = np.where((tw <= 0.2)[..., None], near, res).astype(np.float32)
+    return np.where(inside[..., None], res, np.asarray(fill, np.float32)[None, None, :])
+
+
+@pytest.mark.parametrize("model,k", [(1, (0.08, 0.0, 0.0)), (2, (0.1, -0.05, 0.01)), (2, (-0.25, 0.08, 0.0)), (3, (0.05, 0.02, -0.01))])
+def test_undistort_matches_independent_restatement(model, k):
+    from oracle import oracle
+    lib = oracle.load()
+    rng = np.random.default_rng(model * 7 + 1)
+    H, W = 75, 101
+    src = rng.random((H, W, 4), dtype=np.float32)
+    fx, fy, ox, oy = 90.0, 88.0, 2.25, -1.5
+    cam = abi.Intrinsic(width=W, height=H, scale_x=fx, scale_y=fy, offset_x=ox, offset_y=oy, distortion_model=model, k=(C.c_double * 3)(*k))
+    fill = (C.c_float * 4)(0.25, 0.5, 0.75, 0.0)
+    got = np.zeros_like(src)
+    assert lib.avo_image_undistort(oracle.ptr(got), W * 16, oracle.ptr(src), W * 16, C.byref(cam), C.byref(fill)) == 0
+    want = _np_undistort(src, W, H, fx, fy, ox, oy, model, k, list(fill))
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+    # barrel / pincushion distortion leaves part of the frame without a source pixel: the fill colour shows up (or not) accordingly
+    filled = np.all(got == np.asarray(list(fill), np.float32), axis=-1).mean()
+    assert 0.0 <= filled < 0.5
+
+
+def test_undistort_without_distortion_is_a_copy():
+    from oracle import oracle
+    lib = oracle.load()
+    src = np.random.default_rng(2).random((20, 30, 4), dtype=np.float32)
+    cam = abi.Intrinsic(width=30, height=20, scale_x=40.0, scale_y=40.0, offset_x=0.0, offset_y=0.0, distortion_model=0, k=(C.c_double * 3)(0, 0, 0))
+    fill = (C.c_float * 4)(0, 0, 0, 0)
+    got = np.zeros_like(src)
+    assert lib.avo_image_undistort(oracle.ptr(got), 30 * 16, oracle.ptr(src), 30 * 16, C.byref(cam), C.byref(fill)) == 0
+    assert np.array_equal(got, src)
