@@ -30,6 +30,39 @@ def optimize_scratch(lib, X, Y, Z, device="cuda"):
     return torch.empty(max(n, 4), dtype=torch.uint8, device=device)
 
 
+def optimize_tiles_batched(tiles, rc, timers=None):
+    """avdm_volume_optimize_tiles over the pending volumes of several DepthMapTile objects (run_sgm(..., optimize="defer")): all tiles of a
+    depth map aggregated by one launch per axis, as host/DepthMapEstimator.cpp does for every group of tiles; then each tile's WTA map."""
+    lib = tiles[0].lib
+    sp = tiles[0].sgm
+    n = len(tiles)
+    arr = (abi.SgmTile * n)()
+    total = 0
+    sizes = []
+    for t in tiles:
+        roi = t.droi(sp.scale * sp.stepXY)
+        Z = t._sgm_pending[1]
+        sizes.append(int(lib.avdm_volume_optimize_scratch_bytes(roi.width, roi.height, Z)))
+        total += sizes[-1]
+    dev = tiles[0].best.device
+    key = (n, total)
+    if getattr(tiles[0], "_batch_scratch_key", None) != key:
+        tiles[0]._batch_scratch = torch.empty(max(total, 4), dtype=torch.uint8, device=dev)
+        tiles[0]._batch_scratch_key = key
+    for i, t in enumerate(tiles):
+        roi = t.droi(sp.scale * sp.stepXY)
+        Z = t._sgm_pending[1]
+        arr[i] = abi.SgmTile(t.best.data_ptr(), t.second.data_ptr(), roi.width * t.Zp, t.Zp, Z, roi, C.pointer(t.pyr[rc].desc))
+    rng = timers.range("sgm_optimize") if timers is not None else None
+    if rng is not None:
+        rng.__enter__()
+    abi.check(lib.avdm_volume_optimize_tiles(n, arr, _ptr(tiles[0]._batch_scratch), C.byref(sp), _stream()), "volume_optimize_tiles")
+    if rng is not None:
+        rng.__exit__(None, None, None)
+    for t in tiles:
+        t.finish_sgm(rc, t._sgm_pending[1])
+
+
 class StageTimers:
     """HIP-event timing of stage ranges on the current stream (torch events wrap hipEvent on the same stream)."""
 
@@ -202,12 +235,25 @@ class DepthMapTile:
             abi.check(lib.avdm_volume_update_uninitialized(_ptr(self.best), _ptr(self.second), py, pxx, X, Y, Z, st), "update_uninitialized")
         if keep_raw:
             self.best_raw = self.best.clone()
+        if optimize == "defer":  # the caller aggregates the volumes of several tiles in one batched call (optimize_tiles_batched)
+            self._sgm_pending = (rc, Z)
+            return None
         if optimize:
             with T.range("sgm_optimize"):
                 abi.check(lib.avdm_volume_optimize(_ptr(self.best), _ptr(self.second), py, pxx, _ptr(self.sgm_scratch), C.byref(self.pyr[rc].desc),
                                                    C.byref(sp), Z, roi, st), "volume_optimize")
         else:
             self.best.copy_(self.second)
+        return self.finish_sgm(rc, Z)
+
+    def finish_sgm(self, rc, Z):
+        """winner-take-all depth / thickness from the aggregated volume (second half of Sgm::sgmRc)"""
+        lib, sp = self.lib, self.sgm
+        roi = self.droi(sp.scale * sp.stepXY)
+        X, Zp = roi.width, self.Zp
+        py, pxx = X * Zp, Zp
+        st = _stream()
+        T = self.timers
         rc1 = self.cam(rc, 1)
         with T.range("sgm_retrieve_best_depth"):
             abi.check(lib.avdm_volume_retrieve_best_depth(_ptr(self.sgm_depth_thickness), X * 8, _ptr(self.sgm_depth_sim), X * 8,

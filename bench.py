@@ -33,7 +33,7 @@ import numpy as np
 import torch
 
 from alicevision_amd import abi
-from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+from alicevision_amd.pipeline import DepthMapTile, DevicePyramid, optimize_tiles_batched
 from alicevision_amd.sharding import ViewExchange, cameras_of_rank, owner_of_view
 from alicevision_amd.synthetic import make_scene, plane_depths
 
@@ -155,8 +155,15 @@ def main():
             with tile.timers.range("pyramid_exchange"):
                 exchange.publish_round([cams_of[r][i % len(cams_of[r])] for r in range(world)])
         out = None
+        if len(tiles) == 1:
+            tiles[0].run_sgm(rc, tcs, depths)
+            return tiles[0].run_refine(rc, tcs)
+        # several tiles per depth map (cfg5): sweep every tile, aggregate ALL their volumes with one launch per axis
+        # (avdm_volume_optimize_tiles, what host/DepthMapEstimator.cpp does for every group of tiles), then refine every tile
         for t in tiles:
-            t.run_sgm(rc, tcs, depths)
+            t.run_sgm(rc, tcs, depths, optimize="defer")
+        optimize_tiles_batched(tiles, rc, timers=tile.timers)
+        for t in tiles:
             out = t.run_refine(rc, tcs)
         return out
 
@@ -197,18 +204,21 @@ def main():
         # 11 B/voxel + 64 B/pixel for the four paths = two launches of sgm_pair_kernel (forward + reverse path of one
         # axis per launch); AVDM_SGM_PAIR=0 runs the four sequential sgm_path_kernel launches instead
         n_launches = 4 if os.environ.get("AVDM_SGM_PAIR") == "0" else 2
-        alg_bytes_per_volume = sum(11.0 * x * y * Z + 64.0 * x * y for x, y in vols) / len(vols)
+        # several tiles per depth map are aggregated by ONE call (all their volumes per launch): the "volume" of the accounting is then the batch
+        batched = len(vols) > 1
+        n_calls = 1 if batched else len(vols)
+        alg_bytes_per_volume = sum(11.0 * x * y * Z + 64.0 * x * y for x, y in vols) / n_calls
         alg_bytes_per_launch = alg_bytes_per_volume / n_launches
         # average duration of one path-aggregation kernel launch (HIP events around the launches alone, on their stream);
         # stages["sgm_optimize"] is the whole avdm_volume_optimize call, i.e. these launches + the adaptive-P2 map kernel
-        if k_n.value != n_launches * args.steps * len(vols):
-            raise SystemExit(f"expected {n_launches * args.steps * len(vols)} path-kernel launches in the timed region, the library timed {k_n.value}")
+        if k_n.value != n_launches * args.steps * n_calls:
+            raise SystemExit(f"expected {n_launches * args.steps * n_calls} path-kernel launches in the timed region, the library timed {k_n.value}")
         sgm_ms_per_launch = k_ms.value / k_n.value
         achieved = alg_bytes_per_launch / (sgm_ms_per_launch * 1e-3) / 1e9
-        whole_call_ms = stages["sgm_optimize"] / len(vols)
+        whole_call_ms = stages["sgm_optimize"] / n_calls
         roof = {"bound": "hbm", "kernel": "sgm_pair_kernel" if n_launches == 2 else "sgm_path_kernel", "achieved": achieved, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "alg_bytes_per_launch": alg_bytes_per_launch,
-                "ms_per_launch": sgm_ms_per_launch, "launches_per_volume": n_launches,
+                "ms_per_launch": sgm_ms_per_launch, "launches_per_volume": n_launches, "volumes_per_launch": len(vols) if batched else 1,
                 # the same bytes over the whole avdm_volume_optimize call (path launches + sgm_p2_map_kernel, whose 64 B/pixel are in the numerator)
                 "ms_whole_call_per_volume": whole_call_ms, "frac_whole_call": alg_bytes_per_volume / (whole_call_ms * 1e-3) / 1e9 / 8000.0,
                 "frac_kernels_only": achieved / 8000.0}

@@ -907,3 +907,25 @@ def test_parity_table_cfg1():
     assert lit["final_depth"]["validity_differs"] < 2e-3
     g = lit["median_abs_vs_ground_truth"]
     assert g["gpu"] <= 1.02 * g["oracle"] + 1e-6, g
+
+
+def test_harness_batched_aggregation_equals_per_tile():
+    """bench.py's multi-tile workloads sweep every tile, aggregate all their volumes with one avdm_volume_optimize_tiles call
+    (pipeline.optimize_tiles_batched, what the C++ host does per group of tiles) and then finish each tile: same maps as tile by tile"""
+    torch = _torch()
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid, optimize_tiles_batched
+    sc, sgm, ref, depths = small_case(width=320, height=240, n_planes=40, seed=4)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(3)]
+    rois = [(0, 192, 0, 240), (128, 320, 0, 240)]
+    seq = []
+    for r in rois:
+        t = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=r)
+        t.run_sgm(0, [1, 2], depths)
+        seq.append(t.sgm_depth_sim.cpu().numpy().copy())
+    tiles = [DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=r) for r in rois]
+    for t in tiles:
+        assert t.run_sgm(0, [1, 2], depths, optimize="defer") is None
+    optimize_tiles_batched(tiles, 0)
+    torch.cuda.synchronize()
+    for t, want in zip(tiles, seq):
+        assert np.array_equal(t.sgm_depth_sim.cpu().numpy(), want)
