@@ -39,6 +39,14 @@ constexpr int kNccUnroll = AVDM_NCC_UNROLL;
 #define AVDM_NCC_W3_MODE 2 // 7-tap rows (wsh 3, the Refine default): 0 = plain `unroll 3` (spills), 1 = no unroll, 2 = 3 + 3 + 1 with fences
 #endif
 constexpr bool kLdsSplitReads = true;
+#ifndef AVDM_SGM_CHUNKS_PER_WG
+#define AVDM_SGM_CHUNKS_PER_WG 4
+#endif
+constexpr unsigned kSgmChunksPerWg = AVDM_SGM_CHUNKS_PER_WG; // SGM similarity: chunks of 4 planes per workgroup
+#ifndef AVDM_REFINE_CHUNKS_PER_WG
+#define AVDM_REFINE_CHUNKS_PER_WG 4
+#endif
+constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: chunks of 8 planes per workgroup (they share one R tile, T window and pixel set-up)
 
 struct PatchTable
 {
@@ -779,7 +787,9 @@ __global__ void __launch_bounds__(256, 3)
     pixel_of_lane(tx, ty);
     const unsigned vx = blockIdx.x * 16 + tx, vy = blockIdx.y * 16 + ty;
     const bool inRoi = vx < roi.x.end - roi.x.begin && vy < roi.y.end - roi.y.begin;
-    const unsigned z0 = ((zBegin >> 2) + blockIdx.z) << 2;
+    // kSgmChunksPerWg chunks of 4 planes per workgroup (one R tile, one T window, one pixel set-up)
+    const unsigned z0 = ((zBegin >> 2) + blockIdx.z * kSgmChunksPerWg) << 2;
+    constexpr unsigned kPlanesPerWg = 4u * kSgmChunksPerWg;
 
     // paired LDS records only feed the packed FIXED8 path (uniform)
     const bool paired = PAIRED && FIXED8 && !A.noPacked;
@@ -808,14 +818,8 @@ __global__ void __launch_bounds__(256, 3)
         rValid = !(rcCenter.w < (255.f * 0.9f));
     }
 
-    uint8_t* pb = best + (long long)vy * pitch_y + (long long)vx * pitch_x + z0;
-    uint8_t* ps = second + (long long)vy * pitch_y + (long long)vx * pitch_x + z0;
-    unsigned wb = 0, ws = 0;
-    if(inRoi)
-    {
-        wb = *reinterpret_cast<const unsigned*>(pb);
-        ws = *reinterpret_cast<const unsigned*>(ps);
-    }
+    uint8_t* const pb0 = best + (long long)vy * pitch_y + (long long)vx * pitch_x + z0;
+    uint8_t* const ps0 = second + (long long)vy * pitch_y + (long long)vx * pitch_x + z0;
 
     const RayConsts RK = make_ray_consts(rc, tc, C, v, x, y);
     // geometry of my patch on plane vz (see the Refine kernel): false when the patch centre fails the border test in T
@@ -852,7 +856,7 @@ __global__ void __launch_bounds__(256, 3)
     bool lanePart = false;
     if(FIXED8 && (paired || halfPaired) && A.chunkWindow)
     {
-        const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + 4u < zEnd) ? z0 + 4u : zEnd;
+        const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + kPlanesPerWg < zEnd) ? z0 + kPlanesPerWg : zEnd;
         if(ka < kbEnd) // uniform
         {
             float bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
@@ -890,9 +894,29 @@ __global__ void __launch_bounds__(256, 3)
     }
 
 #pragma unroll 1
+    for(unsigned c = 0; c < kSgmChunksPerWg; ++c)
+    {
+    const unsigned zc = z0 + 4u * c;
+    if(zc >= zEnd) // uniform
+        break;
+    uint8_t* const pb = pb0 + 4u * c;
+    uint8_t* const ps = ps0 + 4u * c;
+    unsigned wb = 0, ws = 0;
+    if(inRoi)
+    {
+        wb = *reinterpret_cast<const unsigned*>(pb);
+        ws = *reinterpret_cast<const unsigned*>(ps);
+    }
+    if(!chunkWin && c > 0)
+    { // the per-plane fall-back reuses the box entries of the previous chunk
+        __syncthreads();
+        init_shared(sh);
+        __syncthreads();
+    }
+#pragma unroll 1
     for(int k = 0; k < 4; ++k)
     {
-        const unsigned vz = z0 + k;
+        const unsigned vz = zc + k;
         if(vz < zBegin || vz >= zEnd) // uniform
             continue;
 
@@ -962,6 +986,7 @@ __global__ void __launch_bounds__(256, 3)
         *reinterpret_cast<unsigned*>(pb) = wb;
         *reinterpret_cast<unsigned*>(ps) = ws;
     }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -983,7 +1008,9 @@ __global__ void __launch_bounds__(256, 3)
     pixel_of_lane(tx, ty);
     const unsigned vx = blockIdx.x * 16 + tx, vy = blockIdx.y * 16 + ty;
     const bool inRoi = vx < roi.x.end - roi.x.begin && vy < roi.y.end - roi.y.begin;
-    const unsigned z0 = ((zBegin >> 3) + blockIdx.z) << 3;
+    // kRefineChunksPerWg chunks of 8 planes per workgroup: one R tile, one T window and one pixel set-up for 16 planes
+    const unsigned z0 = ((zBegin >> 3) + blockIdx.z * kRefineChunksPerWg) << 3;
+    constexpr unsigned kPlanesPerWg = 8u * kRefineChunksPerWg;
 
     // paired LDS records only feed the packed FIXED8 path (uniform)
     const bool paired = PAIRED && FIXED8 && !A.noPacked;
@@ -1014,10 +1041,7 @@ __global__ void __launch_bounds__(256, 3)
         rValid = !(rcCenter.w < (255.f * 0.9f));
     }
 
-    __half* pv = vol + ((long long)vy * pitch_y + (long long)vx * pitch_x) / 2 + z0;
-    uint4 packed = make_uint4(0u, 0u, 0u, 0u);
-    if(pixActive)
-        packed = *reinterpret_cast<const uint4*>(pv);
+    __half* const pv0 = vol + ((long long)vy * pitch_y + (long long)vx * pitch_x) / 2 + z0;
 
     const RayConsts RK = make_ray_consts(rc, tc, C, dir, x, y);
     // geometry of my patch on plane vz: the 3-D point, the patch axes and their projections; false when the patch centre fails the border
@@ -1069,7 +1093,7 @@ __global__ void __launch_bounds__(256, 3)
     bool lanePart = false;        // my patch was part of the hull (valid on the first or the last plane of the chunk)
     if(CHUNK_CAPABLE && paired && A.chunkWindow)
     {
-        const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + 8u < zEnd) ? z0 + 8u : zEnd;
+        const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + kPlanesPerWg < zEnd) ? z0 + kPlanesPerWg : zEnd;
         if(ka < kbEnd) // uniform
         {
             float bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
@@ -1107,9 +1131,25 @@ __global__ void __launch_bounds__(256, 3)
     }
 
 #pragma unroll 1
+    for(unsigned c = 0; c < kRefineChunksPerWg; ++c)
+    {
+    const unsigned zc = z0 + 8u * c;
+    if(zc >= zEnd) // uniform
+        break;
+    __half* const pv = pv0 + 8u * c;
+    uint4 packed = make_uint4(0u, 0u, 0u, 0u);
+    if(pixActive)
+        packed = *reinterpret_cast<const uint4*>(pv);
+    if(!chunkWin && c > 0)
+    { // the per-plane fall-back reuses the box entries of the previous chunk
+        __syncthreads();
+        init_shared(sh);
+        __syncthreads();
+    }
+#pragma unroll 1
     for(int k = 0; k < 8; ++k)
     {
-        const unsigned vz = z0 + k;
+        const unsigned vz = zc + k;
         if(vz < zBegin || vz >= zEnd) // uniform
             continue;
 
@@ -1182,6 +1222,7 @@ __global__ void __launch_bounds__(256, 3)
     }
     if(pixActive)
         *reinterpret_cast<uint4*>(pv) = packed;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1721,7 +1762,7 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
                            depths, *rc, *tc, A, tab, S, sp->stepXY, dr.begin, dr.end, roi);
         AVDM_LAUNCH_CHECK("avdm_volume_compute_similarity(consistent scale)");
     }
-    dim3 grid(divUp(roi.x.end - roi.x.begin, 16), divUp(roi.y.end - roi.y.begin, 16), nchunks);
+    dim3 grid(divUp(roi.x.end - roi.x.begin, 16), divUp(roi.y.end - roi.y.begin, 16), divUp(nchunks, kSgmChunksPerWg));
     const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
 #define LAUNCH(F8, W, PR)                                                                                                                                 \
     hipLaunchKernelGGL((similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
@@ -1787,7 +1828,7 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
                            sgm_normal, normal_pitch, pitch_y, pitch_x, (const float*)nullptr, *rc, *tc, A, tab, S, rp->stepXY, dr.begin, dr.end, roi);
         AVDM_LAUNCH_CHECK("avdm_volume_refine_similarity(consistent scale)");
     }
-    dim3 grid(divUp(roi.x.end - roi.x.begin, 16), divUp(roi.y.end - roi.y.begin, 16), nchunks);
+    dim3 grid(divUp(roi.x.end - roi.x.begin, 16), divUp(roi.y.end - roi.y.begin, 16), divUp(nchunks, kRefineChunksPerWg));
     const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
 #define LAUNCH(F8, W, PR)                                                                                                                          \
     hipLaunchKernelGGL((refine_similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,   \
