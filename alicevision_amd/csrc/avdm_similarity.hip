@@ -64,6 +64,8 @@ struct NccArgs
     float mipmapLevel;
     int wsh;
     int rcap, tcap;   // LDS capacities in texels (R tile, T window)
+    int rpitch;       // row pitch of the R tile in texel positions: the same for every workgroup of a launch (the kernels specialised on it fold
+                      // the second-row tap of R into the offset field of the LDS read)
     int forceGeneric; // debugging / A-B switch: never use the LDS path
     int noPacked;     // debugging / A-B switch: LDS path with the plain fp32 tap arithmetic
     int chunkWindow;  // packed path: ONE T window for the planes of a chunk (0: one window per plane, the A/B reference)
@@ -442,7 +444,7 @@ __device__ __forceinline__ Lab3x4 hlerp3x4_halfpaired(uint2 r0, unsigned r0n, ui
     return o;
 }
 
-template <int WSH, bool TInvert, bool PAIRED>
+template <int WSH, bool TInvert, bool PAIRED, int RP = 0>
 __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const LdsWindows& Wn,
                                                            float4 rcCenter, float4 tcCenter)
 {
@@ -489,13 +491,17 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
                 Lab3x4 h;
                 if(PAIRED)
                 {
-                    const uint4 r0 = lds_record(oR), r1 = lds_record(oR + Wn.rPitchB), t0 = lds_record(oT), t1 = lds_record(oT + Wn.tPitchB);
+                    // RP > 0: the R pitch is a compile-time constant and the bottom tap is the top tap's address + an immediate offset
+                    __builtin_assume(oR < 65536u);
+                    const unsigned oRb = RP > 0 ? oR + (unsigned)(RP * 16) : oR + Wn.rPitchB;
+                    const uint4 r0 = lds_record(oR), r1 = lds_record(oRb), t0 = lds_record(oT), t1 = lds_record(oT + Wn.tPitchB);
                     h = hlerp3x4_paired(r0, r1, t0, t1, wr, wt);
                 }
                 else
                 {
                     // half-paired records: column c whole (ds_read_b64), of column c + 1 only the {a | b} dword (ds_read_b32 at +12)
-                    const unsigned oRb = oR + Wn.rPitchB, oTb = oT + Wn.tPitchB;
+                    __builtin_assume(oR < 65536u);
+                    const unsigned oRb = RP > 0 ? oR + (unsigned)(RP * 8) : oR + Wn.rPitchB, oTb = oT + Wn.tPitchB;
                     const uint2 r0 = lds_texel(oR), r1 = lds_texel(oRb), t0 = lds_texel(oT), t1 = lds_texel(oTb);
                     const unsigned r0n = lds_u32(oR + 12u), r1n = lds_u32(oRb + 12u), t0n = lds_u32(oT + 12u), t1n = lds_u32(oTb + 12u);
                     h = hlerp3x4_halfpaired(r0, r0n, r1, r1n, t0, t0n, t1, t1n, wr, wt);
@@ -635,8 +641,8 @@ __device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int w
     T.y0 = y0;
     T.w = x1 - x0 + 1;
     T.h = y1 - y0 + 1;
-    T.pitch = lds_pitch_for(T.w);
-    T.ok = !A.forceGeneric && T.w > 1 && T.h > 1 && T.pitch * T.h * (paired ? 2 : 1) <= A.rcap;
+    T.pitch = A.rpitch; // the full-width pitch also where the image border clips the tile
+    T.ok = !A.forceGeneric && T.w > 1 && T.h > 1 && T.w <= T.pitch && T.pitch * T.h * (paired ? 2 : 1) <= A.rcap;
     if(T.ok)
     {
         if(paired)
@@ -772,7 +778,7 @@ __device__ __forceinline__ void init_shared(BlockShared& sh)
 // ---------------------------------------------------------------------------------------------
 // SGM similarity: best / second-best uint8 volumes, 4 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-template <bool FIXED8, int WSH, bool PAIRED>
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0>
 __global__ void __launch_bounds__(256, 3)
   similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
                     avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
@@ -961,7 +967,7 @@ __global__ void __launch_bounds__(256, 3)
         {
             float s;
             if(Wd.ok && laneLds && FIXED8 && !A.noPacked)
-                s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
+                s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED, RP>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
                                                           tcCenter);
             else if(Wd.ok && laneLds)
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
@@ -992,7 +998,7 @@ __global__ void __launch_bounds__(256, 3)
 // ---------------------------------------------------------------------------------------------
 // Refine similarity: fp16 volume += sigmoid-filtered NCC, 8 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-template <bool FIXED8, int WSH, bool PAIRED>
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0>
 __global__ void __launch_bounds__(256, 3)
   refine_similarity_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize,
                            int map_pitch, const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A,
@@ -1201,7 +1207,7 @@ __global__ void __launch_bounds__(256, 3)
         {
             float s;
             if(Wd.ok && laneLds && FIXED8 && !A.noPacked)
-                s = ncc_accumulate_lds_fixed8<WSH, true, PAIRED>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
+                s = ncc_accumulate_lds_fixed8<WSH, true, PAIRED, RP>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
                                                          tcCenter);
             else if(Wd.ok && laneLds)
                 s = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
@@ -1567,6 +1573,7 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
         if(paired && (lds_pitch_for(rw) * rw * 2 + lds_pitch_for(tw) * tw * 3) * 8 > third)
             paired = false;
     }
+    A.rpitch = lds_pitch_for(rw);
     A.rcap = lds_pitch_for(rw) * rw * (paired ? 2 : 1);
     A.tcap = lds_pitch_for(tw) * tw * (paired ? 2 : 1);
     // both kernels run 3 workgroups per CU (168 VGPRs): the T window may use what is left of a third of the 160 KiB — a T view at a
@@ -1767,7 +1774,10 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
 #define LAUNCH(F8, W, PR)                                                                                                                                 \
     hipLaunchKernelGGL((similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
                        sp->stepXY, dr.begin, dr.end, roi)
-    if(fixed8 && paired)
+    if(fixed8 && !paired && sp->wsh == 4 && A.rpitch == 56 && !A.noPacked)
+        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc,
+                           A, tab, sp->stepXY, dr.begin, dr.end, roi); // the default: scale 2, stepXY 2, wsh 4
+    else if(fixed8 && paired)
     {
         if(sp->wsh == 4) LAUNCH(true, 4, true);
         else if(sp->wsh == 3) LAUNCH(true, 3, true);
@@ -1833,7 +1843,11 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
 #define LAUNCH(F8, W, PR)                                                                                                                          \
     hipLaunchKernelGGL((refine_similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,   \
                        (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi)
-    if(fixed8 && paired)
+    if(fixed8 && paired && rp->wsh == 3 && A.rpitch == 40 && !A.noPacked)
+        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
+                           (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end,
+                           roi); // the default: scale 1, stepXY 1, wsh 3
+    else if(fixed8 && paired)
     {
         if(rp->wsh == 3) LAUNCH(true, 3, true);
         else if(rp->wsh == 4) LAUNCH(true, 4, true);
