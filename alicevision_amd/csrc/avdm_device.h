@@ -18,6 +18,12 @@ int set_error(hipError_t e, const char* where);
 int set_error_msg(int code, const char* msg);
 #define AVDM_LAUNCH_CHECK(name) return ::avdm::set_error(hipGetLastError(), name)
 
+// Library-owned temporary of an entry point whose reference signature has no room for it: one buffer per (device, stream), grown on
+// demand and reused by the later calls on that stream (stream order makes the reuse safe).  NOT the stream-ordered allocator: with two
+// host threads on one device, hipMallocAsync in one and hipEventRecord / hipStreamWaitEvent in the other deadlocked inside the runtime
+// about once in 25 two-worker runs (profiles/r02_multiworker_hang.md).  nullptr when the allocation fails.
+void* stream_scratch(hipStream_t st, size_t bytes);
+
 static inline unsigned divUp(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------------------

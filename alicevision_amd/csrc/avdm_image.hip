@@ -8,6 +8,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace avdm {
 
 static thread_local char g_err[512] = "";
@@ -23,6 +27,68 @@ int set_error_msg(int code, const char* msg)
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;
+}
+
+namespace {
+struct ScratchBlock
+{
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    unsigned long long lastUse = 0;
+};
+std::mutex g_scratchMutex;
+std::map<std::pair<int, hipStream_t>, ScratchBlock> g_scratch;
+unsigned long long g_scratchTick = 0;
+constexpr size_t kMaxScratchBlocks = 64; // stream handles come and go (one set per DepthMapEstimator::compute): bound what stays behind
+} // namespace
+
+void* stream_scratch(hipStream_t st, size_t bytes)
+{
+    int dev = 0;
+    if(hipGetDevice(&dev) != hipSuccess)
+        return nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    const auto key = std::make_pair(dev, st);
+    auto it = g_scratch.find(key);
+    ++g_scratchTick;
+    if(it != g_scratch.end() && it->second.bytes >= bytes)
+    {
+        it->second.lastUse = g_scratchTick;
+        return it->second.ptr;
+    }
+    if(it == g_scratch.end() && g_scratch.size() >= kMaxScratchBlocks)
+    {
+        // drop the block that has been idle longest (its stream is most likely gone); hipFree waits for the device, so no kernel of any
+        // stream, live or destroyed, still reads it
+        auto oldest = g_scratch.begin();
+        for(auto i = g_scratch.begin(); i != g_scratch.end(); ++i)
+            if(i->second.lastUse < oldest->second.lastUse)
+                oldest = i;
+        int cur = dev;
+        if(oldest->first.first != dev)
+            (void)hipSetDevice(oldest->first.first);
+        (void)hipFree(oldest->second.ptr);
+        if(oldest->first.first != dev)
+            (void)hipSetDevice(cur);
+        g_scratch.erase(oldest);
+    }
+    ScratchBlock& b = g_scratch[key];
+    if(b.ptr != nullptr)
+    {
+        (void)hipStreamSynchronize(st); // earlier calls on this stream may still use the smaller block
+        (void)hipFree(b.ptr);
+        b = ScratchBlock{};
+    }
+    if(hipMalloc(&b.ptr, bytes) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        g_scratch.erase(key);
+        return nullptr;
+    }
+    b.bytes = bytes;
+    b.lastUse = g_scratchTick;
+    return b.ptr;
 }
 
 // ---------------------------------------------------------------------------------------------

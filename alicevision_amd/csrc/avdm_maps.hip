@@ -1165,8 +1165,8 @@ int avdm_image_resize(float* dst_rgba, int dst_pitch, int dst_w, int dst_h, cons
     const int xtaps = oiio_resize_taps(dst_w, src_w, wx, fx), ytaps = oiio_resize_taps(dst_h, src_h, wy, fy);
     const size_t bwx = (wx.size() * sizeof(float) + 255) & ~(size_t)255, bwy = (wy.size() * sizeof(float) + 255) & ~(size_t)255;
     const size_t bfx = (fx.size() * sizeof(int) + 255) & ~(size_t)255, bfy = (fy.size() * sizeof(int) + 255) & ~(size_t)255;
-    char* tab = nullptr;
-    if(hipMallocAsync((void**)&tab, bwx + bwy + bfx + bfy, st) != hipSuccess || tab == nullptr)
+    char* tab = (char*)stream_scratch(st, bwx + bwy + bfx + bfy);
+    if(tab == nullptr)
         return set_error_msg(2, "avdm_image_resize: scratch allocation failed");
     hipError_t e = hipMemcpyAsync(tab, wx.data(), wx.size() * sizeof(float), hipMemcpyHostToDevice, st);
     if(e == hipSuccess)
@@ -1182,7 +1182,6 @@ int avdm_image_resize(float* dst_rgba, int dst_pitch, int dst_w, int dst_h, cons
                            (const float*)(tab + bwx), (const int*)(tab + bwx + bwy + bfx), ytaps);
         e = hipGetLastError();
     }
-    (void)hipFreeAsync(tab, st);
     // the tap tables live in pageable host memory: they must outlive the copies
     const hipError_t es = hipStreamSynchronize(st);
     return ::avdm::set_error(e != hipSuccess ? e : es, "avdm_image_resize");
@@ -1237,27 +1236,14 @@ int avdm_depth_sim_map_optimize_gradient_descent(float* out_opt_depth_sim, int o
     }
     if(nIter <= 0)
         return 0;
-    // point-map form (see optimize_step_points_kernel): two float4 maps of the tile, stream-ordered scratch (several tiles may be in
+    // point-map form (see optimize_step_points_kernel): two float4 maps of the tile in the stream's scratch block (several tiles may be in
     // flight on different streams); `tmp_depth` — the reference's copy of the depth map — is not needed.  The depth texture is the tile
     // itself (the reference binds the whole allocated buffer and reads cells no kernel of the tile wrote).
     const int texW = std::min<int>(tmp_w, (int)roiW), texH = std::min<int>(tmp_h, (int)roiH);
     const int ptsPitch = (int)(((size_t)roiW * sizeof(float4) + 255) & ~(size_t)255);
     const size_t mapBytes = (size_t)ptsPitch * roiH;
-    char* scratch = nullptr;
-    {
-        static std::once_flag once[64];
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::call_once(once[dev & 63], [&] {
-            hipMemPool_t pool;
-            if(hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
-            {
-                uint64_t keep = UINT64_MAX; // keep freed blocks in the pool: one allocation per tile size, not one per call
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-            }
-        });
-    }
-    if(hipMallocAsync((void**)&scratch, 2 * mapBytes, st) != hipSuccess || scratch == nullptr)
+    char* scratch = (char*)stream_scratch(st, 2 * mapBytes);
+    if(scratch == nullptr)
         return set_error_msg(2, "avdm_depth_sim_map_optimize_gradient_descent: scratch allocation failed");
     float4* pts[2] = {(float4*)scratch, (float4*)(scratch + mapBytes)};
     hipLaunchKernelGGL(optimize_init_points_kernel, grid, dim3(256), 0, st, pts[0], ptsPitch, (const float2*)sgm_depth_pixsize, sgm_pitch, *rc, roi);
@@ -1272,9 +1258,7 @@ int avdm_depth_sim_map_optimize_gradient_descent(float* out_opt_depth_sim, int o
                                (float2*)out_opt_depth_sim, out_pitch, (const float2*)sgm_depth_pixsize, sgm_pitch, (const float2*)refine_depth_sim,
                                ref_pitch, img_variance, var_pitch, texW, texH, *rc, roi);
     }
-    const hipError_t launchErr = hipGetLastError();
-    (void)hipFreeAsync(scratch, st);
-    return ::avdm::set_error(launchErr, "avdm_depth_sim_map_optimize_gradient_descent");
+    return ::avdm::set_error(hipGetLastError(), "avdm_depth_sim_map_optimize_gradient_descent");
 }
 
 } // extern "C"

@@ -1346,8 +1346,10 @@ static void launch_pair(const SgmPathBatch& S, int nWorkgroups, int K, bool full
     constexpr bool HAS_FULL = NW == 1;
     if(!HAS_FULL)
         full = false;
-    static std::once_flag once;
-    std::call_once(once, [&] {
+    static std::once_flag once[64]; // the attribute belongs to the function on ONE device: once per device, not once per process
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & 63], [&] {
         // the stash of the widest instantiations exceeds the 64 KB a kernel gets without asking
         if(HAS_FULL)
         {

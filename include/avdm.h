@@ -194,6 +194,7 @@ typedef struct avdm_intrinsic
     int distortion_model;       /* AVDM_DISTORTION_*                                                          */
     double k[3];                /* distortion parameters                                                      */
 } avdm_intrinsic_t;
+/* camera::UndistortImage (camera/cameraUndistortImage.hpp:81-139), as described above the model constants */
 int avdm_image_undistort(float* dst_rgba, int dst_pitch, const float* src_rgba, int src_pitch, const avdm_intrinsic_t* cam, const float fill_rgba[4],
                          void* stream);
 /* convenience: the whole of DeviceCache::addMipmapImage (cuda/host/DeviceCache.cpp:222-281) + DeviceMipmapImage::fill

@@ -23,7 +23,7 @@ TOOL = os.path.join(BIN, "avdm_host_tool")
 
 
 def run(cmd, check=True):
-    r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=300)
     if check:
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r
