@@ -35,6 +35,10 @@ namespace avdm {
 #define AVDM_NCC_UNROLL 3
 #endif
 constexpr int kNccUnroll = AVDM_NCC_UNROLL;
+#ifndef AVDM_NCC_PAIR_UNROLL
+#define AVDM_NCC_PAIR_UNROLL 3
+#endif
+constexpr int kNccPairUnroll = AVDM_NCC_PAIR_UNROLL; // sample loop of the plane-pair form (wsh != 3)
 #ifndef AVDM_NCC_W3_MODE
 #define AVDM_NCC_W3_MODE 2 // 7-tap rows (wsh 3, the Refine default): 0 = plain `unroll 3` (spills), 1 = no unroll, 2 = 3 + 3 + 1 with fences
 #endif
@@ -69,6 +73,7 @@ struct NccArgs
     int forceGeneric; // debugging / A-B switch: never use the LDS path
     int noPacked;     // debugging / A-B switch: LDS path with the plain fp32 tap arithmetic
     int chunkWindow;  // packed path: ONE T window for the planes of a chunk (0: one window per plane, the A/B reference)
+    int planePairs;   // packed path with a chunk window: two adjacent planes per pass over the patch (0: one plane per pass, the A/B reference)
     unsigned* stats;  // optional device counters per plane-workgroup: {LDS path, R tile unusable, T taps leave the image, T window too large}
 };
 
@@ -444,6 +449,44 @@ __device__ __forceinline__ Lab3x4 hlerp3x4_halfpaired(uint2 r0, unsigned r0n, ui
     return o;
 }
 
+// R side of a PLANE PAIR (ncc_accumulate_lds_fixed8_pair): the six products of one image, top and bottom texel row
+struct Lab3x2
+{
+    Lab3 t, b;
+};
+__device__ __forceinline__ Lab3x2 hlerp3x2_paired(uint4 r0, uint4 r1, v2h wr)
+{
+    Lab3x2 o;
+    const unsigned uwr = __builtin_bit_cast(unsigned, wr);
+    asm("v_dot2_f32_f16 %0, %6, %12, 0\n\t"
+        "v_dot2_f32_f16 %1, %7, %12, 0\n\t"
+        "v_dot2_f32_f16 %2, %8, %12, 0\n\t"
+        "v_dot2_f32_f16 %3, %9, %12, 0\n\t"
+        "v_dot2_f32_f16 %4, %10, %12, 0\n\t"
+        "v_dot2_f32_f16 %5, %11, %12, 0\n\t"
+        "s_nop 2"
+        : "=&v"(o.t.L), "=&v"(o.t.a), "=&v"(o.t.b), "=&v"(o.b.L), "=&v"(o.b.a), "=&v"(o.b.b)
+        : "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(uwr));
+    return o;
+}
+__device__ __forceinline__ Lab3x2 hlerp3x2_halfpaired(uint2 r0, unsigned r0n, uint2 r1, unsigned r1n, v2h wr)
+{
+    Lab3x2 o;
+    const unsigned uwr = __builtin_bit_cast(unsigned, wr);
+    const unsigned p1 = __builtin_amdgcn_perm(r0n, r0.y, AVDM_PERM_LO), p2 = __builtin_amdgcn_perm(r0n, r0.y, AVDM_PERM_HI);
+    const unsigned p4 = __builtin_amdgcn_perm(r1n, r1.y, AVDM_PERM_LO), p5 = __builtin_amdgcn_perm(r1n, r1.y, AVDM_PERM_HI);
+    asm("v_dot2_f32_f16 %0, %6, %12, 0\n\t"
+        "v_dot2_f32_f16 %1, %7, %12, 0\n\t"
+        "v_dot2_f32_f16 %2, %8, %12, 0\n\t"
+        "v_dot2_f32_f16 %3, %9, %12, 0\n\t"
+        "v_dot2_f32_f16 %4, %10, %12, 0\n\t"
+        "v_dot2_f32_f16 %5, %11, %12, 0\n\t"
+        "s_nop 2"
+        : "=&v"(o.t.L), "=&v"(o.t.a), "=&v"(o.t.b), "=&v"(o.b.L), "=&v"(o.b.a), "=&v"(o.b.b)
+        : "v"(r0.x), "v"(p1), "v"(p2), "v"(r1.x), "v"(p4), "v"(p5), "v"(uwr));
+    return o;
+}
+
 template <int WSH, bool TInvert, bool PAIRED, int RP = 0>
 __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const LdsWindows& Wn,
                                                            float4 rcCenter, float4 tcCenter)
@@ -560,6 +603,175 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
     if(TInvert)
         return sigmoid(0.0f, 1.0f, 0.7f, -0.7f, sim);
     return sim;
+}
+
+// the taps of one sample of a plane pair, between the two stages of ncc_accumulate_lds_fixed8_pair's pipeline
+template <bool PAIRED>
+struct PairTaps;
+template <>
+struct PairTaps<true>
+{
+    uint4 r0, r1, a0, a1, b0, b1; // paired records: R top / bottom, plane A top / bottom, plane B top / bottom
+    v2f nnb, wb;                  // T vertical weights {plane A, plane B}
+    float rNy, rWy;               // R vertical weights
+    v2h wr, wtA, wtB;             // horizontal weight pairs
+    __device__ __forceinline__ void load(unsigned oR, unsigned oRb, unsigned oA, unsigned oAb, unsigned oB, unsigned oBb)
+    {
+        r0 = lds_record(oR), r1 = lds_record(oRb), a0 = lds_record(oA), a1 = lds_record(oAb), b0 = lds_record(oB), b1 = lds_record(oBb);
+    }
+    __device__ __forceinline__ Lab3x2 r_products() const { return hlerp3x2_paired(r0, r1, wr); }
+    __device__ __forceinline__ Lab3x4 t_products() const { return hlerp3x4_paired(a0, a1, b0, b1, wtA, wtB); }
+};
+template <>
+struct PairTaps<false>
+{
+    uint2 r0, r1, a0, a1, b0, b1; // half-paired records: column c whole, of column c + 1 the {a | b} dword
+    unsigned r0n, r1n, a0n, a1n, b0n, b1n;
+    v2f nnb, wb;
+    float rNy, rWy;
+    v2h wr, wtA, wtB;
+    __device__ __forceinline__ void load(unsigned oR, unsigned oRb, unsigned oA, unsigned oAb, unsigned oB, unsigned oBb)
+    {
+        r0 = lds_texel(oR), r1 = lds_texel(oRb), a0 = lds_texel(oA), a1 = lds_texel(oAb), b0 = lds_texel(oB), b1 = lds_texel(oBb);
+        r0n = lds_u32(oR + 12u), r1n = lds_u32(oRb + 12u), a0n = lds_u32(oA + 12u), a1n = lds_u32(oAb + 12u), b0n = lds_u32(oB + 12u),
+        b1n = lds_u32(oBb + 12u);
+    }
+    __device__ __forceinline__ Lab3x2 r_products() const { return hlerp3x2_halfpaired(r0, r0n, r1, r1n, wr); }
+    __device__ __forceinline__ Lab3x4 t_products() const { return hlerp3x4_halfpaired(a0, a0n, a1, a1n, b0, b0n, b1, b1n, wtA, wtB); }
+};
+
+// Two ADJACENT planes of a pixel in one pass over the patch (the default path of both kernels when the chunk's T window serves both):
+// the packed registers carry {T of plane A, T of plane B} instead of {R, T}, and the R side — position, taps, colour distance — is
+// evaluated ONCE per sample for both planes, from plane A's patch.  The R taps of the two planes differ only through the tilt of the
+// patch's x axis (ay and the centre's R projection do not depend on the plane): for planes one depth step apart that moves an R tap by
+// ~1e-4 texel at most, below one ulp of the fp32 pixel coordinate of a 12 MP image (2.4e-4), i.e. inside the rounding noise of the
+// reference's own per-plane evaluation.  Per pair of plane-samples: 33 (R) + 60 (T pair) + 13 instead of 2 x 68 VALU instructions
+// (half-paired records; 29 + 52 + 13 instead of 2 x 60 with paired records).
+template <int WSH, bool TInvert, bool PAIRED, int RP = 0>
+__device__ __forceinline__ void ncc_accumulate_lds_fixed8_pair(f3 rax, f3 ray, f3 hr0, const PatchProj& QA, const PatchProj& QB, const NccArgs& A,
+                                                               const PatchTable& tab, const LdsWindows& Wn, float4 rcCenter, float4 tcCenterA,
+                                                               float4 tcCenterB, float& simA, float& simB)
+{
+    const int wsh = WSH > 0 ? WSH : A.wsh;
+    const int n = 2 * wsh + 1;
+    // T side, {plane A, plane B}
+    const v2f ax = {QA.tax.x, QB.tax.x}, ay = {QA.tax.y, QB.tax.y}, az = {QA.tax.z, QB.tax.z};
+    const v2f bx = {QA.tay.x, QB.tay.x}, by = {QA.tay.y, QB.tay.y}, bz = {QA.tay.z, QB.tay.z};
+    const v2f h0x = {QA.ht0.x, QB.ht0.x}, h0y = {QA.ht0.y, QB.ht0.y}, h0z = {QA.ht0.z, QB.ht0.z};
+    const v2f axS = ax * A.tcSx, ayS = ay * A.tcSy;
+    const float S16 = 65536.0f;
+    const v2f cL = v2f{tcCenterA.x, tcCenterB.x} * S16, ca = v2f{tcCenterA.y, tcCenterB.y} * S16, cb = v2f{tcCenterA.z, tcCenterB.z} * S16;
+    // R side, {x, y} of the one image
+    const v2f raS = {rax.x * A.rcSx, rax.y * A.rcSy};
+    const v2f rS = {A.rcSx, A.rcSy}, rO = {A.rcOx, A.rcOy};
+    const v2f rcLa = v2f{rcCenter.x, rcCenter.y} * S16;
+    const float rcb = rcCenter.z * S16;
+    const float kC = A.negInvGammaC_log2e * (1.0f / 65536.0f);
+    constexpr float recB = PAIRED ? 16.0f : 8.0f;
+
+    v2f wsum = {0.f, 0.f};
+    v2f s1R = {0.f, 0.f}, s1T = {0.f, 0.f}, s2R = {0.f, 0.f}, s2T = {0.f, 0.f}, sxy = {0.f, 0.f};
+
+#pragma unroll 1
+    for(int yp = -wsh; yp <= wsh; ++yp)
+    {
+        const float fy = (float)yp;
+        const v2f rowx = (fy * bx + h0x) * A.tcSx, rowy = (fy * by + h0y) * A.tcSy, rowz = fy * bz + h0z;
+        const v2f rrow = (fy * v2f{ray.x, ray.y} + v2f{hr0.x, hr0.y}) * rS;
+        const float rrowz = fmaf(fy, ray.z, hr0.z);
+        const float* trow = tab.c + (yp + wsh) * n + wsh;
+        // One sample in two stages: fetch() — positions, weights and the LDS reads of the R image and of both planes' T taps, issued
+        // together — then consume().  (A hand-pipelined row, fetch(xp + 1) fenced in front of consume(xp), measured 12 % / 34 % SLOWER
+        // than this form for the SGM / Refine kernel: DESIGN.md §4.4.)
+        auto fetch = [&](int xp) __attribute__((always_inline)) -> PairTaps<PAIRED> {
+            PairTaps<PAIRED> t;
+            const float fx = (float)xp;
+            // ---- R: one image, {X, Y} packed
+            const float rinv = fast_rcp(fmaf(fx, rax.z, rrowz));
+            const v2f rXY = (fx * raS + rrow) * rinv + rO;
+            const v2f rF = floor2(rXY);
+            const v2f rW = floor2((rXY - rF) * 256.0f + 0.5f);           // {A, B} of quant8(), in units of 1/256
+            const v2f rN = rW * v2f{-1.0f, 1.0f} + v2f{256.0f, -256.0f}; // {256 - A, -(256 - B)}
+            const unsigned oR = (unsigned)(int)fmaf(rF.y, Wn.rPitchBF, fmaf(rF.x, recB, Wn.rOffB));
+            __builtin_assume(oR < 65536u);
+            t.wr = pk_half_weights(rN.x, rW.x);
+            t.rNy = rN.y;
+            t.rWy = rW.y;
+            // ---- T: {plane A, plane B}
+            const v2f hz = fx * az + rowz;
+            const v2f inv = {fast_rcp(hz.x), fast_rcp(hz.y)};
+            const v2f X = (fx * axS + rowx) * inv + A.tcOx;
+            const v2f Y = (fx * ayS + rowy) * inv + A.tcOy;
+            const v2f fX = floor2(X), fY = floor2(Y);
+            const v2f wa = floor2((X - fX) * 256.0f + 0.5f);
+            t.wb = floor2((Y - fY) * 256.0f + 0.5f);
+            const v2f na = 256.0f - wa;
+            t.nnb = t.wb - 256.0f;
+            const v2f oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
+            const unsigned oA = (unsigned)(int)oidx.x, oB = (unsigned)(int)oidx.y;
+            t.wtA = pk_half_weights(na.x, wa.x);
+            t.wtB = pk_half_weights(na.y, wa.y);
+            const unsigned oRb = RP > 0 ? oR + (unsigned)(RP * (PAIRED ? 16 : 8)) : oR + Wn.rPitchB;
+            t.load(oR, oRb, oA, oA + Wn.tPitchB, oB, oB + Wn.tPitchB);
+            return t;
+        };
+        auto consume = [&](int xp, const PairTaps<PAIRED>& t) __attribute__((always_inline)) {
+            const Lab3x2 hr = t.r_products();
+            const v2f dRLa = (v2f{hr.t.L, hr.t.a} * t.rNy + rcLa) - v2f{hr.b.L, hr.b.a} * t.rWy;
+            const float dRb = fmaf(hr.t.b, t.rNy, rcb) - hr.b.b * t.rWy;
+            const v2f qR = dRLa * dRLa;
+            const float base = fmaf(__builtin_amdgcn_sqrtf(fmaf(dRb, dRb, qR.x + qR.y)), kC, -trow[xp]);
+            const float dLR = dRLa.x;
+
+            const Lab3x4 h = t.t_products(); // rt / rb = plane A top / bottom row, tt / tb = plane B
+            const v2f dL = (v2f{h.rt.L, h.tt.L} * t.nnb + cL) - v2f{h.rb.L, h.tb.L} * t.wb;
+            const v2f da = (v2f{h.rt.a, h.tt.a} * t.nnb + ca) - v2f{h.rb.a, h.tb.a} * t.wb;
+            const v2f db = (v2f{h.rt.b, h.tt.b} * t.nnb + cb) - v2f{h.rb.b, h.tb.b} * t.wb;
+            const v2f sq = dL * dL + (da * da + db * db);
+            const v2f e = v2f{__builtin_amdgcn_sqrtf(sq.x), __builtin_amdgcn_sqrtf(sq.y)} * kC + base;
+            const v2f w = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+
+            const v2f wgR = w * dLR, wgT = w * dL;
+            wsum += w;
+            s1R += wgR;
+            s1T += wgT;
+            s2R = wgR * dLR + s2R;
+            s2T = wgT * dL + s2T;
+            sxy = wgR * dL + sxy;
+        };
+        if(WSH == 3)
+        {
+            // 7 taps per row as 3 + 3 + 1 (see ncc_accumulate_lds_fixed8)
+#pragma unroll
+            for(int xp = -3; xp < 0; ++xp)
+                consume(xp, fetch(xp));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for(int xp = 0; xp < 3; ++xp)
+                consume(xp, fetch(xp));
+            __builtin_amdgcn_sched_barrier(0);
+            consume(3, fetch(3));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        else
+        {
+#pragma unroll kNccPairUnroll
+            for(int xp = -wsh; xp <= wsh; ++xp)
+                consume(xp, fetch(xp));
+        }
+    }
+
+    auto finish = [&](float ws, float x1, float y1, float xx, float yy, float xy) __attribute__((always_inline)) -> float {
+        const float iw = fast_rcp(ws);
+        const float varXW = (xx - x1 * x1 * iw) * iw;
+        const float varYW = (yy - y1 * y1 * iw) * iw;
+        const float varXYW = (xy - x1 * y1 * iw) * iw;
+        const float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
+        const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
+        return TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, sim) : sim;
+    };
+    simA = finish(wsum.x, s1R.x, s1T.x, s2R.x, s2T.x, sxy.x);
+    simB = finish(wsum.y, s1R.y, s1T.y, s2R.y, s2T.y, sxy.y);
 }
 
 // recB = bytes per window record: 8 (one texel) or 16 (paired layout); rcap stays in 8-byte units
@@ -778,7 +990,7 @@ __device__ __forceinline__ void init_shared(BlockShared& sh)
 // ---------------------------------------------------------------------------------------------
 // SGM similarity: best / second-best uint8 volumes, 4 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-template <bool FIXED8, int WSH, bool PAIRED, int RP = 0>
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, bool PAIRS = false>
 __global__ void __launch_bounds__(256, 3)
   similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
                     avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
@@ -919,8 +1131,86 @@ __global__ void __launch_bounds__(256, 3)
         init_shared(sh);
         __syncthreads();
     }
+    // best / second-best update of plane k of the chunk (kernels.cuh:180-200)
+    auto commit = [&](int k, float fsim) __attribute__((always_inline)) {
+        const unsigned sh8 = 8u * k;
+        const unsigned b1 = (wb >> sh8) & 0xffu, b2 = (ws >> sh8) & 0xffu;
+        if(fsim < (float)b1)
+        {
+            ws = (ws & ~(0xffu << sh8)) | (b1 << sh8);
+            wb = (wb & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
+        }
+        else if(fsim < (float)b2)
+            ws = (ws & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
+    };
+    auto to_fsim = [](float s) __attribute__((always_inline)) -> float {
+        s = (s + 1.0f) * 0.5f;
+        s = fminf(1.0f, fmaxf(0.0f, s));
+        return s * 254.0f;
+    };
+    // geometry, centre colour and tap source of plane vz when the chunk window is in use
+    auto prep = [&](unsigned vz, PatchProj& Q, float4& tcCenter, bool& valid, bool& laneLds) __attribute__((always_inline)) {
+        valid = rValid;
+        tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
+        float tpx = 0.f, tpy = 0.f;
+        if(valid)
+            valid = plane_geometry(vz, Q, tpx, tpy);
+        laneLds = true;
+        if(valid)
+        {
+            const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
+            tcCenter = tex_bilinear_px<FIXED8>(A.tcL, cxT, cyT);
+            valid = !(tcCenter.w < (255.f * 0.4f));
+            // (a lane that was valid on neither extreme plane has no extent on record: it never reads the window)
+            laneLds = lanePart && (cxT - extX - 1.0f >= (float)Wc.x0) && (cxT + extX + 2.0f <= (float)(Wc.x0 + Wc.w - 1)) &&
+                      (cyT - extY - 1.0f >= (float)Wc.y0) && (cyT + extY + 2.0f <= (float)(Wc.y0 + Wc.h - 1));
+        }
+        laneLds = __ballot(valid && !laneLds) == 0ull; // wave-uniform choice of the tap source (see the Refine kernel)
+    };
 #pragma unroll 1
-    for(int k = 0; k < 4; ++k)
+    for(int k0 = 0; k0 < 4; k0 += 2)
+    {
+        bool pairDone = false;
+        {
+            const unsigned vzA = zc + k0, vzB = vzA + 1u;
+            // two adjacent planes in one pass over the patch (ncc_accumulate_lds_fixed8_pair): uniform conditions
+            if(PAIRS && FIXED8 && chunkWin && A.planePairs && !A.noPacked && vzA >= zBegin && vzB < zEnd)
+            {
+                PatchProj QA, QB;
+                float4 cA, cB;
+                bool validA, validB, ldsA, ldsB;
+                prep(vzA, QA, cA, validA, ldsA);
+                prep(vzB, QB, cB, validB, ldsB);
+                if(ldsA && ldsB) // wave-uniform
+                {
+                    float sA = 0.f, sB = 0.f;
+                    if(validA || validB)
+                    {
+                        // a lane with one valid plane runs it in both halves
+                        if(!validA)
+                        {
+                            QA = QB;
+                            cA = cB;
+                        }
+                        if(!validB)
+                        {
+                            QB = QA;
+                            cB = cA;
+                        }
+                        ncc_accumulate_lds_fixed8_pair<WSH, false, PAIRED, RP>(QA.rax, QA.ray, QA.hr0, QA, QB, A, tab,
+                                                                               make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8),
+                                                                               rcCenter, cA, cB, sA, sB);
+                    }
+                    commit(k0, validA ? to_fsim(sA) : 255.0f);
+                    commit(k0 + 1, validB ? to_fsim(sB) : 255.0f);
+                    pairDone = true;
+                }
+            }
+        }
+        if(pairDone)
+            continue;
+#pragma unroll 1
+    for(int k = k0; k < k0 + 2; ++k)
     {
         const unsigned vz = zc + k;
         if(vz < zBegin || vz >= zEnd) // uniform
@@ -973,19 +1263,10 @@ __global__ void __launch_bounds__(256, 3)
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
             else
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
-            s = (s + 1.0f) * 0.5f;
-            s = fminf(1.0f, fmaxf(0.0f, s));
-            fsim = s * 254.0f;
+            fsim = to_fsim(s);
         }
-        const unsigned sh8 = 8u * k;
-        const unsigned b1 = (wb >> sh8) & 0xffu, b2 = (ws >> sh8) & 0xffu;
-        if(fsim < (float)b1)
-        {
-            ws = (ws & ~(0xffu << sh8)) | (b1 << sh8);
-            wb = (wb & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
-        }
-        else if(fsim < (float)b2)
-            ws = (ws & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
+        commit(k, fsim);
+    }
     }
     if(inRoi)
     {
@@ -998,7 +1279,7 @@ __global__ void __launch_bounds__(256, 3)
 // ---------------------------------------------------------------------------------------------
 // Refine similarity: fp16 volume += sigmoid-filtered NCC, 8 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-template <bool FIXED8, int WSH, bool PAIRED, int RP = 0>
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, bool PAIRS = false>
 __global__ void __launch_bounds__(256, 3)
   refine_similarity_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize,
                            int map_pitch, const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A,
@@ -1152,8 +1433,86 @@ __global__ void __launch_bounds__(256, 3)
         init_shared(sh);
         __syncthreads();
     }
+    // packed[k] += s without indexing the register quad dynamically (that would spill it to scratch)
+    auto commit = [&](int k, float s) __attribute__((always_inline)) {
+        const unsigned sel = (unsigned)k >> 1, hiHalf = (unsigned)k & 1u;
+        unsigned word = sel == 0 ? packed.x : (sel == 1 ? packed.y : (sel == 2 ? packed.z : packed.w));
+        const unsigned short hbits = (unsigned short)(hiHalf ? (word >> 16) : (word & 0xffffu));
+        const __half hs = __float2half(__half2float(__ushort_as_half(hbits)) + s);
+        const unsigned nb = (unsigned)__half_as_ushort(hs);
+        word = hiHalf ? ((word & 0x0000ffffu) | (nb << 16)) : ((word & 0xffff0000u) | nb);
+        packed.x = sel == 0 ? word : packed.x;
+        packed.y = sel == 1 ? word : packed.y;
+        packed.z = sel == 2 ? word : packed.z;
+        packed.w = sel == 3 ? word : packed.w;
+    };
+    // geometry, centre colour and tap source of plane vz when the chunk window is in use
+    auto prep = [&](unsigned vz, PatchProj& Q, float4& tcCenter, bool& valid, bool& laneLds) __attribute__((always_inline)) {
+        valid = rValid;
+        tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
+        float tpx = 0.f, tpy = 0.f;
+        if(valid)
+            valid = plane_geometry(vz, Q, tpx, tpy);
+        laneLds = true;
+        if(valid)
+        {
+            const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
+            laneLds = lanePart && (cxT - extX - 1.0f >= (float)Wc.x0) && (cxT + extX + 2.0f <= (float)(Wc.x0 + Wc.w - 1)) &&
+                      (cyT - extY - 1.0f >= (float)Wc.y0) && (cyT + extY + 2.0f <= (float)(Wc.y0 + Wc.h - 1));
+            if(laneLds)
+                tcCenter = lds_center_paired(sT, Wc.pitch, Wc.x0, Wc.y0, cxT, cyT);
+            else
+                tcCenter = tex_bilinear_px<FIXED8>(A.tcL, cxT, cyT);
+            valid = !(tcCenter.w < (255.f * 0.4f));
+        }
+        laneLds = __ballot(valid && !laneLds) == 0ull;
+    };
 #pragma unroll 1
-    for(int k = 0; k < 8; ++k)
+    for(int k0 = 0; k0 < 8; k0 += 2)
+    {
+        bool pairDone = false;
+        {
+            const unsigned vzA = zc + k0, vzB = vzA + 1u;
+            // two adjacent planes in one pass over the patch (ncc_accumulate_lds_fixed8_pair): uniform conditions
+            if(PAIRS && CHUNK_CAPABLE && chunkWin && A.planePairs && !A.noPacked && vzA >= zBegin && vzB < zEnd)
+            {
+                PatchProj QA, QB;
+                float4 cA, cB;
+                bool validA, validB, ldsA, ldsB;
+                prep(vzA, QA, cA, validA, ldsA);
+                prep(vzB, QB, cB, validB, ldsB);
+                if(ldsA && ldsB) // wave-uniform
+                {
+                    if(validA || validB)
+                    {
+                        float sA = 0.f, sB = 0.f;
+                        // a lane with one valid plane runs it in both halves
+                        if(!validA)
+                        {
+                            QA = QB;
+                            cA = cB;
+                        }
+                        if(!validB)
+                        {
+                            QB = QA;
+                            cB = cA;
+                        }
+                        ncc_accumulate_lds_fixed8_pair<WSH, true, PAIRED, RP>(QA.rax, QA.ray, QA.hr0, QA, QB, A, tab,
+                                                                              make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8),
+                                                                              rcCenter, cA, cB, sA, sB);
+                        if(validA)
+                            commit(k0, sA);
+                        if(validB)
+                            commit(k0 + 1, sB);
+                    }
+                    pairDone = true;
+                }
+            }
+        }
+        if(pairDone)
+            continue;
+#pragma unroll 1
+    for(int k = k0; k < k0 + 2; ++k)
     {
         const unsigned vz = zc + k;
         if(vz < zBegin || vz >= zEnd) // uniform
@@ -1213,18 +1572,9 @@ __global__ void __launch_bounds__(256, 3)
                 s = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
             else
                 s = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
-            // packed[k] += s without indexing the register quad dynamically (that would spill it to scratch)
-            const unsigned sel = (unsigned)k >> 1, hiHalf = (unsigned)k & 1u;
-            unsigned word = sel == 0 ? packed.x : (sel == 1 ? packed.y : (sel == 2 ? packed.z : packed.w));
-            const unsigned short hbits = (unsigned short)(hiHalf ? (word >> 16) : (word & 0xffffu));
-            const __half hs = __float2half(__half2float(__ushort_as_half(hbits)) + s);
-            const unsigned nb = (unsigned)__half_as_ushort(hs);
-            word = hiHalf ? ((word & 0x0000ffffu) | (nb << 16)) : ((word & 0xffff0000u) | nb);
-            packed.x = sel == 0 ? word : packed.x;
-            packed.y = sel == 1 ? word : packed.y;
-            packed.z = sel == 2 ? word : packed.z;
-            packed.w = sel == 3 ? word : packed.w;
+            commit(k, s);
         }
+    }
     }
     if(pixActive)
         *reinterpret_cast<uint4*>(pv) = packed;
@@ -1599,6 +1949,8 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
     A.noPacked = (pk && pk[0] == '0') ? 1 : 0;
     const char* cw = getenv("AVDM_SIM_CHUNK_WINDOW"); // 0: one T window per plane (the A/B reference of the chunk window)
     A.chunkWindow = (cw && cw[0] == '0') ? 0 : 1;
+    const char* pp = getenv("AVDM_SIM_PLANE_PAIRS"); // 0: one plane per pass over the patch (the A/B reference of the plane pairs)
+    A.planePairs = (pp && pp[0] == '0') ? 0 : 1;
     A.stats = nullptr;
     const char* st = getenv("AVDM_SIM_STATS");
     if(st && st[0] == '1')
@@ -1775,8 +2127,8 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
     hipLaunchKernelGGL((similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
                        sp->stepXY, dr.begin, dr.end, roi)
     if(fixed8 && !paired && sp->wsh == 4 && A.rpitch == 56 && !A.noPacked)
-        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc,
-                           A, tab, sp->stepXY, dr.begin, dr.end, roi); // the default: scale 2, stepXY 2, wsh 4
+        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, true>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc,
+                           *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi); // the default: scale 2, stepXY 2, wsh 4 — with plane pairs
     else if(fixed8 && paired)
     {
         if(sp->wsh == 4) LAUNCH(true, 4, true);

@@ -411,6 +411,7 @@ def test_refine_chunk_window_equals_per_plane_windows(case):
     vols = []
     for flag in ("1", "0"):
         os.environ["AVDM_SIM_CHUNK_WINDOW"] = flag
+        os.environ["AVDM_SIM_PLANE_PAIRS"] = "0"  # one plane per pass in both runs: the plane pairs have their own test
         try:
             h = make_hip_from_oracle(o, sc, sgm, ref)
             h._alloc(len(depths))
@@ -424,11 +425,52 @@ def test_refine_chunk_window_equals_per_plane_windows(case):
             vols.append(h.refine_volume.cpu().numpy().astype(np.float32))
         finally:
             os.environ.pop("AVDM_SIM_CHUNK_WINDOW", None)
+            os.environ.pop("AVDM_SIM_PLANE_PAIRS", None)
     a, b = vols
     diff = np.abs(a - b)
     assert (diff > 0).mean() < 2e-3, (diff > 0).mean()
     assert diff.max() <= 4e-3, diff.max()
     assert (a != 0).mean() > 0.3
+
+
+def test_plane_pairs_equal_single_planes(case, capsys):
+    """Both similarity kernels run two adjacent planes per pass over the patch (ncc_accumulate_lds_fixed8_pair: the R side of a sample is
+    evaluated once, from the first plane's patch, for both); AVDM_SIM_PLANE_PAIRS=0 keeps one plane per pass.  The R taps of the second
+    plane move by < 1e-4 texel (the tilt of the patch's x axis between adjacent planes) and the sums are associated differently: the
+    volumes must agree to the storage quantum almost everywhere — SGM: uint8 levels, Refine: fp16 sums — and the statistics are printed."""
+    import os
+    torch = _torch()
+    sc, sgm, ref, depths, o = case
+    Z = len(depths)
+    out = {}
+    for flag in ("1", "0"):
+        os.environ["AVDM_SIM_PLANE_PAIRS"] = flag
+        try:
+            h = make_hip_from_oracle(o, sc, sgm, ref)
+            h.run_sgm(0, [1, 2], depths, optimize=False, keep_raw=True)
+            torch.cuda.synchronize()
+            best, second = h.best_raw.cpu().numpy()[..., :Z].copy(), h.second.cpu().numpy()[..., :Z].copy()
+            h2 = make_hip_from_oracle(o, sc, sgm, ref)
+            h2._alloc(Z)
+            h2.sgm_depth_thickness.copy_(torch.from_numpy(o.sgm_depth_thickness))
+            h2.run_refine(0, [1, 2], optimize_enabled=False)
+            torch.cuda.synchronize()
+            out[flag] = (best, second, h2.refine_volume.cpu().numpy().astype(np.float32))
+        finally:
+            os.environ.pop("AVDM_SIM_PLANE_PAIRS", None)
+    (b1, s1, r1), (b0, s0, r0) = out["1"], out["0"]
+    fb, mb = level_mismatch(b0, b1)
+    fs, ms = level_mismatch(s0, s1)
+    d = np.abs(r1 - r0)
+    with capsys.disabled():
+        print("\nplane pairs vs single planes: SGM best %.4f of the voxels differ (max %d levels), second %.4f (max %d); Refine %.4f differ, "
+              "%.5f by more than one fp16 quantum (2e-3), max %.2e" % (fb, mb, fs, ms, (d > 0).mean(), (d > 2e-3).mean(), d.max()))
+    assert fb <= 0.02 and fs <= 0.02, (fb, fs)          # uint8 truncation boundaries only
+    assert mb <= 2 and ms <= 2, (mb, ms)
+    assert ((b0 == 255) != (b1 == 255)).mean() == 0.0   # validity is decided before the samples: identical
+    assert (d > 2e-3).mean() <= 1e-3, (d > 2e-3).mean()
+    assert d.max() <= 8e-3, d.max()
+    assert (r1 != 0).mean() > 0.3 and (b1 != 255).mean() > 0.3
 
 
 def test_refine_best_depth_bit_exact(case):
