@@ -265,7 +265,8 @@ def main():
                 break
         # the similarity kernels are VALU / LDS-gather bound, HBM fraction is not their figure.  Work units: a voxel-T is
         # (2 wsh + 1)^2 patch samples (81 SGM, 49 Refine); flops per voxel-T from SURVEY §8(a) (8.1 k / 4.9 k); LDS bytes per sample as the
-        # kernels read them (SGM: half-paired 8-byte records, 4 x 8 + 4 x 4 B; Refine: paired 16-byte records, 4 x 16 B)
+        # kernels read them (SGM: half-paired 8-byte records, 2 x 8 + 2 x 4 B per image; with two planes per pass the R taps are read once
+        # for both planes: 24 + 12 B per plane-sample; Refine: paired 16-byte records, 4 x 16 B)
         px_sgm = sum(x * y for x, y in vols)
         px_ref = sum(((r[1] - r[0]) * (r[3] - r[2])) if r is not None else W * H for r in rois)
         nz_ref = 2 * ref.halfNbDepths + 1
@@ -282,7 +283,7 @@ def main():
                        "pyramid_setup_broadcast_s": t_ex, "pyramid_bytes_received_per_rank": exchange.bytes_received},
             "roofline": roof,
             "similarity": {"sgm_voxelT_per_s": vt_sgm, "refine_voxelT_per_s": vt_ref, "sgm_samples_per_s": s_sgm, "refine_samples_per_s": s_ref,
-                           "sgm_lds_GBps": s_sgm * 48.0 / 1e9, "refine_lds_GBps": s_ref * 64.0 / 1e9, "lds_peak_GBps": 150000.0,
+                           "sgm_lds_GBps": s_sgm * (48.0 if os.environ.get("AVDM_SIM_PLANE_PAIRS") == "0" else 36.0) / 1e9, "refine_lds_GBps": s_ref * 64.0 / 1e9, "lds_peak_GBps": 150000.0,
                            "sgm_fp32_TFLOPs": vt_sgm * 8.1e3 / 1e12, "refine_fp32_TFLOPs": vt_ref * 4.9e3 / 1e12,
                            "sgm_fp32_frac": vt_sgm * 8.1e3 / 157.3e12, "refine_fp32_frac": vt_ref * 4.9e3 / 157.3e12, "fp32_vector_peak_TFLOPs": 157.3},
             "stages_ms": stages, "valid_fraction": valid,
