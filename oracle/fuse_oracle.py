@@ -1,5 +1,6 @@
 """ctypes / numpy front end of oracle/avdm_fuse_oracle.c — the CPU restatement of fuseCut::Fuser's depth-map filtering
-(Fuser.cpp:66-304).  TEST INFRASTRUCTURE ONLY (tests/, smoke, cpu_baseline); parity unpinned (see the C file's header)."""
+(Fuser.cpp:66-304).  TEST INFRASTRUCTURE ONLY (tests/, smoke, cpu_baseline); pinned to the reference's own functions by
+tests/test_fuse_ref.py (oracle/fuse_ref.py, see the C file's header)."""
 import ctypes as C
 
 import numpy as np

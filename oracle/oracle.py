@@ -1,7 +1,7 @@
 """Python face of the CPU parity oracle (oracle/libavdm_oracle.so) — TEST INFRASTRUCTURE ONLY.
 
-Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module (parity unpinned: see the
-header of avdm_oracle.c).  Struct layouts are shared with the product ABI (alicevision_amd/abi.py mirrors include/avdm.h);
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module (pinned to the reference's own kernels through
+oracle/_ref, tests/test_oracle_ref.py; what stays unpinned is listed in the header of avdm_oracle.c).  Struct layouts are shared with the product ABI (alicevision_amd/abi.py mirrors include/avdm.h);
 all buffers are numpy arrays in host memory.
 
 `OracleDepthMap` restates the per-tile control flow of the reference:

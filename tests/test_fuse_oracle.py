@@ -1,5 +1,6 @@
 """CPU tests of the depth-map filtering restatement (oracle/avdm_fuse_oracle.c <- fuseCut/Fuser.cpp:66-304).  The reference has no
-tests or golden vectors for this step (parity unpinned): the restatement is checked against the geometry it encodes."""
+tests or golden vectors for this step: here the restatement is checked against the geometry it encodes; tests/test_fuse_ref.py pins it,
+bit for bit, to the reference's own functions compiled for the CPU."""
 import numpy as np
 import pytest
 

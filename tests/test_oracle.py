@@ -1,8 +1,8 @@
 """CPU tests of the parity oracle (oracle/avdm_oracle.c): known-answer checks against independent restatements written from
 the algorithm description (numpy / pure Python, small cases), analytic properties, and the committed golden fixtures.
 
-The reference holds no test or golden vector for depthMap, so these are what pins the oracle ("parity unpinned"
-with respect to a run of the reference itself)."""
+The reference holds no test or golden vector for depthMap; these checks stand beside tests/test_oracle_ref.py, which
+pins the oracle bit for bit to the reference's own kernels compiled for the CPU (oracle/_ref)."""
 import ctypes as C
 import math
 import os
