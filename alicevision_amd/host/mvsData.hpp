@@ -55,7 +55,9 @@ struct Pixel
     int x = 0, y = 0;
     Pixel() = default;
     Pixel(int x_, int y_) : x(x_), y(y_) {}
-    explicit Pixel(const Point2d& p) : x(static_cast<int>(p.x)), y(static_cast<int>(p.y)) {}
+    // rounds half up like the reference (mvsData/Pixel.hpp:30-34) — found by the pin against the reference's own SgmDepthList.cpp
+    // (tests/test_host_ref.py): truncation kept / dropped other epipolar samples at the border of the T image
+    explicit Pixel(const Point2d& p) : x(static_cast<int>(std::floor(p.x + 0.5))), y(static_cast<int>(std::floor(p.y + 0.5))) {}
 };
 
 // row-major 3x3, m[3*r + c]

@@ -1,4 +1,4 @@
-"""Python face of oracle/_ref/libavdm_fuse_ref.so — the REFERENCE's own depth-map filtering functions (fuseCut::Fuser::filterGroupsRC /
+"""Python face of oracle/_ref/libavdm_host_ref.so — the REFERENCE's own depth-map filtering functions (fuseCut::Fuser::filterGroupsRC /
 filterDepthMapsRC / updateInSurr and the MultiViewParams / common.cpp / geometry.cpp helpers they call), compiled for this CPU from the
 reference's text where it lies under /root/reference (oracle/ref/Makefile, gen_extract.py, fuse_standin.hpp, fuse_driver.cpp).
 
@@ -12,7 +12,7 @@ import numpy as np
 from .fuse_oracle import FuseCam
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_ref", "libavdm_fuse_ref.so")
+LIB_PATH = os.path.join(HERE, "_ref", "libavdm_host_ref.so")
 _lib_handle = None
 
 

@@ -139,7 +139,7 @@ class Cameras:
         return x[:2] / x[2]
 
     def pixel_in_image(self, pix, margin=2):
-        px, py = int(pix[0]), int(pix[1])  # Pixel(Point2d) truncates
+        px, py = int(math.floor(pix[0] + 0.5)), int(math.floor(pix[1] + 0.5))  # Pixel(Point2d), mvsData/Pixel.hpp:30-34: rounds half up
         return margin <= px < self.width - margin and margin <= py < self.height - margin
 
     def cam_pixel_size(self, x0, cam, d):

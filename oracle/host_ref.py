@@ -1,0 +1,70 @@
+"""Python face of the depth-plane-list entry point of oracle/_ref/libavdm_host_ref.so — the REFERENCE's own depthMap/SgmDepthList.cpp
+compiled whole and unchanged for this CPU (oracle/ref/Makefile, host_driver.cpp), over the reference's mvsData and the stand-ins of
+oracle/ref/shim_host/.  TEST INFRASTRUCTURE ONLY: tests/test_host_ref.py holds oracle/host_oracle.py against it (and
+tests/test_host_cpu.py holds the C++ host against host_oracle.py).  `available()` is False where the library did not travel."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_ref", "libavdm_host_ref.so")
+_lib_handle = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def _lib():
+    global _lib_handle
+    if _lib_handle is None:
+        lib = C.CDLL(LIB_PATH)
+        dp, ip, fp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_float)
+        lib.avref_sgm_depth_list.restype = C.c_int
+        lib.avref_sgm_depth_list.argtypes = [C.c_int, dp, ip, ip, C.c_int, C.c_float, C.c_float, C.c_int, dp, ip, ip, dp, C.c_int, C.c_int, ip, ip,
+                                             C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, fp, C.c_int, ip, ip]
+        _lib_handle = lib
+    return _lib_handle
+
+
+def depth_list(K, Rs, Cs, width, height, landmarks, rc, tcams, roi, process_downscale=1, min_angle=2.0, max_angle=70.0, sgm_scale=2, max_depths=1500,
+               step_z=-1, seeds_range_inflate=0.2, use_sfm_seeds=True, depth_list_per_tile=False):
+    """SgmDepthList::computeListRc of the reference for one tile: (depths float32 array, [(first, count)] per T camera), ([], []) when the
+    reference produces no list.  Same scene description as host_oracle.Cameras / host_oracle.depth_list: full-resolution K, R_i, C_i and
+    image size, landmarks = [(X, {view index: (u, v)})] with full-resolution observations, roi = (x0, x1, y0, y1) at process resolution."""
+    lib = _lib()
+    n = len(Rs)
+    K = np.asarray(K, np.float64)
+    P = np.stack([K @ np.concatenate([np.asarray(Rs[i], np.float64), (-np.asarray(Rs[i], np.float64) @ np.asarray(Cs[i], np.float64))[:, None]], axis=1)
+                  for i in range(n)]).astype(np.float64)
+    P = np.ascontiguousarray(P.reshape(n, 12))
+    w = np.full(n, width // process_downscale, np.int32)
+    h = np.full(n, height // process_downscale, np.int32)
+    X = np.ascontiguousarray(np.array([l[0] for l in landmarks], np.float64).reshape(-1, 3))
+    begin, views, xy = [0], [], []
+    for _, obs in landmarks:
+        for v in sorted(obs):
+            views.append(v)
+            xy.append(obs[v])
+        begin.append(len(views))
+    begin = np.asarray(begin, np.int32)
+    views = np.asarray(views, np.int32)
+    xy = np.ascontiguousarray(np.asarray(xy, np.float64).reshape(-1, 2))
+    tc = np.asarray(list(tcams), np.int32)
+    r = np.asarray(roi, np.int32)
+    cap = 65536
+    out = np.zeros(cap, np.float32)
+    out_n = C.c_int(0)
+    lim = np.zeros((max(len(tc), 1), 2), np.int32)
+    dp, ip, fp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_float)
+    st = lib.avref_sgm_depth_list(n, P.ctypes.data_as(dp), w.ctypes.data_as(ip), h.ctypes.data_as(ip), int(process_downscale), float(min_angle), float(max_angle),
+                                  len(landmarks), X.ctypes.data_as(dp), begin.ctypes.data_as(ip), views.ctypes.data_as(ip), xy.ctypes.data_as(dp), int(rc),
+                                  len(tc), tc.ctypes.data_as(ip), r.ctypes.data_as(ip), int(sgm_scale), int(max_depths), int(step_z), float(seeds_range_inflate),
+                                  int(bool(use_sfm_seeds)), int(bool(depth_list_per_tile)), out.ctypes.data_as(fp), cap, C.byref(out_n), lim.ctypes.data_as(ip))
+    if st != 0:
+        raise RuntimeError("avref_sgm_depth_list: the reference threw (see stderr)")
+    k = out_n.value
+    if k == 0:
+        return np.zeros(0, np.float32), []
+    return out[:k].copy(), [(int(a), int(b)) for a, b in lim[:len(tc)]]

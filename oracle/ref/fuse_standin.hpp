@@ -3,10 +3,10 @@
 // MultiViewParams::getPixelFor3DPoint / getCamPixelSize* / isPixelInImage / decomposeProjectionMatrix (mvsUtils/MultiViewParams.cpp),
 // get2dLineImageIntersection / getTarEpipolarDirectedLine / triangulateMatch (mvsUtils/common.cpp) — are compiled from the reference's
 // own text (gen_extract.py), and mvsData (Point3d, Point2d, Pixel, Matrix3x3, Matrix3x4, StaticVector, geometry.cpp) is the reference's
-// own code included where it lies.  What is declared HERE is only their environment, none of which computes anything:
-//   * MultiViewParams: the camera arrays as plain members (the reference fills them in loadMatricesFromRawProjectionMatrix,
-//     MultiViewParams.cpp:283-297; the driver fills them from the arrays the test hands to BOTH sides), image sizes, g_border = 2
-//     (MultiViewParams.hpp:111), and findNearestCamsFromLandmarks answering with the T-camera list of the test;
+// own code included where it lies.  What is declared HERE (and in shim_host/aliceVision/mvsUtils/MultiViewParams.hpp) is only their
+// environment, none of which computes anything:
+//   * MultiViewParams (shim_host/): the camera arrays as plain members, image sizes, g_border = 2, and findNearestCamsFromLandmarks
+//     answering with the T-camera list of the test;
 //   * image::Image<T>: row-major pixels with the accessors the functions use (image/Image.hpp is an Eigen matrix);
 //   * readMap / writeMap / readImage / writeImageWithFloat / utils::exists: an in-memory store instead of EXR files.
 #pragma once
@@ -21,14 +21,7 @@
 #include <utility>
 #include <vector>
 
-#include <aliceVision/system/Logger.hpp>
-#include <aliceVision/mvsData/Point2d.hpp>
-#include <aliceVision/mvsData/Point3d.hpp>
-#include <aliceVision/mvsData/Pixel.hpp>
-#include <aliceVision/mvsData/Matrix3x3.hpp>
-#include <aliceVision/mvsData/Matrix3x4.hpp>
-#include <aliceVision/mvsData/StaticVector.hpp>
-#include <aliceVision/mvsData/geometry.hpp>
+#include "host_standin.hpp" // the reference's own mvsData / common.hpp declarations + the stand-in MultiViewParams (shim_host/)
 
 namespace aliceVision {
 
@@ -66,48 +59,6 @@ namespace mvsUtils {
 
 enum class EFileType { depthMap, simMap, nmodMap, depthMapFiltered, simMapFiltered };
 
-class MultiViewParams
-{
-  public:
-    std::vector<Matrix3x4> camArr;
-    std::vector<Matrix3x3> iCamArr;
-    std::vector<Point3d> CArr;
-    std::vector<int> widths, heights;
-    std::vector<int> nearest; // answer of findNearestCamsFromLandmarks
-    int g_border = 2;         // MultiViewParams.hpp:111
-
-    int getViewId(int index) const { return index; }
-    int getWidth(int index) const { return widths.at(index); }
-    int getHeight(int index) const { return heights.at(index); }
-    StaticVector<int> findNearestCamsFromLandmarks(int, int) const
-    {
-        StaticVector<int> out;
-        for(int c : nearest)
-            out.push_back(c);
-        return out;
-    }
-
-    // defined by the reference's own text (gen/fuse_MultiViewParams.cpp)
-    void getPixelFor3DPoint(Point2d* out, const Point3d& X, const Matrix3x4& P) const;
-    void getPixelFor3DPoint(Point2d* out, const Point3d& X, int rc) const;
-    void getPixelFor3DPoint(Pixel* out, const Point3d& X, int rc) const;
-    double getCamPixelSize(const Point3d& x0, int cam) const;
-    double getCamPixelSize(const Point3d& x0, int cam, float d) const;
-    double getCamPixelSizeRcTc(const Point3d& p, int rc, int tc, float d) const;
-    double getCamPixelSizePlaneSweepAlpha(const Point3d& p, int rc, int tc, int scale, int step) const;
-    double getCamPixelSizePlaneSweepAlpha(const Point3d& p, int rc, StaticVector<int>* tcams, int scale, int step) const;
-    bool isPixelInImage(const Pixel& pix, int camId, int margin) const;
-    bool isPixelInImage(const Pixel& pix, int camId) const;
-    bool isPixelInImage(const Point2d& pix, int camId) const;
-    bool isPixelInImage(const Point2d& pix, int camId, int margin) const;
-    void decomposeProjectionMatrix(Point3d& Co, Matrix3x3& Ro, Matrix3x3& iRo, Matrix3x3& Ko, Matrix3x3& iKo, Matrix3x3& iPo, const Matrix3x4& P) const;
-};
-
-// defined by the reference's own text (gen/fuse_common.cpp)
-bool get2dLineImageIntersection(Point2d* pFrom, Point2d* pTo, Point2d linePoint1, Point2d linePoint2, const MultiViewParams& mp, int camId);
-bool getTarEpipolarDirectedLine(Point2d* pFromTar, Point2d* pToTar, Point2d refpix, int refCam, int tarCam, const MultiViewParams& mp);
-bool triangulateMatch(Point3d& out, const Point2d& refpix, const Point2d& tarpix, int refCam, int tarCam, const MultiViewParams& mp);
-
 // ---- the in-memory map store (fuse_driver.cpp) ----
 struct MapStore
 {
@@ -128,7 +79,6 @@ inline void writeMap(int rc, const MultiViewParams&, const EFileType fileType, c
 {
     store().f32[{rc, (int)fileType}] = in;
 }
-inline void printfElapsedTime(long, const std::string& = "") {}
 } // namespace mvsUtils
 
 namespace image {

@@ -5,10 +5,10 @@ compiled whole here: they include OpenImageIO, Boost, Eigen and the SfMData mode
 the depth-map filtering step consists of use none of that.  This script reads a reference source where it lies under /root/reference,
 finds every definition whose qualified name is in the list (all overloads, unless one is excluded by a substring of its parameter
 list), and writes them — text untouched, `#line` directives pointing back at the reference — into oracle/_ref/gen/ (git-ignored).
-They are then compiled against the stand-in declarations of oracle/ref/fuse_standin.hpp.  Reference sources are never copied into the
+They are then compiled against stand-in declarations (oracle/ref/fuse_standin.hpp, oracle/ref/shim_host/aliceVision/...).  Reference sources are never copied into the
 repository.
 
-    python gen_extract.py <in.cpp> <out.cpp> <namespace path, e.g. aliceVision::mvsUtils> name[!excluded-substring] ...
+    python gen_extract.py <in.cpp> <out.cpp> <header to include> <namespace path, e.g. aliceVision::mvsUtils> name[!excluded-substring] ...
 """
 import re
 import sys
@@ -72,7 +72,7 @@ def find_definitions(text, qualname):
         yield m.start(), k, code[m.end():i]
 
 
-def main(src, dst, namespace, names):
+def main(src, dst, header, namespace, names):
     text = open(src, encoding="utf-8-sig").read()
     chunks = []
     for spec in names:
@@ -88,7 +88,7 @@ def main(src, dst, namespace, names):
             raise SystemExit("%s: no definition of %s" % (src, name))
     chunks.sort()
     with open(dst, "w") as f:
-        f.write('#include "fuse_standin.hpp"\n')
+        f.write('#include %s\n' % header)
         for ns in namespace.split("::"):
             f.write("namespace %s {\n" % ns)
         for _, c in chunks:
@@ -98,4 +98,4 @@ def main(src, dst, namespace, names):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4:])
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:])

@@ -1,0 +1,71 @@
+// oracle/_ref (host): STAND-IN for aliceVision/mvsUtils/MultiViewParams.hpp.  Test infrastructure only.
+// The class as the code under test sees it: the camera arrays as plain members (the reference fills them in
+// loadMatricesFromRawProjectionMatrix, MultiViewParams.cpp:283-297; the drivers fill them the same way, with the reference's own
+// Matrix3x4::decomposeProjectionMatrix), image sizes, the view-angle limits, the landmarks, g_border = 2 (MultiViewParams.hpp:111).
+// The METHODS that compute — getPixelFor3DPoint, getCamPixelSize*, isPixelInImage, decomposeProjectionMatrix — are only declared here:
+// their definitions are the reference's own text (gen_extract.py -> oracle/_ref/gen/fuse_MultiViewParams.cpp).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include <aliceVision/mvsData/Matrix3x3.hpp>
+#include <aliceVision/mvsData/Matrix3x4.hpp>
+#include <aliceVision/mvsData/Pixel.hpp>
+#include <aliceVision/mvsData/Point2d.hpp>
+#include <aliceVision/mvsData/Point3d.hpp>
+#include <aliceVision/mvsData/ROI.hpp>
+#include <aliceVision/mvsData/StaticVector.hpp>
+#include <aliceVision/sfmData/SfMData.hpp>
+
+namespace aliceVision {
+namespace mvsUtils {
+
+class MultiViewParams
+{
+  public:
+    std::vector<Matrix3x4> camArr;
+    std::vector<Matrix3x3> KArr, iKArr, RArr, iRArr, iCamArr;
+    std::vector<Point3d> CArr;
+    std::vector<int> widths, heights, viewIds;
+    std::vector<int> nearest; // answer of findNearestCamsFromLandmarks (fuse driver)
+    sfmData::SfMData sfm;
+    int processDownscale = 1;
+    float minViewAngle = 2.0f, maxViewAngle = 70.0f;
+    int g_border = 2; // MultiViewParams.hpp:111
+
+    int getNbCameras() const { return (int)camArr.size(); }
+    int getViewId(int index) const { return viewIds.empty() ? index : viewIds.at(index); }
+    int getWidth(int index) const { return widths.at(index); }
+    int getHeight(int index) const { return heights.at(index); }
+    int getProcessDownscale() const { return processDownscale; }
+    float getMinViewAngle() const { return minViewAngle; }
+    float getMaxViewAngle() const { return maxViewAngle; }
+    const sfmData::SfMData& getInputSfMData() const { return sfm; }
+    std::string getDepthMapsFolder() const { return "/tmp/"; }
+    StaticVector<int> findNearestCamsFromLandmarks(int, int) const
+    {
+        StaticVector<int> out;
+        for(int c : nearest)
+            out.push_back(c);
+        return out;
+    }
+
+    // defined by the reference's own text
+    void getPixelFor3DPoint(Point2d* out, const Point3d& X, const Matrix3x4& P) const;
+    void getPixelFor3DPoint(Point2d* out, const Point3d& X, int rc) const;
+    void getPixelFor3DPoint(Pixel* out, const Point3d& X, int rc) const;
+    double getCamPixelSize(const Point3d& x0, int cam) const;
+    double getCamPixelSize(const Point3d& x0, int cam, float d) const;
+    double getCamPixelSizeRcTc(const Point3d& p, int rc, int tc, float d) const;
+    double getCamPixelSizePlaneSweepAlpha(const Point3d& p, int rc, int tc, int scale, int step) const;
+    double getCamPixelSizePlaneSweepAlpha(const Point3d& p, int rc, StaticVector<int>* tcams, int scale, int step) const;
+    bool isPixelInImage(const Pixel& pix, int camId, int margin) const;
+    bool isPixelInImage(const Pixel& pix, int camId) const;
+    bool isPixelInImage(const Point2d& pix, int camId) const;
+    bool isPixelInImage(const Point2d& pix, int camId, int margin) const;
+    void decomposeProjectionMatrix(Point3d& Co, Matrix3x3& Ro, Matrix3x3& iRo, Matrix3x3& Ko, Matrix3x3& iKo, Matrix3x3& iPo, const Matrix3x4& P) const;
+};
+
+} // namespace mvsUtils
+} // namespace aliceVision

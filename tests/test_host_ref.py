@@ -1,0 +1,82 @@
+"""The depth-plane list pinned to the REFERENCE'S OWN code: oracle/host_oracle.depth_list — which the C++ host equals
+(tests/test_host_cpu.py) — against depthMap/SgmDepthList.cpp compiled whole and unchanged for this CPU (oracle/_ref/libavdm_host_ref.so,
+oracle/ref/host_driver.cpp): same cameras, landmarks, tile and parameters into both.
+
+The two sides derive K, R, C from the projection matrix with different RQ codes (numpy there, the reference's Matrix3x3::RQ here) and
+the oracle evaluates the geometry in numpy double expressions: the planes agree to fp32 rounding (the bar of test_host_cpu.py, 2e-6
+relative), their NUMBER and the per-T-camera limits agree exactly."""
+import numpy as np
+import pytest
+
+from alicevision_amd import scene_io
+from alicevision_amd.synthetic import make_scene
+from oracle import host_oracle as ho
+from oracle import host_ref as hr
+
+pytestmark = pytest.mark.skipif(not hr.available(), reason="oracle/_ref/libavdm_host_ref.so not built (no reference tree)")
+
+
+@pytest.fixture(scope="module")
+def scene():
+    sc = make_scene(6, 640, 480, seed=9, baseline=0.9, amp=0.6, render=[])
+    return sc, scene_io.sample_landmarks(sc, 600, amp=0.6)
+
+
+def _both(sc, lms, rc, tcams, roi, ds=1, **kw):
+    cams = ho.Cameras(sc.K, sc.R, sc.C, sc.width, sc.height, process_downscale=ds)
+    a = ho.depth_list(cams, lms, rc, tcams, roi, **kw)
+    b = hr.depth_list(sc.K, sc.R, sc.C, sc.width, sc.height, lms, rc, tcams, roi, process_downscale=ds, **kw)
+    return a, b
+
+
+def _same(a, b):
+    (da, la), (db, lb) = a, b
+    assert len(da) == len(db), (len(da), len(db))
+    if len(da):
+        assert np.allclose(np.asarray(da, np.float64), np.asarray(db, np.float64), rtol=2e-6, atol=0.0), np.abs(np.asarray(da) - np.asarray(db)).max()
+        assert [tuple(l) for l in la] == [tuple(l) for l in lb], (la, lb)
+
+
+@pytest.mark.parametrize("max_depths", [1500, 96, 12])
+def test_depth_list_full_image_equals_reference(scene, max_depths):
+    """whole-image tile of every camera against its landmark-ranked neighbours; uncapped, capped (second pass with a scale) and heavily capped"""
+    sc, lms = scene
+    cams = ho.Cameras(sc.K, sc.R, sc.C, sc.width, sc.height)
+    n_planes = []
+    for rc in range(6):
+        tc = ho.nearest_cams_from_landmarks(cams, lms, rc, 10)
+        a, b = _both(sc, lms, rc, tc, (0, 640, 0, 480), sgm_scale=2, max_depths=max_depths)
+        _same(a, b)
+        n_planes.append(len(a[0]))
+    assert min(n_planes) > 8
+    if max_depths < 1500:
+        assert max(n_planes) <= max_depths
+
+
+def test_depth_list_per_tile_and_downscale_equals_reference(scene):
+    """tiles of the image with depthListPerTile (landmark selection by ROI, reference pixel = ROI centre), at process downscale 1 and 2,
+    stepZ given, SfM seeds off"""
+    sc, lms = scene
+    for ds in (1, 2):
+        cams = ho.Cameras(sc.K, sc.R, sc.C, sc.width, sc.height, process_downscale=ds)
+        W, H = 640 // ds, 480 // ds
+        rois = ho.tile_roi_list(416 // ds, 352 // ds, 32 // ds, W, H, 4)
+        assert len(rois) == 4
+        for rc in (0, 3):
+            tc = ho.nearest_cams_from_landmarks(cams, lms, rc, 4)
+            for roi in rois:
+                tt = ho.tile_nearest_cams(cams, lms, rc, 3, tc, roi)
+                if not tt:
+                    continue
+                for kw in (dict(depth_list_per_tile=True, max_depths=64), dict(depth_list_per_tile=True, max_depths=1500, step_z=2),
+                           dict(depth_list_per_tile=False, max_depths=200, use_sfm_seeds=False), dict(seeds_range_inflate=0.5, max_depths=1500)):
+                    a, b = _both(sc, lms, rc, tt, roi, ds=ds, sgm_scale=2, **kw)
+                    _same(a, b)
+
+
+def test_no_landmarks_no_list(scene):
+    """a tile whose ROI holds no landmark of the R camera gets no depth list from either (SgmDepthList.cpp:60-66)"""
+    sc, lms = scene
+    few = [(X, obs) for X, obs in lms if 0 in obs and obs[0][0] > 400]
+    a, b = _both(sc, few, 0, [1, 2], (0, 200, 0, 200), sgm_scale=2, max_depths=64, depth_list_per_tile=True)
+    assert len(a[0]) == 0 and len(b[0]) == 0
