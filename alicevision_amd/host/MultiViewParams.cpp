@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cfloat>
 #include <cmath>
 #include <set>
@@ -216,8 +217,19 @@ void MultiViewParams::decomposeProjectionMatrix(Point3d& Co, Matrix3x3& Ro, Matr
 }
 
 // MultiViewParams.cpp:519-575.  Scores = number of common landmarks whose two rays form an angle inside [min, max] view
-// angle; cameras sorted by descending score (the reference's qsort leaves the order of equal scores unspecified: here the
-// lower camera index wins a tie), at least 21 common landmarks required.
+// angle; cameras sorted by descending score with the C library's qsort and a comparator that, like the reference's
+// (mvsData/structures.cpp:37-47), never reports equality — so equal scores come out in the order the reference's own call produces on
+// the same C library (glibc: a merge sort that takes the element of the SECOND half on a tie; pinned by tests/test_host_ref.py) —
+// at least 21 common landmarks required.
+namespace {
+int bySortedIdValueDescending(const void* pa, const void* pb)
+{
+    const SortedId& a = *static_cast<const SortedId*>(pa);
+    const SortedId& b = *static_cast<const SortedId*>(pb);
+    return a.value > b.value ? -1 : 1; // never 0, like the reference's comparator
+}
+} // namespace
+
 std::vector<int> MultiViewParams::findNearestCamsFromLandmarks(int rc, int nbNearestCams) const
 {
     std::vector<int> out;
@@ -253,7 +265,8 @@ std::vector<int> MultiViewParams::findNearestCamsFromLandmarks(int rc, int nbNea
             ++ids.at(idIt->second).value;
         }
     }
-    std::stable_sort(ids.begin(), ids.end(), [](const SortedId& a, const SortedId& b) { return a.value > b.value; });
+    if(!ids.empty())
+        std::qsort(ids.data(), ids.size(), sizeof(SortedId), bySortedIdValueDescending);
     const int maxTc = std::min({getNbCameras(), nbNearestCams, static_cast<int>(ids.size())});
     out.reserve(maxTc);
     for(int i = 0; i < maxTc; ++i)
@@ -317,7 +330,8 @@ std::vector<int> MultiViewParams::findTileNearestCams(int rc, int nbNearestCams,
     for(const auto& p : tcScore)
         if(p.second > 0.0f)
             ids.push_back({p.first, p.second});
-    std::stable_sort(ids.begin(), ids.end(), [](const SortedId& a, const SortedId& b) { return a.value > b.value; });
+    if(!ids.empty())
+        std::qsort(ids.data(), ids.size(), sizeof(SortedId), bySortedIdValueDescending);
     const int maxTc = std::min(std::min(getNbCameras(), nbNearestCams), static_cast<int>(ids.size()));
     for(int i = 0; i < maxTc; ++i)
         out.push_back(ids[i].id);

@@ -2,8 +2,12 @@
 
 Only tests/ may import this module; the product is the C++ code under alicevision_amd/host/.  It is written from the reference
 sources, independently of the C++ host (different language, different data structures), and the tests compare the two on the
-same scenes.  PARITY UNPINNED like the kernel oracle: the reference has no test or golden vector for these functions
- and cannot be built here.  Paths relative to /root/reference/src/aliceVision.
+same scenes (tests/test_host_cpu.py).  PINNED to the reference's own code since round 2: tests/test_host_ref.py holds every function
+below against oracle/_ref/libavdm_host_ref.so — depthMap/SgmDepthList.cpp and mvsUtils/TileParams.cpp compiled whole and unchanged,
+the T-camera selection, the tile-merge weights and the projection / pixel-size / epipolar helpers compiled from the reference's text
+(oracle/ref/Makefile) — which found and fixed two deviations (Pixel(Point2d) rounds half up; equal scores keep the order of the C
+library's qsort).  Unpinned remainders, restated on both sides: boost::accumulators' tail quantile and camera::angleBetweenRays
+(Eigen code over the camera model).  Paths relative to /root/reference/src/aliceVision.
 
     tile_roi_list               mvsUtils/TileParams.cpp:15-61
     tile_weight_map             mvsUtils/mapIO.cpp:170-311 (weightTileBorder / addSingleTileMapWeighted)
@@ -165,9 +169,29 @@ def angle_between_rays(K, R1, R2, x1, x2):
     return math.degrees(math.acos(c))
 
 
+def _qsort_sorted_id_desc(ids):
+    """qsort(ids, qsortCompareSortedIdDesc) as glibc executes it: the comparator (mvsData/structures.cpp:37-47) returns -1 when
+    a.value > b.value and +1 otherwise — never 0 — and glibc's qsort is a top-down merge sort (stdlib/msort.c: halves n / 2 and n - n / 2,
+    `cmp(b1, b2) <= 0` takes the element of the first half), so on equal values the element of the SECOND half goes first.
+    ids: list of (id, value)."""
+    n = len(ids)
+    if n <= 1:
+        return list(ids)
+    a, b = _qsort_sorted_id_desc(ids[:n // 2]), _qsort_sorted_id_desc(ids[n // 2:])
+    out, i, j = [], 0, 0
+    while i < len(a) and j < len(b):
+        if a[i][1] > b[j][1]:
+            out.append(a[i])
+            i += 1
+        else:
+            out.append(b[j])
+            j += 1
+    return out + a[i:] + b[j:]
+
+
 def nearest_cams_from_landmarks(cams, landmarks, rc, nb):
-    """landmarks: list of (X, {view index: (u, v) in FULL-size pixels}).  Ties broken by camera index (the reference's qsort is
-    unstable; the C++ host uses the same tie rule)."""
+    """landmarks: list of (X, {view index: (u, v) in FULL-size pixels}).  Equal scores keep the order the reference's qsort call gives
+    them (_qsort_sorted_id_desc; pinned against the reference's own function, tests/test_host_ref.py)."""
     score = np.zeros(cams.n, np.float32)
     for _, obs in landmarks:
         if rc not in obs:
@@ -179,7 +203,7 @@ def nearest_cams_from_landmarks(cams, landmarks, rc, nb):
             if a < cams.min_angle or a > cams.max_angle:
                 continue
             score[tc] += 1
-    order = sorted(range(cams.n), key=lambda i: (-score[i], i))
+    order = [i for i, _ in _qsort_sorted_id_desc([(i, score[i]) for i in range(cams.n)])]
     return [i for i in order[:min(cams.n, nb)] if score[i] > 20]
 
 
@@ -208,8 +232,7 @@ def tile_nearest_cams(cams, landmarks, rc, nb, tcams, roi):
                 continue
             a = angle_between_rays(cams.K_full, cams.R_full[rc], cams.R_full[tc], obs[rc], x)
             score[tc] = f32(score[tc] + plateau(1, 10, 50, 150, int(a)))
-    ids = [(tc, s) for tc, s in sorted(score.items()) if s > 0]
-    ids.sort(key=lambda t: -t[1])  # stable: ties keep ascending camera index
+    ids = _qsort_sorted_id_desc([(tc, s) for tc, s in sorted(score.items()) if s > 0])
     return [tc for tc, _ in ids[:min(cams.n, nb)]]
 
 

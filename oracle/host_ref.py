@@ -24,8 +24,71 @@ def _lib():
         lib.avref_sgm_depth_list.restype = C.c_int
         lib.avref_sgm_depth_list.argtypes = [C.c_int, dp, ip, ip, C.c_int, C.c_float, C.c_float, C.c_int, dp, ip, ip, dp, C.c_int, C.c_int, ip, ip,
                                              C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, fp, C.c_int, ip, ip]
+        lib.avref_nearest_cams.restype = C.c_int
+        lib.avref_nearest_cams.argtypes = [C.c_int, dp, dp, C.c_int, C.c_float, C.c_float, C.c_int, ip, ip, dp, C.c_int, C.c_int, C.c_int, ip, ip, ip]
+        lib.avref_tile_roi_list.restype = C.c_int
+        lib.avref_tile_roi_list.argtypes = [C.c_int] * 6 + [ip, C.c_int]
+        lib.avref_tile_weight_map.restype = C.c_int
+        lib.avref_tile_weight_map.argtypes = [C.c_int, C.c_int, ip, C.c_int, C.c_int, fp, fp]
         _lib_handle = lib
     return _lib_handle
+
+
+def _landmark_arrays(landmarks):
+    begin, views, xy = [0], [], []
+    for _, obs in landmarks:
+        for v in sorted(obs):
+            views.append(v)
+            xy.append(obs[v])
+        begin.append(len(views))
+    return np.asarray(begin, np.int32), np.asarray(views, np.int32), np.ascontiguousarray(np.asarray(xy, np.float64).reshape(-1, 2))
+
+
+def nearest_cams(K, Rs, landmarks, rc, nb, tcams=None, roi=None, process_downscale=1, min_angle=2.0, max_angle=70.0):
+    """MultiViewParams::findNearestCamsFromLandmarks of the reference (tcams None) or findTileNearestCams (tcams, roi at process
+    resolution): the list of T camera indices.  K: full-resolution pinhole matrix shared by the views, Rs: world -> camera rotations."""
+    lib = _lib()
+    n = len(Rs)
+    K = np.asarray(K, np.float64)
+    k4 = np.ascontiguousarray(np.tile(np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]], np.float64), (n, 1)))
+    R = np.ascontiguousarray(np.stack([np.asarray(r, np.float64) for r in Rs]).reshape(n, 9))
+    begin, views, xy = _landmark_arrays(landmarks)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    tc = np.asarray(list(tcams) if tcams is not None else [0], np.int32)
+    r = np.asarray(roi if roi is not None else (0, 0, 0, 0), np.int32)
+    out = np.zeros(max(n, 1), np.int32)
+    k = lib.avref_nearest_cams(n, k4.ctypes.data_as(dp), R.ctypes.data_as(dp), int(process_downscale), float(min_angle), float(max_angle), len(landmarks),
+                               begin.ctypes.data_as(ip), views.ctypes.data_as(ip), xy.ctypes.data_as(dp), int(rc), int(nb),
+                               -1 if tcams is None else len(tc), tc.ctypes.data_as(ip), r.ctypes.data_as(ip), out.ctypes.data_as(ip))
+    if k < 0:
+        raise RuntimeError("avref_nearest_cams: the reference threw (see stderr)")
+    return [int(v) for v in out[:k]]
+
+
+def tile_roi_list(buffer_w, buffer_h, padding, image_w, image_h, max_downscale):
+    """mvsUtils::getTileRoiList of the reference (TileParams.cpp compiled whole): [(x0, x1, y0, y1)]"""
+    out = np.zeros((4096, 4), np.int32)
+    n = _lib().avref_tile_roi_list(int(buffer_w), int(buffer_h), int(padding), int(image_w), int(image_h), int(max_downscale),
+                                   out.ctypes.data_as(C.POINTER(C.c_int)), 4096)
+    return [tuple(int(v) for v in out[i]) for i in range(n)]
+
+
+def tile_weight_map(roi, image_w, image_h, padding, downscale):
+    """addSingleTileMapWeighted of the reference (mapIO.cpp:206-311) applied to a tile of ones: (weights of the tile at roi / downscale,
+    the full map at image / downscale after the addition)"""
+    x0, x1, y0, y1 = roi
+    tw = (x1 + downscale - 1) // downscale - x0 // downscale
+    th = (y1 + downscale - 1) // downscale - y0 // downscale
+    fw, fh = (image_w + downscale - 1) // downscale, (image_h + downscale - 1) // downscale
+    w = np.zeros((th, tw), np.float32)
+    full = np.zeros((fh, fw), np.float32)
+    r = np.asarray(roi, np.int32)
+    fp = C.POINTER(C.c_float)
+    st = _lib().avref_tile_weight_map(int(image_w), int(image_h), r.ctypes.data_as(C.POINTER(C.c_int)), int(padding), int(downscale), w.ctypes.data_as(fp),
+                                      full.ctypes.data_as(fp))
+    if st != 0:
+        raise RuntimeError("avref_tile_weight_map")
+    return w, full
 
 
 def depth_list(K, Rs, Cs, width, height, landmarks, rc, tcams, roi, process_downscale=1, min_angle=2.0, max_angle=70.0, sgm_scale=2, max_depths=1500,

@@ -8,7 +8,7 @@ list), and writes them — text untouched, `#line` directives pointing back at t
 They are then compiled against stand-in declarations (oracle/ref/fuse_standin.hpp, oracle/ref/shim_host/aliceVision/...).  Reference sources are never copied into the
 repository.
 
-    python gen_extract.py <in.cpp> <out.cpp> <header to include> <namespace path, e.g. aliceVision::mvsUtils> name[!excluded-substring] ...
+    python gen_extract.py <in.cpp> <out.cpp> <header to include> <namespace path, e.g. aliceVision::mvsUtils> name[!excluded-substring] ... [old=new ...]
 """
 import re
 import sys
@@ -73,6 +73,9 @@ def find_definitions(text, qualname):
 
 
 def main(src, dst, header, namespace, names):
+    # `old=new` among the names: a `#define old new` after the include (the stand-in declares the function under the other name)
+    defines = [n.split("=") for n in names if "=" in n]
+    names = [n for n in names if "=" not in n]
     text = open(src, encoding="utf-8-sig").read()
     chunks = []
     for spec in names:
@@ -81,6 +84,9 @@ def main(src, dst, header, namespace, names):
         for a, b, params in find_definitions(text, name):
             if excluded and excluded in params:
                 continue
+            prev = text.rfind("\n", 0, a - 1) + 1  # a definition that is a template keeps its `template<...>` line
+            if text[prev:a].lstrip().startswith("template"):
+                a = prev
             line = text.count("\n", 0, a) + 1
             chunks.append((a, '#line %d "%s"\n%s\n' % (line, src, text[a:b])))
             found += 1
@@ -89,6 +95,8 @@ def main(src, dst, header, namespace, names):
     chunks.sort()
     with open(dst, "w") as f:
         f.write('#include %s\n' % header)
+        for old, new in defines:
+            f.write("#define %s %s\n" % (old, new))
         for ns in namespace.split("::"):
             f.write("namespace %s {\n" % ns)
         for _, c in chunks:

@@ -5,8 +5,19 @@
 // tests/test_host_ref.py holds oracle/host_oracle.py (which the C++ host equals, tests/test_host_cpu.py) against it.
 // Stand-ins: shim_host/ (MultiViewParams as plain arrays, the landmark containers, Boost's tail quantile — the one unpinned piece).
 #include <aliceVision/depthMap/SgmDepthList.hpp>
+#include <aliceVision/mvsUtils/TileParams.hpp>
+
+#include "fuse_standin.hpp" // image::Image<T>
 
 #include <algorithm>
+
+namespace aliceVision {
+namespace mvsUtils {
+// mvsUtils/mapIO.cpp:170-311 (file-local templates there), from the reference's text: gen/host_mapIO.cpp instantiates them for float
+void addSingleTileMapWeightedFloat(int rc, const MultiViewParams& mp, const TileParams& tileParams, const ROI& roi, int downscale,
+                                   image::Image<float>& in_tileMap, image::Image<float>& inout_map);
+} // namespace mvsUtils
+} // namespace aliceVision
 
 using namespace aliceVision;
 
@@ -28,8 +39,8 @@ int avref_sgm_depth_list(int n_cams, const double* P, const int* widths, const i
     {
         mvsUtils::MultiViewParams mp;
         mp.processDownscale = process_downscale;
-        mp.minViewAngle = min_view_angle;
-        mp.maxViewAngle = max_view_angle;
+        mp._minViewAngle = min_view_angle;
+        mp._maxViewAngle = max_view_angle;
         for(int i = 0; i < n_cams; ++i)
         {
             Matrix3x4 pMatrix;
@@ -89,6 +100,105 @@ int avref_sgm_depth_list(int n_cams, const double* P, const int* widths, const i
     catch(const std::exception& e)
     {
         std::cerr << "[ref] avref_sgm_depth_list: " << e.what() << std::endl;
+        return 2;
+    }
+}
+
+// MultiViewParams::findNearestCamsFromLandmarks (MultiViewParams.cpp:519-575) and findTileNearestCams (:577-667), from the reference's
+// text.  Cameras: pinhole K = (fx, fy, cx, cy) per view at full resolution and world -> camera rotations R (row-major); landmarks as in
+// avref_sgm_depth_list.  tcams_in / roi only for the tile form (n_tc_in < 0: the whole-image ranking).  Returns the number of cameras.
+int avref_nearest_cams(int n_cams, const double* K4, const double* R, int process_downscale, float min_view_angle, float max_view_angle, int n_landmarks,
+                       const int* obs_begin, const int* obs_view, const double* obs_xy, int rc, int nb_nearest, int n_tc_in, const int* tcams_in,
+                       const int roi[4], int* out)
+{
+    try
+    {
+        mvsUtils::MultiViewParams mp;
+        mp.processDownscale = process_downscale;
+        mp._minViewAngle = min_view_angle;
+        mp._maxViewAngle = max_view_angle;
+        for(int i = 0; i < n_cams; ++i)
+        {
+            mp.camArr.push_back(Matrix3x4());
+            auto v = std::make_shared<sfmData::View>();
+            v->intrinsicId = (IndexT)i;
+            std::copy_n(R + 9 * i, 9, v->pose.R);
+            mp.sfm.views[(IndexT)i] = v;
+            mp.sfm.intrinsics[(IndexT)i] = camera::IntrinsicBase{K4[4 * i], K4[4 * i + 1], K4[4 * i + 2], K4[4 * i + 3]};
+        }
+        for(int l = 0; l < n_landmarks; ++l)
+        {
+            sfmData::Landmark lm;
+            lm.X = Vec3{{0, 0, 0}};
+            for(int o = obs_begin[l]; o < obs_begin[l + 1]; ++o)
+                lm.observations[(IndexT)obs_view[o]] = sfmData::Observation{Vec2{{obs_xy[2 * o], obs_xy[2 * o + 1]}}};
+            mp.sfm.landmarks[(IndexT)l] = lm;
+        }
+        int n = 0;
+        if(n_tc_in < 0)
+        {
+            const StaticVector<int> got = mp.findNearestCamsFromLandmarksRef(rc, nb_nearest);
+            for(int i = 0; i < got.size(); ++i)
+                out[n++] = got[i];
+        }
+        else
+        {
+            const std::vector<int> tc(tcams_in, tcams_in + n_tc_in);
+            const ROI r((unsigned)roi[0], (unsigned)roi[1], (unsigned)roi[2], (unsigned)roi[3]);
+            for(const int c : mp.findTileNearestCams(rc, nb_nearest, tc, r))
+                out[n++] = c;
+        }
+        return n;
+    }
+    catch(const std::exception& e)
+    {
+        std::cerr << "[ref] avref_nearest_cams: " << e.what() << std::endl;
+        return -1;
+    }
+}
+
+// mvsUtils::getTileRoiList (TileParams.cpp:15-61, compiled whole): out = x0, x1, y0, y1 per tile; returns the number of tiles
+int avref_tile_roi_list(int buffer_w, int buffer_h, int padding, int image_w, int image_h, int max_downscale, int* out, int cap)
+{
+    mvsUtils::TileParams tp;
+    tp.bufferWidth = buffer_w;
+    tp.bufferHeight = buffer_h;
+    tp.padding = padding;
+    std::vector<ROI> rois;
+    mvsUtils::getTileRoiList(tp, image_w, image_h, max_downscale, rois);
+    for(size_t i = 0; i < rois.size() && (int)i < cap; ++i)
+    {
+        out[4 * i] = (int)rois[i].x.begin, out[4 * i + 1] = (int)rois[i].x.end;
+        out[4 * i + 2] = (int)rois[i].y.begin, out[4 * i + 3] = (int)rois[i].y.end;
+    }
+    return (int)rois.size();
+}
+
+// addSingleTileMapWeighted (mapIO.cpp:206-311) on a tile of ones: the weight every pixel of the tile is multiplied with before it is
+// added to the full map.  out_w: (roi / downscale) pixels, row-major; out_sum: the full map after the addition ((image / downscale) pixels).
+int avref_tile_weight_map(int image_w, int image_h, const int roi[4], int padding, int downscale, float* out_w, float* out_sum)
+{
+    try
+    {
+        mvsUtils::MultiViewParams mp;
+        mp.widths.push_back(image_w);
+        mp.heights.push_back(image_h);
+        mvsUtils::TileParams tp;
+        tp.padding = padding;
+        const ROI r((unsigned)roi[0], (unsigned)roi[1], (unsigned)roi[2], (unsigned)roi[3]);
+        const ROI d = downscaleROI(r, downscale);
+        image::Image<float> tile((int)d.width(), (int)d.height(), true, 1.0f);
+        const int fw = (image_w + downscale - 1) / downscale, fh = (image_h + downscale - 1) / downscale;
+        image::Image<float> full(fw, fh, true, 0.0f);
+        mvsUtils::addSingleTileMapWeightedFloat(0, mp, tp, r, downscale, tile, full);
+        std::copy_n(tile.data(), (size_t)tile.size(), out_w);
+        if(out_sum != nullptr)
+            std::copy_n(full.data(), (size_t)full.size(), out_sum);
+        return 0;
+    }
+    catch(const std::exception& e)
+    {
+        std::cerr << "[ref] avref_tile_weight_map: " << e.what() << std::endl;
         return 2;
     }
 }

@@ -16,6 +16,7 @@
 #include <aliceVision/mvsData/Point3d.hpp>
 #include <aliceVision/mvsData/ROI.hpp>
 #include <aliceVision/mvsData/StaticVector.hpp>
+#include <aliceVision/mvsData/structures.hpp>
 #include <aliceVision/sfmData/SfMData.hpp>
 
 namespace aliceVision {
@@ -30,17 +31,21 @@ class MultiViewParams
     std::vector<int> widths, heights, viewIds;
     std::vector<int> nearest; // answer of findNearestCamsFromLandmarks (fuse driver)
     sfmData::SfMData sfm;
+    const sfmData::SfMData& _sfmData = sfm; // the member name the reference's methods use
     int processDownscale = 1;
-    float minViewAngle = 2.0f, maxViewAngle = 70.0f;
+    float _minViewAngle = 2.0f, _maxViewAngle = 70.0f;
     int g_border = 2; // MultiViewParams.hpp:111
+    MultiViewParams() = default;
+    MultiViewParams(const MultiViewParams&) = delete;
 
     int getNbCameras() const { return (int)camArr.size(); }
     int getViewId(int index) const { return viewIds.empty() ? index : viewIds.at(index); }
     int getWidth(int index) const { return widths.at(index); }
     int getHeight(int index) const { return heights.at(index); }
     int getProcessDownscale() const { return processDownscale; }
-    float getMinViewAngle() const { return minViewAngle; }
-    float getMaxViewAngle() const { return maxViewAngle; }
+    float getMinViewAngle() const { return _minViewAngle; }
+    float getMaxViewAngle() const { return _maxViewAngle; }
+    int getIndexFromViewId(IndexT viewId) const { return (int)viewId; }
     const sfmData::SfMData& getInputSfMData() const { return sfm; }
     std::string getDepthMapsFolder() const { return "/tmp/"; }
     StaticVector<int> findNearestCamsFromLandmarks(int, int) const
@@ -51,7 +56,10 @@ class MultiViewParams
         return out;
     }
 
-    // defined by the reference's own text
+    // defined by the reference's own text; the landmark ranking under another name (Makefile: -D on that one generated file) because the
+    // filtering driver answers findNearestCamsFromLandmarks with the list of its test
+    StaticVector<int> findNearestCamsFromLandmarksRef(int rc, int nbNearestCams) const;
+    std::vector<int> findTileNearestCams(int rc, int nbNearestCams, const std::vector<int>& tCams, const ROI& roi) const;
     void getPixelFor3DPoint(Point2d* out, const Point3d& X, const Matrix3x4& P) const;
     void getPixelFor3DPoint(Point2d* out, const Point3d& X, int rc) const;
     void getPixelFor3DPoint(Pixel* out, const Point3d& X, int rc) const;

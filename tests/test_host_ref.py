@@ -80,3 +80,65 @@ def test_no_landmarks_no_list(scene):
     few = [(X, obs) for X, obs in lms if 0 in obs and obs[0][0] > 400]
     a, b = _both(sc, few, 0, [1, 2], (0, 200, 0, 200), sgm_scale=2, max_depths=64, depth_list_per_tile=True)
     assert len(a[0]) == 0 and len(b[0]) == 0
+
+
+@pytest.mark.parametrize("case", [(4000, 3000, 1024, 1024, 64, 4), (6000, 4000, 1664, 1152, 64, 4), (1920, 1080, 1024, 1024, 64, 4),
+                                  (640, 480, 1024, 1024, 64, 2), (1001, 777, 300, 260, 32, 4), (5000, 900, 1024, 1024, 128, 8),
+                                  (640, 480, 416, 352, 32, 4), (320, 240, 208, 176, 16, 4)])
+def test_tile_roi_list_equals_reference(case):
+    """mvsUtils::getTileRoiList (TileParams.cpp:15-61, compiled whole): the tile grid of BASELINE's configurations and of odd sizes"""
+    W, H, bw, bh, pad, md = case
+    assert ho.tile_roi_list(bw, bh, pad, W, H, md) == hr.tile_roi_list(bw, bh, pad, W, H, md)
+
+
+@pytest.mark.parametrize("case", [(640, 480, 416, 352, 32, 4, 1), (640, 480, 416, 352, 32, 4, 2), (1001, 777, 300, 260, 32, 4, 1),
+                                  (1001, 777, 300, 260, 32, 4, 2), (4000, 3000, 1024, 1024, 64, 4, 4)])
+def test_tile_weights_equal_reference(case):
+    """weightTileBorder / addSingleTileMapWeighted (mapIO.cpp:170-311, from the reference's text): the weight map of every tile of the
+    grid, bit for bit, and the weights of all tiles summing to one wherever tiles overlap as the reference's merge assumes"""
+    W, H, bw, bh, pad, md, ds = case
+    total = None
+    for roi in ho.tile_roi_list(bw, bh, pad, W, H, md):
+        a, (bx, ex, by, ey) = ho.tile_weight_map(roi, W, H, pad, ds)
+        b, full = hr.tile_weight_map(roi, W, H, pad, ds)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (roi, float(np.abs(a - b).max()))
+        total = full if total is None else total + full
+        assert np.array_equal(full[by:ey, bx:ex], b)
+    assert total.min() > 0.0
+
+
+def test_nearest_cams_equal_reference(scene):
+    """MultiViewParams::findNearestCamsFromLandmarks (MultiViewParams.cpp:519-575) and findTileNearestCams (:577-667), from the
+    reference's text: the landmark ranking of every camera for several list lengths, and the per-tile selection for every tile of a
+    2 x 2 grid, at process downscale 1 and 2 (camera::angleBetweenRays is a stand-in: the one unpinned function on this path)"""
+    sc, lms = scene
+    for ds in (1, 2):
+        cams = ho.Cameras(sc.K, sc.R, sc.C, sc.width, sc.height, process_downscale=ds)
+        rois = ho.tile_roi_list(416 // ds, 352 // ds, 32 // ds, 640 // ds, 480 // ds, 4)
+        for rc in range(6):
+            for nb in (10, 4, 2):
+                a = ho.nearest_cams_from_landmarks(cams, lms, rc, nb)
+                b = hr.nearest_cams(sc.K, sc.R, lms, rc, nb, process_downscale=ds)
+                assert a == b, (ds, rc, nb, a, b)
+            tc = ho.nearest_cams_from_landmarks(cams, lms, rc, 10)
+            for roi in rois + [(0, 640 // ds, 0, 480 // ds)]:
+                for nb in (3, 2, 10):
+                    a = ho.tile_nearest_cams(cams, lms, rc, nb, tc, roi)
+                    b = hr.nearest_cams(sc.K, sc.R, lms, rc, nb, tcams=tc, roi=roi, process_downscale=ds)
+                    assert a == b, (ds, rc, roi, nb, a, b)
+
+
+def test_nearest_cams_ties_equal_reference():
+    """equal scores: the reference sorts with qsort and a comparator that never returns 0 (mvsData/structures.cpp:37-47); what that does
+    with ties is part of the behaviour"""
+    sc = make_scene(7, 320, 240, seed=4, baseline=0.9, amp=0.3, render=[])
+    lms = scene_io.sample_landmarks(sc, 250, amp=0.3)
+    # every landmark seen by all views: equal counts for every T camera that passes the angle test
+    full = [(X, obs) for X, obs in lms if len(obs) == 7]
+    assert len(full) > 40
+    cams = ho.Cameras(sc.K, sc.R, sc.C, sc.width, sc.height)
+    for rc in range(7):
+        for nb in (10, 3):
+            a = ho.nearest_cams_from_landmarks(cams, full, rc, nb)
+            b = hr.nearest_cams(sc.K, sc.R, full, rc, nb)
+            assert a == b, (rc, nb, a, b)
