@@ -2,7 +2,7 @@
  *
  * TEST INFRASTRUCTURE ONLY: nothing under alicevision_amd/ may call into this file.  The reference holds no golden vectors or
  * known-answer tests for fuseCut::Fuser and its translation units cannot be built whole here (OpenImageIO, Boost, Eigen,
- * SfMData); PINNED instead against the reference's OWN functions: oracle/_ref/libavdm_fuse_ref.so is every function listed below compiled
+ * SfMData); PINNED instead against the reference's OWN functions: oracle/_ref/libavdm_host_ref.so is every function listed below compiled
  * from the reference's text where it lies (oracle/ref/Makefile: gen_extract.py pulls the definitions out of Fuser.cpp,
  * MultiViewParams.cpp and common.cpp; mvsData is included unchanged), and tests/test_fuse_ref.py holds this file against it with ==
  * (pixel size incl. its NaN paths, modal-count maps, filtered maps).

@@ -1,5 +1,5 @@
 """The depth-map filtering restatement pinned to the REFERENCE'S OWN functions (CPU): oracle/avdm_fuse_oracle.c against
-oracle/_ref/libavdm_fuse_ref.so, which is fuseCut::Fuser::updateInSurr / filterGroupsRC / filterDepthMapsRC, MultiViewParams'
+oracle/_ref/libavdm_host_ref.so, which is fuseCut::Fuser::updateInSurr / filterGroupsRC / filterDepthMapsRC, MultiViewParams'
 projection and pixel-size functions, common.cpp's epipolar helpers and mvsData's geometry compiled from the reference's text
 (oracle/ref/Makefile).  Same arrays into both, results compared with ==.
 
@@ -11,7 +11,7 @@ from fuse_scene import make_fuse_scene
 from oracle import fuse_oracle as fo
 from oracle import fuse_ref as fr
 
-pytestmark = pytest.mark.skipif(not fr.available(), reason="oracle/_ref/libavdm_fuse_ref.so not built (no reference tree)")
+pytestmark = pytest.mark.skipif(not fr.available(), reason="oracle/_ref/libavdm_host_ref.so not built (no reference tree)")
 
 
 def reference_cameras(fs):
