@@ -28,7 +28,7 @@ using namespace avdm_host;
 
 static int usage()
 {
-    std::cerr << "usage: avdm_host_tool tiles|exr-copy|exr-info|merge-ones ..." << std::endl;
+    std::cerr << "usage: avdm_host_tool params|tiles|exr-copy|exr-info|merge-ones ..." << std::endl;
     return 2;
 }
 
@@ -40,6 +40,76 @@ int main(int argc, char** argv)
             return usage();
         const std::string cmd = argv[1];
         Logger::setLevel("error");
+        if(cmd == "params" && argc == 2)
+        {
+            // the default value of every parameter of the stage as this host holds it ("group.name=value"): compared with the reference's
+            // own headers by tests/test_host_ref.py
+            const SgmParams sgm;
+            const RefineParams refine;
+            const DepthMapParams dm;
+            const TileParams tile;
+            std::ostream& os = std::cout;
+            os.precision(17);
+            os << "sgm.scale=" << sgm.scale << "\n";
+            os << "sgm.stepXY=" << sgm.stepXY << "\n";
+            os << "sgm.stepZ=" << sgm.stepZ << "\n";
+            os << "sgm.wsh=" << sgm.wsh << "\n";
+            os << "sgm.maxDepths=" << sgm.maxDepths << "\n";
+            os << "sgm.maxTCamsPerTile=" << sgm.maxTCamsPerTile << "\n";
+            os << "sgm.seedsRangeInflate=" << sgm.seedsRangeInflate << "\n";
+            os << "sgm.depthThicknessInflate=" << sgm.depthThicknessInflate << "\n";
+            os << "sgm.maxSimilarity=" << sgm.maxSimilarity << "\n";
+            os << "sgm.gammaC=" << sgm.gammaC << "\n";
+            os << "sgm.gammaP=" << sgm.gammaP << "\n";
+            os << "sgm.p1=" << sgm.p1 << "\n";
+            os << "sgm.p2Weighting=" << sgm.p2Weighting << "\n";
+            os << "sgm.filteringAxes=" << sgm.filteringAxes << "\n";
+            os << "sgm.useSfmSeeds=" << sgm.useSfmSeeds << "\n";
+            os << "sgm.depthListPerTile=" << sgm.depthListPerTile << "\n";
+            os << "sgm.useConsistentScale=" << sgm.useConsistentScale << "\n";
+            os << "sgm.useCustomPatchPattern=" << sgm.useCustomPatchPattern << "\n";
+            os << "sgm.exportIntermediateDepthSimMaps=" << sgm.exportIntermediateDepthSimMaps << "\n";
+            os << "sgm.exportIntermediateNormalMaps=" << sgm.exportIntermediateNormalMaps << "\n";
+            os << "sgm.exportIntermediateVolumes=" << sgm.exportIntermediateVolumes << "\n";
+            os << "sgm.exportIntermediateCrossVolumes=" << sgm.exportIntermediateCrossVolumes << "\n";
+            os << "sgm.exportIntermediateTopographicCutVolumes=" << sgm.exportIntermediateTopographicCutVolumes << "\n";
+            os << "sgm.exportIntermediateVolume9pCsv=" << sgm.exportIntermediateVolume9pCsv << "\n";
+            os << "sgm.exportDepthsTxtFiles=" << sgm.exportDepthsTxtFiles << "\n";
+            os << "sgm.updateUninitializedSim=" << sgm.updateUninitializedSim << "\n";
+            os << "sgm.prematchingMaxDepthScale=" << sgm.prematchingMaxDepthScale << "\n";
+            os << "sgm.seedsRangePercentile=" << sgm.seedsRangePercentile << "\n";
+            os << "sgm.doSgmOptimizeVolume=" << sgm.doSgmOptimizeVolume << "\n";
+            os << "refine.scale=" << refine.scale << "\n";
+            os << "refine.stepXY=" << refine.stepXY << "\n";
+            os << "refine.wsh=" << refine.wsh << "\n";
+            os << "refine.halfNbDepths=" << refine.halfNbDepths << "\n";
+            os << "refine.nbSubsamples=" << refine.nbSubsamples << "\n";
+            os << "refine.maxTCamsPerTile=" << refine.maxTCamsPerTile << "\n";
+            os << "refine.optimizationNbIterations=" << refine.optimizationNbIterations << "\n";
+            os << "refine.sigma=" << refine.sigma << "\n";
+            os << "refine.gammaC=" << refine.gammaC << "\n";
+            os << "refine.gammaP=" << refine.gammaP << "\n";
+            os << "refine.interpolateMiddleDepth=" << refine.interpolateMiddleDepth << "\n";
+            os << "refine.useConsistentScale=" << refine.useConsistentScale << "\n";
+            os << "refine.useCustomPatchPattern=" << refine.useCustomPatchPattern << "\n";
+            os << "refine.useRefineFuse=" << refine.useRefineFuse << "\n";
+            os << "refine.useColorOptimization=" << refine.useColorOptimization << "\n";
+            os << "refine.exportIntermediateDepthSimMaps=" << refine.exportIntermediateDepthSimMaps << "\n";
+            os << "refine.exportIntermediateNormalMaps=" << refine.exportIntermediateNormalMaps << "\n";
+            os << "refine.exportIntermediateCrossVolumes=" << refine.exportIntermediateCrossVolumes << "\n";
+            os << "refine.exportIntermediateTopographicCutVolumes=" << refine.exportIntermediateTopographicCutVolumes << "\n";
+            os << "refine.exportIntermediateVolume9pCsv=" << refine.exportIntermediateVolume9pCsv << "\n";
+            os << "refine.useSgmNormalMap=" << refine.useSgmNormalMap << "\n";
+            os << "tile.bufferWidth=" << tile.bufferWidth << "\n";
+            os << "tile.bufferHeight=" << tile.bufferHeight << "\n";
+            os << "tile.padding=" << tile.padding << "\n";
+            os << "depthMap.maxTCams=" << dm.maxTCams << "\n";
+            os << "depthMap.chooseTCamsPerTile=" << dm.chooseTCamsPerTile << "\n";
+            os << "depthMap.exportTilePattern=" << dm.exportTilePattern << "\n";
+            os << "depthMap.autoAdjustSmallImage=" << dm.autoAdjustSmallImage << "\n";
+            os << "depthMap.useRefine=" << dm.useRefine << "\n";
+            return 0;
+        }
         if(cmd == "tiles" && argc == 8)
         {
             TileParams tp;

@@ -26,12 +26,22 @@ def _lib():
                                              C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, fp, C.c_int, ip, ip]
         lib.avref_nearest_cams.restype = C.c_int
         lib.avref_nearest_cams.argtypes = [C.c_int, dp, dp, C.c_int, C.c_float, C.c_float, C.c_int, ip, ip, dp, C.c_int, C.c_int, C.c_int, ip, ip, ip]
+        lib.avref_default_params.restype = C.c_int
+        lib.avref_default_params.argtypes = [C.c_char_p, C.c_int]
         lib.avref_tile_roi_list.restype = C.c_int
         lib.avref_tile_roi_list.argtypes = [C.c_int] * 6 + [ip, C.c_int]
         lib.avref_tile_weight_map.restype = C.c_int
         lib.avref_tile_weight_map.argtypes = [C.c_int, C.c_int, ip, C.c_int, C.c_int, fp, fp]
         _lib_handle = lib
     return _lib_handle
+
+
+def default_params():
+    """{"group.name": "value"} of the reference's own parameter headers (SgmParams.hpp, RefineParams.hpp, DepthMapParams.hpp, TileParams.hpp)"""
+    buf = C.create_string_buffer(1 << 14)
+    n = _lib().avref_default_params(buf, len(buf))
+    assert n > 0
+    return dict(line.split("=", 1) for line in buf.value.decode().strip().splitlines())
 
 
 def _landmark_arrays(landmarks):

@@ -4,12 +4,14 @@
 // common.cpp's epipolar helpers from the reference's text (gen_extract.py) and mvsData as it lies.  Test infrastructure only:
 // tests/test_host_ref.py holds oracle/host_oracle.py (which the C++ host equals, tests/test_host_cpu.py) against it.
 // Stand-ins: shim_host/ (MultiViewParams as plain arrays, the landmark containers, Boost's tail quantile — the one unpinned piece).
+#include <aliceVision/depthMap/DepthMapParams.hpp>
 #include <aliceVision/depthMap/SgmDepthList.hpp>
 #include <aliceVision/mvsUtils/TileParams.hpp>
 
 #include "fuse_standin.hpp" // image::Image<T>
 
 #include <algorithm>
+#include <sstream>
 
 namespace aliceVision {
 namespace mvsUtils {
@@ -155,6 +157,82 @@ int avref_nearest_cams(int n_cams, const double* K4, const double* R, int proces
         std::cerr << "[ref] avref_nearest_cams: " << e.what() << std::endl;
         return -1;
     }
+}
+
+// The default value of every parameter of the stage, read from the reference's own headers (depthMap/SgmParams.hpp, RefineParams.hpp,
+// DepthMapParams.hpp, mvsUtils/TileParams.hpp): "group.name=value" lines.  Returns the length written (0 if cap is too small).
+int avref_default_params(char* out, int cap)
+{
+    const depthMap::SgmParams sgm{};
+    const depthMap::RefineParams refine{};
+    const depthMap::DepthMapParams dm{};
+    const mvsUtils::TileParams tile{};
+    std::ostringstream os;
+    os.precision(17);
+    os << "sgm.scale=" << sgm.scale << "\n";
+    os << "sgm.stepXY=" << sgm.stepXY << "\n";
+    os << "sgm.stepZ=" << sgm.stepZ << "\n";
+    os << "sgm.wsh=" << sgm.wsh << "\n";
+    os << "sgm.maxDepths=" << sgm.maxDepths << "\n";
+    os << "sgm.maxTCamsPerTile=" << sgm.maxTCamsPerTile << "\n";
+    os << "sgm.seedsRangeInflate=" << sgm.seedsRangeInflate << "\n";
+    os << "sgm.depthThicknessInflate=" << sgm.depthThicknessInflate << "\n";
+    os << "sgm.maxSimilarity=" << sgm.maxSimilarity << "\n";
+    os << "sgm.gammaC=" << sgm.gammaC << "\n";
+    os << "sgm.gammaP=" << sgm.gammaP << "\n";
+    os << "sgm.p1=" << sgm.p1 << "\n";
+    os << "sgm.p2Weighting=" << sgm.p2Weighting << "\n";
+    os << "sgm.filteringAxes=" << sgm.filteringAxes << "\n";
+    os << "sgm.useSfmSeeds=" << sgm.useSfmSeeds << "\n";
+    os << "sgm.depthListPerTile=" << sgm.depthListPerTile << "\n";
+    os << "sgm.useConsistentScale=" << sgm.useConsistentScale << "\n";
+    os << "sgm.useCustomPatchPattern=" << sgm.useCustomPatchPattern << "\n";
+    os << "sgm.exportIntermediateDepthSimMaps=" << sgm.exportIntermediateDepthSimMaps << "\n";
+    os << "sgm.exportIntermediateNormalMaps=" << sgm.exportIntermediateNormalMaps << "\n";
+    os << "sgm.exportIntermediateVolumes=" << sgm.exportIntermediateVolumes << "\n";
+    os << "sgm.exportIntermediateCrossVolumes=" << sgm.exportIntermediateCrossVolumes << "\n";
+    os << "sgm.exportIntermediateTopographicCutVolumes=" << sgm.exportIntermediateTopographicCutVolumes << "\n";
+    os << "sgm.exportIntermediateVolume9pCsv=" << sgm.exportIntermediateVolume9pCsv << "\n";
+    os << "sgm.exportDepthsTxtFiles=" << sgm.exportDepthsTxtFiles << "\n";
+    os << "sgm.updateUninitializedSim=" << sgm.updateUninitializedSim << "\n";
+    os << "sgm.prematchingMaxDepthScale=" << sgm.prematchingMaxDepthScale << "\n";
+    os << "sgm.seedsRangePercentile=" << sgm.seedsRangePercentile << "\n";
+    os << "sgm.doSgmOptimizeVolume=" << sgm.doSgmOptimizeVolume << "\n";
+    os << "refine.scale=" << refine.scale << "\n";
+    os << "refine.stepXY=" << refine.stepXY << "\n";
+    os << "refine.wsh=" << refine.wsh << "\n";
+    os << "refine.halfNbDepths=" << refine.halfNbDepths << "\n";
+    os << "refine.nbSubsamples=" << refine.nbSubsamples << "\n";
+    os << "refine.maxTCamsPerTile=" << refine.maxTCamsPerTile << "\n";
+    os << "refine.optimizationNbIterations=" << refine.optimizationNbIterations << "\n";
+    os << "refine.sigma=" << refine.sigma << "\n";
+    os << "refine.gammaC=" << refine.gammaC << "\n";
+    os << "refine.gammaP=" << refine.gammaP << "\n";
+    os << "refine.interpolateMiddleDepth=" << refine.interpolateMiddleDepth << "\n";
+    os << "refine.useConsistentScale=" << refine.useConsistentScale << "\n";
+    os << "refine.useCustomPatchPattern=" << refine.useCustomPatchPattern << "\n";
+    os << "refine.useRefineFuse=" << refine.useRefineFuse << "\n";
+    os << "refine.useColorOptimization=" << refine.useColorOptimization << "\n";
+    os << "refine.exportIntermediateDepthSimMaps=" << refine.exportIntermediateDepthSimMaps << "\n";
+    os << "refine.exportIntermediateNormalMaps=" << refine.exportIntermediateNormalMaps << "\n";
+    os << "refine.exportIntermediateCrossVolumes=" << refine.exportIntermediateCrossVolumes << "\n";
+    os << "refine.exportIntermediateTopographicCutVolumes=" << refine.exportIntermediateTopographicCutVolumes << "\n";
+    os << "refine.exportIntermediateVolume9pCsv=" << refine.exportIntermediateVolume9pCsv << "\n";
+    os << "refine.useSgmNormalMap=" << refine.useSgmNormalMap << "\n";
+    os << "tile.bufferWidth=" << tile.bufferWidth << "\n";
+    os << "tile.bufferHeight=" << tile.bufferHeight << "\n";
+    os << "tile.padding=" << tile.padding << "\n";
+    os << "depthMap.maxTCams=" << dm.maxTCams << "\n";
+    os << "depthMap.chooseTCamsPerTile=" << dm.chooseTCamsPerTile << "\n";
+    os << "depthMap.exportTilePattern=" << dm.exportTilePattern << "\n";
+    os << "depthMap.autoAdjustSmallImage=" << dm.autoAdjustSmallImage << "\n";
+    os << "depthMap.useRefine=" << dm.useRefine << "\n";
+    const std::string text = os.str();
+    if((int)text.size() + 1 > cap)
+        return 0;
+    std::copy(text.begin(), text.end(), out);
+    out[text.size()] = 0;
+    return (int)text.size();
 }
 
 // mvsUtils::getTileRoiList (TileParams.cpp:15-61, compiled whole): out = x0, x1, y0, y1 per tile; returns the number of tiles

@@ -142,3 +142,26 @@ def test_nearest_cams_ties_equal_reference():
             a = ho.nearest_cams_from_landmarks(cams, full, rc, nb)
             b = hr.nearest_cams(sc.K, sc.R, full, rc, nb)
             assert a == b, (rc, nb, a, b)
+
+
+def test_parameter_defaults_equal_reference_headers():
+    """every default of SgmParams / RefineParams / DepthMapParams / TileParams as the C++ host holds it (avdm_host_tool params) against
+    the reference's own headers compiled into the pin library, and the kernel-side defaults of the Python harness (abi.py)"""
+    import os
+    import subprocess
+    from alicevision_amd import abi
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alicevision_amd", "bin", "avdm_host_tool")
+    assert os.path.exists(tool), "host tool not built"
+    out = subprocess.run([tool, "params"], capture_output=True, text=True, timeout=60, check=True).stdout
+    host = dict(line.split("=", 1) for line in out.strip().splitlines())
+    ref = hr.default_params()
+    assert len(ref) > 50 and set(ref) == set(host)
+    assert ref == host, {k: (ref[k], host[k]) for k in ref if ref[k] != host[k]}
+    s, r = abi.SgmParams.default(), abi.RefineParams.default()
+    for k in ("scale", "stepXY", "wsh", "gammaC", "gammaP", "p1", "p2Weighting", "maxSimilarity", "depthThicknessInflate", "useConsistentScale",
+              "useCustomPatchPattern"):
+        assert float(getattr(s, k)) == float(ref["sgm." + k]), k
+    assert s.filteringAxes.decode() == ref["sgm.filteringAxes"]
+    for k in ("scale", "stepXY", "wsh", "halfNbDepths", "nbSubsamples", "optimizationNbIterations", "sigma", "gammaC", "gammaP", "interpolateMiddleDepth",
+              "useConsistentScale", "useCustomPatchPattern"):
+        assert float(getattr(r, k)) == float(ref["refine." + k]), k
