@@ -47,18 +47,18 @@ WORKLOADS = {
 }
 
 
-def tile_rois(W, H, n_side, buffer_w=1664, buffer_h=1152, padding=64):
-    """getTileRoiList (mvsUtils/TileParams.cpp:15-61) for the cfg5 geometry: effective tile = buffer - 2 * padding, tiles start every
-    effective width / height and extend by the padding on both sides, clipped to the image"""
+def tile_rois(W, H, n_side, buffer_w=1664, buffer_h=1152, padding=64, max_downscale=4):
+    """mvsUtils::getTileRoiList (mvsUtils/TileParams.cpp:15-61) for the cfg5 geometry, as (x0, x1, y0, y1): the number of tiles per side
+    from the buffer size without its padding, tiles of equal effective size (a multiple of the largest downscale, SGM scale x step = 4)
+    that start every effective width / height and extend by the padding at their END only, clipped to the image; column-major order.
+    (tests/test_host_ref.py pins this layout to the reference's own function.)"""
     if n_side == 1:
         return [None]
-    ew, eh = buffer_w - 2 * padding, buffer_h - 2 * padding
-    out = []
-    for j in range((H + eh - 1) // eh):
-        for i in range((W + ew - 1) // ew):
-            x0, y0 = i * ew, j * eh
-            out.append((max(x0 - padding, 0), min(x0 + ew + padding, W), max(y0 - padding, 0), min(y0 + eh + padding, H)))
-    return out
+    ceil_div = lambda a, b: (a + b - 1) // b
+    nx, ny = ceil_div(W, buffer_w - 2 * padding), ceil_div(H, buffer_h - 2 * padding)
+    ew = ceil_div(ceil_div(W, max_downscale), nx) * max_downscale
+    eh = ceil_div(ceil_div(H, max_downscale), ny) * max_downscale
+    return [(i * ew, min((i + 1) * ew + padding, W), j * eh, min((j + 1) * eh + padding, H)) for i in range(nx) for j in range(ny)]
 
 
 def cpu_baseline(sc_small, sgm, ref, n_planes, full_px, full_t):

@@ -91,6 +91,19 @@ def test_tile_roi_list_equals_reference(case):
     assert ho.tile_roi_list(bw, bh, pad, W, H, md) == hr.tile_roi_list(bw, bh, pad, W, H, md)
 
 
+def test_bench_cfg5_tiles_are_the_reference_grid():
+    """bench.py's multi-tile workload (cfg5: 24 MP, tile buffer 1664 x 1152, padding 64) sweeps the tiles the reference would make"""
+    import ast
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "tile_rois"][0]
+    ns = {}
+    exec(compile(ast.Module([fn], []), "bench.py", "exec"), ns)
+    got = ns["tile_rois"](6000, 4000, 4)
+    assert got == hr.tile_roi_list(1664, 1152, 64, 6000, 4000, 4) and len(got) == 16
+    assert ns["tile_rois"](4000, 3000, 1) == [None]
+
+
 @pytest.mark.parametrize("case", [(640, 480, 416, 352, 32, 4, 1), (640, 480, 416, 352, 32, 4, 2), (1001, 777, 300, 260, 32, 4, 1),
                                   (1001, 777, 300, 260, 32, 4, 2), (4000, 3000, 1024, 1024, 64, 4, 4)])
 def test_tile_weights_equal_reference(case):
