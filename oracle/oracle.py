@@ -167,18 +167,25 @@ class OracleDepthMap:
         return abi.ROI.make(x0 // ds, ceil_div(x1, ds), y0 // ds, ceil_div(y1, ds))
 
     # ---- Sgm::sgmRc ----
-    def run_sgm(self, rc, tcs, depths, tc_ranges=None, optimize=True):
+    def run_sgm(self, rc, tcs, depths, tc_ranges=None, optimize=True, tile_buffer=None):
+        """tile_buffer = (bufferWidth, bufferHeight) of the tile workflow.  The reference allocates its volumes for the tile BUFFER
+        (Sgm.cpp:37-72), fills them with 255, sweeps the tile's ROI into their corner — and AGGREGATES OVER THE ALLOCATED EXTENT
+        (cuda_volumeAggregatePath takes its dimensions from the volume, deviceSimilarityVolume.cu:278-283): the reverse paths, seeded
+        from slice 0 (the quirk restated in avo_volume_optimize), cross the 255-filled remainder before they enter the ROI, so the
+        result inside the ROI depends on the buffer size.  None: a buffer the size of this tile's ROI."""
         lib, sp = self.lib, self.sgm
         ds = sp.scale * sp.stepXY
         roi = self.droi(ds)
         X, Y, Z = roi.width, roi.height, len(depths)
+        AX, AY = (X, Y) if tile_buffer is None else (ceil_div(tile_buffer[0], ds), ceil_div(tile_buffer[1], ds))
+        assert AX >= X and AY >= Y, "the tile does not fit its buffer"
         Zp = ceil_div(Z, 4) * 4
         self.vol_dims = (X, Y, Z, Zp)
-        best = np.empty((Y, X, Zp), np.uint8)
-        second = np.empty((Y, X, Zp), np.uint8)
-        py, pxx = X * Zp, Zp
-        lib.avo_volume_initialize_u8(ptr(best), py, pxx, X, Y, Zp, 255)
-        lib.avo_volume_initialize_u8(ptr(second), py, pxx, X, Y, Zp, 255)
+        best = np.empty((AY, AX, Zp), np.uint8)
+        second = np.empty((AY, AX, Zp), np.uint8)
+        py, pxx = AX * Zp, Zp
+        lib.avo_volume_initialize_u8(ptr(best), py, pxx, AX, AY, Zp, 255)
+        lib.avo_volume_initialize_u8(ptr(second), py, pxx, AX, AY, Zp, 255)
         depths = np.ascontiguousarray(depths, np.float32)
         rcCam = self.cam(rc, sp.scale)
         for ti, tc in enumerate(tcs):
@@ -186,14 +193,14 @@ class OracleDepthMap:
             r = tc_ranges[ti] if tc_ranges else (0, Z)
             lib.avo_volume_compute_similarity(ptr(best), ptr(second), py, pxx, ptr(depths), C.byref(rcCam), C.byref(tcCam),
                                               C.byref(self.pyr[rc].desc), C.byref(self.pyr[tc].desc), C.byref(sp), abi.Range(r[0], r[1]), roi)
-        self.best_raw = best.copy()
-        lib.avo_volume_update_uninitialized(ptr(best), ptr(second), py, pxx, X, Y, Z)
-        self.second = second
+        self.best_raw = best[:Y, :X].copy()
+        lib.avo_volume_update_uninitialized(ptr(best), ptr(second), py, pxx, AX, AY, Z)
+        self.second = second[:Y, :X]
         if optimize:
-            lib.avo_volume_optimize(ptr(best), ptr(second), py, pxx, X, Y, C.byref(self.pyr[rc].desc), C.byref(sp), Z, roi)
+            lib.avo_volume_optimize(ptr(best), ptr(second), py, pxx, AX, AY, C.byref(self.pyr[rc].desc), C.byref(sp), Z, roi)
         else:
             best[...] = second
-        self.filtered = best
+        self.filtered = best[:Y, :X]
         dt = np.empty((Y, X, 2), np.float32)
         dsm = np.empty((Y, X, 2), np.float32)
         rc1 = self.cam(rc, 1)
@@ -204,7 +211,9 @@ class OracleDepthMap:
         return dt, dsm
 
     # ---- Sgm::smoothThicknessMap + Refine::refineRc ----
-    def run_refine(self, rc, tcs, refine_enabled=True, optimize_enabled=True):
+    def run_refine(self, rc, tcs, refine_enabled=True, optimize_enabled=True, tile_buffer=None):
+        """tile_buffer = (bufferWidth, bufferHeight) of the tile workflow: the reference allocates its maps for the tile BUFFER and takes the
+        upscale ratio from those allocated widths (deviceDepthSimilarityMap.cu:115-117); None: a buffer the size of this tile's ROI"""
         lib, sp, rp = self.lib, self.sgm, self.refine
         dsS = sp.scale * sp.stepXY
         dsR = rp.scale * rp.stepXY
@@ -215,7 +224,10 @@ class OracleDepthMap:
         X, Y = roiR.width, roiR.height
         rcCam = self.cam(rc, rp.scale)
         up = np.empty((Y, X, 2), np.float32)
-        ratio = np.float32(roiS.width) / np.float32(X)  # allocated widths == ROI widths here (single tile)
+        if tile_buffer is None:
+            ratio = np.float32(roiS.width) / np.float32(X)  # allocated widths == ROI widths
+        else:
+            ratio = np.float32(ceil_div(tile_buffer[0], dsS)) / np.float32(ceil_div(tile_buffer[0], dsR))
         lib.avo_compute_sgm_upscaled_depth_pixsize_map(ptr(up), X * 8, ptr(dt), roiS.width * 8, C.byref(rcCam), C.byref(self.pyr[rc].desc),
                                                        C.byref(rp), ratio, roiR)
         self.sgm_upscaled = up

@@ -31,6 +31,10 @@ _SIG = {
     "avr_image_level": (f32, [vp, i32]),
     "avr_image_dimensions": (None, [vp, i32, P(i32), P(i32)]),
     "avr_build_custom_patch_pattern": (i32, [i32, P(abi.PatchSubpartParams), i32, P(abi.PatchPattern)]),
+    "avr_cache_clear": (None, []),
+    "avr_cache_register_image": (None, [i32, vp]),
+    "avr_cache_register_camera": (None, [i32, i32, i32]),
+    "avr_tile_run": (i32, [i32, i32, P(i32), i32, i32, P(i32), P(abi.SgmParams), i32, P(abi.RefineParams), i32, i32, vp, i32, P(i32), i32, vp, vp, vp, vp, vp]),
     "avr_volume_initialize_u8": (None, [vp, i64, i32, i32, i32, i32, u8]),
     "avr_volume_update_uninitialized": (None, [vp, vp, i64, i32, i32, i32, i32]),
     "avr_volume_compute_similarity": (None, [vp, vp, i64, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, P(abi.SgmParams), abi.Range, abi.ROI]),
@@ -230,3 +234,40 @@ class RefDepthMap:
             opt = refined.copy()
         self.optimized = opt
         return opt
+
+
+class RefTile(RefDepthMap):
+    """One tile through the reference's OWN host classes: depthMap/Sgm.cpp and depthMap/Refine.cpp compiled whole and unchanged
+    (oracle/ref/tile_driver.cpp) — their constructors' buffer sizes, Sgm::sgmRc, Sgm::smoothThicknessMap, Refine::refineRc, i.e. the
+    sequence of wrapper calls and every argument the reference passes — where RefDepthMap sequences the wrappers from Python.
+    The pyramids and camera blocks are the ones RefDepthMap builds (DeviceMipmapImage::fill of the reference; the camera block from
+    the oracle's avo_camera_fill), registered with the stand-in DeviceCache."""
+
+    def run_tile(self, rc, tcs, depths, limits, tile_buffer=(1024, 1024), max_depths=1500, compute_normal=False, refine=True, use_refine_fuse=True,
+                 use_color_optimization=True):
+        lib, sp, rp = self.lib, self.sgm, self.refine
+        lib.avr_set_filter_mode(self.filter_mode)
+        lib.avr_cache_clear()
+        for c in [rc] + list(tcs):
+            lib.avr_cache_register_image(c, self.img[c].h)
+            for scale in sorted({sp.scale, rp.scale, 1}):
+                lib.avr_cache_register_camera(c, scale, self.slot(c, scale))
+        roiS, roiR = self.droi(sp.scale * sp.stepXY), self.droi(rp.scale * rp.stepXY)
+        XS, YS, XR, YR = roiS.width, roiS.height, roiR.width, roiR.height
+        dt = np.zeros((YS, XS, 2), np.float32)
+        dsm = np.zeros((YS, XS, 2), np.float32)
+        dts = np.zeros((YS, XS, 2), np.float32)
+        nrm = np.zeros((YS, XS, 3), np.float32) if compute_normal else None
+        out = np.zeros((YR, XR, 2), np.float32) if refine else None
+        depths = np.ascontiguousarray(depths, np.float32)
+        tc = np.asarray(list(tcs), np.int32)
+        lim = np.ascontiguousarray(np.asarray(limits, np.int32).reshape(-1, 2))
+        roi = np.asarray(self.roi, np.int32)
+        st = lib.avr_tile_run(int(tile_buffer[0]), int(tile_buffer[1]), roi.ctypes.data_as(P(i32)), int(rc), len(tc), tc.ctypes.data_as(P(i32)), C.byref(sp),
+                              int(max_depths), C.byref(rp), int(bool(use_refine_fuse)), int(bool(use_color_optimization)), ptr(depths), len(depths),
+                              lim.ctypes.data_as(P(i32)), int(bool(compute_normal)), ptr(dt), ptr(dsm), ptr(dts), ptr(nrm) if compute_normal else None,
+                              ptr(out) if refine else None)
+        if st != 0:
+            raise RuntimeError("avr_tile_run: the reference threw (see stderr)")
+        self.sgm_depth_thickness, self.sgm_depth_sim, self.sgm_depth_thickness_smooth, self.sgm_normal, self.optimized = dt, dsm, dts, nrm, out
+        return out

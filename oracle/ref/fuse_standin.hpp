@@ -21,43 +21,14 @@
 #include <utility>
 #include <vector>
 
-#include "host_standin.hpp" // the reference's own mvsData / common.hpp declarations + the stand-in MultiViewParams (shim_host/)
+#include "host_standin.hpp"
+#include <aliceVision/image/Image.hpp>   // stand-in (shim_host/)
+#include <aliceVision/mvsUtils/fileIO.hpp> // stand-in: getFileNameFromIndex, the key of the in-memory store // the reference's own mvsData / common.hpp declarations + the stand-in MultiViewParams (shim_host/)
 
 namespace aliceVision {
 
-namespace image {
-template <class T>
-class Image
-{
-  public:
-    Image() = default;
-    Image(int width, int height, bool fInit = false, const T val = T()) : _w(width), _h(height), _d((size_t)width * height, fInit ? val : T()) {}
-    int width() const { return _w; }
-    int height() const { return _h; }
-    int size() const { return _w * _h; }
-    T& operator()(int y, int x) { return _d[(size_t)y * _w + x]; }
-    const T& operator()(int y, int x) const { return _d[(size_t)y * _w + x]; }
-    T& operator()(int i) { return _d[i]; }
-    const T& operator()(int i) const { return _d[i]; }
-    T* data() { return _d.data(); }
-    const T* data() const { return _d.data(); }
-
-  private:
-    int _w = 0, _h = 0;
-    std::vector<T> _d;
-};
-enum class EImageColorSpace { LINEAR, NO_CONVERSION };
-enum class EStorageDataType { Float };
-struct ImageWriteOptions
-{
-    ImageWriteOptions& toColorSpace(EImageColorSpace) { return *this; }
-    ImageWriteOptions& storageDataType(EStorageDataType) { return *this; }
-};
-} // namespace image
 
 namespace mvsUtils {
-
-enum class EFileType { depthMap, simMap, nmodMap, depthMapFiltered, simMapFiltered };
 
 // ---- the in-memory map store (fuse_driver.cpp) ----
 struct MapStore
@@ -66,10 +37,6 @@ struct MapStore
     std::map<std::string, image::Image<unsigned char>> u8;
 };
 MapStore& store();
-inline std::string getFileNameFromIndex(const MultiViewParams&, int index, EFileType fileType, const std::string& = "", int = -1, int = -1)
-{
-    return std::to_string(index) + ":" + std::to_string((int)fileType);
-}
 inline void readMap(int rc, const MultiViewParams&, const EFileType fileType, image::Image<float>& out, int = 1, int = 1, const std::string& = "")
 {
     const auto it = store().f32.find({rc, (int)fileType});

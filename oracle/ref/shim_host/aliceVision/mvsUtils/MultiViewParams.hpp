@@ -22,6 +22,13 @@
 namespace aliceVision {
 namespace mvsUtils {
 
+// the file kinds the code under test names (MultiViewParams.hpp:33-84 of the reference; only ever compared or passed on here)
+enum class EFileType
+{
+    depthMap, depthMapFiltered, simMap, simMapFiltered, normalMap, normalMapFiltered, thicknessMap, pixSizeMap, nmodMap, volume, volumeCross,
+    volumeTopographicCut, stats9p, tilePattern, none
+};
+
 class MultiViewParams
 {
   public:

@@ -244,6 +244,47 @@ def test_whole_tile_equals_reference(W, H, NP, mode, roi, sgm_kw, ref_kw, tcr):
     _eq(wo, wr, "optimised depth / sim")
 
 
+@pytest.mark.parametrize("W,H,NP,mode,roi,sgm_kw,ref_kw,tcr,buf", [
+    (250, 186, 20, F8, None, {}, {}, None, (1024, 1024)),                               # default buffer, image not divisible by the SGM downscale
+    (250, 186, 20, F8, None, {}, {}, None, (250, 186)),                                 # buffer = image
+    (256, 192, 16, F8, (64, 192, 32, 160), {}, {}, [(0, 16), (3, 13)], (160, 160)),     # a tile with offsets in a small tile buffer
+    (256, 192, 16, F8, None, dict(stepXY=1, wsh=3, filteringAxes=b"XY", p2Weighting=30.0), dict(wsh=2, halfNbDepths=7, nbSubsamples=5, sigma=7.0), None,
+     (256, 256)),
+    (190, 142, 12, EX, (40, 167, 24, 119), dict(p2Weighting=-75.5, p1=7.0, depthThicknessInflate=0.3, maxSimilarity=0.8), {}, None, (1024, 1024)),
+])
+def test_tile_control_flow_equals_reference_host_classes(W, H, NP, mode, roi, sgm_kw, ref_kw, tcr, buf):
+    """the per-tile CONTROL FLOW pinned to the reference's own host classes: depthMap/Sgm.cpp and depthMap/Refine.cpp compiled whole
+    and unchanged (their buffer sizes — volumes of maxDepths planes, maps of the tile buffer —, the order of the wrapper calls, every
+    argument: which camera block at which downscale, which ROI and plane range, the allocated depth as volDimZ) against
+    OracleDepthMap.run_sgm / run_refine, which the C++ host's Sgm / Refine classes and the Python harness mirror.  Maps must be
+    identical, bit for bit, wherever the tile has data."""
+    ref = _ref()
+    sc, sgm, rp, depths = small_case(width=W, height=H, n_planes=NP, **sgm_kw)
+    rp.optimizationNbIterations = 6
+    for k, v in ref_kw.items():
+        setattr(rp, k, v)
+    Z = len(depths)
+    limits = [(a, b - a) for a, b in tcr] if tcr else [(0, Z), (0, Z)]
+    for max_depths in (Z, Z + 9):  # the reference sizes its volumes by maxDepths, not by the tile's planes
+        o = make_oracle(sc, sgm, rp, filter_mode=mode, roi=roi)
+        r = ref.RefTile(sc.images.numpy(), sc.K, sc.R, sc.C, sgm, rp, filter_mode=mode, roi=roi)
+        o.run_sgm(0, [1, 2], depths, tc_ranges=tcr, tile_buffer=buf)
+        wo = o.run_refine(0, [1, 2], tile_buffer=buf)
+        wr = r.run_tile(0, [1, 2], depths, limits, tile_buffer=buf, max_depths=max_depths)
+        _eq(o.sgm_depth_sim, r.sgm_depth_sim, "SGM depth / sim (maxDepths %d)" % max_depths)
+        _eq(o.sgm_depth_thickness, r.sgm_depth_thickness, "SGM depth / thickness (maxDepths %d)" % max_depths)
+        _eq(o.sgm_depth_thickness_smooth, r.sgm_depth_thickness_smooth, "smoothed thickness")
+        x0, x1, y0, y1 = roi if roi is not None else (0, W, 0, H)
+        if (x1 - x0, y1 - y0) == tuple(buf):
+            _eq(wo, wr, "optimised depth / sim")
+        else:
+            # a buffer larger than the tile: the reference's colour optimisation binds the WHOLE allocated temporary depth map as a texture
+            # and its border pixels read texels beyond the tile that no kernel wrote (whatever the allocation held; SURVEY A.7); every
+            # iteration carries that one pixel further in — a frame of (iterations + 1) pixels is undefined there, everything inside must agree
+            b = rp.optimizationNbIterations + 1
+            _eq(wo[b:-b, b:-b], wr[b:-b, b:-b], "optimised depth / sim (interior)")
+
+
 def test_sgm_aggregation_equals_reference_at_scale():
     """cuda_volumeOptimize (deviceSimilarityVolume.cu:262-425, ~3 kernel launches per slice) on a 120 x 90 x 64 volume with adaptive P2
     and ROI offsets, both axis orders: the oracle's aggregate_path loop == the reference's wrapper + kernels.  The reference's P2 uses
