@@ -1,6 +1,8 @@
 // Sgm.cpp — see Sgm.hpp.
 #include "Sgm.hpp"
 
+#include <cstdlib>
+
 #include "depthMapUtils.hpp"
 #include "log.hpp"
 
@@ -60,11 +62,26 @@ double Sgm::deviceMemoryConsumption(const TileParams& tileParams, const SgmParam
     return double(bytes) / (1024.0 * 1024.0);
 }
 
+// AVDM_SGM_BUFFER_EXTENT=1 (off by default, NOT yet validated on a GPU — DESIGN.md section 8, last paragraph): lay the volumes out for the
+// tile BUFFER and aggregate over that extent, like the reference, whose cuda_volumeAggregatePath takes its dimensions from the allocated
+// volume (deviceSimilarityVolume.cu:278-283).  The tile's ROI lives in the corner of the volume, the rest stays at the 255 it is
+// initialised with; every other kernel keeps the ROI.  Differs from the default only for tiles that do not start at the image origin.
+static bool sgmBufferExtent()
+{
+    const char* e = std::getenv("AVDM_SGM_BUFFER_EXTENT");
+    return e != nullptr && e[0] == '1';
+}
+
 void Sgm::layoutFor(const Tile& tile, int nbDepths)
 {
     const ROI roi = downscaleROI(tile.roi, float(_sgmParams.scale * _sgmParams.stepXY));
     _volX = (int)roi.width();
     _volY = (int)roi.height();
+    if(sgmBufferExtent() && _volX <= _mapWidth && _volY <= _mapHeight)
+    {
+        _volX = _mapWidth;
+        _volY = _mapHeight;
+    }
     _volZ = nbDepths;
     _pitchX = divideRoundUp(nbDepths, 4) * 4;
     _pitchY = (long long)_volX * _pitchX;
@@ -164,6 +181,8 @@ avdm_sgm_tile_t Sgm::sgmTileDescriptor(const Tile& tile, const SgmDepthList& til
     t.pitch_x = _pitchX;
     t.last_depth_index = (int)tileDepthList.getDepths().size();
     t.roi = {{downscaledRoi.x.begin, downscaledRoi.x.end}, {downscaledRoi.y.begin, downscaledRoi.y.end}};
+    if(sgmBufferExtent()) // the aggregation walks the laid-out extent (layoutFor), image coordinates still start at the ROI's begin
+        t.roi = {{downscaledRoi.x.begin, downscaledRoi.x.begin + (unsigned)_volX}, {downscaledRoi.y.begin, downscaledRoi.y.begin + (unsigned)_volY}};
     t.rc_pyr = &_deviceCache.requestMipmapImage(tile.rc, _mp).pyramid();
     return t;
 }
@@ -171,6 +190,8 @@ avdm_sgm_tile_t Sgm::sgmTileDescriptor(const Tile& tile, const SgmDepthList& til
 size_t Sgm::optimizeScratchBytes(const Tile& tile, const SgmDepthList& tileDepthList) const
 {
     const ROI r = downscaleROI(tile.roi, float(_sgmParams.scale * _sgmParams.stepXY));
+    if(sgmBufferExtent())
+        return avdm_volume_optimize_scratch_bytes(_mapWidth, _mapHeight, (int)tileDepthList.getDepths().size());
     return avdm_volume_optimize_scratch_bytes((int)r.width(), (int)r.height(), (int)tileDepthList.getDepths().size());
 }
 
