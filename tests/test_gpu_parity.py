@@ -301,6 +301,40 @@ def test_sgm_aggregation_at_scale_bit_exact(big_pyramid, X, Y, Z, axes, x0, y0, 
     assert len(np.unique(want[2:-2, 2:-2, 1:Z - 1])) > 100
 
 
+@pytest.mark.parametrize("BX,BY,X,Y,Z,axes,x0,y0", [(256, 256, 216, 204, 256, b"YX", 54, 51), (128, 96, 100, 71, 64, b"XY", 9, 30)])
+def test_sgm_aggregation_over_buffer_extent_bit_exact(big_pyramid, BX, BY, X, Y, Z, axes, x0, y0):
+    """the extent the REFERENCE aggregates over (last paragraph): the volume of the tile BUFFER (BX x BY), the tile's
+    similarities (X x Y) in its corner and 255 everywhere else, ROI begin at the tile's offset.  The reverse paths cross the 255-filled
+    remainder before they enter the tile.  HIP == avo_volume_optimize byte for byte over the whole buffer — what
+    OracleDepthMap.run_sgm(tile_buffer=...) does on the CPU, which equals the reference's own Sgm.cpp (tests/test_oracle_ref.py)."""
+    torch = _torch()
+    from oracle import oracle
+    from alicevision_amd.pipeline import DevicePyramid, optimize_scratch
+    sc, o = big_pyramid
+    sgm = abi.SgmParams.default(filteringAxes=axes, strictRoiQuirk=1)
+    lib, olib = abi.load(), oracle.load()
+    rng = np.random.RandomState(BX + Z)
+    Zp = (Z + 3) // 4 * 4
+    roi = abi.ROI.make(x0, x0 + BX, y0, y0 + BY)
+    vin = np.full((BY, BX, Zp), 255, np.uint8)
+    vin[:Y, :X] = _structured_volume(rng, Y, X, Zp)
+    want = np.full_like(vin, 9)
+    olib.avo_volume_optimize(oracle.ptr(want), oracle.ptr(vin), BX * Zp, Zp, BX, BY, C.byref(o.pyr[0].desc), C.byref(sgm), Z, roi)
+    pyr = DevicePyramid.from_host_bytes(o.pyr[0].desc, o.pyr[0].buf)
+    tin = torch.from_numpy(vin).cuda()
+    tout = torch.full_like(tin, 9)
+    scratch = optimize_scratch(lib, BX, BY, Z)
+    abi.check(lib.avdm_volume_optimize(_ptr(tout), _ptr(tin), BX * Zp, Zp, _ptr(scratch), C.byref(pyr.desc), C.byref(sgm), Z, roi, _st()))
+    torch.cuda.synchronize()
+    got = tout.cpu().numpy()
+    assert np.array_equal(got, want), level_mismatch(got, want)
+    # and the extent matters: the same tile aggregated over its own ROI only gives other bytes inside the tile
+    alone = np.full((Y, X, Zp), 9, np.uint8)
+    tile_in = np.ascontiguousarray(vin[:Y, :X])
+    olib.avo_volume_optimize(oracle.ptr(alone), oracle.ptr(tile_in), X * Zp, Zp, X, Y, C.byref(o.pyr[0].desc), C.byref(sgm), Z, abi.ROI.make(x0, x0 + X, y0, y0 + Y))
+    assert (alone[..., :Z] != want[:Y, :X, :Z]).mean() > 0.01
+
+
 def test_sgm_aggregation_tiles_batch_at_scale_bit_exact(big_pyramid):
     """avdm_volume_optimize_tiles with three large tiles (different sizes / offsets / depth counts) in one launch per axis == the oracle
     tile by tile"""
