@@ -285,6 +285,34 @@ def test_tile_control_flow_equals_reference_host_classes(W, H, NP, mode, roi, sg
             _eq(wo[b:-b, b:-b], wr[b:-b, b:-b], "optimised depth / sim (interior)")
 
 
+@pytest.mark.parametrize("fuse,opt", [(False, True), (True, False), (False, False)])
+def test_tile_control_flow_switches_equal_reference_host_classes(fuse, opt):
+    """Refine::refineRc's other branches in the reference's own Refine.cpp: useRefineFuse off (cuda_depthSimMapCopyDepthOnly instead of the
+    Refine volume, Refine.cpp:141-150) and useColorOptimization off (the refined map copied through, :163-170) — the switches behind
+    --refineEnabled / --colorOptimizationEnabled — and the SGM normal map of Sgm::sgmRc (Sgm.cpp:167-184)"""
+    ref = _ref()
+    sc, sgm, rp, depths = small_case(width=200, height=152, n_planes=14)
+    rp.optimizationNbIterations = 5
+    Z = len(depths)
+    o = make_oracle(sc, sgm, rp, filter_mode=F8)
+    r = ref.RefTile(sc.images.numpy(), sc.K, sc.R, sc.C, sgm, rp, filter_mode=F8)
+    o.run_sgm(0, [1, 2], depths, tile_buffer=(200, 152))
+    wo = o.run_refine(0, [1, 2], refine_enabled=fuse, optimize_enabled=opt, tile_buffer=(200, 152))
+    wr = r.run_tile(0, [1, 2], depths, [(0, Z), (0, Z)], tile_buffer=(200, 152), max_depths=Z, compute_normal=True, use_refine_fuse=fuse,
+                    use_color_optimization=opt)
+    _eq(o.sgm_depth_sim, r.sgm_depth_sim, "SGM depth / sim")
+    _eq(wo, wr, "final depth / sim")
+    # the SGM normal map (cuda_depthSimMapComputeNormal on the SGM depth / sim map, R camera at the SGM scale, Sgm.cpp:170-176).  With a
+    # buffer the size of the tile the reference's neighbourhood cannot leave the tile either (DESIGN.md section 8: deliberate deviations).
+    from oracle import oracle
+    roiS = o.droi(sgm.scale * sgm.stepXY)
+    nrm = np.zeros((roiS.height, roiS.width, 3), np.float32)
+    cam = o.cam(0, sgm.scale)
+    o.lib.avo_depth_sim_map_compute_normal(oracle.ptr(nrm), roiS.width * 12, oracle.ptr(np.ascontiguousarray(o.sgm_depth_sim)), roiS.width * 8, C.byref(cam),
+                                           sgm.stepXY, roiS)
+    _eq(nrm, r.sgm_normal, "SGM normal map")
+
+
 def test_sgm_aggregation_equals_reference_at_scale():
     """cuda_volumeOptimize (deviceSimilarityVolume.cu:262-425, ~3 kernel launches per slice) on a 120 x 90 x 64 volume with adaptive P2
     and ROI offsets, both axis orders: the oracle's aggregate_path loop == the reference's wrapper + kernels.  The reference's P2 uses
