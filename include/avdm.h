@@ -222,7 +222,11 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
                                   const avdm_camera_t* rc, const avdm_camera_t* tc,
                                   const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
                                   const avdm_refine_params_t* params, avdm_range_t depth_range, avdm_roi_t roi, void* stream);
-/* cuda_volumeOptimize :120-129.  `scratch` must hold avdm_volume_optimize_scratch_bytes() bytes (device memory, 4-byte aligned). */
+/* cuda_volumeOptimize :120-129.  `scratch` must hold avdm_volume_optimize_scratch_bytes() bytes (device memory, 4-byte aligned).
+ * The paths are walked over roi.width() x roi.height() columns starting at the volume's origin; image coordinates (adaptive P2) start at
+ * roi's begin.  The reference walks the ALLOCATED volume (deviceSimilarityVolume.cu:278-283: the tile in the corner of a buffer-sized
+ * volume whose remainder holds 255): a caller that wants its bytes for tiles with an offset hands over roi.end = roi.begin + that
+ * extent. */
 size_t avdm_volume_optimize_scratch_bytes(int dimX, int dimY, int dimZ);
 int avdm_volume_optimize(uint8_t* out_vol, const uint8_t* in_vol, long long pitch_y, int pitch_x, void* scratch,
                          const avdm_pyramid_t* rc_pyr, const avdm_sgm_params_t* params, int last_depth_index, avdm_roi_t roi, void* stream);
