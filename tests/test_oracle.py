@@ -426,3 +426,21 @@ def test_undistort_without_distortion_is_a_copy():
     got = np.zeros_like(src)
     assert lib.avo_image_undistort(oracle.ptr(got), 30 * 16, oracle.ptr(src), 30 * 16, C.byref(cam), C.byref(fill)) == 0
     assert np.array_equal(got, src)
+
+
+@pytest.mark.parametrize("w,h,dw,dh", [(64, 48, 32, 24), (101, 77, 50, 38), (400, 300, 100, 75), (640, 480, 213, 160)])
+def test_image_resize_agrees_with_an_independent_lanczos3(oracle_lib, w, h, dw, dh):
+    """avo_image_resize restates OpenImageIO's default resize filter, which cannot be run here (parity unpinned).  An INDEPENDENT
+    implementation of the same published filter — Pillow's LANCZOS: lanczos3 stretched by the shrink factor, sampled at pixel centres,
+    weights normalised — must give the same interior to float rounding, integer and fractional ratios alike; the treatment of taps that
+    leave the image is OpenImageIO's own (read from its source) and is what stays unchecked."""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import oracle
+    olib = oracle.load()
+    rng = np.random.RandomState(w + dh)
+    src = rng.rand(h, w, 4).astype(np.float32)
+    dst = np.zeros((dh, dw, 4), np.float32)
+    assert olib.avo_image_resize(oracle.ptr(dst), dw * 16, dw, dh, oracle.ptr(src), w * 16, w, h, 4) == 0
+    pil = np.stack([np.asarray(Image.fromarray(src[..., c], mode="F").resize((dw, dh), Image.LANCZOS)) for c in range(4)], axis=-1)
+    b = 4
+    assert np.abs(dst - pil)[b:-b, b:-b].max() < 5e-5
