@@ -26,6 +26,8 @@ def _lib():
                                              C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, fp, C.c_int, ip, ip]
         lib.avref_nearest_cams.restype = C.c_int
         lib.avref_nearest_cams.argtypes = [C.c_int, dp, dp, C.c_int, C.c_float, C.c_float, C.c_int, ip, ip, dp, C.c_int, C.c_int, C.c_int, ip, ip, ip]
+        lib.avref_image_undistort.restype = C.c_int
+        lib.avref_image_undistort.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.avref_default_params.restype = C.c_int
         lib.avref_default_params.argtypes = [C.c_char_p, C.c_int]
         lib.avref_tile_roi_list.restype = C.c_int
@@ -34,6 +36,22 @@ def _lib():
         lib.avref_tile_weight_map.argtypes = [C.c_int, C.c_int, ip, C.c_int, C.c_int, fp, fp]
         _lib_handle = lib
     return _lib_handle
+
+
+def image_undistort(src, cam, fill):
+    """camera::UndistortImage of the reference (cameraUndistortImage.hpp:81-139, with IntrinsicScaleOffsetDisto::getDistortedPixel, the
+    radial distortion classes and image/Sampler.hpp's bilinear sampler — the reference's own code, oracle/ref/undistort_standin.hpp) on
+    a float RGBA image (H, W, 4); cam: alicevision_amd.abi.Intrinsic; fill: 4 floats.  Returns the undistorted image."""
+    src = np.ascontiguousarray(src, np.float32)
+    h, w = src.shape[:2]
+    assert (w, h) == (cam.width, cam.height)
+    dst = np.zeros_like(src)
+    f = (C.c_float * 4)(*[float(v) for v in fill])
+    st = _lib().avref_image_undistort(dst.ctypes.data_as(C.c_void_p), w * 16, src.ctypes.data_as(C.c_void_p), w * 16, C.cast(C.byref(cam), C.c_void_p),
+                                      C.cast(f, C.c_void_p))
+    if st != 0:
+        raise RuntimeError("avref_image_undistort")
+    return dst
 
 
 def default_params():

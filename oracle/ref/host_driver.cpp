@@ -66,9 +66,9 @@ int avref_sgm_depth_list(int n_cams, const double* P, const int* widths, const i
         for(int l = 0; l < n_landmarks; ++l)
         {
             sfmData::Landmark lm;
-            lm.X = Vec3{{X[3 * l], X[3 * l + 1], X[3 * l + 2]}};
+            lm.X.v[0] = X[3 * l], lm.X.v[1] = X[3 * l + 1], lm.X.v[2] = X[3 * l + 2];
             for(int o = obs_begin[l]; o < obs_begin[l + 1]; ++o)
-                lm.observations[(IndexT)obs_view[o]] = sfmData::Observation{Vec2{{obs_xy[2 * o], obs_xy[2 * o + 1]}}};
+                lm.observations[(IndexT)obs_view[o]] = sfmData::Observation{Vec2(obs_xy[2 * o], obs_xy[2 * o + 1])};
             mp.sfm.landmarks[(IndexT)l] = lm;
         }
         depthMap::SgmParams sp;
@@ -131,9 +131,9 @@ int avref_nearest_cams(int n_cams, const double* K4, const double* R, int proces
         for(int l = 0; l < n_landmarks; ++l)
         {
             sfmData::Landmark lm;
-            lm.X = Vec3{{0, 0, 0}};
+            
             for(int o = obs_begin[l]; o < obs_begin[l + 1]; ++o)
-                lm.observations[(IndexT)obs_view[o]] = sfmData::Observation{Vec2{{obs_xy[2 * o], obs_xy[2 * o + 1]}}};
+                lm.observations[(IndexT)obs_view[o]] = sfmData::Observation{Vec2(obs_xy[2 * o], obs_xy[2 * o + 1])};
             mp.sfm.landmarks[(IndexT)l] = lm;
         }
         int n = 0;

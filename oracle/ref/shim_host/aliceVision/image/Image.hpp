@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <vector>
 
+#include <aliceVision/image/pixelTypes.hpp>
 #include <aliceVision/numeric/numeric.hpp> // image/Image.hpp:10 of the reference includes it too (divideRoundUp, clamp reach Sgm.cpp this way)
 
 namespace aliceVision {
@@ -17,6 +18,12 @@ class Image
     int width() const { return _w; }
     int height() const { return _h; }
     int size() const { return _w * _h; }
+    bool contains(int y, int x) const { return 0 <= x && x < _w && 0 <= y && y < _h; } // image/Image.hpp:178
+    void resize(int width, int height, bool fInit = true, const T& val = T())
+    {
+        _w = width, _h = height;
+        _d.assign((size_t)width * height, fInit ? val : T());
+    }
     T& operator()(int y, int x) { return _d[(size_t)y * _w + x]; }
     const T& operator()(int y, int x) const { return _d[(size_t)y * _w + x]; }
     T& operator()(int i) { return _d[i]; }
@@ -34,17 +41,6 @@ struct ImageWriteOptions
 {
     ImageWriteOptions& toColorSpace(EImageColorSpace) { return *this; }
     ImageWriteOptions& storageDataType(EStorageDataType) { return *this; }
-};
-struct RGBfColor
-{
-    float v[3] = {0.f, 0.f, 0.f};
-    float& r() { return v[0]; }
-    float& g() { return v[1]; }
-    float& b() { return v[2]; }
-};
-struct RGBAfColor
-{
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
 };
 } // namespace image
 } // namespace aliceVision

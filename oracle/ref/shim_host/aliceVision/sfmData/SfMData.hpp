@@ -11,20 +11,10 @@
 #include <map>
 #include <memory>
 
+#include <aliceVision/numeric/standin_vec.hpp>
+
 namespace aliceVision {
 using IndexT = uint32_t;
-struct Vec2
-{
-    double v[2];
-    double x() const { return v[0]; }
-    double y() const { return v[1]; }
-    double operator()(int i) const { return v[i]; }
-};
-struct Vec3
-{
-    double v[3];
-    double operator()(int i) const { return v[i]; }
-};
 namespace geometry {
 struct Pose3
 {

@@ -178,3 +178,27 @@ def test_parameter_defaults_equal_reference_headers():
     for k in ("scale", "stepXY", "wsh", "halfNbDepths", "nbSubsamples", "optimizationNbIterations", "sigma", "gammaC", "gammaP", "interpolateMiddleDepth",
               "useConsistentScale", "useCustomPatchPattern"):
         assert float(getattr(r, k)) == float(ref["refine." + k]), k
+
+
+@pytest.mark.parametrize("model,k,size", [(1, (0.08, 0.0, 0.0), (101, 75)), (2, (0.1, -0.05, 0.01), (101, 75)), (2, (-0.25, 0.08, 0.0), (160, 120)),
+                                          (3, (0.05, 0.02, -0.01), (101, 75)), (0, (0.0, 0.0, 0.0), (40, 30))])
+def test_undistort_equals_reference(model, k, size):
+    """the image-ingest slice: avo_image_undistort — which the HIP kernel equals bit for bit
+    (tests/test_gpu_parity.py::test_image_undistort_bit_exact) — against the reference's own camera::UndistortImage with its distortion
+    classes, pixel <-> camera transforms and bilinear sampler (out-of-range neighbours dropped and renormalised, nearest pixel below 0.2
+    of the weight): identical, pixel for pixel, barrel and pincushion, fill colour where the distorted position leaves the image"""
+    import ctypes as C
+    from alicevision_amd import abi
+    from oracle import oracle
+    lib = oracle.load()
+    W, H = size
+    rng = np.random.default_rng(model * 7 + W)
+    src = rng.random((H, W, 4), dtype=np.float32)
+    cam = abi.Intrinsic(width=W, height=H, scale_x=0.9 * W, scale_y=0.88 * W, offset_x=2.25, offset_y=-1.5, distortion_model=model, k=(C.c_double * 3)(*k))
+    fill = (C.c_float * 4)(0.25, 0.5, 0.75, 0.0)
+    got = np.zeros_like(src)
+    assert lib.avo_image_undistort(oracle.ptr(got), W * 16, oracle.ptr(src), W * 16, C.byref(cam), C.byref(fill)) == 0
+    want = hr.image_undistort(src, cam, list(fill))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (float(np.abs(got - want).max()), float((got != want).mean()))
+    if model:
+        assert not np.array_equal(got, src)
