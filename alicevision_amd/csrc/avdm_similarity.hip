@@ -51,6 +51,12 @@ constexpr unsigned kSgmChunksPerWg = AVDM_SGM_CHUNKS_PER_WG; // SGM similarity: 
 #define AVDM_REFINE_CHUNKS_PER_WG 4
 #endif
 constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: chunks of 8 planes per workgroup (they share one R tile, T window and pixel set-up)
+#ifndef AVDM_SIM_WAVES_PER_SIMD
+#define AVDM_SIM_WAVES_PER_SIMD 3 // occupancy the two kernels are compiled for: 3 -> 168 VGPRs, 2 -> 256 VGPRs
+#endif
+#ifndef AVDM_REFINE_PAIRS
+#define AVDM_REFINE_PAIRS 0 // two planes per pass over the patch in the default Refine instantiation
+#endif
 
 struct PatchTable
 {
@@ -991,7 +997,7 @@ __device__ __forceinline__ void init_shared(BlockShared& sh)
 // SGM similarity: best / second-best uint8 volumes, 4 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
 template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, bool PAIRS = false>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
                     avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
 {
@@ -1280,7 +1286,7 @@ __global__ void __launch_bounds__(256, 3)
 // Refine similarity: fp16 volume += sigmoid-filtered NCC, 8 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
 template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, bool PAIRS = false>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   refine_similarity_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize,
                            int map_pitch, const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A,
                            PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
@@ -2196,7 +2202,7 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
     hipLaunchKernelGGL((refine_similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,   \
                        (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi)
     if(fixed8 && paired && rp->wsh == 3 && A.rpitch == 40 && !A.noPacked)
-        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
+        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, AVDM_REFINE_PAIRS != 0>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
                            (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end,
                            roi); // the default: scale 1, stepXY 1, wsh 3
     else if(fixed8 && paired)

@@ -62,14 +62,15 @@ double Sgm::deviceMemoryConsumption(const TileParams& tileParams, const SgmParam
     return double(bytes) / (1024.0 * 1024.0);
 }
 
-// AVDM_SGM_BUFFER_EXTENT=1 (off by default, NOT yet validated on a GPU — DESIGN.md section 8, last paragraph): lay the volumes out for the
-// tile BUFFER and aggregate over that extent, like the reference, whose cuda_volumeAggregatePath takes its dimensions from the allocated
-// volume (deviceSimilarityVolume.cu:278-283).  The tile's ROI lives in the corner of the volume, the rest stays at the 255 it is
-// initialised with; every other kernel keeps the ROI.  Differs from the default only for tiles that do not start at the image origin.
+// The SGM volumes are laid out for the tile BUFFER and the path aggregation walks that extent, like the reference: its
+// cuda_volumeAggregatePath takes X / Y from the allocated volume (deviceSimilarityVolume.cu:278-283; Sgm.cpp:37-72 allocates for the
+// buffer), so the reverse paths cross the 255-filled remainder of the buffer before they enter the tile.  The tile's ROI lives in the
+// corner of the volume, every other kernel keeps the ROI.  Differs from an aggregation over the ROI only for tiles that do not start at
+// the image origin.  AVDM_SGM_BUFFER_EXTENT=0 is the A/B switch back to the ROI extent (rounds 1-2).
 static bool sgmBufferExtent()
 {
     const char* e = std::getenv("AVDM_SGM_BUFFER_EXTENT");
-    return e != nullptr && e[0] == '1';
+    return !(e != nullptr && e[0] == '0');
 }
 
 void Sgm::layoutFor(const Tile& tile, int nbDepths)

@@ -40,9 +40,9 @@ def optimize_tiles_batched(tiles, rc, timers=None):
     total = 0
     sizes = []
     for t in tiles:
-        roi = t.droi(sp.scale * sp.stepXY)
+        AX, AY = t.sgm_extent()
         Z = t._sgm_pending[1]
-        sizes.append(int(lib.avdm_volume_optimize_scratch_bytes(roi.width, roi.height, Z)))
+        sizes.append(int(lib.avdm_volume_optimize_scratch_bytes(AX, AY, Z)))
         total += sizes[-1]
     dev = tiles[0].best.device
     key = (n, total)
@@ -50,9 +50,9 @@ def optimize_tiles_batched(tiles, rc, timers=None):
         tiles[0]._batch_scratch = torch.empty(max(total, 4), dtype=torch.uint8, device=dev)
         tiles[0]._batch_scratch_key = key
     for i, t in enumerate(tiles):
-        roi = t.droi(sp.scale * sp.stepXY)
+        AX, _ = t.sgm_extent()
         Z = t._sgm_pending[1]
-        arr[i] = abi.SgmTile(t.best.data_ptr(), t.second.data_ptr(), roi.width * t.Zp, t.Zp, Z, roi, C.pointer(t.pyr[rc].desc))
+        arr[i] = abi.SgmTile(t.best.data_ptr(), t.second.data_ptr(), AX * t.Zp, t.Zp, Z, t.sgm_extent_roi(), C.pointer(t.pyr[rc].desc))
     rng = timers.range("sgm_optimize") if timers is not None else None
     if rng is not None:
         rng.__enter__()
@@ -153,9 +153,15 @@ class DevicePyramid:
 
 class DepthMapTile:
     """One tile of one R camera: SGM (similarity volume, path aggregation, WTA) then Refine (re-sweep, sub-sample arg-min,
-    colour optimisation).  roi = (x0, x1, y0, y1) in process-resolution pixels."""
+    colour optimisation).  roi = (x0, x1, y0, y1) in process-resolution pixels.
 
-    def __init__(self, pyramids, K, Rs, Cs, sgm, refine, roi=None, device="cuda"):
+    tile_buffer = (bufferWidth, bufferHeight) of the tile workflow (TileParams).  The reference allocates a tile's volumes and maps for the
+    tile BUFFER (Sgm.cpp:37-72), sweeps the ROI into their corner, and its path aggregation walks the ALLOCATED extent
+    (cuda_volumeAggregatePath takes X / Y from the volume, deviceSimilarityVolume.cu:278-283), so the reverse paths cross the 255-filled
+    remainder of the buffer before they enter the ROI; the upscale ratio comes from the allocated map widths
+    (deviceDepthSimilarityMap.cu:115-117).  None = a buffer the size of the ROI (single whole-image tile)."""
+
+    def __init__(self, pyramids, K, Rs, Cs, sgm, refine, roi=None, device="cuda", tile_buffer=None):
         self.lib = abi.load()
         self.pyr = pyramids
         self.K, self.Rs, self.Cs = K, Rs, Cs
@@ -163,6 +169,7 @@ class DepthMapTile:
         self.device = device
         W, H = pyramids[0].desc.width0, pyramids[0].desc.height0
         self.roi = roi if roi is not None else (0, W, 0, H)
+        self.tile_buffer = tile_buffer
         self._alloc_for = None
         self.timers = StageTimers()
 
@@ -182,20 +189,38 @@ class DepthMapTile:
         x0, x1, y0, y1 = self.roi
         return abi.ROI.make(x0 // ds, ceil_div(x1, ds), y0 // ds, ceil_div(y1, ds))
 
+    def sgm_extent(self):
+        """(X, Y) the SGM volumes are laid out for and aggregated over: the downscaled tile buffer (the ROI without one)"""
+        ds = self.sgm.scale * self.sgm.stepXY
+        roi = self.droi(ds)
+        if self.tile_buffer is None:
+            return roi.width, roi.height
+        AX, AY = ceil_div(self.tile_buffer[0], ds), ceil_div(self.tile_buffer[1], ds)
+        if AX < roi.width or AY < roi.height:
+            raise ValueError("the tile does not fit its buffer")
+        return AX, AY
+
+    def sgm_extent_roi(self):
+        """the ROI handed to the path aggregation: image coordinates start at the tile's ROI, the extent is the laid-out volume"""
+        roi = self.droi(self.sgm.scale * self.sgm.stepXY)
+        AX, AY = self.sgm_extent()
+        return abi.ROI.make(roi.x.begin, roi.x.begin + AX, roi.y.begin, roi.y.begin + AY)
+
     def _alloc(self, Z):
         sp, rp = self.sgm, self.refine
         roiS, roiR = self.droi(sp.scale * sp.stepXY), self.droi(rp.scale * rp.stepXY)
-        key = (Z, roiS.width, roiS.height, roiR.width, roiR.height)
+        AX, AY = self.sgm_extent()
+        key = (Z, roiS.width, roiS.height, roiR.width, roiR.height, AX, AY)
         if self._alloc_for == key:
             return
         dev = self.device
         X, Y = roiS.width, roiS.height
         Zp = ceil_div(Z, 4) * 4
         self.Zp = Zp
-        self.best = torch.empty((Y, X, Zp), dtype=torch.uint8, device=dev)
-        self.second = torch.empty((Y, X, Zp), dtype=torch.uint8, device=dev)
+        self.best = torch.empty((AY, AX, Zp), dtype=torch.uint8, device=dev)
+        self.second = torch.empty((AY, AX, Zp), dtype=torch.uint8, device=dev)
         self.depths_d = torch.empty(Z, dtype=torch.float32, device=dev)
-        self.sgm_scratch = optimize_scratch(self.lib, X, Y, Z, dev)
+        self.sgm_scratch = optimize_scratch(self.lib, AX, AY, Z, dev)
         self.sgm_depth_thickness = torch.empty((Y, X, 2), dtype=torch.float32, device=dev)
         self.sgm_depth_sim = torch.empty((Y, X, 2), dtype=torch.float32, device=dev)
         XR, YR = roiR.width, roiR.height
@@ -215,14 +240,15 @@ class DepthMapTile:
         Z = len(depths)
         self._alloc(Z)
         roi = self.droi(sp.scale * sp.stepXY)
-        X, Y, Zp = roi.width, roi.height, self.Zp
-        py, pxx = X * Zp, Zp
+        AX, AY = self.sgm_extent()
+        Zp = self.Zp
+        py, pxx = AX * Zp, Zp
         st = _stream()
         self.depths_d.copy_(torch.as_tensor(depths, dtype=torch.float32), non_blocking=False)
         T = self.timers
         with T.range("sgm_volume_init"):
-            abi.check(lib.avdm_volume_initialize_u8(_ptr(self.best), py, pxx, X, Y, Zp, 255, st), "volume_initialize")
-            abi.check(lib.avdm_volume_initialize_u8(_ptr(self.second), py, pxx, X, Y, Zp, 255, st), "volume_initialize")
+            abi.check(lib.avdm_volume_initialize_u8(_ptr(self.best), py, pxx, AX, AY, Zp, 255, st), "volume_initialize")
+            abi.check(lib.avdm_volume_initialize_u8(_ptr(self.second), py, pxx, AX, AY, Zp, 255, st), "volume_initialize")
         rcCam = self.cam(rc, sp.scale)
         with T.range("sgm_similarity"):
             for ti, tc in enumerate(tcs):
@@ -232,7 +258,7 @@ class DepthMapTile:
                                                              C.byref(tcCam), C.byref(self.pyr[rc].desc), C.byref(self.pyr[tc].desc), C.byref(sp),
                                                              abi.Range(r[0], r[1]), roi, st), "volume_compute_similarity")
         with T.range("sgm_update_uninit"):
-            abi.check(lib.avdm_volume_update_uninitialized(_ptr(self.best), _ptr(self.second), py, pxx, X, Y, Z, st), "update_uninitialized")
+            abi.check(lib.avdm_volume_update_uninitialized(_ptr(self.best), _ptr(self.second), py, pxx, AX, AY, Z, st), "update_uninitialized")
         if keep_raw:
             self.best_raw = self.best.clone()
         if optimize == "defer":  # the caller aggregates the volumes of several tiles in one batched call (optimize_tiles_batched)
@@ -241,7 +267,7 @@ class DepthMapTile:
         if optimize:
             with T.range("sgm_optimize"):
                 abi.check(lib.avdm_volume_optimize(_ptr(self.best), _ptr(self.second), py, pxx, _ptr(self.sgm_scratch), C.byref(self.pyr[rc].desc),
-                                                   C.byref(sp), Z, roi, st), "volume_optimize")
+                                                   C.byref(sp), Z, self.sgm_extent_roi(), st), "volume_optimize")
         else:
             self.best.copy_(self.second)
         return self.finish_sgm(rc, Z)
@@ -251,7 +277,7 @@ class DepthMapTile:
         lib, sp = self.lib, self.sgm
         roi = self.droi(sp.scale * sp.stepXY)
         X, Zp = roi.width, self.Zp
-        py, pxx = X * Zp, Zp
+        py, pxx = self.sgm_extent()[0] * Zp, Zp
         st = _stream()
         T = self.timers
         rc1 = self.cam(rc, 1)
@@ -269,7 +295,10 @@ class DepthMapTile:
         T = self.timers
         X, Y = roiR.width, roiR.height
         rcCam = self.cam(rc, rp.scale)
-        ratio = float(roiS.width) / float(X)
+        if self.tile_buffer is None:
+            ratio = float(roiS.width) / float(X)  # allocated widths == ROI widths
+        else:  # the ratio of the ALLOCATED map widths (deviceDepthSimilarityMap.cu:115-117)
+            ratio = float(ceil_div(self.tile_buffer[0], sp.scale * sp.stepXY)) / float(ceil_div(self.tile_buffer[0], rp.scale * rp.stepXY))
         with T.range("smooth_and_upscale"):
             abi.check(lib.avdm_depth_thickness_smooth_thickness(_ptr(self.sgm_depth_thickness), roiS.width * 8, C.byref(sp), C.byref(rp), roiS, st),
                       "smooth_thickness")

@@ -47,7 +47,10 @@ WORKLOADS = {
 }
 
 
-def tile_rois(W, H, n_side, buffer_w=1664, buffer_h=1152, padding=64, max_downscale=4):
+TILE_BUFFER = (1664, 1152)  # cfg5: 4 x 4 tiles of a 6000 x 4000 image with the default padding of 64
+
+
+def tile_rois(W, H, n_side, buffer_w=TILE_BUFFER[0], buffer_h=TILE_BUFFER[1], padding=64, max_downscale=4):
     """mvsUtils::getTileRoiList (mvsUtils/TileParams.cpp:15-61) for the cfg5 geometry, as (x0, x1, y0, y1): the number of tiles per side
     from the buffer size without its padding, tiles of equal effective size (a multiple of the largest downscale, SGM scale x step = 4)
     that start every effective width / height and extend by the padding at their END only, clipped to the image; column-major order.
@@ -147,7 +150,9 @@ def main():
         t_ex = time.time() - t0
     depths = plane_depths(sc, Z)
     rois = tile_rois(W, H, n_side)
-    tiles = [DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=r, device=dev) for r in rois]
+    # several tiles per depth map: volumes laid out for and aggregated over the tile BUFFER like the reference (pipeline.DepthMapTile)
+    tile_buffer = TILE_BUFFER if n_side > 1 else None
+    tiles = [DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=r, device=dev, tile_buffer=tile_buffer) for r in rois]
     for t in tiles:
         t.timers = tiles[0].timers
     tile = tiles[0]
@@ -209,10 +214,12 @@ def main():
         value = world * args.steps / elapsed
         # roofline of the SGM path-aggregation kernel (BASELINE.json: "SGM HBM GB/s vs roofline")
         ds = sgm.scale * sgm.stepXY
-        vols = []  # (X, Y) of the SGM volume of every tile of a depth map
+        # (X, Y) the path aggregation walks for every tile of a depth map: the tile's buffer extent (= its ROI for a whole-image tile)
+        vols = [t.sgm_extent() for t in tiles]
+        swept = []  # (X, Y) of the ROI the similarity kernel sweeps
         for r in rois:
             x0, x1, y0, y1 = r if r is not None else (0, W, 0, H)
-            vols.append(((x1 + ds - 1) // ds - x0 // ds, (y1 + ds - 1) // ds - y0 // ds))
+            swept.append(((x1 + ds - 1) // ds - x0 // ds, (y1 + ds - 1) // ds - y0 // ds))
         # 11 B/voxel + 64 B/pixel for the four paths = two launches of sgm_pair_kernel (forward + reverse path of one
         # axis per launch); AVDM_SGM_PAIR=0 runs the four sequential sgm_path_kernel launches instead
         n_launches = 4 if os.environ.get("AVDM_SGM_PAIR") == "0" else 2
@@ -267,7 +274,7 @@ def main():
         # (2 wsh + 1)^2 patch samples (81 SGM, 49 Refine); flops per voxel-T from SURVEY §8(a) (8.1 k / 4.9 k); LDS bytes per sample as the
         # kernels read them (SGM: half-paired 8-byte records, 2 x 8 + 2 x 4 B per image; with two planes per pass the R taps are read once
         # for both planes: 24 + 12 B per plane-sample; Refine: paired 16-byte records, 4 x 16 B)
-        px_sgm = sum(x * y for x, y in vols)
+        px_sgm = sum(x * y for x, y in swept)
         px_ref = sum(((r[1] - r[0]) * (r[3] - r[2])) if r is not None else W * H for r in rois)
         nz_ref = 2 * ref.halfNbDepths + 1
         t_sgm, t_ref = stages["sgm_similarity"] * 1e-3, stages["refine_similarity"] * 1e-3

@@ -196,11 +196,13 @@ class OracleDepthMap:
         self.best_raw = best[:Y, :X].copy()
         lib.avo_volume_update_uninitialized(ptr(best), ptr(second), py, pxx, AX, AY, Z)
         self.second = second[:Y, :X]
+        self.second_buffer = second  # the whole laid-out volume (tile in its corner, 255 elsewhere): what the aggregation walks
         if optimize:
             lib.avo_volume_optimize(ptr(best), ptr(second), py, pxx, AX, AY, C.byref(self.pyr[rc].desc), C.byref(sp), Z, roi)
         else:
             best[...] = second
         self.filtered = best[:Y, :X]
+        self.filtered_buffer = best
         dt = np.empty((Y, X, 2), np.float32)
         dsm = np.empty((Y, X, 2), np.float32)
         rc1 = self.cam(rc, 1)

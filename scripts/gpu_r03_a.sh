@@ -55,3 +55,5 @@ PY
 find $OUT -name "*.csv" -size +2M -delete
 find $OUT -name "*.db" -delete
 echo "== done" | tee -a $OUT/log.txt
+echo "== PMC passes over the similarity kernels (shipped pair kernel)" | tee -a $OUT/log.txt
+bash scripts/pmc_similarity.sh $TAG 2>&1 | tail -30

@@ -18,11 +18,11 @@ def make_oracle(sc, sgm, ref, filter_mode=abi.FILTER_CUDA_FIXED8, roi=None):
     return oracle.OracleDepthMap(sc.images.numpy(), sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi)
 
 
-def make_hip_from_oracle(o, sc, sgm, ref, roi=None):
+def make_hip_from_oracle(o, sc, sgm, ref, roi=None, tile_buffer=None):
     """HIP tile driver fed with the ORACLE's pyramids (bit-identical inputs for the stage-level parity tests)."""
     from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
     pyr = [DevicePyramid.from_host_bytes(p.desc, p.buf) for p in o.pyr]
-    return DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=roi)
+    return DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=roi, tile_buffer=tile_buffer)
 
 
 def level_mismatch(a, b):

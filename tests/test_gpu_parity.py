@@ -335,6 +335,66 @@ def test_sgm_aggregation_over_buffer_extent_bit_exact(big_pyramid, BX, BY, X, Y,
     assert (alone[..., :Z] != want[:Y, :X, :Z]).mean() > 0.01
 
 
+@pytest.mark.parametrize("mode,axes,W,H,NP,roi,buf,tcr", [
+    (abi.FILTER_CUDA_FIXED8, b"YX", 320, 240, 48, (80, 240, 40, 200), (192, 176), None),           # interior tile, buffer larger than the tile
+    (abi.FILTER_EXACT, b"XY", 320, 240, 40, (128, 320, 96, 240), (256, 256), [(0, 40), (5, 33)]),  # tile at the far image corner, other axis order
+    (abi.FILTER_CUDA_FIXED8, b"YX", 250, 186, 32, (60, 187, 0, 119), (160, 128), None),            # offset in x only, sizes not divisible by 4
+])
+def test_offset_tile_equals_oracle_over_buffer_extent(mode, axes, W, H, NP, roi, buf, tcr):
+    """A tile that does not start at the image origin, laid out and aggregated over its tile BUFFER like the reference does
+    (deviceSimilarityVolume.cu:278-283, Sgm.cpp:37-72) — the harness (pipeline.DepthMapTile(tile_buffer=...)) against
+    OracleDepthMap.run_sgm / run_refine(tile_buffer=...), which tests/test_oracle_ref.py pins to the reference's own Sgm.cpp / Refine.cpp
+    bit for bit.  Stage by stage on identical inputs, then end to end."""
+    torch = _torch()
+    from oracle import oracle
+    from alicevision_amd.pipeline import optimize_scratch
+    sc, sgm, ref, depths = small_case(width=W, height=H, n_planes=NP, seed=11, filteringAxes=axes)
+    Z = len(depths)
+    o = make_oracle(sc, sgm, ref, filter_mode=mode, roi=roi)
+    with oracle.well_posed():
+        o.run_sgm(0, [1, 2], depths, tc_ranges=tcr, tile_buffer=buf)
+        want = o.run_refine(0, [1, 2], tile_buffer=buf)
+    X, Y = o.second.shape[1], o.second.shape[0]
+    AY, AX = o.second_buffer.shape[:2]
+    assert (AX, AY) != (X, Y)
+    # (a) sweep: the tile's similarities in the corner of the buffer volume (tolerance class), 255 in the remainder
+    h = make_hip_from_oracle(o, sc, sgm, ref, roi=roi, tile_buffer=buf)
+    assert h.sgm_extent() == (AX, AY)
+    h.run_sgm(0, [1, 2], depths, tc_ranges=tcr, optimize=False, keep_raw=True)
+    torch.cuda.synchronize()
+    sec = h.second.cpu().numpy()
+    frac, mx = level_mismatch(o.second[..., :Z], sec[:Y, :X, :Z])
+    assert frac <= (0.03 if mode == abi.FILTER_CUDA_FIXED8 else 0.01), (frac, mx)
+    rest = np.ones((AY, AX), bool)
+    rest[:Y, :X] = False
+    assert np.all(sec[rest][:, :Z] == 255) and np.all(h.best_raw.cpu().numpy()[rest][:, :Z] == 255)
+    # (b) path aggregation over the buffer extent on IDENTICAL input bytes: bit-exact over the whole buffer, then WTA bit-exact
+    h.second.copy_(torch.from_numpy(o.second_buffer))
+    lib = abi.load()
+    abi.check(lib.avdm_volume_optimize(_ptr(h.best), _ptr(h.second), AX * h.Zp, h.Zp, _ptr(h.sgm_scratch), C.byref(h.pyr[0].desc), C.byref(sgm), Z,
+                                       h.sgm_extent_roi(), _st()))
+    torch.cuda.synchronize()
+    got = h.best.cpu().numpy()
+    assert np.array_equal(got[..., :Z], o.filtered_buffer[..., :Z]), level_mismatch(got[..., :Z], o.filtered_buffer[..., :Z])
+    dt, dsm = h.finish_sgm(0, Z)
+    torch.cuda.synchronize()
+    assert np.array_equal(dt.cpu().numpy(), o.sgm_depth_thickness)
+    assert np.array_equal(dsm.cpu().numpy(), o.sgm_depth_sim)
+    # ... and the extent is what makes it so: aggregated over its ROI alone the same tile gives other bytes
+    alone = np.full((Y, X, h.Zp), 9, np.uint8)
+    tile_in = np.ascontiguousarray(o.second_buffer[:Y, :X])
+    oracle.load().avo_volume_optimize(oracle.ptr(alone), oracle.ptr(tile_in), X * h.Zp, h.Zp, X, Y, C.byref(o.pyr[0].desc), C.byref(sgm), Z, o.droi(sgm.scale * sgm.stepXY))
+    assert (alone[..., :Z] != o.filtered[..., :Z]).mean() > 0.005
+    # (c) end to end, everything on the GPU (from the same pyramids): BASELINE's bar
+    h.run_sgm(0, [1, 2], depths, tc_ranges=tcr)
+    out = h.run_refine(0, [1, 2]).cpu().numpy()
+    both = (want[..., 0] > 0) & (out[..., 0] > 0)
+    assert both.mean() > 0.5 and ((want[..., 0] > 0) != (out[..., 0] > 0)).mean() < 5e-3
+    err = (out[..., 0] - want[..., 0])[both]
+    rmse = np.sqrt(np.mean(np.sort(err ** 2)[: int(0.995 * err.size)]))
+    assert rmse < 1e-3, (rmse, float(np.sqrt(np.mean(err ** 2))))
+
+
 def test_sgm_aggregation_tiles_batch_at_scale_bit_exact(big_pyramid):
     """avdm_volume_optimize_tiles with three large tiles (different sizes / offsets / depth counts) in one launch per axis == the oracle
     tile by tile"""

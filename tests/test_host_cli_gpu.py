@@ -167,6 +167,90 @@ def test_tiled_run_merges(dataset):
     assert np.median(np.abs(d1 - d4)[m]) < 1e-3
 
 
+def _merge_tiles(tile_maps, rois, pad, ss):
+    """mapIO.cpp's weighted tile merge (addSingleTileMapWeighted) of per-tile maps at 1 / ss resolution; also returns how many tiles cover a pixel"""
+    from oracle import host_oracle as ho
+    out = np.zeros((-(-H // ss), -(-W // ss)), np.float32)
+    cover = np.zeros(out.shape, np.int32)
+    for m, roi in zip(tile_maps, rois):
+        wmap, (bx, ex, by, ey) = ho.tile_weight_map(tuple(roi), W, H, pad, ss)
+        out[by:ey, bx:ex] += (m.astype(np.float32) * wmap).astype(np.float32)
+        cover[by:ey, bx:ex] += 1
+    return out, cover
+
+
+def test_tiled_run_equals_harness_and_oracle_per_tile(dataset):
+    """The default workflow is TILED, and tiles that do not start at the image origin are where the extent of the SGM aggregation matters:
+    the reference's volumes are allocated for the tile buffer and its path aggregation walks that extent (deviceSimilarityVolume.cu:278-283).
+    The program's 2 x 2-tile run, tile by tile on the program's own plan, against (1) the harness with the same buffer (bit for bit: pins
+    host/Sgm.cpp's layout and descriptors, the batched aggregation and the merge) and (2) OracleDepthMap(tile_buffer=...), which
+    tests/test_oracle_ref.py holds to the reference's own Sgm.cpp / Refine.cpp bit for bit (depth RMSE < 1e-3, BASELINE.json)."""
+    import torch
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    from oracle import oracle
+    sc, sfm, img, d = dataset
+    out4 = os.path.join(d, "out_tiled_pin")
+    buf, pad = (416, 352), 32
+    args4 = common_args(sfm, img, out4) + ["--autoAdjustSmallImage", 0, "--tileBufferWidth", buf[0], "--tileBufferHeight", buf[1], "--tilePadding", pad,
+                                           "--exportIntermediateDepthSimMaps", 1]
+    plan = json.loads(run_cli(args4 + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
+    tiles = plan["tiles"]
+    assert len(tiles) == 4 and sum(1 for t in tiles if t["roi"][0] > 0 or t["roi"][2] > 0) == 3
+    run_cli(args4)
+    depth, sim, _, _ = read_maps(out4)
+    vid = scene_io.view_id(0)
+    sgm_depth = exr_io.read_exr(os.path.join(out4, "%d_depthMap_sgm.exr" % vid))[0]["Y"]
+
+    sgm = abi.SgmParams.default(scale=plan["sgmScale"], stepXY=plan["sgmStepXY"])
+    ref = abi.RefineParams.default(optimizationNbIterations=OPT_ITERS)
+    torch.cuda.set_device(0)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(NVIEWS)]
+    o_pyr = None
+    got_final, got_sgm, want_final, rois = [], [], [], []
+    for t in tiles:
+        roi = tuple(t["roi"])
+        depths = np.asarray(t["depths"], np.float32)
+        ranges = [(a, a + n) for a, n in t["depthsTcLimits"]]
+        h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=roi, tile_buffer=buf)
+        _, dsm = h.run_sgm(0, t["sgmTCams"], depths, tc_ranges=ranges)
+        got_sgm.append(dsm[..., 0].cpu().numpy().copy())
+        got_final.append(h.run_refine(0, t["refineTCams"]).cpu().numpy().copy())
+        o = oracle.OracleDepthMap(sc.images.numpy(), sc.K, sc.R, sc.C, sgm, ref, roi=roi, pyramids=o_pyr)
+        o_pyr = o.pyr
+        with oracle.well_posed():
+            o.run_sgm(0, t["sgmTCams"], depths, tc_ranges=ranges, tile_buffer=buf)
+            want_final.append(o.run_refine(0, t["refineTCams"], tile_buffer=buf).copy())
+        rois.append(roi)
+
+    # (1) the program == the harness: exactly where one tile alone contributes with weight 1, to float rounding of the weighted sum elsewhere
+    hd, cover = _merge_tiles([g[..., 0] for g in got_final], rois, pad, 1)
+    single = cover == 1
+    assert single.mean() > 0.5
+    assert np.array_equal(depth[single], hd[single]), float(np.abs(depth - hd)[single].max())
+    assert np.allclose(depth, hd, rtol=1e-6, atol=1e-6)
+    hs, cover4 = _merge_tiles(got_sgm, rois, pad, 4)
+    assert np.array_equal(sgm_depth[cover4 == 1], hs[cover4 == 1])
+    # and the extent is what the program computes with: over the tiles' ROIs alone (rounds 1-2) the offset tiles come out differently
+    h0 = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=rois[3])
+    t3 = tiles[3]
+    _, dsm0 = h0.run_sgm(0, t3["sgmTCams"], np.asarray(t3["depths"], np.float32), tc_ranges=[(a, a + n) for a, n in t3["depthsTcLimits"]])
+    assert (dsm0[..., 0].cpu().numpy() != got_sgm[3]).mean() > 1e-3
+
+    # (2) the program against the oracle, tile by tile over the same buffer extent, merged like the program merges
+    wd, _ = _merge_tiles([w[..., 0] for w in want_final], rois, pad, 1)
+    both = (wd > 0) & (depth > 0)
+    assert ((wd > 0) != (depth > 0)).mean() < 0.005
+    err = np.sort((depth - wd)[both] ** 2)
+    rmse = float(np.sqrt(err[: int(0.995 * err.size)].mean()))
+    assert rmse < 1e-3, (rmse, float(np.sqrt(err.mean())))
+    # per tile, offset tiles on their own (no merge in between)
+    for g, w, roi in zip(got_final, want_final, rois):
+        m = (g[..., 0] > 0) & (w[..., 0] > 0)
+        e = np.sort((g[..., 0] - w[..., 0])[m] ** 2)
+        r = float(np.sqrt(e[: int(0.995 * e.size)].mean()))
+        assert r < 1e-3, (roi, r)
+
+
 def test_cli_fails_loudly_without_inputs(dataset):
     sc, sfm, img, d = dataset
     r = run_cli(["-i", os.path.join(d, "missing.sfm"), "--imagesFolder", img, "-o", os.path.join(d, "o")], check=False)
