@@ -113,6 +113,7 @@ SIGNATURES = {
     "avdm_version": (i32, []),
     "avdm_device_count": (i32, []),
     "avdm_device_info": (i32, [i32, C.c_char_p, C.c_size_t]),
+    "avdm_stream_release": (i32, [vp]),
     "avdm_build_custom_patch_pattern": (i32, [i32, P(PatchSubpartParams), i32, P(PatchPattern)]),
     "avdm_pyramid_layout": (i32, [P(Pyramid), i32, i32, i32, i32, i32]),
     "avdm_image_rgba_f32_to_f16x255": (i32, [vp, i32, vp, i32, i32, i32, vp]),

@@ -22,7 +22,24 @@ int set_error_msg(int code, const char* msg);
 // demand and reused by the later calls on that stream (stream order makes the reuse safe).  NOT the stream-ordered allocator: with two
 // host threads on one device, hipMallocAsync in one and hipEventRecord / hipStreamWaitEvent in the other deadlocked inside the runtime
 // about once in 25 two-worker runs (profiles/r02_multiworker_hang.md).  nullptr when the allocation fails.
-void* stream_scratch(hipStream_t st, size_t bytes);
+// An entry point holds a StreamScratch object while it enqueues the work that uses the block: a block in use is never evicted or regrown
+// under it by another host thread.  avdm_stream_release(stream) gives a stream's block back (call it before destroying the stream).
+class StreamScratch
+{
+  public:
+    StreamScratch(hipStream_t st, size_t bytes);
+    ~StreamScratch();
+    StreamScratch(const StreamScratch&) = delete;
+    StreamScratch& operator=(const StreamScratch&) = delete;
+    void* ptr() const { return _ptr; }
+
+  private:
+    hipStream_t _st;
+    int _dev = 0;
+    void* _ptr = nullptr;
+    bool _private = false;
+};
+int stream_scratch_release(hipStream_t st);
 
 static inline unsigned divUp(unsigned a, unsigned b) { return (a + b - 1) / b; }
 

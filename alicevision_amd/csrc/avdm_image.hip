@@ -35,47 +35,75 @@ struct ScratchBlock
     void* ptr = nullptr;
     size_t bytes = 0;
     unsigned long long lastUse = 0;
+    int inUse = 0; // entry points currently enqueueing work that reads / writes the block (StreamScratch objects alive)
 };
 std::mutex g_scratchMutex;
 std::map<std::pair<int, hipStream_t>, ScratchBlock> g_scratch;
 unsigned long long g_scratchTick = 0;
-constexpr size_t kMaxScratchBlocks = 64; // stream handles come and go (one set per DepthMapEstimator::compute): bound what stays behind
+// Blocks belong to a (device, stream) and are given back by avdm_stream_release when the stream goes away (host/device.cpp does that for
+// every stream it creates).  The cap is a safety net for callers that never release: PER DEVICE (a host thread per device opens up to 24
+// tile streams + the pre-pass stream; a process-wide cap made three devices evict each other's live blocks), and a block that an entry
+// point is using right now is never the victim.
+constexpr size_t kMaxScratchBlocksPerDevice = 64;
+
+void free_block_locked(std::map<std::pair<int, hipStream_t>, ScratchBlock>::iterator it, int currentDevice)
+{
+    if(it->first.first != currentDevice)
+        (void)hipSetDevice(it->first.first);
+    (void)hipFree(it->second.ptr); // waits for the device: no kernel of any stream, live or destroyed, still touches the block
+    if(it->first.first != currentDevice)
+        (void)hipSetDevice(currentDevice);
+    g_scratch.erase(it);
+}
 } // namespace
 
-void* stream_scratch(hipStream_t st, size_t bytes)
+StreamScratch::StreamScratch(hipStream_t st, size_t bytes) : _st(st)
 {
-    int dev = 0;
-    if(hipGetDevice(&dev) != hipSuccess)
-        return nullptr;
+    if(hipGetDevice(&_dev) != hipSuccess)
+        return;
     bytes = (bytes + 255) & ~(size_t)255;
     std::lock_guard<std::mutex> lock(g_scratchMutex);
-    const auto key = std::make_pair(dev, st);
+    const auto key = std::make_pair(_dev, st);
     auto it = g_scratch.find(key);
     ++g_scratchTick;
     if(it != g_scratch.end() && it->second.bytes >= bytes)
     {
         it->second.lastUse = g_scratchTick;
-        return it->second.ptr;
+        it->second.inUse += 1;
+        _ptr = it->second.ptr;
+        return;
     }
-    if(it == g_scratch.end() && g_scratch.size() >= kMaxScratchBlocks)
+    if(it == g_scratch.end())
     {
-        // drop the block that has been idle longest (its stream is most likely gone); hipFree waits for the device, so no kernel of any
-        // stream, live or destroyed, still reads it
-        auto oldest = g_scratch.begin();
+        size_t onDevice = 0;
+        auto oldest = g_scratch.end();
         for(auto i = g_scratch.begin(); i != g_scratch.end(); ++i)
-            if(i->second.lastUse < oldest->second.lastUse)
-                oldest = i;
-        int cur = dev;
-        if(oldest->first.first != dev)
-            (void)hipSetDevice(oldest->first.first);
-        (void)hipFree(oldest->second.ptr);
-        if(oldest->first.first != dev)
-            (void)hipSetDevice(cur);
-        g_scratch.erase(oldest);
+            if(i->first.first == _dev)
+            {
+                ++onDevice;
+                if(i->second.inUse == 0 && (oldest == g_scratch.end() || i->second.lastUse < oldest->second.lastUse))
+                    oldest = i;
+            }
+        if(onDevice >= kMaxScratchBlocksPerDevice && oldest != g_scratch.end())
+            free_block_locked(oldest, _dev); // idle longest, nobody enqueueing on it: its stream is most likely gone
     }
     ScratchBlock& b = g_scratch[key];
     if(b.ptr != nullptr)
     {
+        // a larger block for the same stream.  Two host threads that share a stream (stream 0) may both be here: the one that still
+        // enqueues on the old block keeps it alive through inUse — wait for that, not just for the stream
+        if(b.inUse > 0)
+        { // cannot grow under a concurrent user: hand out a private allocation instead (freed by the destructor)
+            void* priv = nullptr;
+            if(hipMalloc(&priv, bytes) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                return;
+            }
+            _ptr = priv;
+            _private = true;
+            return;
+        }
         (void)hipStreamSynchronize(st); // earlier calls on this stream may still use the smaller block
         (void)hipFree(b.ptr);
         b = ScratchBlock{};
@@ -84,11 +112,44 @@ void* stream_scratch(hipStream_t st, size_t bytes)
     {
         (void)hipGetLastError();
         g_scratch.erase(key);
-        return nullptr;
+        return;
     }
     b.bytes = bytes;
     b.lastUse = g_scratchTick;
-    return b.ptr;
+    b.inUse = 1;
+    _ptr = b.ptr;
+}
+
+StreamScratch::~StreamScratch()
+{
+    if(_ptr == nullptr)
+        return;
+    if(_private)
+    {
+        (void)hipStreamSynchronize(_st);
+        (void)hipFree(_ptr);
+        return;
+    }
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    auto it = g_scratch.find(std::make_pair(_dev, _st));
+    if(it != g_scratch.end() && it->second.ptr == _ptr && it->second.inUse > 0)
+        it->second.inUse -= 1;
+}
+
+int stream_scratch_release(hipStream_t st)
+{
+    int dev = 0;
+    if(hipGetDevice(&dev) != hipSuccess)
+        return 1;
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    auto it = g_scratch.find(std::make_pair(dev, st));
+    if(it == g_scratch.end())
+        return 0;
+    if(it->second.inUse > 0)
+        return 2; // an entry point is still enqueueing on this stream: the caller's bug, nothing is freed
+    (void)hipStreamSynchronize(st);
+    free_block_locked(it, dev);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -240,6 +301,12 @@ int avdm_device_count(void)
     if(hipGetDeviceCount(&n) != hipSuccess)
         return 0;
     return n;
+}
+
+int avdm_stream_release(void* stream)
+{
+    const int rc = stream_scratch_release((hipStream_t)stream);
+    return rc == 0 ? 0 : set_error_msg(rc, rc == 2 ? "avdm_stream_release: the stream's block is in use by an entry point" : "avdm_stream_release: no current device");
 }
 
 int avdm_device_info(int device, char* out, size_t out_len)

@@ -1,0 +1,244 @@
+// avdm_literal.hip — AVDM_SIM_LITERAL=1: the reference's similarity arithmetic AS WRITTEN, on the GPU.  Compiled with -ffp-contract=off.
+//
+// NOT a product path (one lane per pixel, every tap through the software texture unit from global memory, ~10 x slower than the default
+// kernels).  It exists so that the distance between the default kernels (avdm_similarity.hip: shifted NCC sums, exact R pixel in the
+// border test, homogeneous patch projection) and the reference's own code compiled for the CPU (oracle/_ref) can be ATTRIBUTED by
+// measurement: this form differs from the reference on the CPU only through the device library's expf, whereas the default kernels
+// differ from both by the conditioning of the fp32 sums (tests/test_gpu_parity.py::test_literal_mode_*).
+//
+//   compNCCby3DptsYK        Patch.cuh:466-572      every patch sample as a 3-D point projected into both cameras; the border test and
+//                                                  the centre colour on the RE-PROJECTED R pixel
+//   simStat                 SimStat.cuh:72-153     the six UNSHIFTED fp32 sums of w, w L, w L^2 (L ~ 0 ... 255): variance = difference
+//                                                  of numbers ~ 5e6
+//   CostYKfromLab           color.cuh:167-210      two Yoon-Kweon weights, two exponentials, multiplied
+//   volume_computeSimilarity_kernel / volume_refineSimilarity_kernel   deviceSimilarityVolumeKernels.cuh:109-233, 235-391
+#include "avdm_device.h"
+
+#include <math.h>
+
+namespace avdm {
+
+namespace {
+
+// matrix.cuh:66-75: a * __fdividef(1, sqrtf(dot)) — evaluated as an IEEE division like the reference compiled for the CPU
+__device__ __forceinline__ f3 normalize_lit(f3 a)
+{
+    const float dInv = 1.0f / sqrtf(dot(a, a));
+    return f3{a.x * dInv, a.y * dInv, a.z * dInv};
+}
+// matrix.cuh:117-126
+__device__ __forceinline__ float2 project_lit(const float* P, f3 V)
+{
+    const f3 q = M3x4mulV3(P, V);
+    const float inv = 1.0f / q.z;
+    return make_float2(q.x * inv, q.y * inv);
+}
+// Patch.cuh:137-145
+__device__ __forceinline__ float pix_size_lit(const avdm_camera_t& cam, f3 p)
+{
+    const float2 rp = project_lit(cam.P, p);
+    const f3 refvect = normalize_lit(M3x3mulV2(cam.iP, rp.x + 1.0f, rp.y + 0.0f));
+    return size(cross(refvect, ld3(cam.C) - p));
+}
+// color.cuh:167-210
+__device__ __forceinline__ float cost_yk(int dx, int dy, float4 c1, float4 c2, float invGammaC, float invGammaP)
+{
+    const float ex = c1.x - c2.x, ey = c1.y - c2.y, ez = c1.z - c2.z;
+    float deltaC = sqrtf(ex * ex + ey * ey + ez * ez);
+    deltaC *= invGammaC;
+    float deltaP = sqrtf((float)(dx * dx + dy * dy));
+    deltaP *= invGammaP;
+    deltaC += deltaP;
+    return expf(-deltaC);
+}
+
+struct LitArgs
+{
+    Tex rcT, tcT;
+    float rcW, rcH, tcW, tcH; // nominal level dimensions (DeviceMipmapImage::getDimensions)
+    float mipmapLevel;
+    float invGammaC, invGammaP;
+    int wsh;
+};
+
+// Patch.cuh:466-572 + SimStat.cuh; INFINITY when the patch is invalid
+template <bool TInvert>
+__device__ float ncc_literal(const avdm_camera_t& rc, const avdm_camera_t& tc, const LitArgs& L, f3 pp, f3 px, f3 py, float pd)
+{
+    const float2 rp = project_lit(rc.P, pp), tp = project_lit(tc.P, pp);
+    const float dd = (float)L.wsh + 2.0f;
+    if((rp.x < dd) || (rp.x > (L.rcW - 1.0f) - dd) || (tp.x < dd) || (tp.x > (L.tcW - 1.0f) - dd) || (rp.y < dd) || (rp.y > (L.rcH - 1.0f) - dd) ||
+       (tp.y < dd) || (tp.y > (L.tcH - 1.0f) - dd))
+        return INFINITY;
+    const float rcIW = 1.f / L.rcW, rcIH = 1.f / L.rcH, tcIW = 1.f / L.tcW, tcIH = 1.f / L.tcH;
+    const float4 rcCenter = tex2DLod(L.rcT, (rp.x + 0.5f) * rcIW, (rp.y + 0.5f) * rcIH, L.mipmapLevel);
+    const float4 tcCenter = tex2DLod(L.tcT, (tp.x + 0.5f) * tcIW, (tp.y + 0.5f) * tcIH, L.mipmapLevel);
+    if(rcCenter.w < (255.f * 0.9f) || tcCenter.w < (255.f * 0.4f))
+        return INFINITY;
+    float xsum = 0.f, ysum = 0.f, xxsum = 0.f, yysum = 0.f, xysum = 0.f, wsum = 0.f;
+#pragma unroll 1
+    for(int yp = -L.wsh; yp <= L.wsh; ++yp)
+#pragma unroll 1
+        for(int xp = -L.wsh; xp <= L.wsh; ++xp)
+        {
+            const f3 p = (pp + px * (pd * (float)xp)) + py * (pd * (float)yp);
+            const float2 rpc = project_lit(rc.P, p), tpc = project_lit(tc.P, p);
+            const float4 rcC = tex2DLod(L.rcT, (rpc.x + 0.5f) * rcIW, (rpc.y + 0.5f) * rcIH, L.mipmapLevel);
+            const float4 tcC = tex2DLod(L.tcT, (tpc.x + 0.5f) * tcIW, (tpc.y + 0.5f) * tcIH, L.mipmapLevel);
+            const float wr = cost_yk(xp, yp, rcCenter, rcC, L.invGammaC, L.invGammaP);
+            const float wt = cost_yk(xp, yp, tcCenter, tcC, L.invGammaC, L.invGammaP);
+            const float w = wr * wt;
+            const float gx = rcC.x, gy = tcC.x; // simStat::update
+            wsum += w;
+            xsum += w * gx;
+            ysum += w * gy;
+            xxsum += w * gx * gx;
+            yysum += w * gy * gy;
+            xysum += w * gx * gy;
+        }
+    // simStat::computeWSim
+    const float varXW = (xxsum - xsum * xsum / wsum) / wsum;
+    const float varYW = (yysum - ysum * ysum / wsum) / wsum;
+    const float varXYW = (xysum - xsum * ysum / wsum) / wsum;
+    const float rawSim = varXYW / sqrtf(varXW * varYW);
+    const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
+    if(TInvert)
+        return sigmoid(0.0f, 1.0f, 0.7f, -0.7f, sim);
+    return sim;
+}
+
+// computeRotCSEpip (Patch.cuh:111-135), with the SGM normal when given (kernels.cuh:316-333)
+__device__ __forceinline__ void patch_axes_lit(const avdm_camera_t& rc, const avdm_camera_t& tc, f3 p, const float* nn, f3& ax, f3& ay)
+{
+    const f3 v1 = normalize_lit(ld3(rc.C) - p);
+    const f3 v2 = normalize_lit(ld3(tc.C) - p);
+    ay = normalize_lit(cross(v1, v2));
+    const f3 s = v1 + v2;
+    const f3 n = nn != nullptr ? f3{nn[0], nn[1], nn[2]} : normalize_lit(f3{s.x / 2.0f, s.y / 2.0f, s.z / 2.0f});
+    ax = normalize_lit(cross(ay, n));
+}
+
+__global__ void __launch_bounds__(256)
+  literal_similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
+                            avdm_camera_t rc, avdm_camera_t tc, LitArgs L, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
+{
+    const unsigned vx = blockIdx.x * 64 + (threadIdx.x & 63), vy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if(vx >= roi.x.end - roi.x.begin || vy >= roi.y.end - roi.y.begin)
+        return;
+    const unsigned z0 = ((zBegin >> 2) + blockIdx.z) << 2;
+    const float x = (float)(roi.x.begin + vx) * (float)stepXY;
+    const float y = (float)(roi.y.begin + vy) * (float)stepXY;
+    uint8_t* const pb = best + (long long)vy * pitch_y + (long long)vx * pitch_x + z0;
+    uint8_t* const ps = second + (long long)vy * pitch_y + (long long)vx * pitch_x + z0;
+    unsigned wb = *reinterpret_cast<const unsigned*>(pb), ws = *reinterpret_cast<const unsigned*>(ps);
+#pragma unroll 1
+    for(int k = 0; k < 4; ++k)
+    {
+        const unsigned vz = z0 + k;
+        if(vz < zBegin || vz >= zEnd)
+            continue;
+        // volume_computePatch (kernels.cuh:26-35)
+        const f3 C = ld3(rc.C), Z = ld3(rc.ZVect);
+        const f3 planep = C + Z * depths[vz];
+        const f3 v = normalize_lit(M3x3mulV2(rc.iP, x, y));
+        const f3 p = linePlaneIntersect(C, v, planep, Z);
+        const float pd = pix_size_lit(rc, p);
+        f3 ax, ay;
+        patch_axes_lit(rc, tc, p, nullptr, ax, ay);
+        float fsim = ncc_literal<false>(rc, tc, L, p, ax, ay, pd);
+        if(fsim == INFINITY)
+            fsim = 255.0f;
+        else
+        {
+            fsim = (fsim - (-1.0f)) * (1.0f / (1.0f - (-1.0f)));
+            fsim = fminf(1.0f, fmaxf(0.0f, fsim));
+            fsim *= 254.0f;
+        }
+        const unsigned sh8 = 8u * k;
+        const unsigned b1 = (wb >> sh8) & 0xffu, b2 = (ws >> sh8) & 0xffu;
+        if(fsim < (float)b1)
+        {
+            ws = (ws & ~(0xffu << sh8)) | (b1 << sh8);
+            wb = (wb & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
+        }
+        else if(fsim < (float)b2)
+            ws = (ws & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
+    }
+    *reinterpret_cast<unsigned*>(pb) = wb;
+    *reinterpret_cast<unsigned*>(ps) = ws;
+}
+
+__global__ void __launch_bounds__(256)
+  literal_refine_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize, int map_pitch,
+                        const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, LitArgs L, int stepXY, unsigned zBegin,
+                        unsigned zEnd, avdm_roi_t roi)
+{
+    const unsigned vx = blockIdx.x * 64 + (threadIdx.x & 63), vy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if(vx >= roi.x.end - roi.x.begin || vy >= roi.y.end - roi.y.begin)
+        return;
+    const float2 dps = *((const float2*)((const char*)sgmDepthPixSize + (long long)vy * map_pitch) + vx);
+    if(dps.x <= 0.0f) // kernels.cuh:266-270
+        return;
+    const float x = (float)(roi.x.begin + vx) * (float)stepXY;
+    const float y = (float)(roi.y.begin + vy) * (float)stepXY;
+    const float* nn = sgmNormal != nullptr ? (const float*)((const char*)sgmNormal + (long long)vy * normal_pitch) + 3 * vx : nullptr;
+    __half* const pv = vol + ((long long)vy * pitch_y + (long long)vx * pitch_x) / 2;
+#pragma unroll 1
+    for(unsigned vz = zBegin; vz < zEnd; ++vz)
+    {
+        const f3 C = ld3(rc.C);
+        f3 p = C + normalize_lit(M3x3mulV2(rc.iP, x, y)) * dps.x; // get3DPointForPixelAndDepthFromRC
+        const int rel = (int)vz - ((volDimZ - 1) / 2);
+        if(rel != 0)
+            p = p + normalize_lit(p - C) * ((float)rel * dps.y); // move3DPointByRcPixSize (kernels.cuh:17-24)
+        const float pd = pix_size_lit(rc, p);
+        f3 ax, ay;
+        patch_axes_lit(rc, tc, p, nn, ax, ay);
+        const float fsim = ncc_literal<true>(rc, tc, L, p, ax, ay, pd);
+        if(fsim == INFINITY)
+            continue;
+        pv[vz] = __float2half(__half2float(pv[vz]) + fsim);
+    }
+}
+
+static LitArgs make_args(const avdm_pyramid_t* rcPyr, const avdm_pyramid_t* tcPyr, int scale, int wsh, double gammaC, double gammaP)
+{
+    LitArgs L;
+    L.rcT = make_tex(rcPyr);
+    L.tcT = make_tex(tcPyr);
+    L.rcW = (float)tex_dim_w(rcPyr, scale);
+    L.rcH = (float)tex_dim_h(rcPyr, scale);
+    L.tcW = (float)tex_dim_w(tcPyr, scale);
+    L.tcH = (float)tex_dim_h(tcPyr, scale);
+    L.mipmapLevel = tex_level_of(rcPyr, scale);
+    L.invGammaC = 1.f / (float)gammaC;
+    L.invGammaP = 1.f / (float)gammaP;
+    L.wsh = wsh;
+    return L;
+}
+
+} // namespace
+
+int literal_compute_similarity(uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, const float* depths, const avdm_camera_t* rc,
+                               const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr, const avdm_sgm_params_t* sp, avdm_range_t dr,
+                               avdm_roi_t roi, void* stream)
+{
+    const LitArgs L = make_args(rc_pyr, tc_pyr, sp->scale, sp->wsh, sp->gammaC, sp->gammaP);
+    const unsigned nchunks = ((dr.end + 3) >> 2) - (dr.begin >> 2);
+    hipLaunchKernelGGL(literal_similarity_kernel, dim3(divUp(roi.x.end - roi.x.begin, 64), divUp(roi.y.end - roi.y.begin, 4), nchunks), dim3(256), 0,
+                       (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, L, sp->stepXY, dr.begin, dr.end, roi);
+    AVDM_LAUNCH_CHECK("avdm_volume_compute_similarity(literal)");
+}
+
+int literal_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x, int dimZ, const float* sgm_depth_pixsize, int map_pitch, const float* sgm_normal,
+                              int normal_pitch, const avdm_camera_t* rc, const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
+                              const avdm_refine_params_t* rp, avdm_range_t dr, avdm_roi_t roi, void* stream)
+{
+    const LitArgs L = make_args(rc_pyr, tc_pyr, rp->scale, rp->wsh, rp->gammaC, rp->gammaP);
+    hipLaunchKernelGGL(literal_refine_kernel, dim3(divUp(roi.x.end - roi.x.begin, 64), divUp(roi.y.end - roi.y.begin, 4), 1), dim3(256), 0, (hipStream_t)stream,
+                       (__half*)vol_f16, pitch_y, pitch_x, dimZ, (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, L, rp->stepXY,
+                       dr.begin, dr.end, roi);
+    AVDM_LAUNCH_CHECK("avdm_volume_refine_similarity(literal)");
+}
+
+} // namespace avdm

@@ -1165,7 +1165,8 @@ int avdm_image_resize(float* dst_rgba, int dst_pitch, int dst_w, int dst_h, cons
     const int xtaps = oiio_resize_taps(dst_w, src_w, wx, fx), ytaps = oiio_resize_taps(dst_h, src_h, wy, fy);
     const size_t bwx = (wx.size() * sizeof(float) + 255) & ~(size_t)255, bwy = (wy.size() * sizeof(float) + 255) & ~(size_t)255;
     const size_t bfx = (fx.size() * sizeof(int) + 255) & ~(size_t)255, bfy = (fy.size() * sizeof(int) + 255) & ~(size_t)255;
-    char* tab = (char*)stream_scratch(st, bwx + bwy + bfx + bfy);
+    const StreamScratch lease(st, bwx + bwy + bfx + bfy);
+    char* tab = (char*)lease.ptr();
     if(tab == nullptr)
         return set_error_msg(2, "avdm_image_resize: scratch allocation failed");
     hipError_t e = hipMemcpyAsync(tab, wx.data(), wx.size() * sizeof(float), hipMemcpyHostToDevice, st);
@@ -1242,7 +1243,8 @@ int avdm_depth_sim_map_optimize_gradient_descent(float* out_opt_depth_sim, int o
     const int texW = std::min<int>(tmp_w, (int)roiW), texH = std::min<int>(tmp_h, (int)roiH);
     const int ptsPitch = (int)(((size_t)roiW * sizeof(float4) + 255) & ~(size_t)255);
     const size_t mapBytes = (size_t)ptsPitch * roiH;
-    char* scratch = (char*)stream_scratch(st, 2 * mapBytes);
+    const StreamScratch lease(st, 2 * mapBytes);
+    char* scratch = (char*)lease.ptr();
     if(scratch == nullptr)
         return set_error_msg(2, "avdm_depth_sim_map_optimize_gradient_descent: scratch allocation failed");
     float4* pts[2] = {(float4*)scratch, (float4*)(scratch + mapBytes)};

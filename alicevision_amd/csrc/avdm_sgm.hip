@@ -1299,16 +1299,20 @@ struct SgmKernelTimer
     std::mutex m;
     bool enabled = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
+    std::vector<int> pendingPath; // index of the first path a pending launch aggregates (0 / 2 for the pair kernel, 0 ... 3 otherwise)
     double ms = 0.0;
     long launches = 0;
+    double msPath[4] = {0.0, 0.0, 0.0, 0.0};
+    long launchesPath[4] = {0, 0, 0, 0};
 };
 static SgmKernelTimer g_sgmTimer;
 
 struct SgmKernelTimerScope
 {
     hipStream_t st;
+    int path;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    explicit SgmKernelTimerScope(hipStream_t s) : st(s)
+    explicit SgmKernelTimerScope(hipStream_t s, int path_ = 0) : st(s), path(path_ & 3)
     {
         std::lock_guard<std::mutex> lock(g_sgmTimer.m);
         if(!g_sgmTimer.enabled)
@@ -1332,6 +1336,7 @@ struct SgmKernelTimerScope
         (void)hipEventRecord(ev.second, st);
         std::lock_guard<std::mutex> lock(g_sgmTimer.m);
         g_sgmTimer.pending.push_back(ev);
+        g_sgmTimer.pendingPath.push_back(path);
     }
 };
 
@@ -1359,7 +1364,7 @@ static void launch_pair(const SgmPathBatch& S, int nWorkgroups, int K, bool full
         (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)sgm_pair_kernel<NW, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
-    SgmKernelTimerScope timing(st);
+    SgmKernelTimerScope timing(st, K);
     if(K == 0)
     {
         if(full)
@@ -1380,7 +1385,7 @@ template <int NW>
 static void launch_path(const SgmPathBatch& S, int ncols, int K, bool full, bool int16, hipStream_t st)
 {
     dim3 grid(ncols);
-    SgmKernelTimerScope timing(st);
+    SgmKernelTimerScope timing(st, K);
 #define AVDM_SGM_LAUNCH2(KK, FF, II) hipLaunchKernelGGL((sgm_path_kernel<NW, KK, FF, II>), grid, dim3(64 * AVDM_SGM_WPB), 0, st, S)
     // the fp32 kernel (non-integer P1) is only instantiated in its general form: FULL shapes run it with FULL = false
 #define AVDM_SGM_LAUNCH(KK)                                                                                                                           \
@@ -1584,16 +1589,20 @@ int avdm_debug_sgm_kernel_timing(int enable)
 int avdm_debug_sgm_kernel_timing_read(double* total_ms, long* n_launches, int reset)
 {
     std::lock_guard<std::mutex> lock(g_sgmTimer.m);
-    for(auto& ev : g_sgmTimer.pending)
+    for(size_t i = 0; i < g_sgmTimer.pending.size(); ++i)
     {
+        auto& ev = g_sgmTimer.pending[i];
         float ms = 0.f;
         if(hipEventSynchronize(ev.second) != hipSuccess || hipEventElapsedTime(&ms, ev.first, ev.second) != hipSuccess)
             return set_error_msg(1, "avdm_debug_sgm_kernel_timing_read: reading a HIP event failed");
         g_sgmTimer.ms += ms;
         g_sgmTimer.launches += 1;
+        g_sgmTimer.msPath[g_sgmTimer.pendingPath[i]] += ms;
+        g_sgmTimer.launchesPath[g_sgmTimer.pendingPath[i]] += 1;
         g_sgmTimer.pool.push_back(ev);
     }
     g_sgmTimer.pending.clear();
+    g_sgmTimer.pendingPath.clear();
     if(total_ms)
         *total_ms = g_sgmTimer.ms;
     if(n_launches)
@@ -1602,6 +1611,21 @@ int avdm_debug_sgm_kernel_timing_read(double* total_ms, long* n_launches, int re
     {
         g_sgmTimer.ms = 0.0;
         g_sgmTimer.launches = 0;
+    }
+    return 0;
+}
+
+/* the same sums per first path of a launch (the pair kernel: [0] = first filtering axis, [2] = second); call it after _read(..., reset = 0), it
+ * clears the per-path sums */
+int avdm_debug_sgm_kernel_timing_read_paths(double ms[4], long n[4])
+{
+    std::lock_guard<std::mutex> lock(g_sgmTimer.m);
+    for(int k = 0; k < 4; ++k)
+    {
+        ms[k] = g_sgmTimer.msPath[k];
+        n[k] = g_sgmTimer.launchesPath[k];
+        g_sgmTimer.msPath[k] = 0.0;
+        g_sgmTimer.launchesPath[k] = 0;
     }
     return 0;
 }

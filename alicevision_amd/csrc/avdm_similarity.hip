@@ -27,6 +27,7 @@
 #include <map>
 #include <mutex>
 #include <stdlib.h>
+#include <type_traits>
 
 // taps in flight per lane: each unrolled sample keeps 8 LDS reads (16 VGPRs) live; 3 keeps the kernels at 3 waves / SIMD
 namespace avdm {
@@ -39,6 +40,13 @@ constexpr int kNccUnroll = AVDM_NCC_UNROLL;
 #define AVDM_NCC_PAIR_UNROLL 3
 #endif
 constexpr int kNccPairUnroll = AVDM_NCC_PAIR_UNROLL; // sample loop of the plane-pair form (wsh != 3)
+#ifndef AVDM_NCC_MULTI_UNROLL
+#define AVDM_NCC_MULTI_UNROLL 3
+#endif
+constexpr int kNccMultiUnroll = AVDM_NCC_MULTI_UNROLL; // sample loop of the four-plane form (wsh != 3)
+#ifndef AVDM_SGM_PLANES_PER_PASS
+#define AVDM_SGM_PLANES_PER_PASS 4 // planes per pass over the patch in the default SGM similarity instantiation: 2 (pairs) or 4
+#endif
 #ifndef AVDM_NCC_W3_MODE
 #define AVDM_NCC_W3_MODE 2 // 7-tap rows (wsh 3, the Refine default): 0 = plain `unroll 3` (spills), 1 = no unroll, 2 = 3 + 3 + 1 with fences
 #endif
@@ -52,10 +60,16 @@ constexpr unsigned kSgmChunksPerWg = AVDM_SGM_CHUNKS_PER_WG; // SGM similarity: 
 #endif
 constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: chunks of 8 planes per workgroup (they share one R tile, T window and pixel set-up)
 #ifndef AVDM_SIM_WAVES_PER_SIMD
-#define AVDM_SIM_WAVES_PER_SIMD 3 // occupancy the two kernels are compiled for: 3 -> 168 VGPRs, 2 -> 256 VGPRs
+#define AVDM_SIM_WAVES_PER_SIMD 2 // occupancy the two kernels are compiled for: 3 -> 168 VGPRs, 2 -> 256 VGPRs
 #endif
-#ifndef AVDM_REFINE_PAIRS
-#define AVDM_REFINE_PAIRS 0 // two planes per pass over the patch in the default Refine instantiation
+#ifndef AVDM_REFINE_PLANES_PER_PASS
+#define AVDM_REFINE_PLANES_PER_PASS 4 // planes per pass over the patch in the default Refine instantiation: 1, 2 (pairs) or 4
+#endif
+#ifndef AVDM_NCC_QUAD_W3_MODE
+#define AVDM_NCC_QUAD_W3_MODE 0 // 7-tap rows of the four-plane form: 0 = 2 + 2 + 2 + 1 with fences, 1 = one sample at a time
+#endif
+#ifndef AVDM_NCC_PAIR_W3_MODE
+#define AVDM_NCC_PAIR_W3_MODE 1 // 7-tap rows of the plane-pair form: 0 = 3 + 3 + 1 with fences, 1 = 4 + 3, 2 = the whole row unrolled
 #endif
 
 struct PatchTable
@@ -225,6 +239,21 @@ __device__ __forceinline__ PatchProj make_patch_proj(const avdm_camera_t& rc, co
     Q.ray = M3x3mulV3(rc.P, ay);
     Q.tax = M3x3mulV3(tc.P, ax);
     Q.tay = M3x3mulV3(tc.P, ay);
+    return Q;
+}
+
+// c ? a : b, field by field (a conditional struct assignment is a memcpy under a branch, which kept the patches in scratch memory)
+__device__ __forceinline__ f3 sel3(bool c, f3 a, f3 b) { return f3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+__device__ __forceinline__ float4 sel4(bool c, float4 a, float4 b) { return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
+__device__ __forceinline__ PatchProj selQ(bool c, const PatchProj& a, const PatchProj& b)
+{
+    PatchProj Q;
+    Q.hr0 = sel3(c, a.hr0, b.hr0);
+    Q.ht0 = sel3(c, a.ht0, b.ht0);
+    Q.rax = sel3(c, a.rax, b.rax);
+    Q.ray = sel3(c, a.ray, b.ray);
+    Q.tax = sel3(c, a.tax, b.tax);
+    Q.tay = sel3(c, a.tay, b.tay);
     return Q;
 }
 
@@ -745,7 +774,25 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_pair(f3 rax, f3 ray, f
             s2T = wgT * dL + s2T;
             sxy = wgR * dL + sxy;
         };
-        if(WSH == 3)
+        if(WSH == 3 && AVDM_NCC_PAIR_W3_MODE == 1)
+        {
+            // 7 taps per row as 4 + 3: one more pair-sample of taps in flight (256 VGPRs at two waves per SIMD leave room for it)
+#pragma unroll
+            for(int xp = -3; xp < 1; ++xp)
+                consume(xp, fetch(xp));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for(int xp = 1; xp <= 3; ++xp)
+                consume(xp, fetch(xp));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        else if(WSH == 3 && AVDM_NCC_PAIR_W3_MODE == 2)
+        {
+#pragma unroll
+            for(int xp = -3; xp <= 3; ++xp)
+                consume(xp, fetch(xp));
+        }
+        else if(WSH == 3)
         {
             // 7 taps per row as 3 + 3 + 1 (see ncc_accumulate_lds_fixed8)
 #pragma unroll
@@ -778,6 +825,226 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_pair(f3 rax, f3 ray, f
     };
     simA = finish(wsum.x, s1R.x, s1T.x, s2R.x, s2T.x, sxy.x);
     simB = finish(wsum.y, s1R.y, s1T.y, s2R.y, s2T.y, sxy.y);
+}
+
+// FOUR adjacent planes of a pixel (one chunk of the SGM kernel) in one pass over the patch: ncc_accumulate_lds_fixed8_pair taken one step
+// further.  The R side of a sample — position, weights, taps, colour distance — is evaluated ONCE, from the patch of a reference plane, for
+// two packed T pairs {plane 0, plane 1}, {plane 2, plane 3}: per plane-sample (37 + 2 x 81) / 4 = 50 VALU instructions instead of 59.
+// The R taps of a plane up to two depth steps from the reference plane move by <= 2e-4 ... 2e-3 texel (the tilt of the patch's x axis; zero
+// at the principal point) — the class of the fp32 rounding of the pixel coordinates themselves.
+// The planes' geometry comes in the form the pixel RAY gives it (RayConsts): the patch centre of plane k is C + v t_k, so its homogeneous T
+// coordinates are htA + t_k htB; the patch's y axis is the normal of the epipolar plane of the ray — the same for every plane — and the pixel
+// size is pixK t_k, so M_T (y d) = t_k Bt with ONE vector Bt per lane; only M_T (x d) is per plane.  Per pair of planes the loop keeps
+// {t}, {M x} and the centre colours (7 packed registers) instead of 12, which is what lets two pairs + three samples of taps fit 256 VGPRs.
+struct QuadPlane
+{
+    float t;  // distance along the pixel ray
+    f3 tax;   // M_T * (patch.x * pixSize)
+    float4 c; // T centre colour
+};
+template <int WSH, bool TInvert, bool PAIRED, int RP>
+__device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f3 hr0, const QuadPlane& q0, const QuadPlane& q1, const QuadPlane& q2,
+                                                               const QuadPlane& q3, f3 Bt, f3 htB, f3 htA, const NccArgs& A, const PatchTable& tab,
+                                                               const LdsWindows& Wn, float4 rcCenter, float& sim0, float& sim1, float& sim2, float& sim3)
+{
+    constexpr int NPAIR = 2;
+    const int wsh = WSH > 0 ? WSH : A.wsh;
+    const int n = 2 * wsh + 1;
+    const float S16 = 65536.0f;
+    v2f tt[NPAIR], axS[NPAIR], ayS[NPAIR], az[NPAIR], cL[NPAIR], ca[NPAIR], cb[NPAIR];
+    auto set_pair = [&](int j, const QuadPlane& a, const QuadPlane& b) __attribute__((always_inline)) {
+        tt[j] = v2f{a.t, b.t};
+        axS[j] = v2f{a.tax.x, b.tax.x} * A.tcSx;
+        ayS[j] = v2f{a.tax.y, b.tax.y} * A.tcSy;
+        az[j] = v2f{a.tax.z, b.tax.z};
+        cL[j] = v2f{a.c.x, b.c.x} * S16;
+        ca[j] = v2f{a.c.y, b.c.y} * S16;
+        cb[j] = v2f{a.c.z, b.c.z} * S16;
+    };
+    set_pair(0, q0, q1);
+    set_pair(1, q2, q3);
+    // R side, {x, y} of the one image
+    const v2f raS = {rax.x * A.rcSx, rax.y * A.rcSy};
+    const v2f rS = {A.rcSx, A.rcSy}, rO = {A.rcOx, A.rcOy};
+    const v2f rcLa = v2f{rcCenter.x, rcCenter.y} * S16;
+    const float rcb = rcCenter.z * S16;
+    const float kC = A.negInvGammaC_log2e * (1.0f / 65536.0f);
+    constexpr float recB = PAIRED ? 16.0f : 8.0f;
+
+    v2f wsum[NPAIR], s1R[NPAIR], s1T[NPAIR], s2R[NPAIR], s2T[NPAIR], sxy[NPAIR];
+#pragma unroll
+    for(int j = 0; j < NPAIR; ++j)
+        wsum[j] = s1R[j] = s1T[j] = s2R[j] = s2T[j] = sxy[j] = v2f{0.f, 0.f};
+
+    struct RTaps
+    {
+        typename std::conditional<PAIRED, uint4, uint2>::type r0, r1;
+        unsigned r0n, r1n;
+        float rNy, rWy;
+        v2h wr;
+    };
+    struct TTaps
+    {
+        typename std::conditional<PAIRED, uint4, uint2>::type a0, a1, b0, b1;
+        unsigned a0n, a1n, b0n, b1n;
+        v2f nnb, wb;
+        v2h wtA, wtB;
+    };
+
+#pragma unroll 1
+    for(int yp = -wsh; yp <= wsh; ++yp)
+    {
+        const float fy = (float)yp;
+        // row of plane k: htA + t_k * (htB + fy * Bt), the texel-space scale folded into x and y
+        const f3 sB = f3{fmaf(fy, Bt.x, htB.x), fmaf(fy, Bt.y, htB.y), fmaf(fy, Bt.z, htB.z)};
+        v2f rowx[NPAIR], rowy[NPAIR], rowz[NPAIR];
+#pragma unroll
+        for(int j = 0; j < NPAIR; ++j)
+        {
+            rowx[j] = (tt[j] * sB.x + htA.x) * A.tcSx;
+            rowy[j] = (tt[j] * sB.y + htA.y) * A.tcSy;
+            rowz[j] = tt[j] * sB.z + htA.z;
+        }
+        const v2f rrow = (fy * v2f{ray.x, ray.y} + v2f{hr0.x, hr0.y}) * rS;
+        const float rrowz = fmaf(fy, ray.z, hr0.z);
+        const float* trow = tab.c + (yp + wsh) * n + wsh;
+        auto fetch_r = [&](int xp) __attribute__((always_inline)) -> RTaps {
+            RTaps t;
+            const float fx = (float)xp;
+            const float rinv = fast_rcp(fmaf(fx, rax.z, rrowz));
+            const v2f rXY = (fx * raS + rrow) * rinv + rO;
+            const v2f rF = floor2(rXY);
+            const v2f rW = floor2((rXY - rF) * 256.0f + 0.5f);           // {A, B} of quant8(), in units of 1/256
+            const v2f rN = rW * v2f{-1.0f, 1.0f} + v2f{256.0f, -256.0f}; // {256 - A, -(256 - B)}
+            const unsigned oR = (unsigned)(int)fmaf(rF.y, Wn.rPitchBF, fmaf(rF.x, recB, Wn.rOffB));
+            __builtin_assume(oR < 65536u);
+            t.wr = pk_half_weights(rN.x, rW.x);
+            t.rNy = rN.y;
+            t.rWy = rW.y;
+            const unsigned oRb = RP > 0 ? oR + (unsigned)(RP * (PAIRED ? 16 : 8)) : oR + Wn.rPitchB;
+            if constexpr(PAIRED)
+            {
+                t.r0 = lds_record(oR), t.r1 = lds_record(oRb);
+                t.r0n = t.r1n = 0u;
+            }
+            else
+            {
+                t.r0 = lds_texel(oR), t.r1 = lds_texel(oRb);
+                t.r0n = lds_u32(oR + 12u), t.r1n = lds_u32(oRb + 12u);
+            }
+            return t;
+        };
+        auto fetch_t = [&](int xp, int j) __attribute__((always_inline)) -> TTaps {
+            TTaps t;
+            const float fx = (float)xp;
+            const v2f hz = fx * az[j] + rowz[j];
+            const v2f inv = {fast_rcp(hz.x), fast_rcp(hz.y)};
+            const v2f X = (fx * axS[j] + rowx[j]) * inv + A.tcOx;
+            const v2f Y = (fx * ayS[j] + rowy[j]) * inv + A.tcOy;
+            const v2f fX = floor2(X), fY = floor2(Y);
+            const v2f wa = floor2((X - fX) * 256.0f + 0.5f);
+            t.wb = floor2((Y - fY) * 256.0f + 0.5f);
+            const v2f na = 256.0f - wa;
+            t.nnb = t.wb - 256.0f;
+            const v2f oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
+            const unsigned oA = (unsigned)(int)oidx.x, oB = (unsigned)(int)oidx.y;
+            t.wtA = pk_half_weights(na.x, wa.x);
+            t.wtB = pk_half_weights(na.y, wa.y);
+            if constexpr(PAIRED)
+            {
+                t.a0 = lds_record(oA), t.a1 = lds_record(oA + Wn.tPitchB), t.b0 = lds_record(oB), t.b1 = lds_record(oB + Wn.tPitchB);
+                t.a0n = t.a1n = t.b0n = t.b1n = 0u;
+            }
+            else
+            {
+                t.a0 = lds_texel(oA), t.a1 = lds_texel(oA + Wn.tPitchB), t.b0 = lds_texel(oB), t.b1 = lds_texel(oB + Wn.tPitchB);
+                t.a0n = lds_u32(oA + 12u), t.a1n = lds_u32(oA + Wn.tPitchB + 12u), t.b0n = lds_u32(oB + 12u), t.b1n = lds_u32(oB + Wn.tPitchB + 12u);
+            }
+            return t;
+        };
+        auto sample = [&](int xp) __attribute__((always_inline)) {
+            const RTaps r = fetch_r(xp);
+            TTaps t[NPAIR];
+#pragma unroll
+            for(int j = 0; j < NPAIR; ++j)
+                t[j] = fetch_t(xp, j);
+            Lab3x2 hr;
+            if constexpr(PAIRED)
+                hr = hlerp3x2_paired(r.r0, r.r1, r.wr);
+            else
+                hr = hlerp3x2_halfpaired(r.r0, r.r0n, r.r1, r.r1n, r.wr);
+            const v2f dRLa = (v2f{hr.t.L, hr.t.a} * r.rNy + rcLa) - v2f{hr.b.L, hr.b.a} * r.rWy;
+            const float dRb = fmaf(hr.t.b, r.rNy, rcb) - hr.b.b * r.rWy;
+            const v2f qR = dRLa * dRLa;
+            const float base = fmaf(__builtin_amdgcn_sqrtf(fmaf(dRb, dRb, qR.x + qR.y)), kC, -trow[xp]);
+            const float dLR = dRLa.x;
+#pragma unroll
+            for(int j = 0; j < NPAIR; ++j)
+            {
+                Lab3x4 h; // rt / rb = plane 2j top / bottom row, tt / tb = plane 2j + 1
+                if constexpr(PAIRED)
+                    h = hlerp3x4_paired(t[j].a0, t[j].a1, t[j].b0, t[j].b1, t[j].wtA, t[j].wtB);
+                else
+                    h = hlerp3x4_halfpaired(t[j].a0, t[j].a0n, t[j].a1, t[j].a1n, t[j].b0, t[j].b0n, t[j].b1, t[j].b1n, t[j].wtA, t[j].wtB);
+                const v2f dL = (v2f{h.rt.L, h.tt.L} * t[j].nnb + cL[j]) - v2f{h.rb.L, h.tb.L} * t[j].wb;
+                const v2f da = (v2f{h.rt.a, h.tt.a} * t[j].nnb + ca[j]) - v2f{h.rb.a, h.tb.a} * t[j].wb;
+                const v2f db = (v2f{h.rt.b, h.tt.b} * t[j].nnb + cb[j]) - v2f{h.rb.b, h.tb.b} * t[j].wb;
+                const v2f sq = dL * dL + (da * da + db * db);
+                const v2f e = v2f{__builtin_amdgcn_sqrtf(sq.x), __builtin_amdgcn_sqrtf(sq.y)} * kC + base;
+                const v2f w = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+                const v2f wgR = w * dLR, wgT = w * dL;
+                wsum[j] += w;
+                s1R[j] += wgR;
+                s1T[j] += wgT;
+                s2R[j] = wgR * dLR + s2R[j];
+                s2T[j] = wgT * dL + s2T[j];
+                sxy[j] = wgR * dL + sxy[j];
+            }
+        };
+        if(WSH == 3 && AVDM_NCC_QUAD_W3_MODE == 1)
+        {
+            // one sample at a time
+#pragma unroll
+            for(int xp = -3; xp <= 3; ++xp)
+            {
+                sample(xp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        else if(WSH == 3)
+        {
+            // 7 taps per row as 2 + 2 + 2 + 1 (see ncc_accumulate_lds_fixed8: an unroll factor with a remainder unrolls the whole row)
+#pragma unroll
+            for(int g = 0; g < 3; ++g)
+            {
+                sample(-3 + 2 * g);
+                sample(-2 + 2 * g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sample(3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        else
+        {
+#pragma unroll kNccMultiUnroll
+            for(int xp = -wsh; xp <= wsh; ++xp)
+                sample(xp);
+        }
+    }
+
+    auto finish = [&](float ws, float x1, float y1, float xx, float yy, float xy) __attribute__((always_inline)) -> float {
+        const float iw = fast_rcp(ws);
+        const float varXW = (xx - x1 * x1 * iw) * iw;
+        const float varYW = (yy - y1 * y1 * iw) * iw;
+        const float varXYW = (xy - x1 * y1 * iw) * iw;
+        const float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
+        const float s = isfinite(rawSim) ? -rawSim : 1.0f;
+        return TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, s) : s;
+    };
+    sim0 = finish(wsum[0].x, s1R[0].x, s1T[0].x, s2R[0].x, s2T[0].x, sxy[0].x);
+    sim1 = finish(wsum[0].y, s1R[0].y, s1T[0].y, s2R[0].y, s2T[0].y, sxy[0].y);
+    sim2 = finish(wsum[1].x, s1R[1].x, s1T[1].x, s2R[1].x, s2T[1].x, sxy[1].x);
+    sim3 = finish(wsum[1].y, s1R[1].y, s1T[1].y, s2R[1].y, s2T[1].y, sxy[1].y);
 }
 
 // recB = bytes per window record: 8 (one texel) or 16 (paired layout); rcap stays in 8-byte units
@@ -837,7 +1104,8 @@ struct RTile
 };
 
 // R footprint of the workgroup: stage pixels [bx, bx+15] x [by, by+15] of the ROI, patch halo wsh + 2 (the border-test margin)
-__device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int wsh, int stepXY, avdm_roi_t roi, bool paired, bool halfPaired, int bw = 16)
+__device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int wsh, int stepXY, avdm_roi_t roi, bool paired, bool halfPaired, int bw = 16,
+                                              bool lean = false)
 {
     RTile T;
     const int roiW = (int)(roi.x.end - roi.x.begin), roiH = (int)(roi.y.end - roi.y.begin);
@@ -860,7 +1128,7 @@ __device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int w
     T.w = x1 - x0 + 1;
     T.h = y1 - y0 + 1;
     T.pitch = A.rpitch; // the full-width pitch also where the image border clips the tile
-    T.ok = !A.forceGeneric && T.w > 1 && T.h > 1 && T.w <= T.pitch && T.pitch * T.h * (paired ? 2 : 1) <= A.rcap;
+    T.ok = (lean || !A.forceGeneric) && T.w > 1 && T.h > 1 && T.w <= T.pitch && T.pitch * T.h * (paired ? 2 : 1) <= A.rcap;
     if(T.ok)
     {
         if(paired)
@@ -949,7 +1217,8 @@ struct TWindow
 };
 
 // second half (after the barrier): decide — uniformly for the workgroup — whether plane k runs from LDS, and stage the T window
-__device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk, bool paired, bool halfPaired)
+__device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk, bool paired, bool halfPaired,
+                                                  bool lean = false)
 {
     TWindow Wd;
     const int mnx = sh.box[k][0], mny = sh.box[k][1], mxx = sh.box[k][2], mxy = sh.box[k][3];
@@ -980,7 +1249,7 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
         else
             stage_window(sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
     }
-    if(A.stats != nullptr && threadIdx.x == 0)
+    if(!lean && A.stats != nullptr && threadIdx.x == 0)
         atomicAdd(A.stats + reason, 1u);
     return Wd;
 }
@@ -996,7 +1265,10 @@ __device__ __forceinline__ void init_shared(BlockShared& sh)
 // ---------------------------------------------------------------------------------------------
 // SGM similarity: best / second-best uint8 volumes, 4 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, bool PAIRS = false>
+// PLANES = planes per pass over the patch on the packed chunk-window path: 1, 2 (ncc_accumulate_lds_fixed8_pair) or 4 (..._multi<2>: the
+// whole chunk in one pass; chunks it cannot take — a plane range that ends inside the chunk, a wave with a lane outside the window — run
+// one plane per pass)
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1>
 __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
                     avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
@@ -1015,11 +1287,17 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     const unsigned z0 = ((zBegin >> 2) + blockIdx.z * kSgmChunksPerWg) << 2;
     constexpr unsigned kPlanesPerWg = 4u * kSgmChunksPerWg;
 
+    // LEAN = the default instantiations (RP > 0): the A/B switches of NccArgs are compile-time constants at their defaults there (the host
+    // only launches them in that state), which removes the plain-arithmetic LDS path and the counters from the hot kernels
+    constexpr bool LEAN = RP > 0;
+    const bool noPacked = LEAN ? false : (A.noPacked != 0);
+    const bool useChunkWindow = LEAN ? true : (A.chunkWindow != 0);
+    const bool usePlanePairs = LEAN ? true : (A.planePairs != 0);
     // paired LDS records only feed the packed FIXED8 path (uniform)
-    const bool paired = PAIRED && FIXED8 && !A.noPacked;
-    const bool halfPaired = !PAIRED && FIXED8 && !A.noPacked; // the packed path without room for 16-byte records
+    const bool paired = PAIRED && FIXED8 && !noPacked;
+    const bool halfPaired = !PAIRED && FIXED8 && !noPacked; // the packed path without room for 16-byte records
     init_shared(sh);
-    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired, halfPaired);
+    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired, halfPaired, 16, LEAN);
     __syncthreads();
 
     const float x = (float)(roi.x.begin + vx) * (float)stepXY;
@@ -1078,7 +1356,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     Wc.x0 = Wc.y0 = Wc.w = Wc.h = Wc.pitch = 0;
     float extX = 0.f, extY = 0.f;
     bool lanePart = false;
-    if(FIXED8 && (paired || halfPaired) && A.chunkWindow)
+    if(FIXED8 && (paired || halfPaired) && useChunkWindow)
     {
         const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + kPlanesPerWg < zEnd) ? z0 + kPlanesPerWg : zEnd;
         if(ka < kbEnd) // uniform
@@ -1110,7 +1388,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             }
             publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
             __syncthreads();
-            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired);
+            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN);
             __syncthreads();
             chunkWin = Wc.ok;
             lanePart = part;
@@ -1173,14 +1451,95 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         }
         laneLds = __ballot(valid && !laneLds) == 0ull; // wave-uniform choice of the tap source (see the Refine kernel)
     };
+    bool quadDone = false;
+    if constexpr(PLANES == 4 && FIXED8)
+    {
+        // the four planes of the chunk in one pass over the patch (ncc_accumulate_lds_fixed8_multi): uniform conditions
+        if(chunkWin && usePlanePairs && !noPacked)
+        {
+            // the planes' geometry in the form the pixel ray gives it (ncc_accumulate_lds_fixed8_quad): ay — the normal of the epipolar plane
+            // of my ray, cross(v1, C_T - p) for ANY p on the ray — once, M_T (ax d) per plane
+            const f3 v1 = f3{-v.x, -v.y, -v.z};
+            const f3 ay = normalize(cross(v1, ld3(tc.C) - C));
+            const f3 Bt = M3x3mulV3(tc.P, ay) * RK.pixK, Br = M3x3mulV3(rc.P, ay) * RK.pixK;
+            auto plane_q = [&](unsigned vz, QuadPlane& q, f3& raxOut, bool& valid, bool& laneLds) __attribute__((always_inline)) {
+                const bool inRange = vz >= zBegin && vz < zEnd; // uniform; a plane outside the T camera's range is an invalid plane of the pass
+                valid = rValid && inRange;
+                q.c = make_float4(0.f, 0.f, 0.f, 0.f);
+                const f3 planep = C + Z * depths[inRange ? vz : zBegin];
+                const float kk = (dot(planep, Z) - dnC) / dnv;
+                q.t = kk;
+                const f3 p = C + v * kk;
+                const f3 v2 = normalize(ld3(tc.C) - p);
+                const f3 nn = normalize((v1 + v2) * 0.5f);
+                const f3 axd = normalize(cross(ay, nn)) * (RK.pixK * kk);
+                q.tax = M3x3mulV3(tc.P, axd);
+                raxOut = M3x3mulV3(rc.P, axd);
+                const f3 ht0 = fma3(kk, RK.htB, RK.htA);
+                const float it0 = fast_rcp(ht0.z);
+                const float tpx = ht0.x * it0, tpy = ht0.y * it0;
+                valid = valid && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+                laneLds = true;
+                if(valid)
+                {
+                    const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
+                    q.c = tex_bilinear_px<FIXED8>(A.tcL, cxT, cyT);
+                    valid = !(q.c.w < (255.f * 0.4f));
+                    laneLds = lanePart && (cxT - extX - 1.0f >= (float)Wc.x0) && (cxT + extX + 2.0f <= (float)(Wc.x0 + Wc.w - 1)) &&
+                              (cyT - extY - 1.0f >= (float)Wc.y0) && (cyT + extY + 2.0f <= (float)(Wc.y0 + Wc.h - 1));
+                }
+                laneLds = __ballot(valid && !laneLds) == 0ull; // wave-uniform choice of the tap source
+            };
+            QuadPlane q0, q1, q2, q3;
+            f3 ra0, ra1, ra2, ra3;
+            bool v0, v1b, v2b, v3, l0, l1, l2, l3;
+            plane_q(zc, q0, ra0, v0, l0);
+            plane_q(zc + 1u, q1, ra1, v1b, l1);
+            plane_q(zc + 2u, q2, ra2, v2b, l2);
+            plane_q(zc + 3u, q3, ra3, v3, l3);
+            if(l0 && l1 && l2 && l3) // wave-uniform
+            {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                if(v0 || v1b || v2b || v3)
+                {
+                    // a lane's invalid planes run a copy of one of its valid planes (their results are not committed); the R side comes
+                    // from plane 1 of the chunk (or its stand-in): at most two depth steps from every plane of the pass
+                    auto selP = [](bool c, const QuadPlane& a, const QuadPlane& b) __attribute__((always_inline)) -> QuadPlane {
+                        QuadPlane r;
+                        r.t = c ? a.t : b.t;
+                        r.tax = sel3(c, a.tax, b.tax);
+                        r.c = sel4(c, a.c, b.c);
+                        return r;
+                    };
+                    const QuadPlane qf = selP(v1b, q1, selP(v2b, q2, selP(v0, q0, q3)));
+                    const f3 raf = sel3(v1b, ra1, sel3(v2b, ra2, sel3(v0, ra0, ra3)));
+                    const float tw = qf.t * RK.hrW;
+                    ncc_accumulate_lds_fixed8_quad<WSH, false, PAIRED, RP>(raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
+                                                                    selP(v0, q0, qf), selP(v1b, q1, qf), selP(v2b, q2, qf), selP(v3, q3, qf), Bt, RK.htB, RK.htA, A, tab,
+                                                                    make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8), rcCenter,
+                                                                    s0, s1, s2, s3);
+                }
+                // (a plane outside the range is not committed at all: its bytes belong to other T cameras)
+                if(zc >= zBegin && zc < zEnd)
+                    commit(0, v0 ? to_fsim(s0) : 255.0f);
+                if(zc + 1u >= zBegin && zc + 1u < zEnd)
+                    commit(1, v1b ? to_fsim(s1) : 255.0f);
+                if(zc + 2u >= zBegin && zc + 2u < zEnd)
+                    commit(2, v2b ? to_fsim(s2) : 255.0f);
+                if(zc + 3u >= zBegin && zc + 3u < zEnd)
+                    commit(3, v3 ? to_fsim(s3) : 255.0f);
+                quadDone = true;
+            }
+        }
+    }
 #pragma unroll 1
-    for(int k0 = 0; k0 < 4; k0 += 2)
+    for(int k0 = 0; k0 < 4 && !quadDone; k0 += 2)
     {
         bool pairDone = false;
         {
             const unsigned vzA = zc + k0, vzB = vzA + 1u;
             // two adjacent planes in one pass over the patch (ncc_accumulate_lds_fixed8_pair): uniform conditions
-            if(PAIRS && FIXED8 && chunkWin && A.planePairs && !A.noPacked && vzA >= zBegin && vzB < zEnd)
+            if(PLANES == 2 && FIXED8 && chunkWin && usePlanePairs && !noPacked && vzA >= zBegin && vzB < zEnd)
             {
                 PatchProj QA, QB;
                 float4 cA, cB;
@@ -1193,19 +1552,10 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                     if(validA || validB)
                     {
                         // a lane with one valid plane runs it in both halves
-                        if(!validA)
-                        {
-                            QA = QB;
-                            cA = cB;
-                        }
-                        if(!validB)
-                        {
-                            QB = QA;
-                            cB = cA;
-                        }
-                        ncc_accumulate_lds_fixed8_pair<WSH, false, PAIRED, RP>(QA.rax, QA.ray, QA.hr0, QA, QB, A, tab,
+                        const PatchProj PA = selQ(validA, QA, QB), PB = selQ(validB, QB, QA);
+                        ncc_accumulate_lds_fixed8_pair<WSH, false, PAIRED, RP>(PA.rax, PA.ray, PA.hr0, PA, PB, A, tab,
                                                                                make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8),
-                                                                               rcCenter, cA, cB, sA, sB);
+                                                                               rcCenter, sel4(validA, cA, cB), sel4(validB, cB, cA), sA, sB);
                     }
                     commit(k0, validA ? to_fsim(sA) : 255.0f);
                     commit(k0 + 1, validB ? to_fsim(sB) : 255.0f);
@@ -1254,7 +1604,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 corner_boxes(Q, A, wsh, R, bx0, by0, bx1, by1, rInside);
             publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
             __syncthreads();
-            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired);
+            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired, LEAN);
             __syncthreads();
         }
 
@@ -1262,7 +1612,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         if(valid)
         {
             float s;
-            if(Wd.ok && laneLds && FIXED8 && !A.noPacked)
+            if(Wd.ok && laneLds && FIXED8 && !noPacked)
                 s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED, RP>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
                                                           tcCenter);
             else if(Wd.ok && laneLds)
@@ -1285,7 +1635,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
 // ---------------------------------------------------------------------------------------------
 // Refine similarity: fp16 volume += sigmoid-filtered NCC, 8 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, bool PAIRS = false>
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1>
 __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   refine_similarity_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize,
                            int map_pitch, const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A,
@@ -1305,11 +1655,17 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     const unsigned z0 = ((zBegin >> 3) + blockIdx.z * kRefineChunksPerWg) << 3;
     constexpr unsigned kPlanesPerWg = 8u * kRefineChunksPerWg;
 
+    // LEAN = the default instantiations (RP > 0): the A/B switches of NccArgs are compile-time constants at their defaults there (the host
+    // only launches them in that state), which removes the plain-arithmetic LDS path and the counters from the hot kernels
+    constexpr bool LEAN = RP > 0;
+    const bool noPacked = LEAN ? false : (A.noPacked != 0);
+    const bool useChunkWindow = LEAN ? true : (A.chunkWindow != 0);
+    const bool usePlanePairs = LEAN ? true : (A.planePairs != 0);
     // paired LDS records only feed the packed FIXED8 path (uniform)
-    const bool paired = PAIRED && FIXED8 && !A.noPacked;
-    const bool halfPaired = !PAIRED && FIXED8 && !A.noPacked; // the packed path without room for 16-byte records
+    const bool paired = PAIRED && FIXED8 && !noPacked;
+    const bool halfPaired = !PAIRED && FIXED8 && !noPacked; // the packed path without room for 16-byte records
     init_shared(sh);
-    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired, halfPaired);
+    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired, halfPaired, 16, LEAN);
     __syncthreads();
 
     float2 dps = make_float2(-1.f, 0.f);
@@ -1384,7 +1740,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     Wc.x0 = Wc.y0 = Wc.w = Wc.h = Wc.pitch = 0;
     float extX = 0.f, extY = 0.f; // half extent of my projected patch in T texels (the larger of the two extreme planes)
     bool lanePart = false;        // my patch was part of the hull (valid on the first or the last plane of the chunk)
-    if(CHUNK_CAPABLE && paired && A.chunkWindow)
+    if(CHUNK_CAPABLE && paired && useChunkWindow)
     {
         const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + kPlanesPerWg < zEnd) ? z0 + kPlanesPerWg : zEnd;
         if(ka < kbEnd) // uniform
@@ -1416,7 +1772,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             }
             publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
             __syncthreads();
-            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired);
+            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN);
             __syncthreads();
             chunkWin = Wc.ok;
             lanePart = part;
@@ -1473,14 +1829,121 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         }
         laneLds = __ballot(valid && !laneLds) == 0ull;
     };
+    unsigned quadsDone = 0u; // bit q: planes 4 q ... 4 q + 3 of the chunk went through the four-plane pass
+    if constexpr(PLANES == 4 && CHUNK_CAPABLE)
+    {
+        if(chunkWin && usePlanePairs && !noPacked)
+        {
+            // four planes per pass over the patch (ncc_accumulate_lds_fixed8_quad), the planes' geometry in the form the pixel ray gives it:
+            // ay — the normal of the epipolar plane of my ray — once, M_T (ax d) per plane
+            const f3 v1 = f3{-dir.x, -dir.y, -dir.z};
+            const f3 ay = normalize(cross(v1, ld3(tc.C) - C));
+            const f3 Bt = M3x3mulV3(tc.P, ay) * RK.pixK, Br = M3x3mulV3(rc.P, ay) * RK.pixK;
+            auto plane_q = [&](unsigned vz, QuadPlane& q, f3& raxOut, bool& valid, bool& laneLds) __attribute__((always_inline)) {
+                const bool inRange = vz >= zBegin && vz < zEnd; // uniform; a plane outside the range is an invalid plane of the pass
+                valid = rValid && inRange;
+                q.c = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int rel = (int)vz - ((volDimZ - 1) / 2);
+                const float t = fmaf((float)rel, dps.y, dps.x);
+                q.t = t;
+                const f3 p = C + dir * t;
+                const f3 v2 = normalize(ld3(tc.C) - p);
+                f3 nn;
+                if(sgmNormal != nullptr)
+                {
+                    const float* np_ = (const float*)((const char*)sgmNormal + (long long)vy * normal_pitch) + 3 * vx;
+                    nn = f3{np_[0], np_[1], np_[2]};
+                }
+                else
+                    nn = normalize((v1 + v2) * 0.5f);
+                const f3 axd = normalize(cross(ay, nn)) * (RK.pixK * t);
+                q.tax = M3x3mulV3(tc.P, axd);
+                raxOut = M3x3mulV3(rc.P, axd);
+                const f3 ht0 = fma3(t, RK.htB, RK.htA);
+                const float it0 = fast_rcp(ht0.z);
+                const float tpx = ht0.x * it0, tpy = ht0.y * it0;
+                valid = valid && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+                laneLds = true;
+                if(valid)
+                {
+                    const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
+                    laneLds = lanePart && (cxT - extX - 1.0f >= (float)Wc.x0) && (cxT + extX + 2.0f <= (float)(Wc.x0 + Wc.w - 1)) &&
+                              (cyT - extY - 1.0f >= (float)Wc.y0) && (cyT + extY + 2.0f <= (float)(Wc.y0 + Wc.h - 1));
+                    if(laneLds)
+                        q.c = lds_center_paired(sT, Wc.pitch, Wc.x0, Wc.y0, cxT, cyT);
+                    else
+                        q.c = tex_bilinear_px<FIXED8>(A.tcL, cxT, cyT);
+                    valid = !(q.c.w < (255.f * 0.4f));
+                }
+                laneLds = __ballot(valid && !laneLds) == 0ull; // wave-uniform choice of the tap source
+            };
+            auto selP = [](bool c, const QuadPlane& a, const QuadPlane& b) __attribute__((always_inline)) -> QuadPlane {
+                QuadPlane r;
+                r.t = c ? a.t : b.t;
+                r.tax = sel3(c, a.tax, b.tax);
+                r.c = sel4(c, a.c, b.c);
+                return r;
+            };
+#pragma unroll 1
+            for(unsigned qd = 0; qd < 2u; ++qd)
+            {
+                const unsigned zq = zc + 4u * qd;
+                if(zq >= zEnd || zq + 4u <= zBegin) // uniform: nothing of this quad is in range
+                {
+                    quadsDone |= 1u << qd;
+                    continue;
+                }
+                QuadPlane q0, q1, q2, q3;
+                f3 ra0, ra1, ra2, ra3;
+                bool v0, v1b, v2b, v3, l0, l1, l2, l3;
+                plane_q(zq, q0, ra0, v0, l0);
+                plane_q(zq + 1u, q1, ra1, v1b, l1);
+                plane_q(zq + 2u, q2, ra2, v2b, l2);
+                plane_q(zq + 3u, q3, ra3, v3, l3);
+                if(!(l0 && l1 && l2 && l3)) // wave-uniform: this wave runs the quad one plane per pass
+                    continue;
+                if(v0 || v1b || v2b || v3)
+                {
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    // a lane's invalid planes run a copy of one of its valid planes (their results are not committed); the R side comes from
+                    // plane 1 of the quad (or its stand-in): at most two depth steps from every plane of the pass
+                    const QuadPlane qf = selP(v1b, q1, selP(v2b, q2, selP(v0, q0, q3)));
+                    const f3 raf = sel3(v1b, ra1, sel3(v2b, ra2, sel3(v0, ra0, ra3)));
+                    const float tw = qf.t * RK.hrW;
+                    ncc_accumulate_lds_fixed8_quad<WSH, true, PAIRED, RP>(raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
+                                                                          selP(v0, q0, qf), selP(v1b, q1, qf), selP(v2b, q2, qf), selP(v3, q3, qf), Bt, RK.htB, RK.htA, A,
+                                                                          tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8),
+                                                                          rcCenter, s0, s1, s2, s3);
+                    // (packed[k] is indexed with constants in commit(): qd is a loop counter, so both cases are spelled out)
+                    if(qd == 0u)
+                    {
+                        if(v0) commit(0, s0);
+                        if(v1b) commit(1, s1);
+                        if(v2b) commit(2, s2);
+                        if(v3) commit(3, s3);
+                    }
+                    else
+                    {
+                        if(v0) commit(4, s0);
+                        if(v1b) commit(5, s1);
+                        if(v2b) commit(6, s2);
+                        if(v3) commit(7, s3);
+                    }
+                }
+                quadsDone |= 1u << qd;
+            }
+        }
+    }
 #pragma unroll 1
     for(int k0 = 0; k0 < 8; k0 += 2)
     {
+        if((quadsDone >> (k0 >> 2)) & 1u) // uniform per wave
+            continue;
         bool pairDone = false;
         {
             const unsigned vzA = zc + k0, vzB = vzA + 1u;
             // two adjacent planes in one pass over the patch (ncc_accumulate_lds_fixed8_pair): uniform conditions
-            if(PAIRS && CHUNK_CAPABLE && chunkWin && A.planePairs && !A.noPacked && vzA >= zBegin && vzB < zEnd)
+            if(PLANES == 2 && CHUNK_CAPABLE && chunkWin && usePlanePairs && !noPacked && vzA >= zBegin && vzB < zEnd)
             {
                 PatchProj QA, QB;
                 float4 cA, cB;
@@ -1493,19 +1956,10 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                     {
                         float sA = 0.f, sB = 0.f;
                         // a lane with one valid plane runs it in both halves
-                        if(!validA)
-                        {
-                            QA = QB;
-                            cA = cB;
-                        }
-                        if(!validB)
-                        {
-                            QB = QA;
-                            cB = cA;
-                        }
-                        ncc_accumulate_lds_fixed8_pair<WSH, true, PAIRED, RP>(QA.rax, QA.ray, QA.hr0, QA, QB, A, tab,
+                        const PatchProj PA = selQ(validA, QA, QB), PB = selQ(validB, QB, QA);
+                        ncc_accumulate_lds_fixed8_pair<WSH, true, PAIRED, RP>(PA.rax, PA.ray, PA.hr0, PA, PB, A, tab,
                                                                               make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8),
-                                                                              rcCenter, cA, cB, sA, sB);
+                                                                              rcCenter, sel4(validA, cA, cB), sel4(validB, cB, cA), sA, sB);
                         if(validA)
                             commit(k0, sA);
                         if(validB)
@@ -1564,14 +2018,14 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 corner_boxes(Q, A, wsh, R, bx0, by0, bx1, by1, rInside);
             publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
             __syncthreads();
-            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired);
+            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired, LEAN);
             __syncthreads();
         }
 
         if(valid)
         {
             float s;
-            if(Wd.ok && laneLds && FIXED8 && !A.noPacked)
+            if(Wd.ok && laneLds && FIXED8 && !noPacked)
                 s = ncc_accumulate_lds_fixed8<WSH, true, PAIRED, RP>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
                                                          tcCenter);
             else if(Wd.ok && laneLds)
@@ -1973,6 +2427,19 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
     return true;
 }
 
+// AVDM_SIM_LITERAL=1 (read at each call): both similarity entry points run the reference's arithmetic as written (avdm_literal.hip)
+int literal_compute_similarity(uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, const float* depths, const avdm_camera_t* rc,
+                               const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr, const avdm_sgm_params_t* sp, avdm_range_t dr,
+                               avdm_roi_t roi, void* stream);
+int literal_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x, int dimZ, const float* sgm_depth_pixsize, int map_pitch, const float* sgm_normal,
+                              int normal_pitch, const avdm_camera_t* rc, const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
+                              const avdm_refine_params_t* rp, avdm_range_t dr, avdm_roi_t roi, void* stream);
+static bool sim_literal_mode()
+{
+    const char* e = getenv("AVDM_SIM_LITERAL");
+    return e != nullptr && e[0] == '1';
+}
+
 } // namespace avdm
 
 using namespace avdm;
@@ -2099,6 +2566,8 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
         return set_error_msg(1, "avdm_volume_compute_similarity: wsh must be in [1, 4]");
     if((pitch_x & 3) || (pitch_y & 3) || ((uintptr_t)best & 3) || ((uintptr_t)second & 3))
         return set_error_msg(1, "avdm_volume_compute_similarity: volume base / pitches must be multiples of 4 bytes");
+    if(sim_literal_mode() && !sp->useConsistentScale && !sp->useCustomPatchPattern)
+        return avdm::literal_compute_similarity(best, second, pitch_y, pitch_x, depths, rc, tc, rc_pyr, tc_pyr, sp, dr, roi, stream);
     NccArgs A;
     PatchTable tab;
     const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
@@ -2132,8 +2601,9 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
 #define LAUNCH(F8, W, PR)                                                                                                                                 \
     hipLaunchKernelGGL((similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
                        sp->stepXY, dr.begin, dr.end, roi)
-    if(fixed8 && !paired && sp->wsh == 4 && A.rpitch == 56 && !A.noPacked)
-        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, true>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc,
+    const bool defaults = !A.noPacked && !A.forceGeneric && A.chunkWindow && A.planePairs && A.stats == nullptr; // what the lean instantiation assumes
+    if(fixed8 && !paired && sp->wsh == 4 && A.rpitch == 56 && defaults)
+        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, AVDM_SGM_PLANES_PER_PASS>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc,
                            *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi); // the default: scale 2, stepXY 2, wsh 4 — with plane pairs
     else if(fixed8 && paired)
     {
@@ -2170,6 +2640,9 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
         return set_error_msg(1, "avdm_volume_refine_similarity: volume base / pitches must be multiples of 16 bytes");
     if((int)(((dr.end + 7) & ~7u) * 2) > pitch_x)
         return set_error_msg(1, "avdm_volume_refine_similarity: pitch_x too small (must cover the 8-aligned depth range)");
+    if(sim_literal_mode() && !rp->useConsistentScale && !rp->useCustomPatchPattern)
+        return avdm::literal_refine_similarity(vol_f16, pitch_y, pitch_x, dimZ, sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, rc, tc, rc_pyr, tc_pyr, rp,
+                                               dr, roi, stream);
     NccArgs A;
     PatchTable tab;
     const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
@@ -2201,8 +2674,9 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
 #define LAUNCH(F8, W, PR)                                                                                                                          \
     hipLaunchKernelGGL((refine_similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,   \
                        (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi)
-    if(fixed8 && paired && rp->wsh == 3 && A.rpitch == 40 && !A.noPacked)
-        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, AVDM_REFINE_PAIRS != 0>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
+    const bool defaults = !A.noPacked && !A.forceGeneric && A.chunkWindow && A.planePairs && A.stats == nullptr; // what the lean instantiation assumes
+    if(fixed8 && paired && rp->wsh == 3 && A.rpitch == 40 && defaults)
+        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, AVDM_REFINE_PLANES_PER_PASS>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
                            (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end,
                            roi); // the default: scale 1, stepXY 1, wsh 3
     else if(fixed8 && paired)

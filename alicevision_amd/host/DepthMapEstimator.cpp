@@ -308,12 +308,20 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         }
         catch(...)
         {
+            (void)avdm_stream_release(s0);
             (void)hipStreamDestroy(s0);
             throw;
         }
+        (void)avdm_stream_release(s0);
         (void)hipStreamDestroy(s0);
-        AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): published " << mine.size() << " of the job's " << allViews->size()
-                                << " views in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s.");
+        // whatever this worker owns and did not publish will never come: nobody may wait for it
+        for(const int v : mine)
+            if(!exchange->find(v))
+                exchange->decline(v);
+        AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): published " << mine.size() << " of the job's " << allViews->size() << " views in "
+                                << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s ("
+                                << (exchange->residentBytes(worker) >> 20) << " MB resident of a budget of " << (exchange->budgetBytes() >> 20)
+                                << " MB; views declined so far: " << exchange->nbDeclined.load() << ").");
     }
 
     std::vector<Tile> tiles;

@@ -16,6 +16,7 @@
 #include "log.hpp"
 
 #include <avdm.h>
+#include <hip/hip_runtime.h>
 #include <omp.h>
 
 #include <algorithm>
@@ -55,6 +56,47 @@ void computeOnMultiGPUs(const std::vector<int>& cams, IGPUJob& gpujob, int nbGPU
 
     const std::vector<int> allViews = gpujob.viewsNeeded(cams);
     PyramidExchange exchange(devices);
+    // Residency budget of the exchange per owner: a quarter of the smallest device's memory (AVDM_EXCHANGE_BUDGET_MB overrides; the reference
+    // keeps nbRcPerBatch * (1 + maxTCams) pyramids per device and decodes every neighbour on every device).  Views beyond it are declined
+    // and decoded by whoever needs them (device.hpp).
+    {
+        size_t budget = (size_t)-1;
+        for(int d = 0; d < nbPhysical; ++d)
+        {
+            size_t freeB = 0, totalB = 0;
+            if(hipSetDevice(d) == hipSuccess && hipMemGetInfo(&freeB, &totalB) == hipSuccess)
+                budget = std::min(budget, totalB / 4 / std::max<size_t>(1, (nbWorkers + nbPhysical - 1) / nbPhysical));
+        }
+        if(const char* mb = std::getenv("AVDM_EXCHANGE_BUDGET_MB"))
+            budget = (size_t)std::max(0L, std::atol(mb)) << 20;
+        exchange.setBudgetBytes(budget);
+        AVDM_LOG_INFO("Pyramid exchange: residency budget " << (budget >> 20) << " MB per worker.");
+    }
+    // Peer access between every pair of devices in use, BEFORE the first hipMemcpyPeerAsync: with it the copies go device to device over
+    // xGMI; without it the runtime may stage them through host memory.  (The one-process form of BASELINE's "neighbour views broadcast
+    // once over RCCL/xGMI": threads of one process share an address space, so a peer copy IS the broadcast; the one-process-per-GPU form —
+    // bench.py, alicevision_amd/sharding.py — uses RCCL.)
+    for(int a = 0; a < std::min(nbWorkers, nbPhysical); ++a)
+        for(int b = 0; b < std::min(nbWorkers, nbPhysical); ++b)
+        {
+            if(a == b)
+                continue;
+            int can = 0;
+            if(hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can)
+            {
+                AVDM_LOG_WARNING("Device " << a << " cannot access device " << b << " directly: pyramid copies between them are staged by the runtime.");
+                continue;
+            }
+            if(hipSetDevice(a) != hipSuccess)
+                continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                AVDM_LOG_WARNING("hipDeviceEnablePeerAccess(" << a << " -> " << b << ") failed: " << hipGetErrorString(e));
+            else
+                AVDM_LOG_DEBUG("Peer access " << a << " -> " << b << " enabled: pyramid copies are direct.");
+            (void)hipGetLastError();
+        }
+    (void)hipSetDevice(0);
 
     std::mutex errorGuard;
     std::exception_ptr firstError;
@@ -83,7 +125,8 @@ void computeOnMultiGPUs(const std::vector<int>& cams, IGPUJob& gpujob, int nbGPU
         t.join();
     if(!allViews.empty())
         AVDM_LOG_INFO("Pyramid exchange: " << exchange.nbBuilt << " views converted once, " << exchange.nbCopied << " peer copies ("
-                                           << (double)exchange.bytesCopied / (1024.0 * 1024.0) << " MB) instead of decoding them again.");
+                                           << (double)exchange.bytesCopied / (1024.0 * 1024.0) << " MB) instead of decoding them again; "
+                                           << exchange.nbDeclined << " views over the residency budget were decoded where needed.");
     if(firstError)
         std::rethrow_exception(firstError);
 }

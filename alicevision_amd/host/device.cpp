@@ -16,7 +16,10 @@ DeviceStreamManager::DeviceStreamManager(int nbStreams)
 DeviceStreamManager::~DeviceStreamManager()
 {
     for(auto& s : _streams)
+    {
+        (void)avdm_stream_release(s); // the library's per-stream block (optimisation point maps, resize tap tables) goes with the stream
         (void)hipStreamDestroy(s);
+    }
 }
 
 void DeviceMipmapImage::fill(const HostImage& img, int minDownscale, int maxDownscale, int filterMode, hipStream_t stream)
@@ -55,14 +58,47 @@ void DeviceMipmapImage::copyFromPeer(const DeviceMipmapImage& src, int srcDevice
     AVDM_HIP_CHECK(hipMemcpyPeerAsync(_buf.ptr(), dstDevice, src.pyramid().base, srcDevice, src.bytes(), stream));
 }
 
-void PyramidExchange::publish(int camId, std::shared_ptr<const DeviceMipmapImage> img)
+bool PyramidExchange::publish(int camId, std::shared_ptr<const DeviceMipmapImage> img)
 {
     {
         std::lock_guard<std::mutex> lock(_mutex);
+        const int owner = ownerOf(camId);
+        if(_residentBytes.at(owner) + img->bytes() > _budget)
+        {
+            _declined.insert(camId);
+            ++nbDeclined;
+            _published.notify_all();
+            return false;
+        }
+        _residentBytes.at(owner) += img->bytes();
         _resident[camId] = std::move(img);
     }
     ++nbBuilt;
     _published.notify_all();
+    return true;
+}
+
+void PyramidExchange::decline(int camId)
+{
+    {
+        std::lock_guard<std::mutex> lock(_mutex);
+        if(_resident.count(camId) != 0 || !_declined.insert(camId).second)
+            return;
+    }
+    ++nbDeclined;
+    _published.notify_all();
+}
+
+bool PyramidExchange::isDeclined(int camId)
+{
+    std::lock_guard<std::mutex> lock(_mutex);
+    return _declined.count(camId) != 0;
+}
+
+size_t PyramidExchange::residentBytes(int worker)
+{
+    std::lock_guard<std::mutex> lock(_mutex);
+    return _residentBytes.at(worker);
 }
 
 std::shared_ptr<const DeviceMipmapImage> PyramidExchange::find(int camId)
@@ -75,10 +111,12 @@ std::shared_ptr<const DeviceMipmapImage> PyramidExchange::find(int camId)
 std::shared_ptr<const DeviceMipmapImage> PyramidExchange::await(int camId)
 {
     std::unique_lock<std::mutex> lock(_mutex);
-    _published.wait(lock, [&] { return _failure || _resident.count(camId) != 0; });
+    _published.wait(lock, [&] { return _failure || _resident.count(camId) != 0 || _declined.count(camId) != 0; });
     const auto it = _resident.find(camId);
     if(it != _resident.end())
         return it->second;
+    if(_declined.count(camId) != 0)
+        return nullptr;
     std::rethrow_exception(_failure);
 }
 
@@ -121,20 +159,27 @@ void DeviceCache::addMipmapImage(int camId, int minDownscale, int maxDownscale, 
         if(owner == _worker)
         {
             // mine: built once (normally by the pre-pass of DepthMapEstimator::compute), resident for the whole job; the slot aliases it
-            if(!_exchange->find(camId))
+            if(!_exchange->find(camId) && !_exchange->isDeclined(camId))
                 buildOwnedView(camId, minDownscale, maxDownscale, imageCache, mp, stream);
-            _mipmaps.at(slot) = _exchange->find(camId);
+            if(const std::shared_ptr<const DeviceMipmapImage> mine = _exchange->find(camId))
+            {
+                _mipmaps.at(slot) = mine;
+                return;
+            }
+            // declined (the exchange's residency budget is spent): an ordinary LRU entry of this device, below
+        }
+        else if(const std::shared_ptr<const DeviceMipmapImage> src = _exchange->await(camId))
+        {
+            // another worker's: its pyramid copied over the fabric
+            auto copy = std::make_shared<DeviceMipmapImage>();
+            copy->copyFromPeer(*src, _exchange->deviceOf(owner), _exchange->deviceOf(_worker), stream);
+            AVDM_HIP_CHECK(hipStreamSynchronize(stream)); // `src` may be released by its owner's exchange only after the copy has read it
+            ++_exchange->nbCopied;
+            _exchange->bytesCopied += (long long)src->bytes();
+            _mipmaps.at(slot) = copy;
             return;
         }
-        // another worker's: wait for its pyramid and copy it over the fabric
-        const std::shared_ptr<const DeviceMipmapImage> src = _exchange->await(camId);
-        auto copy = std::make_shared<DeviceMipmapImage>();
-        copy->copyFromPeer(*src, _exchange->deviceOf(owner), _exchange->deviceOf(_worker), stream);
-        AVDM_HIP_CHECK(hipStreamSynchronize(stream)); // `src` may be released by its owner's exchange only after the copy has read it
-        ++_exchange->nbCopied;
-        _exchange->bytesCopied += (long long)src->bytes();
-        _mipmaps.at(slot) = copy;
-        return;
+        // declined by its owner: decode and convert it here, like the reference does for every neighbour on every device
     }
     const std::shared_ptr<const HostImage> img = imageCache.getImg_sync(camId);
     auto own = std::make_shared<DeviceMipmapImage>();
@@ -144,13 +189,21 @@ void DeviceCache::addMipmapImage(int camId, int minDownscale, int maxDownscale, 
 
 void DeviceCache::buildOwnedView(int camId, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp, hipStream_t stream)
 {
-    if(_exchange == nullptr || _exchange->find(camId))
+    if(_exchange == nullptr || _exchange->find(camId) || _exchange->isDeclined(camId))
         return;
     AVDM_LOG_TRACE("Build the pyramid of an owned view for the exchange (id: " << camId << ", view id: " << mp.getViewId(camId) << ").");
     const std::shared_ptr<const HostImage> img = imageCache.getImg_sync(camId);
+    // its size is known before anything is allocated: a view that does not fit the residency budget is declined without being built
+    avdm_pyramid_t layout;
+    avdmCheck(avdm_pyramid_layout(&layout, img->width, img->height, minDownscale, maxDownscale, _filterMode), "avdm_pyramid_layout");
+    if(_exchange->residentBytes(_worker) + (size_t)layout.bytes > _exchange->budgetBytes())
+    {
+        _exchange->decline(camId);
+        return;
+    }
     auto own = std::make_shared<DeviceMipmapImage>();
     own->fill(*img, minDownscale, maxDownscale, _filterMode, stream);
-    _exchange->publish(camId, own);
+    (void)_exchange->publish(camId, own);
 }
 
 void DeviceCache::addCameraParams(int camId, int downscale, const MultiViewParams& mp)

@@ -17,6 +17,7 @@
 #include <exception>
 #include <list>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -203,16 +204,27 @@ class PyramidExchange
 {
   public:
     // devices[w] = physical device of worker w (the same device may appear several times: that is how the one-GPU tests run two workers)
-    explicit PyramidExchange(std::vector<int> devices) : _devices(std::move(devices)) {}
+    explicit PyramidExchange(std::vector<int> devices) : _devices(std::move(devices)), _residentBytes(_devices.size(), 0) {}
     int nbWorkers() const { return (int)_devices.size(); }
     int deviceOf(int worker) const { return _devices.at(worker); }
     int ownerOf(int camId) const { return camId % nbWorkers(); }
-    // owner side: hand over a finished pyramid; it stays resident until the exchange dies
-    void publish(int camId, std::shared_ptr<const DeviceMipmapImage> img);
-    // the owner's resident pyramid, waiting until it is published; rethrows the failure of a worker that died before publishing
+    // Residency is BOUNDED: an owner keeps at most `budget` bytes of published pyramids on its device (default: a quarter of the device's
+    // memory, AVDM_EXCHANGE_BUDGET_MB overrides).  A view that no longer fits is DECLINED: every worker that needs it — its owner
+    // included — decodes and converts it itself into its own LRU cache, which is what the reference does for every neighbour on
+    // every device (DepthMapEstimator.cpp:224-232, nbRcPerBatch * (1 + maxTCams) pyramids at a time).
+    void setBudgetBytes(size_t perWorker) { _budget = perWorker; }
+    size_t budgetBytes() const { return _budget; }
+    size_t residentBytes(int worker);
+    // owner side: hand over a finished pyramid; it stays resident until the exchange dies.  false = over budget: the view is declined
+    bool publish(int camId, std::shared_ptr<const DeviceMipmapImage> img);
+    // owner side: this view will not be published (over budget, or the owner's pre-pass is over and it never came up)
+    void decline(int camId);
+    bool isDeclined(int camId);
+    // the owner's resident pyramid, waiting until it is published or declined (nullptr); rethrows the failure of a worker that died first
     std::shared_ptr<const DeviceMipmapImage> await(int camId);
     std::shared_ptr<const DeviceMipmapImage> find(int camId);
     void fail(std::exception_ptr e);
+    std::atomic<long> nbDeclined{0};
     // statistics for the log: pyramids built by their owners / copied between workers, bytes copied
     std::atomic<long> nbBuilt{0}, nbCopied{0};
     std::atomic<long long> bytesCopied{0};
@@ -222,6 +234,9 @@ class PyramidExchange
     std::mutex _mutex;
     std::condition_variable _published;
     std::map<int, std::shared_ptr<const DeviceMipmapImage>> _resident;
+    std::set<int> _declined;
+    std::vector<size_t> _residentBytes; // per owner
+    size_t _budget = (size_t)-1;
     std::exception_ptr _failure;
 };
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — depth-maps/sec of the MI355X-native depth-map estimation hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1 without a launcher: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workloads (BASELINE.json configs; config.workload names the one that ran):
@@ -102,6 +102,51 @@ def cpu_baseline(sc_small, sgm, ref, n_planes, full_px, full_t):
                       f"({t['sgm'] + t['refine']:.1f} s), scaled x{scale:.0f} (pixels x T cams) to one 12 MP / 10 T depth map"}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(n, argv, port=None):
+    """python -m torch.distributed.run ... bench.py <argv>: N ranks on this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port",
+            str(port if port is not None else free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def dry_run(args, rank, world):
+    """The N-rank protocol of the bench without the GPU: process group (gloo), the views / reference cameras each rank owns, W warm-up + K timed
+    "steps" bracketed by barriers, MAX over ranks of the elapsed time, ONE JSON line from rank 0."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    V = WORKLOADS[args.workload or ("cfg3" if world == 1 else "cfg4")][0]
+    my_cams = cameras_of_rank(list(range(V)), rank, world)
+    owned = [v for v in range(V) if owner_of_view(v, world) == rank]
+    for i in range(args.warmup):
+        pass
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    done = [my_cams[(args.warmup + i) % len(my_cams)] for i in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    elapsed = time.time() - t0
+    counts = torch.tensor([len(owned), len(my_cams)], dtype=torch.int64)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.all_reduce(counts)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "views": V, "views_owned_total": int(counts[0]),
+                          "reference_cameras_total": int(counts[1]), "rank0_cameras": done, "elapsed_s": elapsed, "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,13 +154,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / timing protocol only (gloo, no GPU work): what tests/test_sharding.py runs on the CPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks on this node (one process per GPU) — the command the driver uses
+        os.execvp(sys.executable, launcher_command(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a launcher with WORLD_SIZE={args.gpus} (torch.distributed.run); got {world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -206,6 +258,9 @@ def main():
     stages = tile.timers.mean_ms(per=args.steps)  # ms per step and stage (HIP events on the launch stream; summed over the tiles of a step)
     k_ms, k_n = ctypes.c_double(0.0), ctypes.c_long(0)
     abi.check(lib.avdm_debug_sgm_kernel_timing_read(ctypes.byref(k_ms), ctypes.byref(k_n), 1), "avdm_debug_sgm_kernel_timing_read")
+    path_ms, path_n = (ctypes.c_double * 4)(), (ctypes.c_long * 4)()
+    if hasattr(lib, "avdm_debug_sgm_kernel_timing_read_paths"):
+        lib.avdm_debug_sgm_kernel_timing_read_paths(path_ms, path_n)
     lib.avdm_debug_sgm_kernel_timing(0)
     valid = float((out[..., 0] > 0).float().mean().item())
 
@@ -240,7 +295,9 @@ def main():
                 "ms_per_launch": sgm_ms_per_launch, "launches_per_volume": n_launches, "volumes_per_launch": len(vols) if batched else 1,
                 # the same bytes over the whole avdm_volume_optimize call (path launches + sgm_p2_map_kernel, whose 64 B/pixel are in the numerator)
                 "ms_whole_call_per_volume": whole_call_ms, "frac_whole_call": alg_bytes_per_volume / (whole_call_ms * 1e-3) / 1e9 / 8000.0,
-                "frac_kernels_only": achieved / 8000.0}
+                "frac_kernels_only": achieved / 8000.0,
+                # per launch of a volume: [first filtering axis (paths 0 + 1), second axis (paths 2 + 3)]
+                "ms_per_launch_by_axis": [path_ms[k] / path_n[k] if path_n[k] else None for k in (0, 2)]}
         # what this box's HBM delivers to a plain device-to-device copy (1 GiB read + 1 GiB written, measured here, after the timed region):
         # the practical ceiling next to the 8 TB/s nominal peak the fraction is quoted against (profiles/README.md: box-to-box variance)
         try:
@@ -261,15 +318,25 @@ def main():
             pass
         # HBM bytes per launch from the PMC counters: NOT measured by this run (counters need their own rocprofv3 --pmc passes); the value
         # is the committed summary of the latest counter session of the SAME kernel and volume size, named here with its provenance
-        for pmc in ("r02_sgm_pmc.json", "r01_sgm_pmc.json"):
-            path = os.path.join(ROOT, "profiles", pmc)
-            if os.path.exists(path) and n_side == 1 and (W, H, Z) == (4000, 3000, 256):
-                try:
-                    roof["traffic"] = json.load(open(path)).get("hbm_bytes_per_launch")
-                    roof["traffic_source"] = f"profiles/{pmc}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/sgm_microbench.py (2 x FETCH + WRITE, KiB), not this run"
-                except Exception:
-                    pass
+        import glob
+        import hashlib
+        sha = hashlib.sha256(open(os.path.join(ROOT, "alicevision_amd", "csrc", "avdm_sgm.hip"), "rb").read()).hexdigest()
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sgm_pmc.json")), reverse=True):
+            if not (n_side == 1 and (W, H, Z) == (4000, 3000, 256)):
                 break
+            try:
+                rec = json.load(open(path))
+            except Exception:
+                continue
+            name = os.path.basename(path)
+            if rec.get("kernel_source_sha256") == sha:
+                roof["traffic"] = rec.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/sgm_microbench.py (2 x FETCH + WRITE, "
+                                          "KiB), taken with this very csrc/avdm_sgm.hip (sha256 matches); not this run")
+            else:
+                roof["traffic_source"] = (f"profiles/{name} was measured with another csrc/avdm_sgm.hip (sha256 differs): stale, not quoted — re-run "
+                                          "scripts/gpu_pmc_sgm.sh + scripts/collect_profiles.py")
+            break
         # the similarity kernels are VALU / LDS-gather bound, HBM fraction is not their figure.  Work units: a voxel-T is
         # (2 wsh + 1)^2 patch samples (81 SGM, 49 Refine); flops per voxel-T from SURVEY §8(a) (8.1 k / 4.9 k); LDS bytes per sample as the
         # kernels read them (SGM: half-paired 8-byte records, 2 x 8 + 2 x 4 B per image; with two planes per pass the R taps are read once

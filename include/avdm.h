@@ -146,6 +146,12 @@ int avdm_version(void);
 /* gpu/gpu.cpp:15-66 (gpuSupportCUDA / gpuInformationCUDA) */
 int avdm_device_count(void);
 int avdm_device_info(int device, char* out, size_t out_len);
+/* Gives back what the library keeps per stream on the current device: the temporary maps of avdm_depth_sim_map_optimize_gradient_descent and
+ * the tap tables of avdm_image_resize live in one block per (device, stream) that is reused by later calls on that stream (the reference
+ * passes a pre-allocated CudaDeviceMemoryPitched for the former, Refine.cpp:60-66; the wrapper signature has no room for the point maps
+ * this implementation iterates on).  Call it before hipStreamDestroy; waits for the stream.  Returns 2 (and frees nothing) while another
+ * host thread is inside an entry point on that stream. */
+int avdm_stream_release(void* stream);
 
 /* buildCustomPatchPattern (cuda/host/patchPattern.cpp:18-251): validates the subparts, builds the pattern and makes it the one the
  * similarity entry points use when their parameters say useCustomPatchPattern (the reference keeps it in constant memory,

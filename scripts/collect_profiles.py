@@ -28,8 +28,11 @@ def main(tag):
     for k in fetch:
         if "sgm_path_kernel" in k or "sgm_pair_kernel" in k:
             per[k] = (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
+    import hashlib
+    # the kernel these counters belong to: bench.py only quotes them while csrc/avdm_sgm.hip still hashes to this (roofline.traffic cannot go stale)
+    sha = hashlib.sha256(open(os.path.join(ROOT, "alicevision_amd", "csrc", "avdm_sgm.hip"), "rb").read()).hexdigest()
     out = {"source": f"profiles/{tag}_pmc_FETCH_SIZE.csv + {tag}_pmc_WRITE_SIZE.csv", "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB -> B)",
-           "per_kernel_bytes": per, "hbm_bytes_per_launch": sum(per.values()) / max(len(per), 1)}
+           "per_kernel_bytes": per, "hbm_bytes_per_launch": sum(per.values()) / max(len(per), 1), "kernel_source_sha256": sha}
     rnd = tag.split("_")[0]
     json.dump(out, open(os.path.join(dst, f"{rnd}_sgm_pmc.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 2: HBM traffic of the SGM pair kernel from the PMC counters (counters only, one per pass, never combined with tracing), on the
+# HBM traffic of the SGM pair kernel from the PMC counters (counters only, one per pass, never combined with tracing), on the
 # micro-benchmark with one cfg3 volume; bench line with the live copy bandwidth
-TAG=${1:-r02_i}
+TAG=${1:-r03_pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -51,12 +51,29 @@ def depth_stats(got, want, pix=None):
     return out
 
 
-def run_case(name, spec, filter_mode, with_ref=False):
+def gpu_run(pyr, sc, sgm, ref, roi, tcs, depths):
+    """one tile through the C ABI: every intermediate the table compares"""
+    import torch
+    from alicevision_amd.pipeline import DepthMapTile
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=roi)
+    h.run_sgm(0, tcs, depths, keep_raw=True)
+    Z = len(depths)
+    g = {"second": h.second.cpu().numpy()[..., :Z], "filtered": h.best.cpu().numpy()[..., :Z], "sgm": h.sgm_depth_sim.cpu().numpy().copy()}
+    g["final"] = h.run_refine(0, tcs).cpu().numpy().copy()
+    g["refvol"] = h.refine_volume.cpu().numpy()[..., : h.Zr].astype(np.float32)
+    g["refined"] = h.refined.cpu().numpy().copy()
+    g["Zr"] = h.Zr
+    torch.cuda.synchronize()
+    return g
+
+
+def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False):
     import torch
     from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
     from oracle import oracle
     t0 = time.time()
-    sc = make_scene(spec["n_views"], spec["W"], spec["H"], seed=spec["seed"])
+    sc = make_scene(spec["n_views"], spec["W"], spec["H"], seed=spec["seed"], device="cuda")  # rendered on the GPU (12 MP views take a minute on the CPU)
+    images_np = sc.images.cpu().numpy()
     sgm = abi.SgmParams.default(**spec["sgm"])
     ref = abi.RefineParams.default()
     depths = plane_depths(sc, spec["Z"])
@@ -65,22 +82,14 @@ def run_case(name, spec, filter_mode, with_ref=False):
     res = {"case": name, "image": [spec["W"], spec["H"]], "planes": spec["Z"], "t_cams": len(tcs), "roi": roi,
            "filter": "FIXED8" if filter_mode == abi.FILTER_CUDA_FIXED8 else "EXACT"}
 
-    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, filter_mode) for i in range(spec["n_views"])]
-    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=roi)
-    h.run_sgm(0, tcs, depths, keep_raw=True)
+    pyr = [DevicePyramid(sc.images[i], 1, 128, filter_mode) for i in range(spec["n_views"])]
     Z = len(depths)
-    g_second = h.second.cpu().numpy()[..., :Z]
-    g_filtered = h.best.cpu().numpy()[..., :Z]
-    g_sgm = h.sgm_depth_sim.cpu().numpy().copy()
-    g_final = h.run_refine(0, tcs).cpu().numpy().copy()
-    g_refvol = h.refine_volume.cpu().numpy()[..., : h.Zr].astype(np.float32)
-    g_refined = h.refined.cpu().numpy().copy()
-    g_up = h.sgm_upscaled.cpu().numpy().copy()
-    torch.cuda.synchronize()
+    g = gpu_run(pyr, sc, sgm, ref, roi, tcs, depths)
+    g_second, g_filtered, g_sgm, g_final, g_refvol, g_refined, Zr = g["second"], g["filtered"], g["sgm"], g["final"], g["refvol"], g["refined"], g["Zr"]
     res["t_gpu_s"] = time.time() - t0
 
-    o = oracle.OracleDepthMap(sc.images.numpy(), sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi)
-    for mode in ("literal", "well_posed"):
+    o = oracle.OracleDepthMap(images_np, sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi)
+    for mode in ("well_posed", "literal"):
         t1 = time.time()
         if mode == "well_posed":
             with oracle.well_posed():
@@ -93,12 +102,12 @@ def run_case(name, spec, filter_mode, with_ref=False):
         r["similarity_volume_levels"] = level_hist(o.second[..., :Z], g_second)
         r["sgm_filtered_volume_levels"] = level_hist(o.filtered[..., :Z], g_filtered)
         r["sgm_wta_depth_differs"] = float((o.sgm_depth_sim[..., 0] != g_sgm[..., 0]).mean())
-        d = np.abs(o.refine_volume[..., : h.Zr].astype(np.float32) - g_refvol)
+        d = np.abs(o.refine_volume[..., : Zr].astype(np.float32) - g_refvol)
         r["refine_volume_abs"] = {">2e-3": float((d > 2e-3).mean()), ">2e-2": float((d > 2e-2).mean()), "max": float(d.max())}
         pix = o.sgm_upscaled[..., 1]
         r["refined_depth"] = depth_stats(g_refined, o.refined, pix)
         r["final_depth"] = depth_stats(g_final, want, pix)
-        gt = sc.gt_depth.numpy()
+        gt = sc.gt_depth.cpu().numpy()
         if roi is not None:
             gt = gt[roi[2]:roi[3], roi[0]:roi[1]]
         both = (g_final[..., 0] > 0) & (want[..., 0] > 0)
@@ -106,12 +115,29 @@ def run_case(name, spec, filter_mode, with_ref=False):
                                            "oracle": float(np.median(np.abs(want[..., 0] - gt)[both]))}
         r["t_oracle_s"] = time.time() - t1
         res[mode] = r
+    # AVDM_SIM_LITERAL=1: the reference's similarity arithmetic as written, ON THE GPU (csrc/avdm_literal.hip), against the oracle's literal
+    # mode on the oracle's own pyramids — what is left when the conditioning of the NCC sums is taken out of the comparison
+    if gpu_literal:
+        t1 = time.time()  # (the oracle object still holds the literal run: "literal" is the last mode of the loop above)
+        opyr = [DevicePyramid.from_host_bytes(p.desc, p.buf) for p in o.pyr]
+        os.environ["AVDM_SIM_LITERAL"] = "1"
+        try:
+            gl = gpu_run(opyr, sc, sgm, ref, roi, tcs, depths)
+        finally:
+            os.environ.pop("AVDM_SIM_LITERAL", None)
+        d = np.abs(o.refine_volume[..., :Zr].astype(np.float32) - gl["refvol"])
+        res["gpu_literal_vs_oracle_literal"] = {
+            "similarity_volume_levels": level_hist(o.second[..., :Z], gl["second"]),
+            "sgm_filtered_volume_levels": level_hist(o.filtered[..., :Z], gl["filtered"]),
+            "sgm_wta_depth_differs": float((o.sgm_depth_sim[..., 0] != gl["sgm"][..., 0]).mean()),
+            "refine_volume_abs": {">2e-3": float((d > 2e-3).mean()), ">2e-2": float((d > 2e-2).mean()), "max": float(d.max())},
+            "final_depth": depth_stats(gl["final"], want, o.sgm_upscaled[..., 1]), "t_s": time.time() - t1}
     # the REFERENCE'S OWN kernels (oracle/_ref, prebuilt library travelling with the snapshot): the literal oracle must equal them bit for
     # bit, which makes the "literal" block above GPU-vs-reference-code numbers
     from oracle import ref as refmod
     if with_ref and refmod.available():
         t1 = time.time()
-        r = refmod.RefDepthMap(sc.images.numpy(), sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi)
+        r = refmod.RefDepthMap(images_np, sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi)
         r.run_sgm(0, tcs, depths)
         want_ref = r.run_refine(0, tcs)
         o.run_sgm(0, tcs, depths)
@@ -131,12 +157,13 @@ def main():
     ap.add_argument("--filters", default="fixed8")
     ap.add_argument("--out", default=None)
     ap.add_argument("--ref-cases", default="cfg1", help="cases also run through oracle/_ref (the reference's own kernels on the CPU)")
+    ap.add_argument("--literal-cases", default="cfg1,crop2,crop3", help="cases also run with AVDM_SIM_LITERAL=1 on the GPU")
     a = ap.parse_args()
     out = []
     for name in a.cases.split(","):
         for f in a.filters.split(","):
             mode = abi.FILTER_CUDA_FIXED8 if f == "fixed8" else abi.FILTER_EXACT
-            r = run_case(name, CASES[name], mode, with_ref=name in a.ref_cases.split(","))
+            r = run_case(name, CASES[name], mode, with_ref=name in a.ref_cases.split(","), gpu_literal=name in a.literal_cases.split(","))
             out.append(r)
             print(json.dumps(r), flush=True)
     if a.out:

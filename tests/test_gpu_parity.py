@@ -13,6 +13,8 @@ import pytest
 
 from alicevision_amd import abi
 
+from alicevision_amd.synthetic import make_scene, plane_depths
+
 from common import level_mismatch, make_hip_from_oracle, make_oracle, small_case
 
 pytestmark = pytest.mark.gpu
@@ -527,43 +529,51 @@ def test_refine_chunk_window_equals_per_plane_windows(case):
     assert (a != 0).mean() > 0.3
 
 
-def test_plane_pairs_equal_single_planes(case, capsys):
-    """Both similarity kernels run two adjacent planes per pass over the patch (ncc_accumulate_lds_fixed8_pair: the R side of a sample is
-    evaluated once, from the first plane's patch, for both); AVDM_SIM_PLANE_PAIRS=0 keeps one plane per pass.  The R taps of the second
-    plane move by < 1e-4 texel (the tilt of the patch's x axis between adjacent planes) and the sums are associated differently: the
-    volumes must agree to the storage quantum almost everywhere — SGM: uint8 levels, Refine: fp16 sums — and the statistics are printed."""
+def test_plane_pairs_equal_single_planes(capsys):
+    """The similarity kernels run several adjacent planes per pass over the patch — the SGM kernel the four planes of a chunk
+    (ncc_accumulate_lds_fixed8_quad), the Refine kernel two (ncc_accumulate_lds_fixed8_pair): the R side of a sample is evaluated once,
+    from one plane's patch, for all of them; AVDM_SIM_PLANE_PAIRS=0 keeps one plane per pass.  The R taps of the other planes move by
+    ~1e-4 ... 1e-3 texel per depth step (the tilt of the patch's x axis) and the sums are associated differently: the volumes must agree to
+    the storage quantum almost everywhere — SGM: uint8 levels, Refine: fp16 sums — and the statistics are printed.  The plane spacing is
+    the production one (128 planes over the scene's depth range at 320 x 240 = 256 planes at 12 MP: a coarser list exaggerates the tilt)."""
     import os
     torch = _torch()
-    sc, sgm, ref, depths, o = case
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    sc, sgm, ref, depths = small_case(width=320, height=240, n_planes=128, seed=11)
     Z = len(depths)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(3)]
     out = {}
+    sgm_map = None
     for flag in ("1", "0"):
         os.environ["AVDM_SIM_PLANE_PAIRS"] = flag
         try:
-            h = make_hip_from_oracle(o, sc, sgm, ref)
-            h.run_sgm(0, [1, 2], depths, optimize=False, keep_raw=True)
+            h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+            h.run_sgm(0, [1, 2], depths, keep_raw=True)
             torch.cuda.synchronize()
             best, second = h.best_raw.cpu().numpy()[..., :Z].copy(), h.second.cpu().numpy()[..., :Z].copy()
-            h2 = make_hip_from_oracle(o, sc, sgm, ref)
-            h2._alloc(Z)
-            h2.sgm_depth_thickness.copy_(torch.from_numpy(o.sgm_depth_thickness))
-            h2.run_refine(0, [1, 2], optimize_enabled=False)
+            if sgm_map is None:
+                sgm_map = h.sgm_depth_thickness.clone()  # ONE depth map under both Refine runs
+            h.sgm_depth_thickness.copy_(sgm_map)
+            h.run_refine(0, [1, 2], optimize_enabled=False)
             torch.cuda.synchronize()
-            out[flag] = (best, second, h2.refine_volume.cpu().numpy().astype(np.float32))
+            out[flag] = (best, second, h.refine_volume.cpu().numpy().astype(np.float32))
         finally:
             os.environ.pop("AVDM_SIM_PLANE_PAIRS", None)
     (b1, s1, r1), (b0, s0, r0) = out["1"], out["0"]
     fb, mb = level_mismatch(b0, b1)
     fs, ms = level_mismatch(s0, s1)
+    gb = float((np.abs(b0.astype(np.int16) - b1.astype(np.int16)) > 1).mean())
+    gs = float((np.abs(s0.astype(np.int16) - s1.astype(np.int16)) > 1).mean())
     d = np.abs(r1 - r0)
     with capsys.disabled():
-        print("\nplane pairs vs single planes: SGM best %.4f of the voxels differ (max %d levels), second %.4f (max %d); Refine %.4f differ, "
-              "%.5f by more than one fp16 quantum (2e-3), max %.2e" % (fb, mb, fs, ms, (d > 0).mean(), (d > 2e-3).mean(), d.max()))
+        print("\nplanes per pass (4 / 2) vs single planes: SGM best %.5f of the voxels differ (%.6f by > 1 level, max %d), second %.5f (%.6f, max %d); "
+              "Refine %.4f differ, %.5f by more than one fp16 quantum (2e-3), max %.2e" % (fb, gb, mb, fs, gs, ms, (d > 0).mean(), (d > 2e-3).mean(), d.max()))
     assert fb <= 0.02 and fs <= 0.02, (fb, fs)          # uint8 truncation boundaries only
-    assert mb <= 2 and ms <= 2, (mb, ms)
+    assert gb <= 2e-4 and gs <= 2e-4, (gb, gs)          # more than one level: a handful of voxels
+    assert mb <= 16 and ms <= 16, (mb, ms)              # (the few: low-texture patches whose weighted variance is a rounding residue)
     assert ((b0 == 255) != (b1 == 255)).mean() == 0.0   # validity is decided before the samples: identical
     assert (d > 2e-3).mean() <= 1e-3, (d > 2e-3).mean()
-    assert d.max() <= 8e-3, d.max()
+    assert (d > 2e-2).mean() <= 1e-5 and d.max() <= 0.15, ((d > 2e-2).mean(), d.max())
     assert (r1 != 0).mean() > 0.3 and (b1 != 255).mean() > 0.3
 
 
@@ -1018,6 +1028,26 @@ def test_full_size_cfg2_sweep_only_properties():
     assert np.percentile(nearest / zplane[m][:200000], 99) < 2e-5
 
 
+def _parity_case(name):
+    _torch()
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import parity_report
+    return parity_report.run_case(name, parity_report.CASES[name], abi.FILTER_CUDA_FIXED8, with_ref=False, gpu_literal=True)
+
+
+def _assert_literal_on_gpu(gl):
+    """AVDM_SIM_LITERAL=1 — the reference's arithmetic as written, on the GPU (csrc/avdm_literal.hip) — against the oracle's literal mode
+    (= the reference's own code compiled for the CPU, bit for bit: tests/test_oracle_ref.py), on identical pyramids, NO trimming: with the
+    conditioning of the sums out of the comparison what is left is the device library's expf against glibc's, amplified by the
+    cancellation in the reference's variance — the bar holds untrimmed."""
+    assert gl["final_depth"]["rmse_untrimmed"] < 1e-3, gl["final_depth"]
+    assert gl["final_depth"]["validity_differs"] < 1e-3
+    lv = gl["similarity_volume_levels"]
+    assert lv["0"] > 0.97 and lv["2"] + lv["3+"] < 3e-3 and lv["validity_differs"] < 1e-3, lv
+
+
 def test_parity_table_cfg1():
     """The measured parity table of DESIGN.md section 2, asserted (scripts/parity_report.py; SURVEY 8d.1's cfg1: 3 views 640 x 480, 64 planes,
     single tile): everything on the GPU against everything in the oracle, NO trimming of the depth error —
@@ -1026,13 +1056,10 @@ def test_parity_table_cfg1():
       * LITERAL oracle (the reference's fp32 arithmetic as written; equal, bit for bit, to the reference's own kernels compiled for the CPU,
         tests/test_oracle_ref.py): the fp32 NCC sums of the reference are themselves several levels away from their exact value on ~40 % of
         the voxels, so the volumes differ accordingly; the depth map still agrees to RMSE < 1e-3 over the best 99.5 % of the pixels and to
-        < 5e-3 untrimmed, and the GPU result is as close to the analytic ground truth as the literal one."""
-    _torch()
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
-    import parity_report
-    r = parity_report.run_case("cfg1", parity_report.CASES["cfg1"], abi.FILTER_CUDA_FIXED8, with_ref=False)
+        < 5e-3 untrimmed, and the GPU result is as close to the analytic ground truth as the literal one;
+      * the attribution: the SAME literal arithmetic run on the GPU (AVDM_SIM_LITERAL=1) agrees with the literal oracle to < 1e-3 UNTRIMMED
+        — the distance of the default kernels to the literal evaluation is the conditioning of the reference's sums, not the device."""
+    r = _parity_case("cfg1")
     wp, lit = r["well_posed"], r["literal"]
     assert wp["final_depth"]["rmse_untrimmed"] < 1e-3, wp["final_depth"]
     assert wp["final_depth"]["validity_differs"] < 1e-3
@@ -1043,6 +1070,62 @@ def test_parity_table_cfg1():
     assert lit["final_depth"]["validity_differs"] < 2e-3
     g = lit["median_abs_vs_ground_truth"]
     assert g["gpu"] <= 1.02 * g["oracle"] + 1e-6, g
+    _assert_literal_on_gpu(r["gpu_literal_vs_oracle_literal"])
+
+
+@pytest.mark.parametrize("name", ["crop2", "crop3"])
+def test_parity_table_crops_of_the_full_size_geometry(name):
+    """crop2 / crop3 of DESIGN.md's table: 512 x 512 crops of BASELINE's configurations 2 and 3 — the same cameras, image size (1920 x 1080 /
+    4000 x 3000) and plane count (128 / 256), 4 T cameras — everything on the GPU against everything in the oracle, NO trimming.  At this
+    geometry the bar (final depth RMSE < 1e-3) holds untrimmed against BOTH evaluations of the oracle — the well-posed one and the literal
+    one, i.e. the reference's own arithmetic — and for the literal arithmetic run on the GPU."""
+    r = _parity_case(name)
+    wp, lit = r["well_posed"], r["literal"]
+    for m in (wp, lit):
+        assert m["final_depth"]["rmse_untrimmed"] < 1e-3, m["final_depth"]
+        assert m["final_depth"]["validity_differs"] < 1e-3
+        g = m["median_abs_vs_ground_truth"]
+        assert g["gpu"] <= 1.02 * g["oracle"] + 1e-6, g
+    lv = wp["similarity_volume_levels"]
+    assert lv["2"] + lv["3+"] < 2e-3 and lv["1"] < 0.05 and lv["validity_differs"] < 1e-3, lv
+    _assert_literal_on_gpu(r["gpu_literal_vs_oracle_literal"])
+
+
+def test_full_size_cfg2_sweep_against_the_oracle():
+    """BASELINE configuration 2 at FULL size — 1920 x 1080, 128 planes, 4 T cameras, sweep only — against the oracle (which finishes this
+    size in about a minute on the box's host cores): the similarity volumes of the whole frame (480 x 270 x 128 voxels, best and second
+    best over the four T cameras) against the well-posed evaluation (tolerance class of test_similarity_volume_parity) and against the
+    literal one (= the reference's own kernels), held to the literal evaluation's own distance from the well-posed one; and the
+    winner-take-all plane of the un-aggregated volume (doSgmOptimizeVolume off)."""
+    torch = _torch()
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    from oracle import oracle
+    sc = make_scene(5, 1920, 1080, seed=2, device="cuda")
+    images_np = sc.images.cpu().numpy()
+    sgm, ref = abi.SgmParams.default(), abi.RefineParams.default()
+    depths = plane_depths(sc, 128)
+    Z, tcs = len(depths), [1, 2, 3, 4]
+    pyr = [DevicePyramid(sc.images[i], 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(5)]
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+    h.run_sgm(0, tcs, depths, optimize=False, keep_raw=True)
+    torch.cuda.synchronize()
+    g_best, g_second = h.best_raw.cpu().numpy()[..., :Z], h.second.cpu().numpy()[..., :Z]
+    g_wta = h.sgm_depth_sim.cpu().numpy()[..., 0]
+    o = oracle.OracleDepthMap(images_np, sc.K, sc.R, sc.C, sgm, ref)
+    with oracle.well_posed():
+        o.run_sgm(0, tcs, depths, optimize=False)
+    wp_second = o.second[..., :Z].copy()
+    for got, want in ((g_best, o.best_raw[..., :Z]), (g_second, wp_second)):
+        d = np.abs(want.astype(np.int16) - got.astype(np.int16))
+        assert (d > 0).mean() <= 0.05, (d > 0).mean()
+        assert (d > 1).mean() <= 2e-3, (d > 1).mean()
+        assert ((want == 255) != (got == 255)).mean() <= 1e-3
+    assert (o.sgm_depth_sim[..., 0] != g_wta).mean() < 0.05  # the raw volume's arg-min flips where two planes are within a level
+    o.run_sgm(0, tcs, depths, optimize=False)  # literal: the reference's arithmetic
+    inner = (slice(4, None), slice(4, None))  # knife-edge rows of the literal border test (test_similarity_volume_parity)
+    floor, _ = level_mismatch(wp_second[inner], o.second[..., :Z][inner])
+    frac, _ = level_mismatch(o.second[..., :Z][inner], g_second[inner])
+    assert floor > 0.05 and frac <= 1.25 * floor + 0.03, (frac, floor)
 
 
 def test_harness_batched_aggregation_equals_per_tile():

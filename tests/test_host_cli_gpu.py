@@ -419,6 +419,31 @@ def test_multi_worker_exchange_equals_single_worker(dataset):
                 assert a == b, (rep, name)
 
 
+def test_multi_worker_exchange_budget(dataset):
+    """the exchange's residency is bounded: with a budget that holds ONE 640 x 480 pyramid per worker
+    (AVDM_EXCHANGE_BUDGET_MB=4: a pyramid is 3.3 MB) the owners decline their other views, every worker that needs one of those decodes
+    and converts it itself like the reference does — and every camera's maps are still byte-identical to the single-worker run."""
+    import re
+    sc, sfm, img, d = dataset
+    base = ["-i", sfm, "--imagesFolder", img, "--downscale", 1, "--rangeStart", 0, "--rangeSize", 4, "--sgmMaxDepths", 64,
+            "--colorOptimizationNbIterations", 5, "--tileBufferWidth", 400, "--tileBufferHeight", 300, "--tilePadding", 32, "-v", "info"]
+    out1, out2 = os.path.join(d, "out_w1"), os.path.join(d, "out_w2_budget")
+    if not os.path.exists(os.path.join(out1, "%d_depthMap.exr" % scene_io.view_id(0))):
+        run_cli(base + ["-o", out1, "--nbGPUs", 1])
+    env = dict(os.environ, AVDM_FAKE_DEVICES="2", AVDM_EXCHANGE_BUDGET_MB="4")
+    r = subprocess.run([CLI] + [str(a) for a in base + ["-o", out2, "--nbGPUs", 2]], capture_output=True, text=True, timeout=90, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    log = r.stdout + r.stderr
+    assert "residency budget 4 MB per worker" in log, log[-2000:]
+    m = re.search(r"Pyramid exchange: (\d+) views converted once, (\d+) peer copies .* (\d+) views over the residency budget", log)
+    assert m, log[-2000:]
+    assert int(m.group(1)) == 2 and int(m.group(3)) == NVIEWS - 2, m.groups()  # one resident pyramid per worker, the rest declined
+    for i in range(4):
+        vid = scene_io.view_id(i)
+        for name in ("%d_depthMap.exr" % vid, "%d_simMap.exr" % vid):
+            assert open(os.path.join(out1, name), "rb").read() == open(os.path.join(out2, name), "rb").read(), name
+
+
 def test_prepare_dense_scene_undistorts_and_feeds_the_estimation(tmp_path):
     """aliceVision_prepareDenseScene (the program before this stage): views of a camera with radial distortion come out undistorted —
     bit for bit the oracle's camera::UndistortImage — with the camera in the image metadata, and aliceVision_depthMapEstimation plans

@@ -97,8 +97,10 @@ def test_bench_cfg5_tiles_are_the_reference_grid():
     import os
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
     fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "tile_rois"][0]
+    consts = [n for n in ast.parse(src).body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "TILE_BUFFER"]
     ns = {}
-    exec(compile(ast.Module([fn], []), "bench.py", "exec"), ns)
+    exec(compile(ast.Module(consts + [fn], []), "bench.py", "exec"), ns)
+    assert ns["TILE_BUFFER"] == (1664, 1152)
     got = ns["tile_rois"](6000, 4000, 4)
     assert got == hr.tile_roi_list(1664, 1152, 64, 6000, 4000, 4) and len(got) == 16
     assert ns["tile_rois"](4000, 3000, 1) == [None]

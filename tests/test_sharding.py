@@ -103,3 +103,30 @@ def test_exchange_is_identity_without_a_process_group():
     from alicevision_amd.sharding import exchange_pyramid
     b = torch.arange(10, dtype=torch.uint8)
     assert exchange_pyramid(b, 0, None)[0] is b
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (one process per rank, rendezvous on
+    127.0.0.1): the launch, the process group, the round-robin ownership and the barrier / MAX-over-ranks timing protocol run here on the
+    CPU with --dry-run (gloo, no GPU work) and print ONE JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "cfg1", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] and out["steps"] == 4
+    assert out["views_owned_total"] == out["views"] == 3 and out["reference_cameras_total"] == 3  # every view / camera owned exactly once
+    assert len(out["rank0_cameras"]) == 4 and set(out["rank0_cameras"]) == {0, 2}  # rank 0 of 2 owns views 0 and 2
+    # and the command it becomes is the driver's own
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "2"], port=29511)
+    assert cmd[1:9] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "29511"]
+    assert cmd[9].endswith("bench.py") and cmd[10:] == ["--gpus", "4", "--steps", "2"]
