@@ -121,6 +121,7 @@ SIGNATURES = {
     "avdm_downscale_with_gaussian_blur": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "avdm_pyramid_build_levels": (i32, [P(Pyramid), vp]),
     "avdm_image_resize": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, vp]),
+    "avdm_image_decode_integer": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "avdm_image_undistort": (i32, [vp, i32, vp, i32, P(Intrinsic), P(C.c_float * 4), vp]),
     "avdm_pyramid_fill": (i32, [P(Pyramid), vp, i32, vp, vp]),
     "avdm_tex2dlod": (i32, [vp, P(Pyramid), vp, i32, vp]),

@@ -276,6 +276,51 @@ __device__ __forceinline__ float4 tex2DLod(const Tex& T, float u, float v, float
     return r;
 }
 
+// tex2DLod at ONE level of detail fixed for a whole launch (a stage's level, DeviceMipmapImage::getLevel): the clamp, the floor and the
+// quantised blend fraction of tex2DLod are evaluated once on the host, the kernel blends two tex2D_level fetches — or fetches one when the
+// level is integral (the default scale combinations).  Same operations as tex2DLod on the same operands: identical floats.  This is
+// what lets the stages run at FRACTIONAL levels (sgmScale / refineScale that are not a power-of-two multiple of the pyramid's first level,
+// e.g. --sgmScale 3 --refineScale 1; DeviceMipmapImage.cpp:92-99, deviceMipmappedArray.cu:348).
+struct TexLod
+{
+    TexLevel l0, l1;
+    float g;  // blend fraction towards l1 (quantised to 1/256 in FIXED8 mode)
+    int two;  // 0: l0 alone
+};
+inline TexLod make_tex_lod(const avdm_pyramid_t* p, int downscale)
+{
+    const Tex t = make_tex(p);
+    const float maxl = (float)(t.levels - 1);
+    float lod = tex_level_of(p, downscale);
+    lod = !(lod > 0.0f) ? 0.0f : (lod > maxl ? maxl : lod);
+    const float fl = floorf(lod);
+    float g = lod - fl;
+    if(t.mode == AVDM_FILTER_CUDA_FIXED8)
+        g = floorf(g * 256.0f + 0.5f) * (1.0f / 256.0f); // quant8
+    const int l0 = (int)fl;
+    TexLod L;
+    L.l0 = t.lv[l0];
+    L.two = (g != 0.0f && l0 + 1 < t.levels) ? 1 : 0;
+    L.l1 = t.lv[L.two ? l0 + 1 : l0];
+    L.g = g;
+    return L;
+}
+template <bool FIXED8>
+__device__ __forceinline__ float4 tex2D_lod(const TexLod& T, float u, float v)
+{
+    const float4 c0 = tex2D_level<FIXED8>(T.l0, u, v);
+    if(!T.two)
+        return c0;
+    const float4 c1 = tex2D_level<FIXED8>(T.l1, u, v);
+    const float g = T.g;
+    float4 r;
+    r.x = (1.0f - g) * c0.x + g * c1.x;
+    r.y = (1.0f - g) * c0.y + g * c1.y;
+    r.z = (1.0f - g) * c0.z + g * c1.z;
+    r.w = (1.0f - g) * c0.w + g * c1.w;
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave64 helpers (DPP)
 // ---------------------------------------------------------------------------------------------

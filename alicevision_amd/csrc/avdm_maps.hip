@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256)
 }
 
 template <bool FIXED8>
-__global__ void __launch_bounds__(256) upscale_depth_pixsize_kernel(float2* out, int out_pitch, const float2* in, int in_pitch, TexLevel L, float sxN,
+__global__ void __launch_bounds__(256) upscale_depth_pixsize_kernel(float2* out, int out_pitch, const float2* in, int in_pitch, TexLod L, float sxN,
                                                                     float syN, int stepXY, int halfNbDepths, float ratio, int bilinear, avdm_roi_t roi)
 {
     MAP_XY();
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256) upscale_depth_pixsize_kernel(float2* out,
     const unsigned y = (roi.y.begin + roiY) * (unsigned)stepXY;
     float2* o = (float2*)((char*)out + (long long)roiY * out_pitch) + roiX;
     // sxN = nominal level width (getDimensions), syN = height
-    const float alpha = tex2D_level<FIXED8>(L, ((float)x + 0.5f) / sxN, ((float)y + 0.5f) / syN).w;
+    const float alpha = tex2D_lod<FIXED8>(L, ((float)x + 0.5f) / sxN, ((float)y + 0.5f) / syN).w;
     const float oy = ((float)roiY - 0.5f) * ratio;
     const float ox = ((float)roiX - 0.5f) * ratio;
     float2 dT;
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256) upscale_depth_pixsize_kernel(float2* out,
 // ---- colour-guided optimisation (mapKernels.cuh:25-101, 479-608; Map.cu:193-263) ----
 template <bool FIXED8>
 __global__ void __launch_bounds__(256)
-  var_L_kernel(float* out, int out_pitch, TexLevel L, float wN, float hN, int stepXY, avdm_roi_t roi)
+  var_L_kernel(float* out, int out_pitch, TexLod L, float wN, float hN, int stepXY, avdm_roi_t roi)
 {
     MAP_XY();
     if(roiX >= roi.x.end - roi.x.begin || roiY >= roi.y.end - roi.y.begin)
@@ -502,10 +502,10 @@ __global__ void __launch_bounds__(256)
     const float x = (float)(roi.x.begin + roiX) * (float)stepXY;
     const float y = (float)(roi.y.begin + roiY) * (float)stepXY;
     const float iw = 1.f / wN, ih = 1.f / hN;
-    const float xM1 = tex2D_level<FIXED8>(L, ((x - 1.f) + 0.5f) * iw, ((y + 0.f) + 0.5f) * ih).x;
-    const float xP1 = tex2D_level<FIXED8>(L, ((x + 1.f) + 0.5f) * iw, ((y + 0.f) + 0.5f) * ih).x;
-    const float yM1 = tex2D_level<FIXED8>(L, ((x + 0.f) + 0.5f) * iw, ((y - 1.f) + 0.5f) * ih).x;
-    const float yP1 = tex2D_level<FIXED8>(L, ((x + 0.f) + 0.5f) * iw, ((y + 1.f) + 0.5f) * ih).x;
+    const float xM1 = tex2D_lod<FIXED8>(L, ((x - 1.f) + 0.5f) * iw, ((y + 0.f) + 0.5f) * ih).x;
+    const float xP1 = tex2D_lod<FIXED8>(L, ((x + 1.f) + 0.5f) * iw, ((y + 0.f) + 0.5f) * ih).x;
+    const float yM1 = tex2D_lod<FIXED8>(L, ((x + 0.f) + 0.5f) * iw, ((y - 1.f) + 0.5f) * ih).x;
+    const float yP1 = tex2D_lod<FIXED8>(L, ((x + 0.f) + 0.5f) * iw, ((y + 1.f) + 0.5f) * ih).x;
     const float gx = xM1 - xP1, gy = yM1 - yP1;
     *((float*)((char*)out + (long long)roiY * out_pitch) + roiX) = sqrtf(gx * gx + gy * gy);
 }
@@ -963,6 +963,31 @@ static int oiio_resize_taps(int dstN, int srcN, std::vector<float>& weights, std
     return taps;
 }
 
+// avdm_image_decode_integer: one lane per pixel; the transfer curve is a table (host-evaluated, see the entry point), alpha is linear
+template <typename T>
+__global__ void __launch_bounds__(256) decode_integer_kernel(float4* dst, int dst_pitch, const T* src, int src_pitch, int width, int height, int channels,
+                                                             const float* __restrict__ lut, float inv)
+{
+    MAP_XY();
+    if(roiX >= (unsigned)width || roiY >= (unsigned)height)
+        return;
+    const T* p = (const T*)((const char*)src + (long long)roiY * src_pitch) + (size_t)roiX * channels;
+    float4 o;
+    if(channels >= 3)
+    {
+        o.x = lut[p[0]];
+        o.y = lut[p[1]];
+        o.z = lut[p[2]];
+        o.w = channels == 4 ? (float)p[3] * inv : 1.0f;
+    }
+    else
+    {
+        o.x = o.y = o.z = lut[p[0]];
+        o.w = channels == 2 ? (float)p[1] * inv : 1.0f;
+    }
+    *((float4*)((char*)dst + (long long)roiY * dst_pitch) + roiX) = o;
+}
+
 static inline dim3 map_grid(unsigned w, unsigned h) { return dim3(divUp(w, 64), divUp(h, 4)); }
 static inline int stream_blocks(long long total)
 {
@@ -1116,20 +1141,49 @@ int avdm_compute_sgm_upscaled_depth_pixsize_map(float* out_map, int out_pitch, c
     const unsigned roiW = roi.x.end - roi.x.begin, roiH = roi.y.end - roi.y.begin;
     if(roiW == 0 || roiH == 0)
         return 0;
-    int level;
-    if(!lod_is_integral(rc_pyr, rp->scale, &level))
-        return set_error_msg(1, "avdm_compute_sgm_upscaled_depth_pixsize_map: non-integral mip level");
-    const Tex t = make_tex(rc_pyr);
+    const TexLod lodTex = make_tex_lod(rc_pyr, rp->scale); // the Refine stage's level of the R image (fractional levels blend two)
     const float wN = (float)tex_dim_w(rc_pyr, rp->scale), hN = (float)tex_dim_h(rc_pyr, rp->scale);
     if(rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8)
         hipLaunchKernelGGL(upscale_depth_pixsize_kernel<true>, map_grid(roiW, roiH), dim3(256), 0, (hipStream_t)stream, (float2*)out_map, out_pitch,
-                           (const float2*)in_sgm_depth_thickness, in_pitch, t.lv[level], wN, hN, rp->stepXY, rp->halfNbDepths, ratio,
+                           (const float2*)in_sgm_depth_thickness, in_pitch, lodTex, wN, hN, rp->stepXY, rp->halfNbDepths, ratio,
                            rp->interpolateMiddleDepth, roi);
     else
         hipLaunchKernelGGL(upscale_depth_pixsize_kernel<false>, map_grid(roiW, roiH), dim3(256), 0, (hipStream_t)stream, (float2*)out_map, out_pitch,
-                           (const float2*)in_sgm_depth_thickness, in_pitch, t.lv[level], wN, hN, rp->stepXY, rp->halfNbDepths, ratio,
+                           (const float2*)in_sgm_depth_thickness, in_pitch, lodTex, wN, hN, rp->stepXY, rp->halfNbDepths, ratio,
                            rp->interpolateMiddleDepth, roi);
     AVDM_LAUNCH_CHECK("avdm_compute_sgm_upscaled_depth_pixsize_map");
+}
+
+int avdm_image_decode_integer(float* dst_rgba, int dst_pitch, const void* src, int src_pitch, int width, int height, int channels, int bits,
+                              int srgb_to_linear, void* stream)
+{
+    if(width <= 0 || height <= 0)
+        return set_error_msg(1, "avdm_image_decode_integer: empty image");
+    if(channels < 1 || channels > 4 || (bits != 8 && bits != 16))
+        return set_error_msg(1, "avdm_image_decode_integer: 1-4 channels of 8 or 16 bits");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = bits == 8 ? 256 : 65536;
+    std::vector<float> lut((size_t)n);
+    const float inv = 1.0f / (float)(n - 1);
+    for(int v = 0; v < n; ++v)
+    {
+        const float x = (float)v * inv;
+        lut[(size_t)v] = !srgb_to_linear ? x : (x <= 0.04045f ? x * (1.0f / 12.92f) : powf((x + 0.055f) * (1.0f / 1.055f), 2.4f));
+    }
+    const StreamScratch lease(st, (size_t)n * sizeof(float));
+    float* dlut = (float*)lease.ptr();
+    if(dlut == nullptr)
+        return set_error_msg(2, "avdm_image_decode_integer: scratch allocation failed");
+    const hipError_t e = hipMemcpyAsync(dlut, lut.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, st);
+    if(e != hipSuccess)
+        return ::avdm::set_error(e, "avdm_image_decode_integer");
+    if(bits == 8)
+        hipLaunchKernelGGL(decode_integer_kernel<uint8_t>, map_grid((unsigned)width, (unsigned)height), dim3(256), 0, st, (float4*)dst_rgba, dst_pitch,
+                           (const uint8_t*)src, src_pitch, width, height, channels, dlut, inv);
+    else
+        hipLaunchKernelGGL(decode_integer_kernel<uint16_t>, map_grid((unsigned)width, (unsigned)height), dim3(256), 0, st, (float4*)dst_rgba, dst_pitch,
+                           (const uint16_t*)src, src_pitch, width, height, channels, dlut, inv);
+    AVDM_LAUNCH_CHECK("avdm_image_decode_integer");
 }
 
 int avdm_image_undistort(float* dst_rgba, int dst_pitch, const float* src_rgba, int src_pitch, const avdm_intrinsic_t* cam, const float fill_rgba[4],
@@ -1207,10 +1261,7 @@ int avdm_depth_sim_map_optimize_gradient_descent(float* out_opt_depth_sim, int o
     const unsigned roiW = roi.x.end - roi.x.begin, roiH = roi.y.end - roi.y.begin;
     if(roiW == 0 || roiH == 0)
         return 0;
-    int level;
-    if(!lod_is_integral(rc_pyr, rp->scale, &level))
-        return set_error_msg(1, "avdm_depth_sim_map_optimize_gradient_descent: non-integral mip level");
-    const Tex t = make_tex(rc_pyr);
+    const TexLod lodTex = make_tex_lod(rc_pyr, rp->scale);
     const float wN = (float)tex_dim_w(rc_pyr, rp->scale), hN = (float)tex_dim_h(rc_pyr, rp->scale);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = map_grid(roiW, roiH);
@@ -1218,9 +1269,9 @@ int avdm_depth_sim_map_optimize_gradient_descent(float* out_opt_depth_sim, int o
     hipLaunchKernelGGL(copy_rows_kernel, grid, dim3(256), 0, st, (float2*)out_opt_depth_sim, out_pitch, (const float2*)sgm_depth_pixsize, sgm_pitch, roiW,
                        roiH);
     if(rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8)
-        hipLaunchKernelGGL(var_L_kernel<true>, grid, dim3(256), 0, st, img_variance, var_pitch, t.lv[level], wN, hN, rp->stepXY, roi);
+        hipLaunchKernelGGL(var_L_kernel<true>, grid, dim3(256), 0, st, img_variance, var_pitch, lodTex, wN, hN, rp->stepXY, roi);
     else
-        hipLaunchKernelGGL(var_L_kernel<false>, grid, dim3(256), 0, st, img_variance, var_pitch, t.lv[level], wN, hN, rp->stepXY, roi);
+        hipLaunchKernelGGL(var_L_kernel<false>, grid, dim3(256), 0, st, img_variance, var_pitch, lodTex, wN, hN, rp->stepXY, roi);
 
     const int nIter = rp->optimizationNbIterations;
     const char* legacy = getenv("AVDM_OPT_DEPTH_MAP_FORM"); // A/B: the two-launches-per-iteration depth-map form

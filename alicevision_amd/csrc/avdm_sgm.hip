@@ -62,7 +62,7 @@ __device__ __forceinline__ float exp_p2(float x)
 // ---- adaptive P2 (kernels.cuh:696-720), evaluated once per (column, slice) into a float map ----------------------------
 struct SgmP2Tile
 {
-    TexLevel L;         // R image at the SGM mip level
+    TexLod L;           // R image at the SGM mip level (one level, or two blended when the level is fractional)
     float rcW, rcH;     // nominal level dims (DeviceMipmapImage::getDimensions)
     int beginX, beginY; // ROI offsets as the reference applies them to (v.x, v.y)
     int A, B;
@@ -104,8 +104,8 @@ __global__ void __launch_bounds__(256) sgm_p2_map_kernel(SgmP2Batch S)
         const int imY1 = (int)((float)imY0 - S.step * (float)(T.scanIsX ? 0 : 1));
         const float u0 = ((float)imX0 + 0.5f) / T.rcW, v0 = ((float)imY0 + 0.5f) / T.rcH;
         const float u1 = ((float)imX1 + 0.5f) / T.rcW, v1 = ((float)imY1 + 0.5f) / T.rcH;
-        const float4 c0 = S.fixed8 ? tex2D_level<true>(T.L, u0, v0) : tex2D_level<false>(T.L, u0, v0);
-        const float4 c1 = S.fixed8 ? tex2D_level<true>(T.L, u1, v1) : tex2D_level<false>(T.L, u1, v1);
+        const float4 c0 = S.fixed8 ? tex2D_lod<true>(T.L, u0, v0) : tex2D_lod<false>(T.L, u0, v0);
+        const float4 c1 = S.fixed8 ? tex2D_lod<true>(T.L, u1, v1) : tex2D_lod<false>(T.L, u1, v1);
         const float dx = c0.x - c1.x, dy = c0.y - c1.y, dz = c0.z - c1.z;
         const float deltaC = sqrtf(dx * dx + dy * dy + dz * dz);
         P2 = 80.f + (255.f - 80.f) * (1.0f / (1.0f + exp_p2(10.0f * ((deltaC - S.P2w) / 80.f))));
@@ -1466,12 +1466,8 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
         {
             const avdm_sgm_tile_t& t = tiles[idx[i]];
             const int dimX = (int)(t.roi.x.end - t.roi.x.begin), dimY = (int)(t.roi.y.end - t.roi.y.begin);
-            int level;
-            if(!lod_is_integral(t.rc_pyr, sp->scale, &level))
-                return set_error_msg(1, "avdm_volume_optimize: non-integral mip level");
-            const Tex tex = make_tex(t.rc_pyr);
             SgmP2Tile& R = Q.t[nq++];
-            R.L = tex.lv[level];
+            R.L = make_tex_lod(t.rc_pyr, sp->scale);
             R.rcW = (float)tex_dim_w(t.rc_pyr, sp->scale);
             R.rcH = (float)tex_dim_h(t.rc_pyr, sp->scale);
             // deviceSimilarityVolumeKernels.cuh:688-689: beginX = (axisT.x == 0) ? roi.x.begin : roi.y.begin, applied to v.x (sic)

@@ -65,6 +65,9 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #ifndef AVDM_REFINE_PLANES_PER_PASS
 #define AVDM_REFINE_PLANES_PER_PASS 4 // planes per pass over the patch in the default Refine instantiation: 1, 2 (pairs) or 4
 #endif
+#ifndef AVDM_EXPERIMENT_FAST_ONLY
+#define AVDM_EXPERIMENT_FAST_ONLY 0 // compile-time experiment (register accounting only): the default instantiations without their fall-back loops
+#endif
 #ifndef AVDM_NCC_QUAD_W3_MODE
 #define AVDM_NCC_QUAD_W3_MODE 0 // 7-tap rows of the four-plane form: 0 = 2 + 2 + 2 + 1 with fences, 1 = one sample at a time
 #endif
@@ -1533,7 +1536,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         }
     }
 #pragma unroll 1
-    for(int k0 = 0; k0 < 4 && !quadDone; k0 += 2)
+    for(int k0 = 0; k0 < 4 && !quadDone && !(AVDM_EXPERIMENT_FAST_ONLY && LEAN); k0 += 2)
     {
         bool pairDone = false;
         {
@@ -1935,7 +1938,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         }
     }
 #pragma unroll 1
-    for(int k0 = 0; k0 < 8; k0 += 2)
+    for(int k0 = 0; k0 < 8 && !(AVDM_EXPERIMENT_FAST_ONLY && LEAN); k0 += 2)
     {
         if((quadsDone >> (k0 >> 2)) & 1u) // uniform per wave
             continue;
@@ -2332,12 +2335,15 @@ static std::mutex g_patchPatternMutex;           // one host thread per device m
 static unsigned* g_stats = nullptr; // device counters, allocated on first use when AVDM_SIM_STATS=1
 
 // paired: in = the caller would like the 16-byte paired records (FIXED8 pyramids only); out = whether the LDS budget allows them
+// fractional: out = the stage's level of detail is not an integral level of the pyramids (scales that are not a power-of-two multiple of the
+// pyramid's first level, e.g. --sgmScale 3 --refineScale 1): the caller runs the plain trilinear kernel (similarity_cs_kernel), whose taps
+// go through the software texture unit at A.mipmapLevel; the sample positions are then expressed in the texel space of the level BELOW
 static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcPyr, const avdm_pyramid_t* tcPyr, int scale, int stepXY, int wsh,
-                          double gammaC, double gammaP, bool& paired)
+                          double gammaC, double gammaP, bool& paired, bool& fractional)
 {
     int rl, tl;
-    if(!lod_is_integral(rcPyr, scale, &rl) || !lod_is_integral(tcPyr, scale, &tl))
-        return false;
+    const bool rInt = lod_is_integral(rcPyr, scale, &rl), tInt = lod_is_integral(tcPyr, scale, &tl);
+    fractional = !(rInt && tInt);
     const Tex rt = make_tex(rcPyr), tt = make_tex(tcPyr);
     A.rcL = rt.lv[rl];
     A.tcL = tt.lv[tl];
@@ -2360,6 +2366,12 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
     const float log2e = 1.44269504088896340736f;
     A.negInvGammaC_log2e = -A.invGammaC * log2e;
     A.mipmapLevel = (float)rl;
+    if(fractional)
+    { // DeviceMipmapImage::getLevel of the R image, clamped like tex2DLod clamps it; both images are sampled at it (Patch.cuh:499-505)
+        const float maxl = (float)(rcPyr->levels - 1);
+        const float l = tex_level_of(rcPyr, scale);
+        A.mipmapLevel = !(l > 0.0f) ? 0.0f : (l > maxl ? maxl : l);
+    }
     A.wsh = wsh;
     const int n = 2 * wsh + 1;
     for(int yp = -wsh; yp <= wsh; ++yp)
@@ -2571,15 +2583,14 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
     NccArgs A;
     PatchTable tab;
     const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
-    bool paired = fixed8;
-    if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, sp->scale, sp->stepXY, sp->wsh, sp->gammaC, sp->gammaP, paired))
-        return set_error_msg(1, "avdm_volume_compute_similarity: non-integral mip level");
+    bool paired = fixed8, fractional = false;
+    fill_ncc_args(A, tab, rc_pyr, tc_pyr, sp->scale, sp->stepXY, sp->wsh, sp->gammaC, sp->gammaP, paired, fractional);
     const unsigned nchunks = ((dr.end + 3) >> 2) - (dr.begin >> 2);
     if(((dr.end + 3) & ~3u) > (unsigned)pitch_x)
         return set_error_msg(1, "avdm_volume_compute_similarity: pitch_x too small for the depth range (must cover the 4-aligned range)");
     if(sp->useCustomPatchPattern && !g_patchPatternSet)
         return set_error_msg(1, "avdm_volume_compute_similarity: useCustomPatchPattern without a pattern (avdm_build_custom_patch_pattern)");
-    if(sp->useConsistentScale || sp->useCustomPatchPattern)
+    if(sp->useConsistentScale || sp->useCustomPatchPattern || fractional)
     {
         CsArgs S;
         S.rcT = make_tex(rc_pyr);
@@ -2646,13 +2657,12 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
     NccArgs A;
     PatchTable tab;
     const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
-    bool paired = fixed8;
-    if(!fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->stepXY, rp->wsh, rp->gammaC, rp->gammaP, paired))
-        return set_error_msg(1, "avdm_volume_refine_similarity: non-integral mip level");
+    bool paired = fixed8, fractional = false;
+    fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->stepXY, rp->wsh, rp->gammaC, rp->gammaP, paired, fractional);
     const unsigned nchunks = ((dr.end + 7) >> 3) - (dr.begin >> 3);
     if(rp->useCustomPatchPattern && !g_patchPatternSet)
         return set_error_msg(1, "avdm_volume_refine_similarity: useCustomPatchPattern without a pattern (avdm_build_custom_patch_pattern)");
-    if(rp->useConsistentScale || rp->useCustomPatchPattern)
+    if(rp->useConsistentScale || rp->useCustomPatchPattern || fractional)
     {
         CsArgs S;
         S.rcT = make_tex(rc_pyr);

@@ -1,11 +1,15 @@
 // MultiViewParams.cpp — see MultiViewParams.hpp for the reference lines restated.
 #include "MultiViewParams.hpp"
+#include "png.hpp"
+
+#include <cctype>
 
 #include "log.hpp"
 
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cfloat>
 #include <cmath>
@@ -29,7 +33,22 @@ struct SortedId
     int id;
     float value;
 };
+bool isPngPath(const std::string& path)
+{
+    if(path.size() < 4)
+        return false;
+    std::string e = path.substr(path.size() - 4);
+    for(char& c : e)
+        c = (char)std::tolower((unsigned char)c);
+    return e == ".png";
+}
 } // namespace
+
+unsigned long long MultiViewParams::nextGeneration()
+{
+    static std::atomic<unsigned long long> counter{0};
+    return ++counter;
+}
 
 MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imagesFolder, const std::string& depthMapsFolder,
                                  const std::string& depthMapsFilterFolder, EFileType fileType, int downscale)
@@ -55,11 +74,22 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
                 path = getFileNameFromViewId(*this, view.viewId, EFileType::normalMap);
             else if(_imagesFolder != "/" && dirExists(_imagesFolder))
             {
-                // one file per view named <viewId>.<ext>; this build decodes OpenEXR only (PrepareDenseScene's output format)
-                const std::string candidate = _imagesFolder + std::to_string(view.viewId) + ".exr";
-                if(!fileExists(candidate))
+                // one file per view named <viewId>.<ext> (MultiViewParams.cpp:83-103: exactly one file with a supported extension); this build
+                // decodes OpenEXR (PrepareDenseScene's output format) and PNG
+                std::string candidate;
+                for(const char* ext : {".exr", ".png"})
+                {
+                    const std::string c = _imagesFolder + std::to_string(view.viewId) + ext;
+                    if(!fileExists(c))
+                        continue;
+                    if(!candidate.empty())
+                        throw std::runtime_error("Ambiguous case: Multiple image file found for the view '" + std::to_string(view.viewId) + "' in folder '" +
+                                                 _imagesFolder + "'.");
+                    candidate = c;
+                }
+                if(candidate.empty())
                     throw std::runtime_error("Cannot find image file coresponding to the view '" + std::to_string(view.viewId) + "' in folder '" +
-                                             _imagesFolder + "' (expected " + std::to_string(view.viewId) + ".exr).");
+                                             _imagesFolder + "' (expected " + std::to_string(view.viewId) + ".exr or .png).");
                 path = candidate;
             }
             dimensions.emplace(view.width, view.height);
@@ -92,7 +122,15 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
         const ImageParams& imgParams = _imagesParams.at(i);
         ExrImage header;
         bool exists = fileExists(imgParams.path);
-        if(exists)
+        if(exists && isPngPath(imgParams.path))
+        {
+            // a PNG carries no AliceVision metadata here: its size gives the scale, the camera comes from the SfMData
+            PngImage png;
+            readPng(imgParams.path, png, true);
+            header.width = png.width;
+            header.height = png.height;
+        }
+        else if(exists)
         {
             try
             {
@@ -429,6 +467,38 @@ std::shared_ptr<const HostImage> ImagesCache::getImg_sync(int camId)
     }
     // decode outside the lock: several images can be read at once (DepthMapEstimator pre-warms the cache of a batch in parallel)
     const std::string& path = _mp.getImagePath(camId);
+    if(isPngPath(path))
+    {
+        // inflate + scan-line filters on the host (sequential by nature); the integer samples go to the device as they are and become linear
+        // float RGBA there (avdm_image_decode_integer: image::readImage(..., LINEAR) for an 8- / 16-bit sRGB file)
+        PngImage png;
+        readPng(path, png);
+        if(_mp.getOriginalWidth(camId) != png.width || _mp.getOriginalHeight(camId) != png.height)
+            throw std::runtime_error("Bad image dimension for camera : " + std::to_string(camId) + "\n\t- image path : " + path + "\n\t- expected dimension : " +
+                                     std::to_string(_mp.getOriginalWidth(camId)) + "x" + std::to_string(_mp.getOriginalHeight(camId)) +
+                                     "\n\t- real dimension : " + std::to_string(png.width) + "x" + std::to_string(png.height));
+        auto full = std::make_shared<HostImage>();
+        full->raw.swap(png.samples);
+        full->rawChannels = png.channels;
+        full->rawBits = png.bits;
+        const int s = _mp.getProcessDownscale();
+        full->srcWidth = png.width;
+        full->srcHeight = png.height;
+        full->width = s > 1 ? png.width / s : png.width;
+        full->height = s > 1 ? png.height / s : png.height;
+        std::shared_ptr<const HostImage> result = full;
+        std::lock_guard<std::mutex> lock(_mutex);
+        if(_cache.size() >= _max)
+        {
+            auto oldest = _cache.begin();
+            for(auto i = _cache.begin(); i != _cache.end(); ++i)
+                if(i->second.first < oldest->second.first)
+                    oldest = i;
+            _cache.erase(oldest);
+        }
+        _cache[camId] = {++_tick, result};
+        return result;
+    }
     ExrImage exr;
     readExr(path, exr);
     if(_mp.getOriginalWidth(camId) != exr.width || _mp.getOriginalHeight(camId) != exr.height)

@@ -73,6 +73,8 @@ class MultiViewParams
     int getMaxImageWidth() const { return _maxImageWidth / _processDownscale; }
     int getMaxImageHeight() const { return _maxImageHeight / _processDownscale; }
     int getNbCameras() const { return (int)_imagesParams.size(); }
+    // unique per constructed object (process-wide counter): caches keyed by the object's address compare it too
+    unsigned long long generation() const { return _generation; }
     int getIndexFromViewId(IndexT viewId) const { return _imageIdsPerViewId.at(viewId); }
     float getMinViewAngle() const { return _minViewAngle; }
     float getMaxViewAngle() const { return _maxViewAngle; }
@@ -99,6 +101,8 @@ class MultiViewParams
     const SfMData& _sfmData;
     std::string _imagesFolder, _depthMapsFolder, _depthMapsFilterFolder;
     int _processDownscale = 1;
+    unsigned long long _generation = nextGeneration();
+    static unsigned long long nextGeneration();
     float _minViewAngle = 2.0f, _maxViewAngle = 70.0f;
     std::vector<ImageParams> _imagesParams;
     std::vector<int> _imagesScale;
@@ -128,6 +132,10 @@ struct HostImage
     int width = 0, height = 0;       // size the process works at: source size / --downscale (integer division, imageAlgo.cpp:326-368)
     int srcWidth = 0, srcHeight = 0; // size of `rgba` as decoded; the --downscale resize runs on the device (avdm_image_resize)
     std::vector<float> rgba;
+    // an integer file (PNG): the decoder's samples as stored; DeviceMipmapImage::fill uploads THESE (a quarter / half of the float RGBA bytes)
+    // and converts them to linear float RGBA on the device (avdm_image_decode_integer).  `rgba` is empty then.
+    std::vector<unsigned char> raw;
+    int rawChannels = 0, rawBits = 0;
 };
 // mvsUtils/fileIO.cpp:389-443 loadImage + mvsUtils/ImagesCache.hpp: a small thread-safe RAM cache keyed by camera index
 class ImagesCache

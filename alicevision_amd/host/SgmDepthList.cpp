@@ -94,6 +94,7 @@ struct Seed
 struct SeedIndex
 {
     const MultiViewParams* mp;
+    unsigned long long mpGeneration; // a new MultiViewParams allocated at the address of a dead one is not the same scene
     int rc;
     std::vector<Seed> seeds;
     std::vector<std::uint64_t> bits; // per seed: ceil(nbCameras / 64) words, bit c = camera index c observes the landmark
@@ -105,6 +106,7 @@ std::shared_ptr<const SeedIndex> buildSeedIndex(const MultiViewParams& mp, int r
 {
     auto idx = std::make_shared<SeedIndex>();
     idx->mp = &mp;
+    idx->mpGeneration = mp.generation();
     idx->rc = rc;
     const int nCams = mp.getNbCameras();
     idx->wordsPerSeed = ((std::size_t)nCams + 63) / 64;
@@ -145,7 +147,7 @@ std::shared_ptr<const SeedIndex> seedIndexOf(const MultiViewParams& mp, int rc)
     static std::list<std::shared_ptr<const SeedIndex>> recent;
     std::lock_guard<std::mutex> lock(guard);
     for(auto it = recent.begin(); it != recent.end(); ++it)
-        if((*it)->mp == &mp && (*it)->rc == rc)
+        if((*it)->mp == &mp && (*it)->mpGeneration == mp.generation() && (*it)->rc == rc)
         {
             recent.splice(recent.begin(), recent, it);
             return recent.front();

@@ -32,10 +32,20 @@ void DeviceMipmapImage::fill(const HostImage& img, int minDownscale, int maxDown
     _pyr = p;
     const int srcW = img.srcWidth > 0 ? img.srcWidth : img.width, srcH = img.srcHeight > 0 ? img.srcHeight : img.height;
     const size_t srcBytes = (size_t)srcW * srcH * 16, imgBytes = (size_t)img.width * img.height * 16;
-    DeviceBuffer rgba(srcBytes), resized, scratch;
+    DeviceBuffer rgba(srcBytes), resized, scratch, samples;
     if(minDownscale > 1)
         scratch.allocate((size_t)img.width * img.height * 8);
-    AVDM_HIP_CHECK(hipMemcpyAsync(rgba.ptr(), img.rgba.data(), srcBytes, hipMemcpyHostToDevice, stream));
+    if(!img.raw.empty())
+    {
+        // an integer file (PNG): upload the decoder's samples, make the linear float RGBA image on the device
+        samples.allocate(img.raw.size());
+        AVDM_HIP_CHECK(hipMemcpyAsync(samples.ptr(), img.raw.data(), img.raw.size(), hipMemcpyHostToDevice, stream));
+        avdmCheck(avdm_image_decode_integer(rgba.as<float>(), srcW * 16, samples.ptr(), srcW * img.rawChannels * (img.rawBits / 8), srcW, srcH, img.rawChannels,
+                                            img.rawBits, 1, stream),
+                  "avdm_image_decode_integer");
+    }
+    else
+        AVDM_HIP_CHECK(hipMemcpyAsync(rgba.ptr(), img.rgba.data(), srcBytes, hipMemcpyHostToDevice, stream));
     const float* processImage = rgba.as<float>();
     if(srcW != img.width || srcH != img.height)
     {

@@ -277,21 +277,19 @@ int aliceVision_main(int argc, char* argv[])
             return EXIT_FAILURE;
         }
     }
-    // Mip levels.  The reference samples its images at the fractional level log2(scale / min(sgmScale, refineScale)) with a mip-linear texture
-    // (deviceMipmappedArray.cu:348, DeviceMipmapImage::getLevel); the default-path kernels of this implementation stage ONE level in LDS, so
-    // the two scales must be a power-of-two multiple of each other (every combination Meshroom's defaults produce).  Said here, at parse
-    // time, instead of failing in the middle of the first tile (out of scope).
+    // Mip levels.  The reference samples its images at the level log2(scale / min(sgmScale, refineScale)) with a mip-linear texture
+    // (deviceMipmappedArray.cu:348, DeviceMipmapImage::getLevel).  Scales that are a power-of-two multiple of each other (every combination
+    // Meshroom's defaults produce) give integral levels and run the LDS-staged kernels; any other combination (e.g. --sgmScale 3
+    // --refineScale 1) gives a FRACTIONAL level: the stage's similarity volume then comes from the plain trilinear kernel (every tap blends
+    // two levels through the software texture unit, ~10 x slower) and the map kernels blend two levels.  Said here once, not per tile.
     if(sgmParams.scale > 0 && refineParams.scale > 0)
     {
         const int lo = std::min(sgmParams.scale, refineParams.scale), hi = std::max(sgmParams.scale, refineParams.scale);
         const int ratio = (hi % lo == 0) ? hi / lo : 0;
         if(ratio == 0 || (ratio & (ratio - 1)) != 0)
-        {
-            AVDM_LOG_ERROR("sgmScale (" << sgmParams.scale << ") and refineScale (" << refineParams.scale
-                                        << ") must be a power-of-two multiple of each other: fractional mip levels (e.g. --sgmScale 3 --refineScale 1) "
-                                           "are not supported by this implementation.");
-            return EXIT_FAILURE;
-        }
+            AVDM_LOG_WARNING("sgmScale (" << sgmParams.scale << ") and refineScale (" << refineParams.scale
+                                          << ") are not a power-of-two multiple of each other: the coarser stage samples a fractional mip level "
+                                             "(trilinear taps, the slow similarity kernel).");
     }
     // filtering axes: the reference maps every character through a table of {X, Y} (std::map::at throws on anything else) and runs two
     // paths per character; this implementation runs one or two axes.

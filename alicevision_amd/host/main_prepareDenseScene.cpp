@@ -79,7 +79,7 @@ static int aliceVision_main(int argc, char* argv[])
     const auto startTime = std::chrono::steady_clock::now();
     std::string sfmDataFilename, outFolder, outImageFileTypeName = "exr", maskExtension = "png", verboseLevel = "info";
     std::vector<std::string> imagesFolders, masksFolders;
-    int rangeStart = -1, rangeSize = -1;
+    int rangeStart = -1, rangeSize = 1; // main_prepareDenseScene.cpp:297-298
     bool saveMetadata = true, saveMatricesTxtFiles = false, evCorrection = false;
     int maxMemoryAvailable = 0, maxCoresAvailable = 0;
 

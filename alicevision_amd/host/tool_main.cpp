@@ -22,6 +22,8 @@
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <iterator>
+#include <fstream>
 #include <string>
 
 using namespace avdm_host;
@@ -131,6 +133,25 @@ int main(int argc, char** argv)
             for(size_t i = 0; i < img.channelNames.size(); ++i)
                 ch.push_back({img.channelNames[i], img.channels[i].data()});
             writeExr(argv[3], img.width, img.height, ch, std::atoi(argv[4]) != 0, img.attributes, img.dataX0, img.dataY0, img.displayW, img.displayH);
+            return 0;
+        }
+        if(cmd == "png-dump" && argc == 4)
+        { // decode a PNG, write "<w> <h> <channels> <bits>" to stdout and the samples (host byte order) to a raw file
+            PngImage img;
+            readPng(argv[2], img);
+            std::cout << img.width << " " << img.height << " " << img.channels << " " << img.bits << "\n";
+            std::ofstream f(argv[3], std::ios::binary);
+            f.write((const char*)img.samples.data(), (std::streamsize)img.samples.size());
+            return f ? 0 : 1;
+        }
+        if(cmd == "png-write" && argc == 8)
+        { // raw samples (host byte order) -> PNG with every scan-line filter type in turn
+            const int w = std::atoi(argv[4]), h = std::atoi(argv[5]), c = std::atoi(argv[6]), bits = std::atoi(argv[7]);
+            std::ifstream f(argv[2], std::ios::binary);
+            std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            if(raw.size() != (size_t)w * h * c * (bits / 8))
+                throw std::runtime_error("png-write: raw size does not match");
+            writePng(argv[3], w, h, c, bits, raw.data());
             return 0;
         }
         if(cmd == "exr-info" && argc == 3)

@@ -53,10 +53,11 @@ class ViewExchange:
                 self.bytes_received += b.numel() * b.element_size()
 
     def publish_round(self, views):
-        """views[q] = the view rank q rebuilt in this round (None: rank q has nothing new).  All pyramids have the same size."""
+        """views[q] = the view rank q rebuilt in this round: every rank contributes one (an all-gather has no empty slots; a rank without new
+        work republishes any view it owns).  All pyramids have the same size."""
         if self.dist is None or self.world == 1:
             return
-        assert len(views) == self.world and views[self.rank] is not None and self.owns(views[self.rank])
+        assert len(views) == self.world and all(v is not None for v in views) and self.owns(views[self.rank])
         mine = self.bufs[views[self.rank]]
         # gather straight into the destination pyramids; my own slot is a scratch (its source is the input tensor)
         if not hasattr(self, "_scratch") or self._scratch.shape != mine.shape:

@@ -147,6 +147,42 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def cli_end_to_end(sc, V, W, H, Z, T, n_cams):
+    """The same scene through the PROGRAM (alicevision_amd/bin/aliceVision_depthMapEstimation, the C++ host above the C ABI): the views written
+    as linear float EXR + an .sfm file, then n_cams reference cameras with the default tiling (tile buffer 1024, padding 64: 20 tiles per
+    12 MP camera, batched SGM aggregation), Z planes, T neighbours — wall time of the process, i.e. start-up, EXR decode, upload, every tile,
+    tile merge and EXR output included."""
+    import subprocess
+    import tempfile
+    from alicevision_amd import exr_io, scene_io
+    cli = os.path.join(ROOT, "alicevision_amd", "bin", "aliceVision_depthMapEstimation")
+    if not os.path.exists(cli):
+        return {"error": "host program not built"}
+    d = tempfile.mkdtemp(prefix="avdm_bench_cli_")
+    os.makedirs(os.path.join(d, "images"))
+    t0 = time.time()
+    lms = scene_io.sample_landmarks(sc, 3000)
+    with open(os.path.join(d, "scene.sfm"), "w") as f:
+        json.dump(scene_io.sfm_dict(sc, lms, os.path.join(d, "images")), f)
+    for i in range(V):
+        im = sc.images[i].cpu().numpy()
+        exr_io.write_exr(os.path.join(d, "images", "%d.exr" % scene_io.view_id(i)), {"R": im[..., 0], "G": im[..., 1], "B": im[..., 2], "A": im[..., 3]},
+                         compression=0)
+    t_write = time.time() - t0
+    cmd = [cli, "-i", os.path.join(d, "scene.sfm"), "--imagesFolder", os.path.join(d, "images"), "-o", os.path.join(d, "out"), "--downscale", "1", "--rangeStart", "0",
+           "--rangeSize", str(n_cams), "--sgmMaxDepths", str(Z), "--maxTCams", str(T), "--sgmMaxTCamsPerTile", str(T), "--refineMaxTCamsPerTile", str(T), "-v",
+           "warning"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    wall = time.time() - t0
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    if r.returncode != 0:
+        return {"error": (r.stdout + r.stderr)[-400:]}
+    return {"value": n_cams / wall, "unit": "depth-maps/s", "cameras": n_cams, "wall_s": wall, "scene_write_s": t_write,
+            "includes": "process start, EXR decode of the views, upload, pyramids, default 1024 tiling (tiles batched per SGM launch), tile merge, EXR output"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +190,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cli-e2e", type=int, default=0, metavar="N",
+                    help="after the timed region (1 GPU): run the C++ program aliceVision_depthMapEstimation on N reference cameras of the same scene "
+                         "(EXR files, default 1024 tiling, I/O included) and add its end-to-end rate to the line as `cli_end_to_end`")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only (gloo, no GPU work): what tests/test_sharding.py runs on the CPU")
     args = ap.parse_args()
@@ -367,6 +406,8 @@ def main():
             abi.load().avdm_debug_similarity_stats(st)
             line["similarity_plane_workgroups"] = {"lds": int(st[0]), "generic_r_tile": int(st[1]), "generic_t_outside": int(st[2]),
                                                    "generic_t_too_large": int(st[3])}
+        if world == 1 and args.cli_e2e > 0:
+            line["cli_end_to_end"] = cli_end_to_end(sc, V, W, H, Z, T, args.cli_e2e)
         if world == 1 and not args.no_cpu_baseline:
             small = make_scene(3, 512, 384, seed=3, device="cpu")
             line["cpu_baseline"] = cpu_baseline(small, sgm, ref, Z, W * H, T)

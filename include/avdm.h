@@ -182,6 +182,13 @@ int avdm_tex2dlod(float* out4, const avdm_pyramid_t* pyr, const float* uvl, int 
  * RGBA, device memory, dst no larger than src (enlarging would select blackman-harris: refused).  dst_w = src_w / downscale and
  * dst_h = src_h / downscale (integer division) are the caller's, like in the reference. */
 int avdm_image_resize(float* dst_rgba, int dst_pitch, int dst_w, int dst_h, const float* src_rgba, int src_pitch, int src_w, int src_h, void* stream);
+/* Integer image samples -> linear float RGBA on the device: what image::readImage(path, img, LINEAR) hands mvsUtils::loadImage
+ * (mvsUtils/fileIO.cpp:386-446) for an 8- / 16-bit file.  v / 255 resp. v / 65535; colour channels through OpenImageIO's sRGB decoding when
+ * `srgb_to_linear` (x <= 0.04045 ? x / 12.92 : ((x + 0.055) / 1.055) ^ 2.4), alpha never; one channel replicated, missing alpha = 1.
+ * `src`: `channels` (1 Y, 2 YA, 3 RGB, 4 RGBA) interleaved samples of `bits` (8, or 16 in host byte order), device memory.  The curve is a
+ * host-evaluated table (C library powf): the device result is a look-up, bit-identical to the oracle's. */
+int avdm_image_decode_integer(float* dst_rgba, int dst_pitch, const void* src, int src_pitch, int width, int height, int channels, int bits,
+                              int srgb_to_linear, void* stream);
 /* Undistortion of an input image (second slice of the image ingest): camera::UndistortImage(imageIn, intrinsic, image_ud,
  * fillcolor) (camera/cameraUndistortImage.hpp:81-139) as software/pipeline/main_prepareDenseScene.cpp:71-79 calls it — for every pixel of
  * the undistorted image the distorted position  cam2ima(addDistortion(ima2cam(p)))  (camera/IntrinsicScaleOffsetDisto.cpp:80,

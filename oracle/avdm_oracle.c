@@ -589,6 +589,44 @@ int avo_image_resize_taps(int dst_n, int src_n, float* weights, int* first)
     return taps;
 }
 
+/* image::readImage(path, img, EImageColorSpace::LINEAR) for an integer file, as mvsUtils::loadImage receives it (mvsUtils/fileIO.cpp:386-446):
+ * the decoder's samples scaled to [0, 1], the colour channels through OpenImageIO's sRGB decoding (third party, restated from its
+ * published source — fmath.h sRGB_to_linear: x <= 0.04045 ? x * (1 / 12.92) : powf((x + 0.055) * (1 / 1.055), 2.4) — parity unpinned),
+ * alpha untouched, one channel replicated, a missing alpha = 1.  16-bit samples in host byte order. */
+int avo_image_decode_integer(float* dst, int dst_pitch, const void* src, int src_pitch, int width, int height, int channels, int bits, int srgb_to_linear)
+{
+    if(width <= 0 || height <= 0 || channels < 1 || channels > 4 || (bits != 8 && bits != 16))
+        return 1;
+    const float inv = 1.0f / (float)((bits == 8 ? 256 : 65536) - 1);
+    for(int y = 0; y < height; ++y)
+    {
+        float* o = (float*)((char*)dst + (long long)y * dst_pitch);
+        const unsigned char* row = (const unsigned char*)src + (long long)y * src_pitch;
+        for(int x = 0; x < width; ++x)
+        {
+            float v[4];
+            for(int c = 0; c < channels; ++c)
+            {
+                const unsigned s = bits == 8 ? row[(size_t)x * channels + c] : ((const uint16_t*)row)[(size_t)x * channels + c];
+                const float f = (float)s * inv;
+                const int isAlpha = (channels == 2 && c == 1) || (channels == 4 && c == 3);
+                v[c] = (isAlpha || !srgb_to_linear) ? f : (f <= 0.04045f ? f * (1.0f / 12.92f) : powf((f + 0.055f) * (1.0f / 1.055f), 2.4f));
+            }
+            if(channels >= 3)
+            {
+                o[4 * x + 0] = v[0], o[4 * x + 1] = v[1], o[4 * x + 2] = v[2];
+                o[4 * x + 3] = channels == 4 ? v[3] : 1.0f;
+            }
+            else
+            {
+                o[4 * x + 0] = o[4 * x + 1] = o[4 * x + 2] = v[0];
+                o[4 * x + 3] = channels == 2 ? v[1] : 1.0f;
+            }
+        }
+    }
+    return 0;
+}
+
 int avo_image_resize(float* dst, int dst_pitch, int dst_w, int dst_h, const float* src, int src_pitch, int src_w, int src_h, int nchannels)
 {
     if(dst_w <= 0 || dst_h <= 0 || src_w <= 0 || src_h <= 0 || nchannels < 1 || nchannels > 4 || dst_w > src_w || dst_h > src_h)

@@ -31,6 +31,7 @@ _SIG = {
     "avo_pyramid_layout": (i32, [P(abi.Pyramid), i32, i32, i32, i32, i32]),
     "avo_image_rgba_f32_to_f16x255": (None, [vp, i32, vp, i32, i32, i32]),
     "avo_image_resize": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, i32]),
+    "avo_image_decode_integer": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32]),
     "avo_image_undistort": (i32, [vp, i32, vp, i32, P(abi.Intrinsic), P(C.c_float * 4)]),
     "avo_image_resize_taps": (i32, [i32, i32, vp, vp]),
     "avo_rgb2lab": (None, [vp, i32, i32, i32]),

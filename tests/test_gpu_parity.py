@@ -103,6 +103,38 @@ def test_image_resize_bit_exact(w, h, s):
     assert lib.avdm_image_resize(_ptr(one), w * 16, w, h, _ptr(tdst), dw * 16, dw, dh, _st()) != 0 or s == 1
 
 
+@pytest.mark.parametrize("bits", [8, 16])
+@pytest.mark.parametrize("ch", [1, 2, 3, 4])
+def test_image_decode_integer_bit_exact(bits, ch):
+    """avdm_image_decode_integer (integer file samples -> linear float RGBA on the device: image::readImage(..., LINEAR) as
+    mvsUtils::loadImage receives it) against the oracle: every sample value, every channel layout, pitched rows, with and without the sRGB
+    decoding — identical floats (the transfer curve is a host-evaluated table)"""
+    torch = _torch()
+    from oracle import oracle
+    lib, olib = abi.load(), oracle.load()
+    n = 1 << bits
+    dt = np.uint8 if bits == 8 else np.uint16
+    rng = np.random.default_rng(bits * 10 + ch)
+    H, W = 9, n
+    src = rng.integers(0, n, size=(H, W, ch)).astype(dt)
+    src[0, :, 0] = np.arange(n).astype(dt)
+    bpp = ch * (bits // 8)
+    pad = 24  # bytes of row padding on the device side
+    dev = np.zeros((H, W * bpp + pad), np.uint8)
+    dev[:, :W * bpp] = src.reshape(H, -1).view(np.uint8)
+    tsrc = torch.from_numpy(dev).cuda()
+    for srgb in (1, 0):
+        want = np.zeros((H, W, 4), np.float32)
+        assert olib.avo_image_decode_integer(oracle.ptr(want), W * 16, oracle.ptr(src), W * bpp, W, H, ch, bits, srgb) == 0
+        tdst = torch.full((H, W + 3, 4), -1.0, dtype=torch.float32, device="cuda")
+        abi.check(lib.avdm_image_decode_integer(_ptr(tdst), (W + 3) * 16, _ptr(tsrc), W * bpp + pad, W, H, ch, bits, srgb, _st()))
+        torch.cuda.synchronize()
+        got = tdst.cpu().numpy()
+        assert np.array_equal(got[:, :W].view(np.uint32), want.view(np.uint32)), float(np.abs(got[:, :W] - want).max())
+        assert np.all(got[:, W:] == -1.0)
+    assert lib.avdm_image_decode_integer(_ptr(tdst), (W + 3) * 16, _ptr(tsrc), W * bpp + pad, W, H, 5, bits, 1, _st()) != 0
+
+
 @pytest.mark.parametrize("model,k", [(0, (0.0, 0.0, 0.0)), (1, (0.08, 0.0, 0.0)), (2, (0.1, -0.05, 0.01)), (2, (-0.3, 0.1, 0.0)), (3, (0.05, 0.02, -0.01))])
 def test_image_undistort_bit_exact(model, k):
     """camera::UndistortImage (PrepareDenseScene): the device kernel against the oracle — double-precision geometry, float sample position,
@@ -796,6 +828,68 @@ def test_consistent_scale_parity():
     assert a.max() > 0.5
     assert (diff > 4e-3).mean() <= 4e-3, (diff > 4e-3).mean()
     assert (diff > 0.02).mean() <= 3e-4, ((diff > 0.02).mean(), diff.max())
+
+
+@pytest.mark.parametrize("sgm_kw,ref_kw", [
+    (dict(scale=3, stepXY=1), dict(scale=1, stepXY=1)),   # SGM at level log2(3) = 1.585 of a pyramid that starts at the Refine scale
+    (dict(scale=2, stepXY=3), dict(scale=3, stepXY=1)),   # Refine at level log2(3 / 2) = 0.585 of a pyramid that starts at the SGM scale
+])
+def test_fractional_mip_levels(sgm_kw, ref_kw):
+    """sgmScale / refineScale that are not a power-of-two multiple of each other put the coarser stage on a FRACTIONAL mip level: the
+    reference's texture unit blends two levels (DeviceMipmapImage.cpp:92-99, deviceMipmappedArray.cu:348).  The similarity volumes of that
+    stage come from the plain trilinear kernel (tolerance class of the consistent-scale test: every tap is a blend of two levels), the map
+    kernels blend two levels with the operations of tex2DLod — the adaptive-P2 aggregation, the upscale and the colour optimisation stay
+    in their bit-exact / tolerance classes on identical inputs — and the tile runs end to end."""
+    torch = _torch()
+    from oracle import oracle
+    from alicevision_amd.pipeline import optimize_scratch
+    sc, sgm, ref, depths = small_case(width=300, height=228, n_planes=24, seed=5, **sgm_kw)
+    for k, v in ref_kw.items():
+        setattr(ref, k, v)
+    ref.optimizationNbIterations = 8
+    Z = len(depths)
+    o = make_oracle(sc, sgm, ref)
+    lvl_s = np.log2(sgm.scale / min(sgm.scale, ref.scale))
+    lvl_r = np.log2(ref.scale / min(sgm.scale, ref.scale))
+    assert (lvl_s != int(lvl_s)) or (lvl_r != int(lvl_r))
+    with oracle.well_posed():
+        o.run_sgm(0, [1, 2], depths)
+        want = o.run_refine(0, [1, 2])
+    h = make_hip_from_oracle(o, sc, sgm, ref)
+    # (a) sweep
+    h.run_sgm(0, [1, 2], depths, optimize=False, keep_raw=True)
+    torch.cuda.synchronize()
+    for got, w in ((h.best_raw.cpu().numpy()[..., :Z], o.best_raw[..., :Z]), (h.second.cpu().numpy()[..., :Z], o.second[..., :Z])):
+        d = np.abs(w.astype(np.int16) - got.astype(np.int16))
+        assert (w != 255).mean() > 0.3
+        assert (d > 0).mean() <= 0.05 and (d > 1).mean() <= 4e-3, ((d > 0).mean(), (d > 1).mean())
+        assert ((w == 255) != (got == 255)).mean() <= 4e-3
+    # (b) aggregation with the adaptive P2 from the (possibly fractional) SGM level: bit-exact on identical input bytes, then WTA
+    lib = abi.load()
+    X, Y = o.second.shape[1], o.second.shape[0]
+    h.second.copy_(torch.from_numpy(np.ascontiguousarray(o.second)))
+    abi.check(lib.avdm_volume_optimize(_ptr(h.best), _ptr(h.second), X * h.Zp, h.Zp, _ptr(h.sgm_scratch), C.byref(h.pyr[0].desc), C.byref(sgm), Z,
+                                       o.droi(sgm.scale * sgm.stepXY), _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(h.best.cpu().numpy()[..., :Z], o.filtered[..., :Z])
+    dt, _ = h.finish_sgm(0, Z)
+    torch.cuda.synchronize()
+    assert np.array_equal(dt.cpu().numpy(), o.sgm_depth_thickness)
+    # (c) Refine on the oracle's SGM map: upscale bit-exact (alpha test on the Refine level), Refine volume in its tolerance class
+    h.sgm_depth_thickness.copy_(torch.from_numpy(o.sgm_depth_thickness))
+    h.run_refine(0, [1, 2], optimize_enabled=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(h.sgm_upscaled.cpu().numpy(), o.sgm_upscaled)
+    Zr = ref.halfNbDepths * 2 + 1
+    diff = np.abs(o.refine_volume[..., :Zr].astype(np.float32) - h.refine_volume.cpu().numpy()[..., :Zr].astype(np.float32))
+    assert (diff > 4e-3).mean() <= 4e-3 and (diff > 0.02).mean() <= 3e-4, ((diff > 4e-3).mean(), (diff > 0.02).mean(), diff.max())
+    # (d) end to end on the GPU
+    h.run_sgm(0, [1, 2], depths)
+    got = h.run_refine(0, [1, 2]).cpu().numpy()
+    both = (want[..., 0] > 0) & (got[..., 0] > 0)
+    assert both.mean() > 0.5 and ((want[..., 0] > 0) != (got[..., 0] > 0)).mean() < 1e-2
+    err = np.sort((got[..., 0] - want[..., 0])[both] ** 2)
+    assert np.sqrt(err[: int(0.99 * err.size)].mean()) < 2e-3
 
 
 def _rerender(base, moved):

@@ -419,6 +419,55 @@ def test_multi_worker_exchange_equals_single_worker(dataset):
                 assert a == b, (rep, name)
 
 
+def test_png_input_is_decoded_on_the_device(dataset, tmp_path):
+    """<viewId>.png in --imagesFolder (the reference reads any format OpenImageIO decodes, mvsUtils/fileIO.cpp:386-446; here PNG next to
+    OpenEXR): the host inflates and un-filters, the INTEGER samples go to the device and become linear float RGBA there
+    (avdm_image_decode_integer).  The program's maps equal, bit for bit, the harness run on the images the ORACLE decodes from the same
+    samples; 16-bit RGB files written with the sRGB encoding of the scene's linear images."""
+    import torch
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    from oracle import oracle
+    sc, sfm, img, d = dataset
+    png_dir = str(tmp_path / "png")
+    os.makedirs(png_dir)
+    tool = os.path.join(ROOT, "alicevision_amd", "bin", "avdm_host_tool")
+    olib = oracle.load()
+    decoded = []
+    for i in range(NVIEWS):
+        lin = sc.images[i].numpy()[..., :3].astype(np.float64)
+        enc = np.where(lin <= 0.0031308, lin * 12.92, 1.055 * np.power(lin, 1.0 / 2.4) - 0.055)
+        q = np.clip(np.rint(enc * 65535.0), 0, 65535).astype(np.uint16)
+        raw = str(tmp_path / "v.raw")
+        q.tofile(raw)
+        r = subprocess.run([tool, "png-write", raw, os.path.join(png_dir, "%d.png" % scene_io.view_id(i)), str(W), str(H), "3", "16"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        out = np.zeros((H, W, 4), np.float32)
+        assert olib.avo_image_decode_integer(oracle.ptr(out), W * 16, oracle.ptr(q), W * 6, W, H, 3, 16, 1) == 0
+        decoded.append(out)
+        assert np.abs(out[..., :3] - lin).max() < 2e-5  # 16-bit quantisation of the encoded value
+    out_dir = os.path.join(d, "out_png")
+    args = ["-i", sfm, "--imagesFolder", png_dir, "-o", out_dir, "--downscale", 1, "--rangeStart", 0, "--rangeSize", 1, "--sgmMaxDepths", 64,
+            "--colorOptimizationNbIterations", 5, "-v", "warning"]
+    plan = json.loads(run_cli(args + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
+    t0 = plan["tiles"][0]
+    run_cli(args)
+    depth, sim, _, _ = read_maps(out_dir)
+    sgm = abi.SgmParams.default(scale=plan["sgmScale"], stepXY=plan["sgmStepXY"])
+    ref = abi.RefineParams.default(optimizationNbIterations=5)
+    torch.cuda.set_device(0)
+    pyr = [DevicePyramid(torch.from_numpy(decoded[i]).cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(NVIEWS)]
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+    h.run_sgm(0, t0["sgmTCams"], np.asarray(t0["depths"], np.float32), tc_ranges=[(a, a + n) for a, n in t0["depthsTcLimits"]])
+    got = h.run_refine(0, t0["refineTCams"]).cpu().numpy()
+    assert np.array_equal(got[..., 0], depth), float(np.abs(got[..., 0] - depth).max())
+    assert np.array_equal(got[..., 1].astype(np.float16).astype(np.float32), sim)
+    # two files for one view are refused like in the reference (MultiViewParams.cpp:96-100)
+    import shutil
+    shutil.copy(os.path.join(img, "%d.exr" % scene_io.view_id(0)), png_dir)
+    r = run_cli(args + ["--dryRun", 1], check=False)
+    assert r.returncode == 1 and "Ambiguous" in (r.stdout + r.stderr)
+
+
 def test_multi_worker_exchange_budget(dataset):
     """the exchange's residency is bounded: with a budget that holds ONE 640 x 480 pyramid per worker
     (AVDM_EXCHANGE_BUDGET_MB=4: a pyramid is 3.3 MB) the owners decline their other views, every worker that needs one of those decodes

@@ -444,3 +444,36 @@ def test_image_resize_agrees_with_an_independent_lanczos3(oracle_lib, w, h, dw, 
     pil = np.stack([np.asarray(Image.fromarray(src[..., c], mode="F").resize((dw, dh), Image.LANCZOS)) for c in range(4)], axis=-1)
     b = 4
     assert np.abs(dst - pil)[b:-b, b:-b].max() < 5e-5
+
+
+@pytest.mark.parametrize("bits", [8, 16])
+def test_image_decode_integer_oracle(bits):
+    """avo_image_decode_integer — image::readImage(..., LINEAR) for an integer file as mvsUtils::loadImage receives it (fileIO.cpp:386-446):
+    samples / max, OpenImageIO's sRGB decoding on the colour channels only, grey replicated, missing alpha = 1 — against an independent
+    double-precision numpy evaluation of the published formula, for every sample value and every channel layout"""
+    from oracle import oracle
+    lib = oracle.load()
+    n = 1 << bits
+    dt = np.uint8 if bits == 8 else np.uint16
+    vals = np.arange(n, dtype=np.int64)
+    x = vals / float(n - 1)
+    lin = np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+    rng = np.random.default_rng(bits)
+    for ch in (1, 2, 3, 4):
+        h = 3
+        src = rng.integers(0, n, size=(h, n, ch)).astype(dt)
+        src[0, :, 0] = vals.astype(dt)  # every value at least once
+        dst = np.full((h, n, 4), -1.0, np.float32)
+        assert lib.avo_image_decode_integer(oracle.ptr(dst), n * 16, oracle.ptr(src), n * ch * (bits // 8), n, h, ch, bits, 1) == 0
+        col = [0, 0, 0] if ch < 3 else [0, 1, 2]
+        for k in range(3):
+            want = lin[src[..., col[k]].astype(np.int64)]
+            assert np.abs(dst[..., k] - want).max() < 2e-7 + 2e-7 * 1.0, (ch, k)
+        if ch in (2, 4):
+            assert np.array_equal(dst[..., 3], (src[..., ch - 1].astype(np.float32) * np.float32(1.0 / (n - 1))))
+        else:
+            assert np.all(dst[..., 3] == 1.0)
+        # without the colour-space conversion: plain scaling
+        assert lib.avo_image_decode_integer(oracle.ptr(dst), n * 16, oracle.ptr(src), n * ch * (bits // 8), n, h, ch, bits, 0) == 0
+        assert np.array_equal(dst[..., 0], src[..., 0].astype(np.float32) * np.float32(1.0 / (n - 1)))
+    assert lib.avo_image_decode_integer(oracle.ptr(dst), n * 16, oracle.ptr(src), n, n, 1, 5, bits, 1) != 0
