@@ -188,6 +188,44 @@ __device__ __forceinline__ void stage_window_paired(uint4* dst, int pitch, const
     }
 }
 
+// 12-byte records {L(c) | L(c + 1)}, {a(c) | a(c + 1)}, {b(c) | b(c + 1)}: the paired record without its alpha word.  The three dwords of a
+// row tap ARE the three v_dot2_f32_f16 operands (no v_perm_b32 per tap, like the 16-byte records) at 3/4 of their LDS footprint — what the
+// SGM kernel's windows (stepXY 2: twice the texels per pixel) fit since the kernels run two workgroups per compute unit (80 KB each).
+// A record is 4-byte aligned: a tap is a ds_read2_b32 + a ds_read_b32.
+struct __attribute__((packed, aligned(4))) Rec12
+{
+    unsigned L, a, b;
+};
+typedef __attribute__((address_space(3))) const Rec12* lds_rec12_ptr;
+__device__ __forceinline__ uint4 lds_record12(unsigned byteAddr)
+{
+    const lds_rec12_ptr p = (lds_rec12_ptr)(size_t)byteAddr;
+    return make_uint4(p->L, p->a, p->b, 0u);
+}
+__device__ __forceinline__ void stage_window_rec12(Rec12* dst, int pitch, const TexLevel& L, int x0, int y0, int w, int h)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for(int r = wave; r < h; r += 4)
+    {
+        const uint2* src = L.base + (long long)(y0 + r) * L.pitch8 + x0;
+        Rec12* d = dst + r * pitch;
+        for(int c0 = 0; c0 < w; c0 += 63)
+        {
+            const int c = c0 + lane;
+            const uint2 t0 = src[min(c, w - 1)]; // the last column is never the left tap of a lerp: its record pairs it with itself
+            uint2 t1;
+            t1.x = (unsigned)__builtin_amdgcn_update_dpp((int)t0.x, (int)t0.x, 0x130, 0xf, 0xf, false);
+            t1.y = (unsigned)__builtin_amdgcn_update_dpp((int)t0.y, (int)t0.y, 0x130, 0xf, 0xf, false);
+            Rec12 rec;
+            rec.L = __builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_LO);
+            rec.a = __builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_HI);
+            rec.b = __builtin_amdgcn_perm(t1.y, t0.y, AVDM_PERM_LO);
+            if(lane < 63 && c < w)
+                d[c] = rec;
+        }
+    }
+}
+
 // "Half-paired" 8-byte records for the packed FIXED8 path when the 16-byte records do not fit: {L(c) | L(c + 1)}, {a(c) | b(c)}.  The L
 // pair of a row tap is ready as stored; the a and b pairs still take one v_perm_b32 each from the second dwords of columns c and
 // c + 1 (8 instead of 12 permutes per sample), and the right-hand column is a ds_read_b32.
@@ -525,7 +563,7 @@ __device__ __forceinline__ Lab3x2 hlerp3x2_halfpaired(uint2 r0, unsigned r0n, ui
     return o;
 }
 
-template <int WSH, bool TInvert, bool PAIRED, int RP = 0>
+template <int WSH, bool TInvert, bool PAIRED, int RP = 0, bool REC12 = false>
 __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const LdsWindows& Wn,
                                                            float4 rcCenter, float4 tcCenter)
 {
@@ -566,7 +604,7 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
                 const v2f wa = floor2((X - fX) * 256.0f + 0.5f), wb = floor2((Y - fY) * 256.0f + 0.5f);
                 const v2f na = 256.0f - wa, nnb = wb - 256.0f; // nnb = -(256 - B)
                 // LDS byte address of the top-left tap, formed in fp32 (exact integers), then one conversion per image
-                const v2f oidx = fY * pitch2 + (fX * (PAIRED ? 16.0f : 8.0f) + off2);
+                const v2f oidx = fY * pitch2 + (fX * (PAIRED ? 16.0f : (REC12 ? 12.0f : 8.0f)) + off2);
                 const unsigned oR = (unsigned)(int)oidx.x, oT = (unsigned)(int)oidx.y;
                 const v2h wr = pk_half_weights(na.x, wa.x), wt = pk_half_weights(na.y, wa.y);
                 Lab3x4 h;
@@ -576,6 +614,14 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
                     __builtin_assume(oR < 65536u);
                     const unsigned oRb = RP > 0 ? oR + (unsigned)(RP * 16) : oR + Wn.rPitchB;
                     const uint4 r0 = lds_record(oR), r1 = lds_record(oRb), t0 = lds_record(oT), t1 = lds_record(oT + Wn.tPitchB);
+                    h = hlerp3x4_paired(r0, r1, t0, t1, wr, wt);
+                }
+                else if(REC12)
+                {
+                    // 12-byte records: the three dwords of a tap are the dot2 operands as stored
+                    __builtin_assume(oR < 65536u);
+                    const unsigned oRb = RP > 0 ? oR + (unsigned)(RP * 12) : oR + Wn.rPitchB;
+                    const uint4 r0 = lds_record12(oR), r1 = lds_record12(oRb), t0 = lds_record12(oT), t1 = lds_record12(oT + Wn.tPitchB);
                     h = hlerp3x4_paired(r0, r1, t0, t1, wr, wt);
                 }
                 else
@@ -845,7 +891,7 @@ struct QuadPlane
     f3 tax;   // M_T * (patch.x * pixSize)
     float4 c; // T centre colour
 };
-template <int WSH, bool TInvert, bool PAIRED, int RP>
+template <int WSH, bool TInvert, bool PAIRED, int RP, bool REC12 = false>
 __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f3 hr0, const QuadPlane& q0, const QuadPlane& q1, const QuadPlane& q2,
                                                                const QuadPlane& q3, f3 Bt, f3 htB, f3 htA, const NccArgs& A, const PatchTable& tab,
                                                                const LdsWindows& Wn, float4 rcCenter, float& sim0, float& sim1, float& sim2, float& sim3)
@@ -872,7 +918,8 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
     const v2f rcLa = v2f{rcCenter.x, rcCenter.y} * S16;
     const float rcb = rcCenter.z * S16;
     const float kC = A.negInvGammaC_log2e * (1.0f / 65536.0f);
-    constexpr float recB = PAIRED ? 16.0f : 8.0f;
+    constexpr float recB = PAIRED ? 16.0f : (REC12 ? 12.0f : 8.0f);
+    constexpr bool WIDE = PAIRED || REC12; // a tap's record IS its three dot2 operands
 
     v2f wsum[NPAIR], s1R[NPAIR], s1T[NPAIR], s2R[NPAIR], s2T[NPAIR], sxy[NPAIR];
 #pragma unroll
@@ -881,14 +928,14 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
 
     struct RTaps
     {
-        typename std::conditional<PAIRED, uint4, uint2>::type r0, r1;
+        typename std::conditional<PAIRED || REC12, uint4, uint2>::type r0, r1;
         unsigned r0n, r1n;
         float rNy, rWy;
         v2h wr;
     };
     struct TTaps
     {
-        typename std::conditional<PAIRED, uint4, uint2>::type a0, a1, b0, b1;
+        typename std::conditional<PAIRED || REC12, uint4, uint2>::type a0, a1, b0, b1;
         unsigned a0n, a1n, b0n, b1n;
         v2f nnb, wb;
         v2h wtA, wtB;
@@ -924,10 +971,15 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             t.wr = pk_half_weights(rN.x, rW.x);
             t.rNy = rN.y;
             t.rWy = rW.y;
-            const unsigned oRb = RP > 0 ? oR + (unsigned)(RP * (PAIRED ? 16 : 8)) : oR + Wn.rPitchB;
+            const unsigned oRb = RP > 0 ? oR + (unsigned)(RP * (PAIRED ? 16 : (REC12 ? 12 : 8))) : oR + Wn.rPitchB;
             if constexpr(PAIRED)
             {
                 t.r0 = lds_record(oR), t.r1 = lds_record(oRb);
+                t.r0n = t.r1n = 0u;
+            }
+            else if constexpr(REC12)
+            {
+                t.r0 = lds_record12(oR), t.r1 = lds_record12(oRb);
                 t.r0n = t.r1n = 0u;
             }
             else
@@ -958,6 +1010,11 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
                 t.a0 = lds_record(oA), t.a1 = lds_record(oA + Wn.tPitchB), t.b0 = lds_record(oB), t.b1 = lds_record(oB + Wn.tPitchB);
                 t.a0n = t.a1n = t.b0n = t.b1n = 0u;
             }
+            else if constexpr(REC12)
+            {
+                t.a0 = lds_record12(oA), t.a1 = lds_record12(oA + Wn.tPitchB), t.b0 = lds_record12(oB), t.b1 = lds_record12(oB + Wn.tPitchB);
+                t.a0n = t.a1n = t.b0n = t.b1n = 0u;
+            }
             else
             {
                 t.a0 = lds_texel(oA), t.a1 = lds_texel(oA + Wn.tPitchB), t.b0 = lds_texel(oB), t.b1 = lds_texel(oB + Wn.tPitchB);
@@ -972,7 +1029,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             for(int j = 0; j < NPAIR; ++j)
                 t[j] = fetch_t(xp, j);
             Lab3x2 hr;
-            if constexpr(PAIRED)
+            if constexpr(WIDE)
                 hr = hlerp3x2_paired(r.r0, r.r1, r.wr);
             else
                 hr = hlerp3x2_halfpaired(r.r0, r.r0n, r.r1, r.r1n, r.wr);
@@ -985,7 +1042,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             for(int j = 0; j < NPAIR; ++j)
             {
                 Lab3x4 h; // rt / rb = plane 2j top / bottom row, tt / tb = plane 2j + 1
-                if constexpr(PAIRED)
+                if constexpr(WIDE)
                     h = hlerp3x4_paired(t[j].a0, t[j].a1, t[j].b0, t[j].b1, t[j].wtA, t[j].wtB);
                 else
                     h = hlerp3x4_halfpaired(t[j].a0, t[j].a0n, t[j].a1, t[j].a1n, t[j].b0, t[j].b0n, t[j].b1, t[j].b1n, t[j].wtA, t[j].wtB);
@@ -1107,8 +1164,11 @@ struct RTile
 };
 
 // R footprint of the workgroup: stage pixels [bx, bx+15] x [by, by+15] of the ROI, patch halo wsh + 2 (the border-test margin)
+// LDS capacity a window of n records takes, in the 8-byte units of NccArgs::rcap / tcap
+__device__ __forceinline__ int lds_units(int n, bool paired, bool rec12) { return paired ? 2 * n : (rec12 ? (3 * n + 1) / 2 : n); }
+
 __device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int wsh, int stepXY, avdm_roi_t roi, bool paired, bool halfPaired, int bw = 16,
-                                              bool lean = false)
+                                              bool lean = false, bool rec12 = false)
 {
     RTile T;
     const int roiW = (int)(roi.x.end - roi.x.begin), roiH = (int)(roi.y.end - roi.y.begin);
@@ -1131,11 +1191,13 @@ __device__ __forceinline__ RTile stage_r_tile(uint2* sR, const NccArgs& A, int w
     T.w = x1 - x0 + 1;
     T.h = y1 - y0 + 1;
     T.pitch = A.rpitch; // the full-width pitch also where the image border clips the tile
-    T.ok = (lean || !A.forceGeneric) && T.w > 1 && T.h > 1 && T.w <= T.pitch && T.pitch * T.h * (paired ? 2 : 1) <= A.rcap;
+    T.ok = (lean || !A.forceGeneric) && T.w > 1 && T.h > 1 && T.w <= T.pitch && lds_units(T.pitch * T.h, paired, rec12) <= A.rcap;
     if(T.ok)
     {
         if(paired)
             stage_window_paired((uint4*)sR, T.pitch, A.rcL, T.x0, T.y0, T.w, T.h);
+        else if(rec12)
+            stage_window_rec12((Rec12*)sR, T.pitch, A.rcL, T.x0, T.y0, T.w, T.h);
         else if(halfPaired)
             stage_window_halfpaired(sR, T.pitch, A.rcL, T.x0, T.y0, T.w, T.h);
         else
@@ -1191,6 +1253,29 @@ __device__ __forceinline__ float wave_max_f32(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    v += dpp_f32<0x111>(0.0f, v);
+    v += dpp_f32<0x112>(0.0f, v);
+    v += dpp_f32<0x114>(0.0f, v);
+    v += dpp_f32<0x118>(0.0f, v);
+    v += dpp_f32<0x142, 0xa>(0.0f, v);
+    v += dpp_f32<0x143, 0xc>(0.0f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Outliers do not stretch the workgroup's T window.  A pixel whose depth is far off its neighbours' (an SGM outlier under the Refine sweep, a
+// depth edge) projects its patch tens of texels away from theirs in a wide-baseline T view; one such lane used to make the hull of the 256
+// lanes exceed the LDS budget and send the WHOLE workgroup to the global-memory taps (~4 x slower; `profiles/r03_i_bench_stats.json`: ~11 %
+// of the Refine workgroups of the bench's outer cameras).  A lane whose hull centre lies farther than `radius` texels from the mean centre
+// of its wave's participating lanes stays out of the hull: only ITS wave takes the global-memory taps for the planes it is valid on.
+__device__ __forceinline__ bool wave_inlier(bool part, float cx, float cy, float radius)
+{
+    const float n = wave_sum_f32(part ? 1.0f : 0.0f);
+    const float mx = wave_sum_f32(part ? cx : 0.0f) / fmaxf(n, 1.0f), my = wave_sum_f32(part ? cy : 0.0f) / fmaxf(n, 1.0f);
+    return part && fabsf(cx - mx) <= radius && fabsf(cy - my) <= radius;
+}
+
 // workgroup reduction of the lanes' T boxes into sh.box[k] (first half; the caller synchronises afterwards)
 __device__ __forceinline__ void publish_box(BlockShared& sh, int k, bool valid, float tminx, float tminy, float tmaxx, float tmaxy, bool rInside)
 {
@@ -1217,15 +1302,17 @@ struct TWindow
 {
     int x0, y0, w, h, pitch;
     bool ok;
+    bool tooLarge; // not ok because the window exceeds the LDS budget (the only failure a smaller hull can cure)
 };
 
 // second half (after the barrier): decide — uniformly for the workgroup — whether plane k runs from LDS, and stage the T window
 __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk, bool paired, bool halfPaired,
-                                                  bool lean = false)
+                                                  bool lean = false, bool rec12 = false)
 {
     TWindow Wd;
     const int mnx = sh.box[k][0], mny = sh.box[k][1], mxx = sh.box[k][2], mxy = sh.box[k][3];
     Wd.ok = false;
+    Wd.tooLarge = false;
     Wd.x0 = Wd.y0 = Wd.w = Wd.h = Wd.pitch = 0;
     int reason = 1; // 0 = LDS path, 1 = R tile unusable / nothing valid, 2 = T taps leave the image, 3 = T window exceeds the LDS budget
     if(rTileOk && !sh.bad[k] && mnx != INT_MAX && mxx != INT_MIN)
@@ -1239,14 +1326,17 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
         Wd.w = x1 - Wd.x0 + 1;
         Wd.h = y1 - Wd.y0 + 1;
         Wd.pitch = lds_pitch_for(Wd.w);
-        const bool fits = Wd.w <= 4096 && Wd.h <= 4096 && Wd.pitch * Wd.h * (paired ? 2 : 1) <= A.tcap;
+        const bool fits = Wd.w <= 4096 && Wd.h <= 4096 && lds_units(Wd.pitch * Wd.h, paired, rec12) <= A.tcap;
         Wd.ok = inImage && fits;
         reason = Wd.ok ? 0 : (inImage ? 3 : 2);
+        Wd.tooLarge = inImage && !fits;
     }
     if(Wd.ok)
     {
         if(paired)
             stage_window_paired((uint4*)sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
+        else if(rec12)
+            stage_window_rec12((Rec12*)sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
         else if(halfPaired)
             stage_window_halfpaired(sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
         else
@@ -1271,7 +1361,7 @@ __device__ __forceinline__ void init_shared(BlockShared& sh)
 // PLANES = planes per pass over the patch on the packed chunk-window path: 1, 2 (ncc_accumulate_lds_fixed8_pair) or 4 (..._multi<2>: the
 // whole chunk in one pass; chunks it cannot take — a plane range that ends inside the chunk, a wave with a lane outside the window — run
 // one plane per pass)
-template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1>
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, bool REC12 = false>
 __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
                     avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
@@ -1297,10 +1387,12 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     const bool useChunkWindow = LEAN ? true : (A.chunkWindow != 0);
     const bool usePlanePairs = LEAN ? true : (A.planePairs != 0);
     // paired LDS records only feed the packed FIXED8 path (uniform)
+    static_assert(!(REC12 && (PAIRED || PLANES == 2)), "12-byte records: one or four planes per pass");
     const bool paired = PAIRED && FIXED8 && !noPacked;
-    const bool halfPaired = !PAIRED && FIXED8 && !noPacked; // the packed path without room for 16-byte records
+    const bool rec12 = REC12 && FIXED8 && !noPacked;                  // 12-byte records (see stage_window_rec12)
+    const bool halfPaired = !PAIRED && !REC12 && FIXED8 && !noPacked; // the packed path without room for wider records
     init_shared(sh);
-    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired, halfPaired, 16, LEAN);
+    const RTile R = stage_r_tile(sR, A, wsh, stepXY, roi, paired, halfPaired, 16, LEAN, rec12);
     __syncthreads();
 
     const float x = (float)(roi.x.begin + vx) * (float)stepXY;
@@ -1356,10 +1448,11 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     bool chunkWin = false;
     TWindow Wc;
     Wc.ok = false;
+    Wc.tooLarge = false;
     Wc.x0 = Wc.y0 = Wc.w = Wc.h = Wc.pitch = 0;
     float extX = 0.f, extY = 0.f;
     bool lanePart = false;
-    if(FIXED8 && (paired || halfPaired) && useChunkWindow)
+    if(FIXED8 && (paired || halfPaired || rec12) && useChunkWindow)
     {
         const unsigned ka = z0 > zBegin ? z0 : zBegin, kbEnd = (z0 + kPlanesPerWg < zEnd) ? z0 + kPlanesPerWg : zEnd;
         if(ka < kbEnd) // uniform
@@ -1391,8 +1484,21 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             }
             publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
             __syncthreads();
-            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN);
+            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12);
             __syncthreads();
+            if(Wc.tooLarge) // uniform
+            {
+                // the hull of ALL lanes does not fit: once more without the outliers (wave_inlier) — their waves then take the global-memory
+                // taps on the planes they are valid on, the rest of the workgroup keeps the LDS path
+                if(threadIdx.x < 4)
+                    sh.box[AVDM_CHUNK_BOX][threadIdx.x] = (threadIdx.x & 2) ? INT_MIN : INT_MAX;
+                __syncthreads();
+                part = wave_inlier(part, 0.5f * (bx0 + bx1), 0.5f * (by0 + by1), 16.0f * (float)stepXY + 16.0f);
+                publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
+                __syncthreads();
+                Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12);
+                __syncthreads();
+            }
             chunkWin = Wc.ok;
             lanePart = part;
         }
@@ -1517,9 +1623,9 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                     const QuadPlane qf = selP(v1b, q1, selP(v2b, q2, selP(v0, q0, q3)));
                     const f3 raf = sel3(v1b, ra1, sel3(v2b, ra2, sel3(v0, ra0, ra3)));
                     const float tw = qf.t * RK.hrW;
-                    ncc_accumulate_lds_fixed8_quad<WSH, false, PAIRED, RP>(raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
+                    ncc_accumulate_lds_fixed8_quad<WSH, false, PAIRED, RP, REC12>(raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
                                                                     selP(v0, q0, qf), selP(v1b, q1, qf), selP(v2b, q2, qf), selP(v3, q3, qf), Bt, RK.htB, RK.htA, A, tab,
-                                                                    make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8), rcCenter,
+                                                                    make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
                                                                     s0, s1, s2, s3);
                 }
                 // (a plane outside the range is not committed at all: its bytes belong to other T cameras)
@@ -1557,7 +1663,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                         // a lane with one valid plane runs it in both halves
                         const PatchProj PA = selQ(validA, QA, QB), PB = selQ(validB, QB, QA);
                         ncc_accumulate_lds_fixed8_pair<WSH, false, PAIRED, RP>(PA.rax, PA.ray, PA.hr0, PA, PB, A, tab,
-                                                                               make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8),
+                                                                               make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)),
                                                                                rcCenter, sel4(validA, cA, cB), sel4(validB, cB, cA), sA, sB);
                     }
                     commit(k0, validA ? to_fsim(sA) : 255.0f);
@@ -1607,7 +1713,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 corner_boxes(Q, A, wsh, R, bx0, by0, bx1, by1, rInside);
             publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
             __syncthreads();
-            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired, LEAN);
+            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired, LEAN, rec12);
             __syncthreads();
         }
 
@@ -1616,7 +1722,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         {
             float s;
             if(Wd.ok && laneLds && FIXED8 && !noPacked)
-                s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED, RP>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : 8), rcCenter,
+                s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED, RP, REC12>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
                                                           tcCenter);
             else if(Wd.ok && laneLds)
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
@@ -1740,6 +1846,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     bool chunkWin = false;
     TWindow Wc;
     Wc.ok = false;
+    Wc.tooLarge = false;
     Wc.x0 = Wc.y0 = Wc.w = Wc.h = Wc.pitch = 0;
     float extX = 0.f, extY = 0.f; // half extent of my projected patch in T texels (the larger of the two extreme planes)
     bool lanePart = false;        // my patch was part of the hull (valid on the first or the last plane of the chunk)
@@ -1777,6 +1884,19 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             __syncthreads();
             Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN);
             __syncthreads();
+            if(Wc.tooLarge) // uniform
+            {
+                // the hull of ALL lanes does not fit: once more without the outliers (wave_inlier) — their waves then take the global-memory
+                // taps on the planes they are valid on, the rest of the workgroup keeps the LDS path
+                if(threadIdx.x < 4)
+                    sh.box[AVDM_CHUNK_BOX][threadIdx.x] = (threadIdx.x & 2) ? INT_MIN : INT_MAX;
+                __syncthreads();
+                part = wave_inlier(part, 0.5f * (bx0 + bx1), 0.5f * (by0 + by1), 16.0f * (float)stepXY + 16.0f);
+                publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
+                __syncthreads();
+                Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN);
+                __syncthreads();
+            }
             chunkWin = Wc.ok;
             lanePart = part;
         }
@@ -2338,8 +2458,12 @@ static unsigned* g_stats = nullptr; // device counters, allocated on first use w
 // fractional: out = the stage's level of detail is not an integral level of the pyramids (scales that are not a power-of-two multiple of the
 // pyramid's first level, e.g. --sgmScale 3 --refineScale 1): the caller runs the plain trilinear kernel (similarity_cs_kernel), whose taps
 // go through the software texture unit at A.mipmapLevel; the sample positions are then expressed in the texel space of the level BELOW
+// budgetBytes: dynamic LDS a workgroup may use — a third of the compute unit's 160 KiB (three workgroups fit by LDS) unless the caller launches an
+// instantiation it has raised the limit for (the default ones: two workgroups per compute unit by registers anyway, half of the LDS each);
+// rec12: out (optional) = 12-byte records instead of the half-paired 8-byte ones (they fit and the caller's instantiation reads them)
+constexpr int kLdsThird = 42 * 1280 - 256, kLdsHalf = 64 * 1280 - 256;
 static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcPyr, const avdm_pyramid_t* tcPyr, int scale, int stepXY, int wsh,
-                          double gammaC, double gammaP, bool& paired, bool& fractional)
+                          double gammaC, double gammaP, bool& paired, bool& fractional, int budgetBytes = kLdsThird, bool* rec12 = nullptr)
 {
     int rl, tl;
     const bool rInt = lod_is_integral(rcPyr, scale, &rl), tInt = lod_is_integral(tcPyr, scale, &tl);
@@ -2382,31 +2506,38 @@ static bool fill_ncc_args(NccArgs& A, PatchTable& tab, const avdm_pyramid_t* rcP
     // markedly larger scale, or a depth edge inside the workgroup, overflows it and takes the generic path).  Row pitches are 8 (mod 16) texels.
     const int rw = 15 * stepXY + 2 * (wsh + 2) + 5;
     const int tw = rw + 1;
-    // bytes of dynamic LDS per workgroup at 3 workgroups per CU.  LDS is allocated in granules (1280 B on gfx950, 160 KiB / 128): 42 granules
-    // per workgroup = 53 760 B, three of them 161 280 of the 163 840 B.  The static shared state (BlockShared, < 256 B) must fit in the same
-    // 42 granules: when it grew by 20 B (round 2: one more box for the chunk window) the old budget (160 KiB / 3 - 1 KiB = 53 589 B) tipped
-    // into a 43rd granule, only TWO workgroups fitted a CU and both kernels ran 20 % slower with identical sample loops.
-    const int third = 42 * 1280 - 256;
+    // bytes of dynamic LDS per workgroup.  LDS is allocated in granules (1280 B on gfx950, 160 KiB / 128): 42 granules per workgroup =
+    // 53 760 B, three of them 161 280 of the 163 840 B (64 granules: two workgroups).  The static shared state (BlockShared, < 256 B) must fit
+    // in the same granules: when it grew by 20 B (round 2: one more box for the chunk window) the old budget (160 KiB / 3 - 1 KiB = 53 589 B)
+    // tipped into a 43rd granule, only TWO workgroups fitted a CU and both kernels ran 20 % slower with identical sample loops.
+    const int budget = budgetBytes;
+    bool r12 = false;
     {
         const char* pe = getenv("AVDM_SIM_PAIRED");
         if(pe && pe[0] == '0')
             paired = false;
         // the paired layout doubles the bytes per texel: only when the R tile and a T window of 1.5 x the R footprint still fit
-        if(paired && (lds_pitch_for(rw) * rw * 2 + lds_pitch_for(tw) * tw * 3) * 8 > third)
+        if(paired && (lds_pitch_for(rw) * rw * 2 + lds_pitch_for(tw) * tw * 3) * 8 > budget)
             paired = false;
+        // 12-byte records (the three dot2 operands of a tap, no alpha) under the same condition
+        const char* p12 = getenv("AVDM_SIM_REC12");
+        if(!paired && rec12 != nullptr && !(p12 && p12[0] == '0') && (lds_pitch_for(rw) * rw * 2 + lds_pitch_for(tw) * tw * 3) * 6 <= budget)
+            r12 = true;
+        if(rec12 != nullptr)
+            *rec12 = r12;
     }
+    auto units = [&](int n) { return paired ? 2 * n : (r12 ? (3 * n + 1) / 2 : n); }; // 8-byte units (lds_units in the kernels)
     A.rpitch = lds_pitch_for(rw);
-    A.rcap = lds_pitch_for(rw) * rw * (paired ? 2 : 1);
-    A.tcap = lds_pitch_for(tw) * tw * (paired ? 2 : 1);
-    // both kernels run 3 workgroups per CU (168 VGPRs): the T window may use what is left of a third of the 160 KiB — a T view at a
-    // larger scale or a slanted surface then still runs from LDS (3 % of the plane-workgroups of cfg3 overflowed the R-sized window
-    // and paid the ~4x slower generic path)
+    A.rcap = units(lds_pitch_for(rw) * rw);
+    A.tcap = units(lds_pitch_for(tw) * tw);
+    // the T window may use what is left of the budget — a T view at a larger scale or a slanted surface then still runs from LDS (3 % of
+    // the plane-workgroups of cfg3 overflowed the R-sized window and paid the ~4x slower generic path)
     {
-        const int room = third / 8 - A.rcap;
+        const int room = budget / 8 - A.rcap;
         if(room > A.tcap)
             A.tcap = room;
     }
-    if((A.rcap + A.tcap) * 8 > 60 * 1024)
+    if((A.rcap + A.tcap) * 8 > (budget > 60 * 1024 ? budget : 60 * 1024))
     { // keep >= 2 workgroups per CU; larger steps take the generic path
         A.rcap = 16;
         A.tcap = 16;
@@ -2583,8 +2714,21 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
     NccArgs A;
     PatchTable tab;
     const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
-    bool paired = fixed8, fractional = false;
-    fill_ncc_args(A, tab, rc_pyr, tc_pyr, sp->scale, sp->stepXY, sp->wsh, sp->gammaC, sp->gammaP, paired, fractional);
+    bool paired = fixed8, fractional = false, rec12 = false;
+    // the default instantiation (scale 2, stepXY 2, wsh 4) runs two workgroups per compute unit by registers: it gets half of the LDS and
+    // 12-byte records; everything else keeps a third (fill_ncc_args).  Whether the call runs it is known before the LDS layout, except for the
+    // A/B switches: those fall back to the general instantiations and their layout.
+    const bool wantDefault = fixed8 && sp->wsh == 4 && lds_pitch_for(15 * sp->stepXY + 2 * (sp->wsh + 2) + 5) == 56;
+    fill_ncc_args(A, tab, rc_pyr, tc_pyr, sp->scale, sp->stepXY, sp->wsh, sp->gammaC, sp->gammaP, paired, fractional, wantDefault ? kLdsHalf : kLdsThird,
+                  (wantDefault && AVDM_SGM_PLANES_PER_PASS != 2) ? &rec12 : nullptr);
+    bool runDefault = wantDefault && !paired && !A.noPacked && !A.forceGeneric && A.chunkWindow && A.planePairs && A.stats == nullptr && !fractional &&
+                      !sp->useConsistentScale && !sp->useCustomPatchPattern;
+    if(wantDefault && !runDefault)
+    {
+        paired = fixed8;
+        rec12 = false;
+        fill_ncc_args(A, tab, rc_pyr, tc_pyr, sp->scale, sp->stepXY, sp->wsh, sp->gammaC, sp->gammaP, paired, fractional);
+    }
     const unsigned nchunks = ((dr.end + 3) >> 2) - (dr.begin >> 2);
     if(((dr.end + 3) & ~3u) > (unsigned)pitch_x)
         return set_error_msg(1, "avdm_volume_compute_similarity: pitch_x too small for the depth range (must cover the 4-aligned range)");
@@ -2612,10 +2756,32 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
 #define LAUNCH(F8, W, PR)                                                                                                                                 \
     hipLaunchKernelGGL((similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
                        sp->stepXY, dr.begin, dr.end, roi)
-    const bool defaults = !A.noPacked && !A.forceGeneric && A.chunkWindow && A.planePairs && A.stats == nullptr; // what the lean instantiation assumes
-    if(fixed8 && !paired && sp->wsh == 4 && A.rpitch == 56 && defaults)
-        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, AVDM_SGM_PLANES_PER_PASS>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc,
-                           *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi); // the default: scale 2, stepXY 2, wsh 4 — with plane pairs
+    if(runDefault)
+    {
+        // the default: scale 2, stepXY 2, wsh 4 — four planes per pass, 12-byte records, up to half of the compute unit's LDS
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if(rec12)
+        {
+            static std::once_flag once[64]; // the attribute belongs to the function on ONE device
+            std::call_once(once[dev & 63], [&] {
+                (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, AVDM_SGM_PLANES_PER_PASS, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);
+            });
+            hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, AVDM_SGM_PLANES_PER_PASS, true>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y,
+                               pitch_x, depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi);
+        }
+        else
+        {
+            static std::once_flag once[64];
+            std::call_once(once[dev & 63], [&] {
+                (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, AVDM_SGM_PLANES_PER_PASS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          kLdsHalf);
+            });
+            hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, AVDM_SGM_PLANES_PER_PASS>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y,
+                               pitch_x, depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi);
+        }
+    }
     else if(fixed8 && paired)
     {
         if(sp->wsh == 4) LAUNCH(true, 4, true);
@@ -2658,7 +2824,18 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
     PatchTable tab;
     const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
     bool paired = fixed8, fractional = false;
-    fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->stepXY, rp->wsh, rp->gammaC, rp->gammaP, paired, fractional);
+    // the default instantiation (scale 1, stepXY 1, wsh 3) gets half of the compute unit's LDS like the SGM one (see there): its T window —
+    // the hull of a chunk of 31 planes, or of one plane when SGM outliers inside the workgroup stretch it — then holds 62 x 62 instead of
+    // 46 x 46 paired records before the workgroup has to take its taps from global memory
+    const bool wantDefault = fixed8 && rp->wsh == 3 && lds_pitch_for(15 * rp->stepXY + 2 * (rp->wsh + 2) + 5) == 40;
+    fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->stepXY, rp->wsh, rp->gammaC, rp->gammaP, paired, fractional, wantDefault ? kLdsHalf : kLdsThird);
+    const bool runDefault = wantDefault && paired && !A.noPacked && !A.forceGeneric && A.chunkWindow && A.planePairs && A.stats == nullptr && !fractional &&
+                            !rp->useConsistentScale && !rp->useCustomPatchPattern;
+    if(wantDefault && !runDefault)
+    {
+        paired = fixed8;
+        fill_ncc_args(A, tab, rc_pyr, tc_pyr, rp->scale, rp->stepXY, rp->wsh, rp->gammaC, rp->gammaP, paired, fractional);
+    }
     const unsigned nchunks = ((dr.end + 7) >> 3) - (dr.begin >> 3);
     if(rp->useCustomPatchPattern && !g_patchPatternSet)
         return set_error_msg(1, "avdm_volume_refine_similarity: useCustomPatchPattern without a pattern (avdm_build_custom_patch_pattern)");
@@ -2684,11 +2861,20 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
 #define LAUNCH(F8, W, PR)                                                                                                                          \
     hipLaunchKernelGGL((refine_similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,   \
                        (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi)
-    const bool defaults = !A.noPacked && !A.forceGeneric && A.chunkWindow && A.planePairs && A.stats == nullptr; // what the lean instantiation assumes
-    if(fixed8 && paired && rp->wsh == 3 && A.rpitch == 40 && defaults)
-        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, AVDM_REFINE_PLANES_PER_PASS>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
-                           (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end,
-                           roi); // the default: scale 1, stepXY 1, wsh 3
+    if(runDefault)
+    {
+        // the default: scale 1, stepXY 1, wsh 3 — four planes per pass, 16-byte records, up to half of the compute unit's LDS
+        static std::once_flag once[64]; // the attribute belongs to the function on ONE device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::call_once(once[dev & 63], [&] {
+            (void)hipFuncSetAttribute((const void*)refine_similarity_kernel<true, 3, true, 40, AVDM_REFINE_PLANES_PER_PASS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kLdsHalf);
+        });
+        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, AVDM_REFINE_PLANES_PER_PASS>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16,
+                           pitch_y, pitch_x, dimZ, (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin,
+                           dr.end, roi);
+    }
     else if(fixed8 && paired)
     {
         if(rp->wsh == 3) LAUNCH(true, 3, true);

@@ -283,8 +283,17 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.time()
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_events[0].record()
+    stats_each = []
     for i in range(args.steps):
         out = step(args.warmup + i)
+        step_events[i + 1].record()
+        if os.environ.get("AVDM_SIM_STATS") == "1":  # diagnosis only (synchronises every step): tap sources of the similarity kernels per step
+            torch.cuda.synchronize()
+            st = (ctypes.c_uint * 4)()
+            lib.avdm_debug_similarity_stats(st)
+            stats_each.append([int(v) for v in st])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -400,12 +409,14 @@ def main():
                            "sgm_fp32_TFLOPs": vt_sgm * 8.1e3 / 1e12, "refine_fp32_TFLOPs": vt_ref * 4.9e3 / 1e12,
                            "sgm_fp32_frac": vt_sgm * 8.1e3 / 157.3e12, "refine_fp32_frac": vt_ref * 4.9e3 / 157.3e12, "fp32_vector_peak_TFLOPs": 157.3},
             "stages_ms": stages, "valid_fraction": valid,
+            # GPU time of every timed step (HIP events between the steps): shows the clock settling under sustained load
+            "ms_per_step_each": [round(step_events[i].elapsed_time(step_events[i + 1]), 2) for i in range(args.steps)],
+            "similarity_ms_each": {k: [round(a.elapsed_time(b), 2) for a, b in tile.timers.events.get(k, [])] for k in ("sgm_similarity", "refine_similarity")}
+            if len(tiles) == 1 else None,
         }
         if os.environ.get("AVDM_SIM_STATS") == "1":
-            st = (ctypes.c_uint * 4)()
-            abi.load().avdm_debug_similarity_stats(st)
-            line["similarity_plane_workgroups"] = {"lds": int(st[0]), "generic_r_tile": int(st[1]), "generic_t_outside": int(st[2]),
-                                                   "generic_t_too_large": int(st[3])}
+            # [LDS path, generic: R tile unusable / nothing valid, generic: T taps leave the image, generic: T window exceeds the LDS budget] per step
+            line["similarity_plane_workgroups_each"] = stats_each
         if world == 1 and args.cli_e2e > 0:
             line["cli_end_to_end"] = cli_end_to_end(sc, V, W, H, Z, T, args.cli_e2e)
         if world == 1 and not args.no_cpu_baseline:

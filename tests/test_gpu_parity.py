@@ -200,6 +200,61 @@ def test_similarity_volume_parity(mode):
     assert frac32 <= 1.25 * floor + 0.03, (frac32, floor)
 
 
+@pytest.mark.parametrize("X,Y,Z", [(37, 29, 20), (64, 48, 33), (5, 3, 256)])
+def test_volume_init_update_add_bit_exact(X, Y, Z):
+    """row a4 of SURVEY section 8 on its own: cuda_volumeInitialize (uint8 / fp16), cuda_volumeUpdateUninitializedSimilarity and cuda_volumeAdd
+    (deviceSimilarityVolume.cu:25-153, kernels.cuh:48-107) on pitched z-fastest volumes with padded planes — identical bytes, padding
+    planes and rows outside the volume untouched"""
+    torch = _torch()
+    from oracle import oracle
+    lib, olib = abi.load(), oracle.load()
+    rng = np.random.default_rng(X * Z)
+    Zp = (Z + 3) // 4 * 4 + 4       # pitch_x with spare planes
+    Xp = X + 3                      # pitch_y with spare pixels
+    py, pxx = Xp * Zp, Zp
+    # uint8 initialise
+    host = rng.integers(0, 255, size=(Y + 2, Xp, Zp), dtype=np.uint8)
+    want = host.copy()
+    olib.avo_volume_initialize_u8(oracle.ptr(want), py, pxx, X, Y, Z, 255)
+    t = torch.from_numpy(host.copy()).cuda()
+    abi.check(lib.avdm_volume_initialize_u8(_ptr(t), py, pxx, X, Y, Z, 255, _st()))
+    torch.cuda.synchronize()
+    got = t.cpu().numpy()
+    # (the device writes whole dwords: the planes up to the next multiple of four belong to the volume's padding and may be written)
+    Z4 = (Z + 3) // 4 * 4
+    assert np.array_equal(got[:Y, :X, :Z], want[:Y, :X, :Z]) and np.all(got[:Y, :X, :Z] == 255)
+    assert np.array_equal(got[Y:], host[Y:]) and np.array_equal(got[:, X:], host[:, X:]) and np.array_equal(got[:, :, Z4:], host[:, :, Z4:])
+    # update uninitialised: second >= 255 takes best
+    best = rng.integers(0, 256, size=(Y, Xp, Zp), dtype=np.uint8)
+    second = rng.integers(200, 256, size=(Y, Xp, Zp), dtype=np.uint8)
+    want2 = second.copy()
+    olib.avo_volume_update_uninitialized(oracle.ptr(best), oracle.ptr(want2), py, pxx, X, Y, Z)
+    tb, ts = torch.from_numpy(best).cuda(), torch.from_numpy(second.copy()).cuda()
+    abi.check(lib.avdm_volume_update_uninitialized(_ptr(tb), _ptr(ts), py, pxx, X, Y, Z, _st()))
+    torch.cuda.synchronize()
+    g2 = ts.cpu().numpy()
+    assert np.array_equal(g2[:, :X, :Z], want2[:, :X, :Z]) and (want2 != second).any()
+    assert np.array_equal(g2[:, X:], second[:, X:]) and np.array_equal(g2[:, :, Z4:], second[:, :, Z4:])
+    # fp16 initialise + add
+    Zh = (Z + 7) // 8 * 8
+    pyh, pxh = Xp * Zh * 2, Zh * 2
+    a = rng.standard_normal((Y, Xp, Zh)).astype(np.float16)
+    b = rng.standard_normal((Y, Xp, Zh)).astype(np.float16)
+    want3 = a.copy()
+    olib.avo_volume_initialize_f16(oracle.ptr(want3), pyh, pxh, X, Y, Z, 0.25)
+    ta = torch.from_numpy(a.copy()).cuda()
+    abi.check(lib.avdm_volume_initialize_f16(_ptr(ta), pyh, pxh, X, Y, Z, 0.25, _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(ta.cpu().numpy().view(np.uint16)[:, :X, :Z], want3.view(np.uint16)[:, :X, :Z])
+    assert np.array_equal(ta.cpu().numpy().view(np.uint16)[:, X:], a.view(np.uint16)[:, X:])
+    want4 = a.copy()
+    olib.avo_volume_add_f16(oracle.ptr(want4), oracle.ptr(b), pyh, pxh, X, Y, Z)
+    ta, tb2 = torch.from_numpy(a.copy()).cuda(), torch.from_numpy(b).cuda()
+    abi.check(lib.avdm_volume_add_f16(_ptr(ta), _ptr(tb2), pyh, pxh, X, Y, Z, _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(ta.cpu().numpy().view(np.uint16)[:, :X, :Z], want4.view(np.uint16)[:, :X, :Z])
+
+
 def test_sgm_aggregation_bit_exact(case):
     torch = _torch()
     sc, sgm, ref, depths, o = case
