@@ -69,7 +69,7 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #define AVDM_EXPERIMENT_FAST_ONLY 0 // compile-time experiment (register accounting only): the default instantiations without their fall-back loops
 #endif
 #ifndef AVDM_NCC_QUAD_W3_MODE
-#define AVDM_NCC_QUAD_W3_MODE 0 // 7-tap rows of the four-plane form: 0 = 2 + 2 + 2 + 1 with fences, 1 = one sample at a time
+#define AVDM_NCC_QUAD_W3_MODE 0 // 7-tap rows of the four-plane form: 0 = 2 + 2 + 2 + 1 with fences, 1 = one sample at a time, 2 = 3 + 3 + 1
 #endif
 #ifndef AVDM_NCC_PAIR_W3_MODE
 #define AVDM_NCC_PAIR_W3_MODE 1 // 7-tap rows of the plane-pair form: 0 = 3 + 3 + 1 with fences, 1 = 4 + 3, 2 = the whole row unrolled
@@ -1071,6 +1071,20 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        else if(WSH == 3 && AVDM_NCC_QUAD_W3_MODE == 2)
+        {
+            // 7 taps per row as 3 + 3 + 1
+#pragma unroll
+            for(int xp = -3; xp < 0; ++xp)
+                sample(xp);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for(int xp = 0; xp < 3; ++xp)
+                sample(xp);
+            __builtin_amdgcn_sched_barrier(0);
+            sample(3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         else if(WSH == 3)
         {
             // 7 taps per row as 2 + 2 + 2 + 1 (see ncc_accumulate_lds_fixed8: an unroll factor with a remainder unrolls the whole row)
@@ -1361,11 +1375,31 @@ __device__ __forceinline__ void init_shared(BlockShared& sh)
 // PLANES = planes per pass over the patch on the packed chunk-window path: 1, 2 (ncc_accumulate_lds_fixed8_pair) or 4 (..._multi<2>: the
 // whole chunk in one pass; chunks it cannot take — a plane range that ends inside the chunk, a wave with a lane outside the window — run
 // one plane per pass)
-template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, bool REC12 = false>
+// MODE (the default instantiations run as TWO launches; everything else as one, MODE 0):
+//   1 = the FAST kernel: the R tile, the chunk window and the four-plane pass — nothing else.  What it cannot take — a workgroup without a
+//       chunk window (image border, hull beyond the LDS budget), a wave with a lane outside the window — it FLAGS in wgFlags (one word per
+//       workgroup: bit 4 c + w = chunk c, wave w) and leaves untouched;
+//   2 = the FIX-UP kernel on the same grid: a workgroup without flags returns at once, the others run the flagged (chunk, wave) units one
+//       plane per pass with per-plane windows / global-memory taps, exactly like MODE 0 does for them; their other waves only keep the
+//       barriers company.  Same NccArgs, hence the same window decisions as the fast kernel.
+// The split keeps the rarely taken paths (~5 % of the plane-workgroups) out of the hot kernel's register allocation.
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, bool REC12 = false, int MODE = 0>
 __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
-                    avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
+                    avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi,
+                    unsigned* __restrict__ wgFlags)
 {
+    constexpr bool FAST = MODE == 1, FIXUP = MODE == 2;
+    static_assert(!FAST || PLANES == 4, "the fast kernel is the four-plane pass");
+    const unsigned wgIndex = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned waveInWg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned myFlags = 0u;
+    if(FIXUP)
+    {
+        myFlags = (unsigned)__builtin_amdgcn_readfirstlane((int)wgFlags[wgIndex]);
+        if(myFlags == 0u) // uniform for the workgroup: nothing was left for it
+            return;
+    }
     extern __shared__ __attribute__((aligned(16))) uint2 smem[];
     uint2* sR = smem;
     uint2* sT = smem + A.rcap;
@@ -1503,6 +1537,12 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             lanePart = part;
         }
     }
+    if(FAST && !chunkWin) // uniform: the whole workgroup goes to the fix-up kernel
+    {
+        if(threadIdx.x == 0)
+            wgFlags[wgIndex] = 0xffffu;
+        return;
+    }
 
 #pragma unroll 1
     for(unsigned c = 0; c < kSgmChunksPerWg; ++c)
@@ -1510,6 +1550,8 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     const unsigned zc = z0 + 4u * c;
     if(zc >= zEnd) // uniform
         break;
+    if(FIXUP && ((myFlags >> (4u * c)) & 0xfu) == 0u) // uniform: the fast kernel finished this chunk for all four waves
+        continue;
     uint8_t* const pb = pb0 + 4u * c;
     uint8_t* const ps = ps0 + 4u * c;
     unsigned wb = 0, ws = 0;
@@ -1561,7 +1603,8 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         laneLds = __ballot(valid && !laneLds) == 0ull; // wave-uniform choice of the tap source (see the Refine kernel)
     };
     bool quadDone = false;
-    if constexpr(PLANES == 4 && FIXED8)
+    const bool mine = !FIXUP || ((myFlags >> (4u * c + waveInWg)) & 1u) != 0u; // fix-up: is this (chunk, wave) unit mine?  (wave-uniform)
+    if constexpr(PLANES == 4 && FIXED8 && !FIXUP)
     {
         // the four planes of the chunk in one pass over the patch (ncc_accumulate_lds_fixed8_multi): uniform conditions
         if(chunkWin && usePlanePairs && !noPacked)
@@ -1639,10 +1682,16 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                     commit(3, v3 ? to_fsim(s3) : 255.0f);
                 quadDone = true;
             }
+            else if(FAST)
+            {
+                // a lane of this wave lies outside the chunk window on one of the planes: the unit is left to the fix-up kernel
+                if((threadIdx.x & 63) == 0)
+                    atomicOr(&wgFlags[wgIndex], 1u << (4u * c + waveInWg));
+            }
         }
     }
 #pragma unroll 1
-    for(int k0 = 0; k0 < 4 && !quadDone && !(AVDM_EXPERIMENT_FAST_ONLY && LEAN); k0 += 2)
+    for(int k0 = 0; k0 < 4 && !quadDone && !FAST && !(AVDM_EXPERIMENT_FAST_ONLY && LEAN); k0 += 2)
     {
         bool pairDone = false;
         {
@@ -1681,7 +1730,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         if(vz < zBegin || vz >= zEnd) // uniform
             continue;
 
-        bool valid = rValid;
+        bool valid = rValid && mine; // (fix-up: the waves whose unit the fast kernel finished only keep the barriers company)
         PatchProj Q;
         float4 tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
         float tpx = 0.f, tpy = 0.f;
@@ -1730,7 +1779,8 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
             fsim = to_fsim(s);
         }
-        commit(k, fsim);
+        if(mine)
+            commit(k, fsim);
     }
     }
     if(inRoi)
@@ -1744,12 +1794,24 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
 // ---------------------------------------------------------------------------------------------
 // Refine similarity: fp16 volume += sigmoid-filtered NCC, 8 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1>
+// MODE: see similarity_kernel (flag bits: 4 (2 c + q) + w = chunk c, quad q of its eight planes, wave w)
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, int MODE = 0>
 __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   refine_similarity_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize,
                            int map_pitch, const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A,
-                           PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
+                           PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi, unsigned* __restrict__ wgFlags)
 {
+    constexpr bool FAST = MODE == 1, FIXUP = MODE == 2;
+    static_assert(!FAST || PLANES == 4, "the fast kernel is the four-plane pass");
+    const unsigned wgIndex = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned waveInWg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned myFlags = 0u;
+    if(FIXUP)
+    {
+        myFlags = (unsigned)__builtin_amdgcn_readfirstlane((int)wgFlags[wgIndex]);
+        if(myFlags == 0u) // uniform for the workgroup: nothing was left for it
+            return;
+    }
     extern __shared__ __attribute__((aligned(16))) uint2 smem[];
     uint2* sR = smem;
     uint2* sT = smem + A.rcap;
@@ -1901,6 +1963,12 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             lanePart = part;
         }
     }
+    if(FAST && !chunkWin) // uniform: the whole workgroup goes to the fix-up kernel
+    {
+        if(threadIdx.x == 0)
+            wgFlags[wgIndex] = 0xffffffffu;
+        return;
+    }
 
 #pragma unroll 1
     for(unsigned c = 0; c < kRefineChunksPerWg; ++c)
@@ -1908,6 +1976,8 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     const unsigned zc = z0 + 8u * c;
     if(zc >= zEnd) // uniform
         break;
+    if(FIXUP && ((myFlags >> (8u * c)) & 0xffu) == 0u) // uniform: the fast kernel finished this chunk for all four waves
+        continue;
     __half* const pv = pv0 + 8u * c;
     uint4 packed = make_uint4(0u, 0u, 0u, 0u);
     if(pixActive)
@@ -1953,7 +2023,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         laneLds = __ballot(valid && !laneLds) == 0ull;
     };
     unsigned quadsDone = 0u; // bit q: planes 4 q ... 4 q + 3 of the chunk went through the four-plane pass
-    if constexpr(PLANES == 4 && CHUNK_CAPABLE)
+    if constexpr(PLANES == 4 && CHUNK_CAPABLE && !FIXUP)
     {
         if(chunkWin && usePlanePairs && !noPacked)
         {
@@ -2023,8 +2093,12 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 plane_q(zq + 1u, q1, ra1, v1b, l1);
                 plane_q(zq + 2u, q2, ra2, v2b, l2);
                 plane_q(zq + 3u, q3, ra3, v3, l3);
-                if(!(l0 && l1 && l2 && l3)) // wave-uniform: this wave runs the quad one plane per pass
+                if(!(l0 && l1 && l2 && l3)) // wave-uniform: this wave runs the quad one plane per pass (fast kernel: leaves it to the fix-up kernel)
+                {
+                    if(FAST && (threadIdx.x & 63) == 0)
+                        atomicOr(&wgFlags[wgIndex], 1u << (4u * (2u * c + qd) + waveInWg));
                     continue;
+                }
                 if(v0 || v1b || v2b || v3)
                 {
                     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -2058,10 +2132,11 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         }
     }
 #pragma unroll 1
-    for(int k0 = 0; k0 < 8 && !(AVDM_EXPERIMENT_FAST_ONLY && LEAN); k0 += 2)
+    for(int k0 = 0; k0 < 8 && !FAST && !(AVDM_EXPERIMENT_FAST_ONLY && LEAN); k0 += 2)
     {
         if((quadsDone >> (k0 >> 2)) & 1u) // uniform per wave
             continue;
+        const bool mine = !FIXUP || ((myFlags >> (4u * (2u * c + (unsigned)(k0 >> 2)) + waveInWg)) & 1u) != 0u; // fix-up: my (chunk, quad, wave) unit?
         bool pairDone = false;
         {
             const unsigned vzA = zc + k0, vzB = vzA + 1u;
@@ -2101,7 +2176,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         if(vz < zBegin || vz >= zEnd) // uniform
             continue;
 
-        bool valid = rValid;
+        bool valid = rValid && mine; // (fix-up: the waves whose unit the fast kernel finished only keep the barriers company)
         PatchProj Q;
         float4 tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
         float tpx = 0.f, tpy = 0.f;
@@ -2577,6 +2652,12 @@ int literal_compute_similarity(uint8_t* best, uint8_t* second, long long pitch_y
 int literal_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x, int dimZ, const float* sgm_depth_pixsize, int map_pitch, const float* sgm_normal,
                               int normal_pitch, const avdm_camera_t* rc, const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
                               const avdm_refine_params_t* rp, avdm_range_t dr, avdm_roi_t roi, void* stream);
+// AVDM_SIM_SPLIT=1 (read at each call): the default instantiations as a fast + a fix-up launch
+static bool sim_split_mode()
+{
+    const char* e = getenv("AVDM_SIM_SPLIT");
+    return e != nullptr && e[0] == '1';
+}
 static bool sim_literal_mode()
 {
     const char* e = getenv("AVDM_SIM_LITERAL");
@@ -2755,32 +2836,57 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
     const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
 #define LAUNCH(F8, W, PR)                                                                                                                                 \
     hipLaunchKernelGGL((similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
-                       sp->stepXY, dr.begin, dr.end, roi)
+                       sp->stepXY, dr.begin, dr.end, roi, (unsigned*)nullptr)
     if(runDefault)
     {
-        // the default: scale 2, stepXY 2, wsh 4 — four planes per pass, 12-byte records, up to half of the compute unit's LDS
+        // the default: scale 2, stepXY 2, wsh 4 — four planes per pass, 12-byte records, up to half of the compute unit's LDS.
+        // AVDM_SIM_SPLIT=1: as TWO launches, the fast kernel and the fix-up kernel for what it flagged (see similarity_kernel): hot kernels
+        // without a VGPR spill, but the second launch over a grid of which ~5 % has work measured 3 % slower per depth map
         int dev = 0;
         (void)hipGetDevice(&dev);
+        if(!sim_split_mode())
+        {
+#define AVDM_SGM_COMBINED_LAUNCH(R12)                                                                                                                     \
+    {                                                                                                                                                     \
+        static std::once_flag once[64]; /* the attribute belongs to the function on ONE device */                                                        \
+        std::call_once(once[dev & 63], [&] {                                                                                                              \
+            (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, 4, R12>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);  \
+        });                                                                                                                                               \
+        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, 4, R12>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x,     \
+                           depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi, (unsigned*)nullptr);                                             \
+    }
+            if(rec12)
+                AVDM_SGM_COMBINED_LAUNCH(true)
+            else
+                AVDM_SGM_COMBINED_LAUNCH(false)
+#undef AVDM_SGM_COMBINED_LAUNCH
+            AVDM_LAUNCH_CHECK("avdm_volume_compute_similarity");
+        }
+        const size_t nWg = (size_t)grid.x * grid.y * grid.z;
+        const StreamScratch lease((hipStream_t)stream, nWg * sizeof(unsigned));
+        unsigned* flags = (unsigned*)lease.ptr();
+        if(flags == nullptr)
+            return set_error_msg(2, "avdm_volume_compute_similarity: scratch allocation failed");
+        const hipError_t me = hipMemsetAsync(flags, 0, nWg * sizeof(unsigned), (hipStream_t)stream);
+        if(me != hipSuccess)
+            return set_error(me, "avdm_volume_compute_similarity");
+#define AVDM_SGM_DEFAULT_LAUNCH(R12)                                                                                                                      \
+    {                                                                                                                                                     \
+        static std::once_flag once[64]; /* the attribute belongs to the function on ONE device */                                                        \
+        std::call_once(once[dev & 63], [&] {                                                                                                              \
+            (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, 4, R12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf); \
+            (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, 1, R12, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf); \
+        });                                                                                                                                               \
+        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, 4, R12, 1>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x,   \
+                           depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi, flags);                                                          \
+        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, 1, R12, 2>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x,   \
+                           depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi, flags);                                                          \
+    }
         if(rec12)
-        {
-            static std::once_flag once[64]; // the attribute belongs to the function on ONE device
-            std::call_once(once[dev & 63], [&] {
-                (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, AVDM_SGM_PLANES_PER_PASS, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);
-            });
-            hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, AVDM_SGM_PLANES_PER_PASS, true>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y,
-                               pitch_x, depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi);
-        }
+            AVDM_SGM_DEFAULT_LAUNCH(true)
         else
-        {
-            static std::once_flag once[64];
-            std::call_once(once[dev & 63], [&] {
-                (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, AVDM_SGM_PLANES_PER_PASS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          kLdsHalf);
-            });
-            hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, AVDM_SGM_PLANES_PER_PASS>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y,
-                               pitch_x, depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi);
-        }
+            AVDM_SGM_DEFAULT_LAUNCH(false)
+#undef AVDM_SGM_DEFAULT_LAUNCH
     }
     else if(fixed8 && paired)
     {
@@ -2860,20 +2966,44 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
     const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
 #define LAUNCH(F8, W, PR)                                                                                                                          \
     hipLaunchKernelGGL((refine_similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,   \
-                       (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi)
+                       (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi, \
+                       (unsigned*)nullptr)
     if(runDefault)
     {
         // the default: scale 1, stepXY 1, wsh 3 — four planes per pass, 16-byte records, up to half of the compute unit's LDS
+        // (AVDM_SIM_SPLIT=1: as two launches, the fast kernel and the fix-up kernel for what it flagged, see similarity_kernel)
+        if(!sim_split_mode())
+        {
+            static std::once_flag once0[64]; // the attribute belongs to the function on ONE device
+            int dev0 = 0;
+            (void)hipGetDevice(&dev0);
+            std::call_once(once0[dev0 & 63], [&] {
+                (void)hipFuncSetAttribute((const void*)refine_similarity_kernel<true, 3, true, 40, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);
+            });
+            hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, 4>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
+                               (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi,
+                               (unsigned*)nullptr);
+            AVDM_LAUNCH_CHECK("avdm_volume_refine_similarity");
+        }
+        const size_t nWg = (size_t)grid.x * grid.y * grid.z;
+        const StreamScratch lease((hipStream_t)stream, nWg * sizeof(unsigned));
+        unsigned* flags = (unsigned*)lease.ptr();
+        if(flags == nullptr)
+            return set_error_msg(2, "avdm_volume_refine_similarity: scratch allocation failed");
+        const hipError_t me = hipMemsetAsync(flags, 0, nWg * sizeof(unsigned), (hipStream_t)stream);
+        if(me != hipSuccess)
+            return set_error(me, "avdm_volume_refine_similarity");
         static std::once_flag once[64]; // the attribute belongs to the function on ONE device
         int dev = 0;
         (void)hipGetDevice(&dev);
         std::call_once(once[dev & 63], [&] {
-            (void)hipFuncSetAttribute((const void*)refine_similarity_kernel<true, 3, true, 40, AVDM_REFINE_PLANES_PER_PASS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kLdsHalf);
+            (void)hipFuncSetAttribute((const void*)refine_similarity_kernel<true, 3, true, 40, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);
+            (void)hipFuncSetAttribute((const void*)refine_similarity_kernel<true, 3, true, 40, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);
         });
-        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, AVDM_REFINE_PLANES_PER_PASS>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16,
-                           pitch_y, pitch_x, dimZ, (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin,
-                           dr.end, roi);
+        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, 4, 1>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
+                           (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi, flags);
+        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, 1, 2>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
+                           (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi, flags);
     }
     else if(fixed8 && paired)
     {

@@ -5,7 +5,11 @@
 // aliceVision_depthMapEstimation prefers over the SfMData: mvsUtils/MultiViewParams.cpp:164-186) and, with --saveMatricesTxtFiles 1,
 // <viewId>_P.txt / <viewId>_KRt.txt.
 // Not built: image formats other than OpenEXR in and out (the reference decodes through OpenImageIO), masks (--masksFolders), exposure
-// compensation (--evCorrection needs the EXIF exposure of every view).  Asking for either is an error, not a silent no-op.
+// compensation (--evCorrection needs the EXIF exposure of every view; for the same reason the AliceVision:EV / AliceVision:EVComp entries of
+// main_prepareDenseScene.cpp:243-247 are not written: the .sfm reader does not keep the views' EXIF metadata — aliceVision_depthMapEstimation
+// reads them only under --correctEV, which this build does not offer either).  Asking for either is an error, not a silent no-op.
+// The range is taken over the views in id order (the reference iterates its hash container's order: chunk MEMBERSHIP may differ, the union
+// over all chunks does not).
 #include "cmdline.hpp"
 #include "device.hpp"
 #include "exr.hpp"
@@ -235,7 +239,10 @@ static int aliceVision_main(int argc, char* argv[])
             if(model < 0)
                 throw std::runtime_error("distortion model '" + intr.distortionType + "' of intrinsic " + std::to_string(intr.intrinsicId) +
                                          " is not supported (none, radialk1, radialk3, radialk3pt)");
-            if(model != AVDM_DISTORTION_NONE)
+            // cam->isValid() && cam->hasDistortion() (main_prepareDenseScene.cpp:72; Pinhole::isValid, camera/Pinhole.hpp:56: focal lengths > 0 and a
+            // non-empty image): an invalid camera's image is copied through
+            const bool camValid = intr.scaleX > 0.0 && intr.scaleY > 0.0 && intr.width != 0 && intr.height != 0;
+            if(camValid && model != AVDM_DISTORTION_NONE)
             {
                 avdm_intrinsic_t cam{};
                 cam.width = intr.width;

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.txt
 timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider --durations=8 > $OUT/pytest.log 2>&1; echo "pytest exit $?"; tail -14 $OUT/pytest.log
 echo "== bench"
-timeout 900 python bench.py --steps 10 --warmup 2 --cli-e2e 11 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
+timeout 900 python bench.py --steps 11 --warmup 2 --cli-e2e 11 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
 python - <<PY
 import json
 r=json.load(open("$OUT/bench.json"))
@@ -29,5 +29,14 @@ for PASS in "FETCH_SIZE" "WRITE_SIZE"; do
   python scripts/rocprof_csv_summary.py $OUT/pmc_$PASS $OUT/pmc_$PASS.csv counters > /dev/null 2>&1
   head -4 $OUT/pmc_$PASS.csv
 done
+echo "== cfg5 (100 views x 24 MP, 4 x 4 tiles per depth map, tile buffers; 1 step on this one GPU)"
+timeout 600 python bench.py --workload cfg5 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err; echo "cfg5 exit $?"
+python - <<PY
+import json
+try:
+    r=json.load(open("$OUT/bench_cfg5.json")); print("cfg5 value", r["value"], "ms/step", r["ms_per_step"], "roofline", {k: r["roofline"].get(k) for k in ("frac","volumes_per_launch","alg_bytes_per_launch")}, "valid", r["valid_fraction"])
+except Exception as e:
+    print("cfg5 failed", e, open("$OUT/bench_cfg5.err").read()[-600:])
+PY
 find $OUT -name "*.db" -delete; find $OUT -name "*.csv" -size +2M -delete
 echo "== done"

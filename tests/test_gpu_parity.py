@@ -664,6 +664,43 @@ def test_plane_pairs_equal_single_planes(capsys):
     assert (r1 != 0).mean() > 0.3 and (b1 != 255).mean() > 0.3
 
 
+def test_split_launches_equal_the_combined_kernels():
+    """AVDM_SIM_SPLIT=1 runs the default similarity instantiations as two launches — the fast kernel (R tile, chunk window, four planes per
+    pass, nothing else) and the fix-up kernel for the (workgroup, chunk, wave) units it flagged: image borders, hulls beyond the LDS budget,
+    waves with a lane outside the window.  Every (pixel, plane) is committed exactly once either way, by the same source code; the two are
+    different instantiations, though, and this file is compiled with FMA contraction allowed, so a handful of voxels (measured: 8e-6 of
+    them) land on the other side of a rounding boundary: the volumes must agree to one storage quantum on all but 1e-4 of the entries and
+    nowhere further — a unit committed twice or not at all would show as whole levels on whole waves — for partial plane ranges and a tile
+    with an offset too."""
+    import os
+    torch = _torch()
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    sc, sgm, ref, depths = small_case(width=330, height=250, n_planes=70, seed=3)
+    Z = len(depths)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(3)]
+    out = {}
+    for flag in ("0", "1"):
+        os.environ["AVDM_SIM_SPLIT"] = flag
+        try:
+            res = []
+            for roi, tcr in ((None, [(0, Z), (5, 61)]), ((64, 330, 48, 250), None)):
+                h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=roi)
+                h.run_sgm(0, [1, 2], depths, tc_ranges=tcr, keep_raw=True)
+                h.run_refine(0, [1, 2], optimize_enabled=False)
+                torch.cuda.synchronize()
+                res.append((h.best_raw.cpu().numpy().copy(), h.second.cpu().numpy().copy(), h.refine_volume.cpu().numpy().copy()))
+            out[flag] = res
+        finally:
+            os.environ.pop("AVDM_SIM_SPLIT", None)
+    for (b0, s0, r0), (b1, s1, r1) in zip(out["0"], out["1"]):
+        assert (b0[..., :Z] != 255).mean() > 0.3 and (r0 != 0).mean() > 0.3
+        for a, b in ((b0, b1), (s0, s1)):
+            d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+            assert d.max() <= 1 and (d > 0).mean() <= 1e-4, (int(d.max()), float((d > 0).mean()))
+        dr = np.abs(r0.astype(np.float32) - r1.astype(np.float32))
+        assert dr.max() <= 4e-3 and (dr > 0).mean() <= 1e-4, (float(dr.max()), float((dr > 0).mean()))
+
+
 def test_refine_best_depth_bit_exact(case):
     torch = _torch()
     sc, sgm, ref, depths, o = case
