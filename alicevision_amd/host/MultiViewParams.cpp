@@ -396,6 +396,9 @@ std::string getFileNameFromViewId(const MultiViewParams& mp, IndexT viewId, EFil
         case EFileType::simMapFiltered: folder = mp.getDepthMapsFilterFolder(), suffix = "_simMap"; break;
         case EFileType::normalMapFiltered: folder = mp.getDepthMapsFilterFolder(), suffix = "_normalMap"; break;
         case EFileType::nmodMap: folder = mp.getDepthMapsFilterFolder(), suffix = "_nmodMap", ext = "png"; break;
+        case EFileType::volume: folder = mp.getDepthMapsFolder(), suffix = "_volume", ext = "abc"; break;
+        case EFileType::volumeCross: folder = mp.getDepthMapsFolder(), suffix = "_volumeCross", ext = "abc"; break;
+        case EFileType::volumeTopographicCut: folder = mp.getDepthMapsFolder(), suffix = "_volumeTopographicCut", ext = "abc"; break;
         case EFileType::stats9p: folder = mp.getDepthMapsFolder(), suffix = "_9p", ext = "csv"; break;
         case EFileType::none: break;
     }

@@ -29,6 +29,9 @@ enum class EFileType
     simMapFiltered,
     normalMapFiltered,
     nmodMap,
+    volume,
+    volumeCross,
+    volumeTopographicCut,
     stats9p,
     P,
     D

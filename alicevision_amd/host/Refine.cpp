@@ -137,12 +137,39 @@ void Refine::refineAndFuseDepthSimMap(const Tile& tile)
     avdmCheck(avdm_volume_refine_best_depth(_refinedDepthSimMap.as<float>(), _mapPitch, _sgmDepthPixSizeMap.as<float>(), _mapPitch, _volumeRefineSim.ptr(),
                                             pitchY, _volPitchX, _volZ, &rp, roi, _stream),
               "avdm_volume_refine_best_depth");
-    if(_refineParams.exportIntermediateVolume9pCsv)
-    { // Refine.cpp:235, :340-349
+    if(_refineParams.exportIntermediateCrossVolumes || _refineParams.exportIntermediateVolume9pCsv)
+    { // Refine.cpp:235, :291-352 (exportVolumeInformation: its early return, too, leaves the topographic cut out)
         const int tileBeginX = tile.nbTiles > 1 ? (int)tile.roi.x.begin : -1, tileBeginY = tile.nbTiles > 1 ? (int)tile.roi.y.begin : -1;
-        AVDM_LOG_INFO(tile << "Export similarity volume 9 points CSV (afterRefine).");
-        exportSimilaritySamplesCSV(_volumeRefineSim.ptr(), true, pitchY, _volPitchX, _volZ, X, Y, "afterRefine",
-                                   getFileNameFromIndex(_mp, tile.rc, EFileType::stats9p, "_refine", tileBeginX, tileBeginY), _stream);
+        if(_refineParams.exportIntermediateCrossVolumes || _refineParams.exportIntermediateTopographicCutVolumes)
+        {
+            // the tile's extent (the reference takes the centre of the ALLOCATED volume, which is the tile's for every full-size tile; for
+            // a smaller border tile it samples cells no kernel of the tile wrote)
+            const HostVolume vol = downloadVolume(_volumeRefineSim.ptr(), true, pitchY, _volPitchX, X, Y, _volZ, _stream);
+            Float2Tile dps;
+            dps.allocate(X, Y);
+            AVDM_HIP_CHECK(hipMemcpy2DAsync(dps.data.data(), (size_t)X * 8, _sgmDepthPixSizeMap.ptr(), (size_t)_mapPitch, (size_t)X * 8, (size_t)Y,
+                                            hipMemcpyDeviceToHost, _stream));
+            AVDM_HIP_CHECK(hipStreamSynchronize(_stream));
+            if(_refineParams.exportIntermediateCrossVolumes)
+            {
+                AVDM_LOG_INFO(tile << "Export similarity volume cross (afterRefine).");
+                exportSimilarityVolumeCross(vol, dps, _mp, tile.rc, _refineParams,
+                                            getFileNameFromIndex(_mp, tile.rc, EFileType::volumeCross, "_afterRefine", tileBeginX, tileBeginY), tile.roi);
+            }
+            if(_refineParams.exportIntermediateTopographicCutVolumes)
+            {
+                AVDM_LOG_INFO(tile << "Export similarity volume topographic cut (afterRefine).");
+                exportSimilarityVolumeTopographicCut(vol, dps, _mp, tile.rc, _refineParams,
+                                                     getFileNameFromIndex(_mp, tile.rc, EFileType::volumeTopographicCut, "_afterRefine", tileBeginX, tileBeginY),
+                                                     tile.roi);
+            }
+        }
+        if(_refineParams.exportIntermediateVolume9pCsv)
+        {
+            AVDM_LOG_INFO(tile << "Export similarity volume 9 points CSV (afterRefine).");
+            exportSimilaritySamplesCSV(_volumeRefineSim.ptr(), true, pitchY, _volPitchX, _volZ, X, Y, "afterRefine",
+                                       getFileNameFromIndex(_mp, tile.rc, EFileType::stats9p, "_refine", tileBeginX, tileBeginY), _stream);
+        }
     }
     AVDM_LOG_INFO(tile << "Refine and fuse depth/sim map volume done.");
 }

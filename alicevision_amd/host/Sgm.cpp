@@ -162,14 +162,43 @@ void Sgm::computeVolumes(const Tile& tile, const SgmDepthList& tileDepthList)
 
 void Sgm::exportVolumeInformation(const Tile& tile, const SgmDepthList& tileDepthList, const DeviceBuffer& volume, const std::string& name) const
 {
-    if(!_sgmParams.exportIntermediateVolume9pCsv)
+    // Sgm.cpp:327-396.  (The reference's early return does not look at exportIntermediateTopographicCutVolumes: asked for alone, it
+    // exports nothing — kept.)
+    if(!_sgmParams.exportIntermediateVolumes && !_sgmParams.exportIntermediateCrossVolumes && !_sgmParams.exportIntermediateVolume9pCsv)
         return;
     const int tileBeginX = tile.nbTiles > 1 ? (int)tile.roi.x.begin : -1, tileBeginY = tile.nbTiles > 1 ? (int)tile.roi.y.begin : -1;
-    AVDM_LOG_INFO(tile << "Export similarity volume 9 points CSV (" << name << ").");
-    const std::string stats9Path = getFileNameFromIndex(_mp, tile.rc, EFileType::stats9p, "_sgm", tileBeginX, tileBeginY);
-    const ROI r = downscaleROI(tile.roi, float(_sgmParams.scale * _sgmParams.stepXY));
-    exportSimilaritySamplesCSV(volume.ptr(), false, _pitchY, _pitchX, (int)tileDepthList.getDepths().size(), (int)r.width(), (int)r.height(), name, stats9Path,
-                               _stream);
+    const int nbPlanes = (int)tileDepthList.getDepths().size();
+    if(_sgmParams.exportIntermediateVolumes || _sgmParams.exportIntermediateCrossVolumes || _sgmParams.exportIntermediateTopographicCutVolumes)
+    {
+        // the reference samples the ALLOCATED volume (in_volume_dmp.getSize()): the laid-out extent here
+        const HostVolume vol = downloadVolume(volume.ptr(), false, _pitchY, _pitchX, _volX, _volY, std::min(nbPlanes, _volZ), _stream);
+        if(_sgmParams.exportIntermediateVolumes)
+        {
+            AVDM_LOG_INFO(tile << "Export similarity volume (" << name << ").");
+            exportSimilarityVolume(vol, tileDepthList.getDepths(), _mp, tile.rc, _sgmParams,
+                                   getFileNameFromIndex(_mp, tile.rc, EFileType::volume, "_" + name, tileBeginX, tileBeginY), tile.roi);
+        }
+        if(_sgmParams.exportIntermediateCrossVolumes)
+        {
+            AVDM_LOG_INFO(tile << "Export similarity volume cross (" << name << ").");
+            exportSimilarityVolumeCross(vol, tileDepthList.getDepths(), _mp, tile.rc, _sgmParams,
+                                        getFileNameFromIndex(_mp, tile.rc, EFileType::volumeCross, "_" + name, tileBeginX, tileBeginY), tile.roi);
+        }
+        if(_sgmParams.exportIntermediateTopographicCutVolumes)
+        {
+            AVDM_LOG_INFO(tile << "Export similarity volume topographic cut (" << name << ").");
+            exportSimilarityVolumeTopographicCut(vol, tileDepthList.getDepths(), _mp, tile.rc, _sgmParams,
+                                                 getFileNameFromIndex(_mp, tile.rc, EFileType::volumeTopographicCut, "_" + name, tileBeginX, tileBeginY),
+                                                 tile.roi);
+        }
+    }
+    if(_sgmParams.exportIntermediateVolume9pCsv)
+    {
+        AVDM_LOG_INFO(tile << "Export similarity volume 9 points CSV (" << name << ").");
+        const std::string stats9Path = getFileNameFromIndex(_mp, tile.rc, EFileType::stats9p, "_sgm", tileBeginX, tileBeginY);
+        const ROI r = downscaleROI(tile.roi, float(_sgmParams.scale * _sgmParams.stepXY));
+        exportSimilaritySamplesCSV(volume.ptr(), false, _pitchY, _pitchX, nbPlanes, (int)r.width(), (int)r.height(), name, stats9Path, _stream);
+    }
 }
 
 avdm_sgm_tile_t Sgm::sgmTileDescriptor(const Tile& tile, const SgmDepthList& tileDepthList) const

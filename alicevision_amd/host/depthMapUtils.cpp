@@ -1,6 +1,9 @@
 // depthMapUtils.cpp — see depthMapUtils.hpp.
 #include "depthMapUtils.hpp"
 
+#include "alembic.hpp"
+#include "sfmData.hpp"
+
 #include "device.hpp"
 #include "exr.hpp"
 #include "log.hpp"
@@ -373,6 +376,234 @@ void exportSimilaritySamplesCSV(const void* volume_d, bool halfFloat, long long 
     std::ofstream file(filepath, std::ios_base::app);
     if(file.is_open())
         file << ss.str();
+}
+
+// ---- similarity volumes as point clouds ---------------------------------------------------------------------------------------------
+float HostVolume::at(int x, int y, int z) const
+{
+    const unsigned char* p = bytes.data() + (long long)y * pitchY + (long long)x * pitchX;
+    return halfFloat ? halfToFloat(reinterpret_cast<const uint16_t*>(p)[z]) : (float)p[z];
+}
+
+HostVolume downloadVolume(const void* volume_d, bool halfFloat, long long pitchY, int pitchX, int X, int Y, int Z, hipStream_t stream)
+{
+    HostVolume v;
+    v.pitchY = pitchY, v.pitchX = pitchX, v.X = X, v.Y = Y, v.Z = Z, v.halfFloat = halfFloat;
+    v.bytes.resize((size_t)pitchY * Y);
+    AVDM_HIP_CHECK(hipMemcpyAsync(v.bytes.data(), volume_d, v.bytes.size(), hipMemcpyDeviceToHost, stream));
+    AVDM_HIP_CHECK(hipStreamSynchronize(stream));
+    return v;
+}
+
+void jetColor(float value, unsigned char rgb[3])
+{
+    // jet(64): with u = { 1/16 .. 16/16, fifteen ones, 16/16 .. 1/16 } (47 values), green = u placed at entries 8 .. 54, red the same
+    // ramp 16 entries later (cut at entry 63), blue 16 entries earlier (starting inside the ramp) — the table of image/jetColorMap.cpp
+    auto u = [](int k) -> float { return k < 0 || k > 46 ? 0.0f : (k < 16 ? (k + 1) / 16.0f : (k < 31 ? 1.0f : (47 - k) / 16.0f)); };
+    auto jet = [&](int i, int channel) -> float { return u(i - (channel == 0 ? 24 : (channel == 1 ? 8 : -8))); };
+    float c[3];
+    if(value <= 0.0f)
+        c[0] = c[1] = c[2] = 0.0f;
+    else if(value >= 1.0f)
+        c[0] = c[1] = c[2] = 1.0f;
+    else
+    {
+        const float idx_f = value * 63.0f;
+        float integral;
+        const float fractB = std::modf(idx_f, &integral);
+        const float fractA = 1.0f - fractB;
+        const int idx = (int)integral;
+        for(int k = 0; k < 3; ++k)
+            c[k] = jet(idx, k) * fractA + jet(idx + 1, k) * fractB;
+    }
+    for(int k = 0; k < 3; ++k)
+        rgb[k] = (unsigned char)(c[k] * 255.0f);
+}
+
+namespace {
+
+// mvsData/geometry.cpp:156-177
+Point3d linePlaneIntersect(const Point3d& linePoint, const Point3d& lineVect, const Point3d& planePoint, const Point3d& planeNormal)
+{
+    const double k = (dot(planePoint, planeNormal) - dot(planeNormal, linePoint)) / dot(planeNormal, lineVect);
+    return linePoint + lineVect * k;
+}
+
+void addPoint(SfMData& cloud, IndexT& id, const Point3d& p, float colourValue)
+{
+    Landmark L;
+    L.X = p;
+    jetColor(colourValue, L.rgb);
+    cloud.landmarks[id++] = L;
+}
+
+void savePointCloud(const SfMData& cloud, const std::string& filepath)
+{
+    saveSfMDataAlembic(cloud, filepath, /*withViews*/ false, /*withObservations*/ false); // ESfMData::STRUCTURE
+}
+
+// the point of pixel (x, y) on the fronto-parallel plane at `planeDepth` (volumeIO.cpp:176-180)
+Point3d planePoint(const MultiViewParams& mp, int camIndex, double x, double y, double planeDepth)
+{
+    const Point3d planen = (mp.iRArr[camIndex] * Point3d(0.0, 0.0, 1.0)).normalize();
+    const Point3d planep = mp.CArr[camIndex] + planen * planeDepth;
+    const Point3d v = (mp.iCamArr[camIndex] * Point2d(x, y)).normalize();
+    return linePlaneIntersect(mp.CArr[camIndex], v, planep, planen);
+}
+
+} // namespace
+
+void exportSimilarityVolume(const HostVolume& vol, const std::vector<float>& depths, const MultiViewParams& mp, int camIndex, const SgmParams& sgmParams,
+                            const std::string& filepath, const ROI& roi)
+{
+    SfMData cloud;
+    const int xyStep = 10;
+    IndexT landmarkId = 0; // (uninitialised in the reference, volumeIO.cpp:159)
+    const int nz = std::min<int>((int)depths.size(), vol.Z);
+    for(int vy = 0; vy < vol.Y; vy += xyStep)
+        for(int vx = 0; vx < vol.X; vx += xyStep)
+        {
+            const double x = roi.x.begin + (vx * sgmParams.scale * sgmParams.stepXY);
+            const double y = roi.y.begin + (vy * sgmParams.scale * sgmParams.stepXY);
+            for(int vz = 0; vz < nz; ++vz)
+            {
+                const float maxValue = 80.f, simValue = vol.at(vx, vy, vz);
+                if(simValue > maxValue)
+                    continue;
+                addPoint(cloud, landmarkId, planePoint(mp, camIndex, x, y, depths[vz]), simValue / maxValue);
+            }
+        }
+    savePointCloud(cloud, filepath);
+}
+
+void exportSimilarityVolumeCross(const HostVolume& vol, const std::vector<float>& depths, const MultiViewParams& mp, int camIndex,
+                                 const SgmParams& sgmParams, const std::string& filepath, const ROI& roi)
+{
+    SfMData cloud;
+    IndexT landmarkId = 0; // (uninitialised in the reference, volumeIO.cpp:206)
+    const int nz = std::min<int>((int)depths.size(), vol.Z);
+    for(int vz = 0; vz < nz; ++vz)
+        for(int vy = 0; vy < vol.Y; ++vy)
+        {
+            const bool vyCenter = (vy >= vol.Y / 2) && ((vy - 1) < vol.Y / 2);
+            const int xIdxStart = vyCenter ? 0 : (vol.X / 2);
+            const int xIdxStop = vyCenter ? vol.X : (xIdxStart + 1);
+            for(int vx = xIdxStart; vx < xIdxStop; ++vx)
+            {
+                const double x = roi.x.begin + (vx * sgmParams.scale * sgmParams.stepXY);
+                const double y = roi.y.begin + (vy * sgmParams.scale * sgmParams.stepXY);
+                const float maxValue = 80.f, simValue = vol.at(vx, vy, vz);
+                if(simValue > maxValue)
+                    continue;
+                addPoint(cloud, landmarkId, planePoint(mp, camIndex, x, y, depths[vz]), simValue / maxValue);
+            }
+        }
+    savePointCloud(cloud, filepath);
+}
+
+void exportSimilarityVolumeCross(const HostVolume& vol, const Float2Tile& dps, const MultiViewParams& mp, int camIndex, const RefineParams& refineParams,
+                                 const std::string& filepath, const ROI& roi)
+{
+    SfMData cloud;
+    IndexT landmarkId = 0;
+    for(int vy = 0; vy < vol.Y; ++vy)
+    {
+        const bool vyCenter = (vy * 2) == vol.Y;
+        const int xIdxStart = vyCenter ? 0 : (vol.X / 2);
+        const int xIdxStop = vyCenter ? vol.X : (xIdxStart + 1);
+        for(int vx = xIdxStart; vx < xIdxStop; ++vx)
+        {
+            const int x = (int)(roi.x.begin + (double(vx) * refineParams.scale * refineParams.stepXY));
+            const int y = (int)(roi.y.begin + (double(vy) * refineParams.scale * refineParams.stepXY));
+            const Point2d pix(x, y);
+            const float depth0 = dps.data[((size_t)vy * dps.width + vx) * 2], pixSize = dps.data[((size_t)vy * dps.width + vx) * 2 + 1];
+            if(depth0 < 0.0f) // original depth invalid or masked
+                continue;
+            for(int vz = 0; vz < vol.Z; ++vz)
+            {
+                const float simValue = vol.at(vx, vy, vz), maxValue = 10.f; // sum of similarity between 0 and 1
+                if(simValue > maxValue)
+                    continue;
+                const int relativeDepthIndexOffset = vz - refineParams.halfNbDepths;
+                const double depth = depth0 + (relativeDepthIndexOffset * pixSize);
+                addPoint(cloud, landmarkId, mp.CArr[camIndex] + (mp.iCamArr[camIndex] * pix).normalize() * depth, simValue / maxValue);
+            }
+        }
+    }
+    savePointCloud(cloud, filepath);
+}
+
+void exportSimilarityVolumeTopographicCut(const HostVolume& vol, const std::vector<float>& depths, const MultiViewParams& mp, int camIndex,
+                                          const SgmParams& sgmParams, const std::string& filepath, const ROI& roi)
+{
+    SfMData cloud;
+    const int vy = divideRoundUp(vol.Y, 2); // centre only
+    if(vy >= vol.Y)
+        return savePointCloud(cloud, filepath);
+    const int nz = std::min<int>((int)depths.size(), vol.Z);
+    float minSim = std::numeric_limits<float>::max(), maxSim = std::numeric_limits<float>::min();
+    for(int vx = 0; vx < vol.X; ++vx)
+        for(int vz = 0; vz < nz; ++vz) // (the reference also scans the planes past the depth list: 255, which it skips)
+        {
+            const float simValue = vol.at(vx, vy, vz);
+            if(simValue > 254.f) // invalid similarity
+                continue;
+            maxSim = std::max(maxSim, simValue);
+            minSim = std::min(minSim, simValue);
+        }
+    const float simNorm = (maxSim == minSim) ? 0.f : (1.f / (maxSim - minSim));
+    const Point3d planen = (mp.iRArr[camIndex] * Point3d(0.0, 0.0, 1.0)).normalize();
+    IndexT landmarkId = 0;
+    for(int vx = 0; vx < vol.X; ++vx)
+    {
+        const double x = roi.x.begin + (vx * sgmParams.scale * sgmParams.stepXY);
+        const double y = roi.y.begin + (vy * sgmParams.scale * sgmParams.stepXY);
+        for(int vz = 0; vz < nz; ++vz)
+        {
+            const float simValue = vol.at(vx, vy, vz);
+            if(simValue > 254.f)
+                continue;
+            const float simValueNorm = (simValue - minSim) * simNorm;
+            const Point3d planep = mp.CArr[camIndex] + planen * (double)depths[vz];
+            const Point3d v = (mp.iCamArr[camIndex] * Point2d(x, y + simValueNorm * 15.0)).normalize();
+            addPoint(cloud, landmarkId, linePlaneIntersect(mp.CArr[camIndex], v, planep, planen), simValueNorm);
+        }
+    }
+    savePointCloud(cloud, filepath);
+}
+
+void exportSimilarityVolumeTopographicCut(const HostVolume& vol, const Float2Tile& dps, const MultiViewParams& mp, int camIndex,
+                                          const RefineParams& refineParams, const std::string& filepath, const ROI& roi)
+{
+    SfMData cloud;
+    const int vy = divideRoundUp(vol.Y, 2); // centre only
+    if(vy >= vol.Y)
+        return savePointCloud(cloud, filepath);
+    const float minSim = 0.f;
+    float maxSim = std::numeric_limits<float>::epsilon();
+    for(int vx = 0; vx < vol.X; ++vx)
+        for(int vz = 0; vz < vol.Z; ++vz)
+            maxSim = std::max(maxSim, vol.at(vx, vy, vz));
+    IndexT landmarkId = 0;
+    for(int vx = 0; vx < vol.X; ++vx)
+    {
+        const double x = roi.x.begin + (vx * refineParams.scale * refineParams.stepXY);
+        const double y = roi.y.begin + (vy * refineParams.scale * refineParams.stepXY);
+        const float depth0 = dps.data[((size_t)vy * dps.width + vx) * 2], pixSize = dps.data[((size_t)vy * dps.width + vx) * 2 + 1];
+        if(depth0 < 0.0f) // middle depth (SGM) invalid or masked
+            continue;
+        for(int vz = 0; vz < vol.Z; ++vz)
+        {
+            const float simValue = vol.at(vx, vy, vz);
+            const float simValueNorm = (simValue - minSim) / (maxSim - minSim);
+            const float simValueColor = 1 - simValueNorm; // best similarity value is 0, worst value is 1
+            const int relativeDepthIndexOffset = vz - refineParams.halfNbDepths;
+            const double depth = depth0 + (relativeDepthIndexOffset * pixSize);
+            const Point3d p = mp.CArr[camIndex] + (mp.iCamArr[camIndex] * Point2d(x, y - simValueNorm * 15.0)).normalize() * depth;
+            addPoint(cloud, landmarkId, p, simValueColor);
+        }
+    }
+    savePointCloud(cloud, filepath);
 }
 
 void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileParams& tileParams, const std::vector<ROI>& tileRoiList,

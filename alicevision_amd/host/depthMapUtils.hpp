@@ -71,6 +71,34 @@ void writeNormalMap(int rc, const MultiViewParams& mp, const TileParams& tilePar
 void exportSimilaritySamplesCSV(const void* volume_d, bool halfFloat, long long pitchY, int pitchX, int nbPlanes, int width, int height, const std::string& name,
                                 const std::string& filepath, hipStream_t stream);
 
+// ---- debug exports of the similarity volumes as coloured point clouds (depthMap/volumeIO.cpp:148-441), saved as Alembic archives like
+// the reference's sfmDataIO::save(pointCloud, path, ESfMData::STRUCTURE).  A volume is copied to the host once and sampled there.
+struct HostVolume
+{
+    std::vector<unsigned char> bytes;
+    long long pitchY = 0;
+    int pitchX = 0, X = 0, Y = 0, Z = 0;
+    bool halfFloat = false;
+    float at(int x, int y, int z) const;
+};
+// X, Y: the extent the volume is laid out for (the reference's volDim: the allocation, not the tile's ROI); Z: number of planes held
+HostVolume downloadVolume(const void* volume_d, bool halfFloat, long long pitchY, int pitchX, int X, int Y, int Z, hipStream_t stream);
+// volumeIO.cpp:148-194: every 10th voxel column of the SGM volume, jet-coloured by similarity / 80 (similarities above 80 skipped)
+void exportSimilarityVolume(const HostVolume& vol, const std::vector<float>& depths, const MultiViewParams& mp, int camIndex, const SgmParams& sgmParams,
+                            const std::string& filepath, const ROI& roi);
+// volumeIO.cpp:196-246 (SGM volume) and :248-304 (Refine volume around the up-scaled SGM depth / pixel-size map): the centre row and column
+void exportSimilarityVolumeCross(const HostVolume& vol, const std::vector<float>& depths, const MultiViewParams& mp, int camIndex,
+                                 const SgmParams& sgmParams, const std::string& filepath, const ROI& roi);
+void exportSimilarityVolumeCross(const HostVolume& vol, const Float2Tile& depthPixSizeMapSgmUpscale, const MultiViewParams& mp, int camIndex,
+                                 const RefineParams& refineParams, const std::string& filepath, const ROI& roi);
+// volumeIO.cpp:306-376 and :378-441: the centre row, every voxel lifted by its normalised similarity (a profile of the cost per plane)
+void exportSimilarityVolumeTopographicCut(const HostVolume& vol, const std::vector<float>& depths, const MultiViewParams& mp, int camIndex,
+                                          const SgmParams& sgmParams, const std::string& filepath, const ROI& roi);
+void exportSimilarityVolumeTopographicCut(const HostVolume& vol, const Float2Tile& depthPixSizeMapSgmUpscale, const MultiViewParams& mp, int camIndex,
+                                          const RefineParams& refineParams, const std::string& filepath, const ROI& roi);
+// image/jetColorMap.cpp:34-53 (getRGBFromJetColorMap): MATLAB's jet(64), linearly interpolated; <= 0 black, >= 1 white
+void jetColor(float value, unsigned char rgb[3]);
+
 // depthMapUtils.cpp:240-277
 void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileParams& tileParams, const std::vector<ROI>& tileRoiList,
                                   const std::vector<Float2Tile>& in_depthSimMapTiles, int scale, int step, const std::string& name = "");

@@ -196,11 +196,6 @@ int aliceVision_main(int argc, char* argv[])
     refineParams.exportIntermediateTopographicCutVolumes = exportIntermediateTopographicCutVolumes;
     refineParams.exportIntermediateVolume9pCsv = exportIntermediateVolume9pCsv;
 
-    if(exportIntermediateVolumes || exportIntermediateCrossVolumes || exportIntermediateTopographicCutVolumes)
-    {
-        AVDM_LOG_ERROR("Intermediate volume exports as Alembic point clouds (volumeIO.cpp:148-505) are not built; --exportIntermediateVolume9pCsv is.");
-        return EXIT_FAILURE;
-    }
     // CustomPatchPatternParams.cpp:16-41 (operator>>): `circle|full:radius:nbCoordinates:level:weight`
     for(const std::string& token : customPatchPatternSubparts)
     {

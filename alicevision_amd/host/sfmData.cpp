@@ -1,6 +1,8 @@
 // sfmData.cpp — .sfm / .json scene reader (see sfmData.hpp for the reference lines restated).
 #include "sfmData.hpp"
 
+#include "alembic.hpp"
+
 #include "json.hpp"
 
 #include <algorithm>
@@ -91,7 +93,7 @@ void loadSfMData(SfMData& out, const std::string& filename)
     const size_t dot = filename.rfind('.');
     const std::string ext = dot == std::string::npos ? "" : filename.substr(dot);
     if(ext == ".abc")
-        throw std::runtime_error("Alembic (.abc) SfMData input is not supported by this build; convert the scene to .sfm/.json");
+        return loadSfMDataAlembic(out, filename); // sfmDataIO::load dispatches on the extension (sfmDataIO.cpp:106-131)
     std::ifstream f(filename, std::ios::binary);
     if(!f)
         throw std::runtime_error("cannot open '" + filename + "'");
@@ -227,6 +229,13 @@ void loadSfMData(SfMData& out, const std::string& filename)
             double X[3] = {0, 0, 0};
             loadVector(n.at("X"), X, 3);
             L.X = Point3d(X[0], X[1], X[2]);
+            if(const JsonValue* col = n.find("color"))
+            {
+                double c[3] = {255, 255, 255};
+                loadVector(*col, c, 3);
+                for(int k = 0; k < 3; ++k)
+                    L.rgb[k] = (unsigned char)c[k];
+            }
             if(const JsonValue* obs = n.find("observations"))
                 for(const JsonValue& o : obs->items)
                 {

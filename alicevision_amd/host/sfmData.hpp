@@ -1,7 +1,8 @@
 // sfmData.hpp — the part of an AliceVision SfMData scene the depth-map stage reads: views, pinhole intrinsics, poses and the
 // landmarks with their 2-D observations.  Restates sfmData/{SfMData,View,Landmark,CameraPose}.hpp and the JSON reader
 // sfmDataIO/jsonIO.cpp:76-111 (views), :244-449 (intrinsics), :533-566 (landmarks), :707-860 (file) of the reference.
-// Not read: rigs, ancestors, features/matches folders, constraints, Alembic (.abc) input.
+// Alembic (.abc) scenes — what Meshroom's StructureFromMotion node writes — are read by alembic.cpp (no Alembic library needed).
+// Not read: rigs, ancestors, features/matches folders, constraints.
 #pragma once
 
 #include "mvsData.hpp"
@@ -67,6 +68,7 @@ struct Observation
 struct Landmark
 {
     Point3d X;
+    unsigned char rgb[3] = {255, 255, 255};  // image::RGBColor (sfmData/Landmark.hpp): white unless the file says otherwise
     std::map<IndexT, Observation> observations;  // viewId -> observation (ordered like the reference's stl::flat_map)
 };
 
@@ -87,7 +89,7 @@ struct SfMData
     const Intrinsic& getIntrinsic(const View& v) const { return intrinsics.at(v.intrinsicId); }
 };
 
-// sfmDataIO::load for .sfm / .json; throws std::runtime_error with the reason
+// sfmDataIO::load for .sfm / .json / .abc; throws std::runtime_error with the reason
 void loadSfMData(SfMData& out, const std::string& filename);
 
 // camera::angleBetweenRays (camera/IntrinsicBase.hpp:475-517): degrees between the world rays of two observations

@@ -8,6 +8,9 @@
 //   png-copy in.png out.png                             decode an 8-bit PNG (first channel) and write it back as greyscale
 //   fuse-cameras sfm depthMapsFolder filterFolder n     cameras as aliceVision_depthMapFiltering sees them (from the depth maps' metadata)
 //                                                       and the n nearest cameras of each, as JSON with round-trip precision
+//   sfm-dump scene.(sfm|json|abc)                      the loaded SfMData as JSON with round-trip precision (views, intrinsics, poses, landmarks)
+//   jet v0 v1 ...                                      the reference's jet colour map (debug volume exports) at the given values
+//   sfm-to-abc scene.(sfm|json|abc) out.abc            write the loaded SfMData as an Alembic archive (AlembicExporter's layout)
 #include "DepthMapEstimator.hpp"
 #include "MultiViewParams.hpp"
 #include "depthMapUtils.hpp"
@@ -16,6 +19,7 @@
 #include "params.hpp"
 #include "png.hpp"
 #include "sfmData.hpp"
+#include "alembic.hpp"
 
 #include <chrono>
 #include <cstdlib>
@@ -227,6 +231,96 @@ int main(int argc, char** argv)
                 std::cout << "]}";
             }
             std::cout << "]}" << std::endl;
+            return 0;
+        }
+        if(cmd == "jet" && argc >= 3)
+        { // getRGBFromJetColorMap of every value given
+            for(int i = 2; i < argc; ++i)
+            {
+                unsigned char c[3];
+                jetColor((float)std::atof(argv[i]), c);
+                std::cout << (int)c[0] << " " << (int)c[1] << " " << (int)c[2] << "\n";
+            }
+            return 0;
+        }
+        if(cmd == "sfm-to-abc" && argc == 4)
+        {
+            SfMData sfm;
+            loadSfMData(sfm, argv[2]);
+            saveSfMDataAlembic(sfm, argv[3]);
+            return 0;
+        }
+        if(cmd == "sfm-dump" && argc == 3)
+        {
+            SfMData sfm;
+            loadSfMData(sfm, argv[2]);
+            std::ostream& os = std::cout;
+            os << std::setprecision(17) << "{\"views\": [";
+            bool first = true;
+            auto str = [](const std::string& t) {
+                std::string o = "\"";
+                for(char c : t)
+                {
+                    if(c == '"' || c == '\\')
+                        o += '\\';
+                    o += c;
+                }
+                return o + "\"";
+            };
+            for(const auto& kv : sfm.views)
+            {
+                const View& v = kv.second;
+                os << (first ? "" : ", ") << "{\"viewId\": " << v.viewId << ", \"poseId\": " << v.poseId << ", \"intrinsicId\": " << v.intrinsicId
+                   << ", \"path\": " << str(v.path) << ", \"width\": " << v.width << ", \"height\": " << v.height << ", \"metadata\": {";
+                bool f2 = true;
+                for(const auto& m : v.metadata)
+                {
+                    os << (f2 ? "" : ", ") << str(m.first) << ": " << str(m.second);
+                    f2 = false;
+                }
+                os << "}}";
+                first = false;
+            }
+            os << "], \"intrinsics\": [";
+            first = true;
+            for(const auto& kv : sfm.intrinsics)
+            {
+                const Intrinsic& I = kv.second;
+                os << (first ? "" : ", ") << "{\"intrinsicId\": " << I.intrinsicId << ", \"type\": " << str(I.type) << ", \"distortionType\": "
+                   << str(I.distortionType) << ", \"width\": " << I.width << ", \"height\": " << I.height << ", \"sensorWidth\": " << I.sensorWidth
+                   << ", \"sensorHeight\": " << I.sensorHeight << ", \"scale\": [" << I.scaleX << ", " << I.scaleY << "], \"offset\": [" << I.offsetX
+                   << ", " << I.offsetY << "], \"isPinhole\": " << (I.isPinhole ? 1 : 0) << ", \"distortionParams\": [";
+                for(size_t i = 0; i < I.distortionParams.size(); ++i)
+                    os << (i ? ", " : "") << I.distortionParams[i];
+                os << "]}";
+                first = false;
+            }
+            os << "], \"poses\": [";
+            first = true;
+            for(const auto& kv : sfm.poses)
+            {
+                os << (first ? "" : ", ") << "{\"poseId\": " << kv.first << ", \"rotation\": [";
+                for(int i = 0; i < 9; ++i)
+                    os << (i ? ", " : "") << kv.second.rotation.m[i];
+                os << "], \"center\": [" << kv.second.center.x << ", " << kv.second.center.y << ", " << kv.second.center.z << "]}";
+                first = false;
+            }
+            os << "], \"landmarks\": [";
+            first = true;
+            for(const auto& kv : sfm.landmarks)
+            {
+                os << (first ? "" : ", ") << "{\"id\": " << kv.first << ", \"X\": [" << kv.second.X.x << ", " << kv.second.X.y << ", " << kv.second.X.z
+                   << "], \"rgb\": [" << (int)kv.second.rgb[0] << ", " << (int)kv.second.rgb[1] << ", " << (int)kv.second.rgb[2] << "], \"obs\": [";
+                bool f2 = true;
+                for(const auto& ob : kv.second.observations)
+                {
+                    os << (f2 ? "" : ", ") << "[" << ob.first << ", " << ob.second.x << ", " << ob.second.y << "]";
+                    f2 = false;
+                }
+                os << "]}";
+                first = false;
+            }
+            os << "]}" << std::endl;
             return 0;
         }
         return usage();

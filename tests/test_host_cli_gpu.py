@@ -540,3 +540,147 @@ def test_prepare_dense_scene_undistorts_and_feeds_the_estimation(tmp_path):
     pb = json.loads(run_cli(b).stdout.strip().splitlines()[-1])
     assert pa["tiles"][0]["sgmTCams"] == pb["tiles"][0]["sgmTCams"]
     assert np.allclose(pa["tiles"][0]["depths"], pb["tiles"][0]["depths"], rtol=1e-5)
+
+
+def test_alembic_scene_gives_the_same_maps_as_the_sfm_scene(dataset, tmp_path):
+    """`-i sfm.abc` — what Meshroom's StructureFromMotion node hands to the DepthMap node (sfmDataIO::load dispatches on the extension,
+    sfmDataIO.cpp:106-131) — read by host/alembic.cpp: the maps of a reference camera equal those of the run on the .sfm file the
+    archive was written from to float precision (cameras identical to the last ulp of the pose inverse; the archive holds the landmarks,
+    which seed the depth-plane list, as float32 like the reference's exporter)."""
+    sc, sfm, img, d = dataset
+    tool = os.path.join(ROOT, "alicevision_amd", "bin", "avdm_host_tool")
+    abc_path = str(tmp_path / "sfm.abc")
+    r = subprocess.run([tool, "sfm-to-abc", sfm, abc_path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    maps = []
+    for k, scene in enumerate((sfm, abc_path)):
+        out_dir = str(tmp_path / ("out%d" % k))
+        run_cli(["-i", scene, "--imagesFolder", img, "-o", out_dir, "--downscale", 1, "--rangeStart", 0, "--rangeSize", 1, "--sgmMaxDepths", 64,
+                 "--colorOptimizationNbIterations", 5, "-v", "warning"])
+        maps.append(read_maps(out_dir)[:2])
+    valid = maps[0][0] > 0
+    assert valid.mean() > 0.5
+    # the depth-plane list is seeded from the landmarks (float32 in the archive, double in the .sfm): the same planes up to 1e-7 relative
+    assert np.array_equal(valid, maps[1][0] > 0)
+    np.testing.assert_allclose(maps[1][0][valid], maps[0][0][valid], rtol=2e-5)
+    assert float(np.abs(maps[1][1] - maps[0][1])[valid].mean()) < 1e-3
+
+
+def test_volume_exports_as_alembic_point_clouds(dataset, tmp_path):
+    """--exportIntermediateVolumes / --exportIntermediateCrossVolumes / --exportIntermediateTopographicCutVolumes (volumeIO.cpp:148-441):
+    the point clouds the program saves (Alembic archives like the reference's sfmDataIO::save(.., STRUCTURE), read back here by the
+    program's own reader) equal a numpy restatement of the reference's loops over the harness's volumes of the same plan."""
+    import torch
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    sc, sfm, img, d = dataset
+    tool = os.path.join(ROOT, "alicevision_amd", "bin", "avdm_host_tool")
+    out = str(tmp_path / "out")
+    args = common_args(sfm, img, out) + ["--exportIntermediateVolumes", 1, "--exportIntermediateCrossVolumes", 1,
+                                         "--exportIntermediateTopographicCutVolumes", 1]
+    plan = json.loads(run_cli(args + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
+    t0 = plan["tiles"][0]
+    run_cli(args)
+    vid = scene_io.view_id(0)
+
+    def cloud(name):
+        r = subprocess.run([tool, "sfm-dump", os.path.join(out, "%d_%s.abc" % (vid, name))], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        doc = json.loads(r.stdout)
+        assert doc["views"] == [] and doc["poses"] == []
+        lm = doc["landmarks"]
+        assert [l["id"] for l in lm] == list(range(len(lm))) and all(l["obs"] == [] for l in lm)
+        return np.array([l["X"] for l in lm]).reshape(-1, 3), np.array([l["rgb"] for l in lm]).reshape(-1, 3)
+
+    sgm = abi.SgmParams.default(scale=plan["sgmScale"], stepXY=plan["sgmStepXY"])
+    ref = abi.RefineParams.default(optimizationNbIterations=OPT_ITERS)
+    depths = np.asarray(t0["depths"], np.float32)
+    ranges = [(a, a + n) for a, n in t0["depthsTcLimits"]]
+    torch.cuda.set_device(0)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(NVIEWS)]
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+    h.run_sgm(0, t0["sgmTCams"], depths, tc_ranges=ranges, keep_raw=True)
+    ss = plan["sgmScale"] * plan["sgmStepXY"]
+    K, R, C0 = sc.K.astype(np.float64), sc.R[0].astype(np.float64), sc.C[0].astype(np.float64)
+    iCam = np.linalg.inv(K @ R)
+    n = R.T @ np.array([0.0, 0.0, 1.0])
+    n /= np.linalg.norm(n)
+
+    def plane_point(x, y, depth):
+        v = iCam @ np.array([x, y, 1.0])
+        v /= np.linalg.norm(v)
+        planep = C0 + n * depth
+        return C0 + v * ((planep @ n - n @ C0) / (n @ v))
+
+    def jet(values):
+        table = np.stack([np.clip(1.5 - np.abs(4.0 * (np.arange(64) + 1) / 64.0 - c), 0.0, 1.0) for c in (3.0, 2.0, 1.0)], axis=1).astype(np.float32)
+        out_ = []
+        for v in np.asarray(values, np.float32):
+            if v <= 0:
+                out_.append([0, 0, 0])
+            elif v >= 1:
+                out_.append([255, 255, 255])
+            else:
+                f = v * np.float32(63.0)
+                i = int(np.floor(f))
+                b = np.float32(f - np.float32(i))
+                a = np.float32(1.0) - b
+                out_.append([int(np.float32(np.float32(table[i, k] * a + table[i + 1, k] * b) * np.float32(255.0))) for k in range(3)])
+        return np.array(out_).reshape(-1, 3)
+
+    for name, vol_t in (("beforeFiltering", h.second), ("afterFiltering", h.best)):
+        vol = vol_t.cpu().numpy()
+        Y, X = vol.shape[:2]
+        Z = len(depths)
+        # the whole volume, every 10th column (volumeIO.cpp:148-194)
+        pts, sims = [], []
+        for vy in range(0, Y, 10):
+            for vx in range(0, X, 10):
+                for vz in range(Z):
+                    s = float(vol[vy, vx, vz])
+                    if s > 80.0:
+                        continue
+                    pts.append(plane_point(vx * ss, vy * ss, float(depths[vz])))
+                    sims.append(s / 80.0)
+        Xg, Cg = cloud("volume_" + name)
+        assert len(pts) == len(Xg) > 100, (len(pts), len(Xg))
+        np.testing.assert_allclose(Xg, np.array(pts), rtol=3e-7, atol=1e-6)  # float32 in the archive
+        assert np.array_equal(Cg, jet(np.float32(sims)))
+        # the cross (volumeIO.cpp:196-246): the centre row in full, the centre column elsewhere
+        pts, sims = [], []
+        for vz in range(Z):
+            for vy in range(Y):
+                centre = (vy >= Y // 2) and ((vy - 1) < Y // 2)
+                for vx in (range(X) if centre else range(X // 2, X // 2 + 1)):
+                    s = float(vol[vy, vx, vz])
+                    if s > 80.0:
+                        continue
+                    pts.append(plane_point(vx * ss, vy * ss, float(depths[vz])))
+                    sims.append(s / 80.0)
+        Xg, Cg = cloud("volumeCross_" + name)
+        assert len(pts) == len(Xg) > 100
+        np.testing.assert_allclose(Xg, np.array(pts), rtol=3e-7, atol=1e-6)
+        assert np.array_equal(Cg, jet(np.float32(sims)))
+        # the topographic cut (volumeIO.cpp:306-376): the row below the centre, lifted by the normalised similarity
+        vy = (Y + 1) // 2
+        row = vol[vy, :, :Z].astype(np.float32)
+        valid = row <= 254.0
+        lo, hi = row[valid].min(), row[valid].max()
+        norm = np.float32(0.0) if hi == lo else np.float32(1.0) / (hi - lo)
+        pts, sims = [], []
+        for vx in range(X):
+            for vz in range(Z):
+                if not valid[vx, vz]:
+                    continue
+                sn = np.float32((row[vx, vz] - lo) * norm)
+                pts.append(plane_point(vx * ss, vy * ss + float(sn) * 15.0, float(depths[vz])))
+                sims.append(sn)
+        Xg, Cg = cloud("volumeTopographicCut_" + name)
+        assert len(sims) == len(Xg) > 100
+        np.testing.assert_allclose(Xg, np.array(pts), rtol=3e-7, atol=1e-6)
+        assert np.array_equal(Cg, jet(np.float32(sims)))
+    # Refine: the cross and the cut exist, hold one point per (pixel of the cross, plane) with a valid middle depth
+    Xg, Cg = cloud("volumeCross_afterRefine")
+    Zr = 2 * ref.halfNbDepths + 1
+    assert len(Xg) > 0 and len(Xg) % Zr == 0 and len(Xg) <= (W + H - 1) * Zr
+    Xg, Cg = cloud("volumeTopographicCut_afterRefine")
+    assert len(Xg) > 0 and len(Xg) % Zr == 0 and len(Xg) <= W * Zr

@@ -442,3 +442,121 @@ def test_png_writer_reader_roundtrip_all_filters(tmp_path, ch, bits):
         from PIL import Image
         back = np.asarray(Image.open(path))
         assert np.array_equal(back.reshape(h, w, ch), arr)
+
+
+# ------------------------------------------------------------------------------------------------ Alembic (.abc) SfMData
+ABC_GOLDEN = os.path.join(ROOT, "tests", "golden", "alembic")
+
+
+def _gunzip(name, tmp_path):
+    import gzip
+    dst = str(tmp_path / name[:-3])
+    with gzip.open(os.path.join(ABC_GOLDEN, name), "rb") as f, open(dst, "wb") as g:
+        g.write(f.read())
+    return dst
+
+
+def _sfm_dump(path):
+    return json.loads(run([TOOL, "sfm-dump", path]).stdout)
+
+
+@pytest.mark.parametrize("version", ["1.2.0", "1.2.2", "1.2.3", "1.2.8", "1.2.11"])
+def test_alembic_reader_on_the_reference_compatibility_scenes(version, tmp_path):
+    """The reference's own scene_v<version>.abc (sfmDataIO/compatibilityData, written by Alembic 1.7.16 / 1.8.4 through its exporter of
+    that version) read by alembic.cpp == the scene as its newest .json twin states it (tests/golden/make_alembic_fixtures.py).
+    Follows sfmDataIOCompatibility_test.cpp, which loads each file and compares it with the generated sample scene."""
+    exp = json.load(open(os.path.join(ABC_GOLDEN, "expected.json")))
+    got = _sfm_dump(_gunzip("scene_v%s.abc.gz" % version, tmp_path))
+    assert [{k: v[k] for k in ("viewId", "poseId", "intrinsicId", "path", "width", "height", "metadata")} for v in got["views"]] == \
+        sorted(exp["views"], key=lambda v: v["viewId"])
+    assert len(got["intrinsics"]) == len(exp["intrinsics"]) == 2
+    for g, e in zip(got["intrinsics"], sorted(exp["intrinsics"], key=lambda i: i["intrinsicId"])):
+        assert (g["intrinsicId"], g["type"], g["distortionType"], g["width"], g["height"], g["isPinhole"]) == \
+            (e["intrinsicId"], e["type"], e["distortionType"], e["width"], e["height"], 1)
+        assert g["sensorWidth"] == e["sensorWidth"] and g["sensorHeight"] == e["sensorHeight"] and g["distortionParams"] == e["distortionParams"]
+        np.testing.assert_allclose(g["scale"], e["scale"], rtol=1e-12)
+        np.testing.assert_allclose(g["offset"], e["offset"], rtol=1e-12)
+    assert [p["poseId"] for p in got["poses"]] == sorted(p["poseId"] for p in exp["poses"])
+    for g, e in zip(got["poses"], sorted(exp["poses"], key=lambda p: p["poseId"])):
+        np.testing.assert_allclose(g["rotation"], e["rotation"], rtol=0, atol=1e-14)
+        np.testing.assert_allclose(g["center"], e["center"], rtol=0, atol=1e-14)
+    assert len(got["landmarks"]) == exp["n_landmarks"] and all(l["obs"] == [] for l in got["landmarks"])
+    for e in exp["landmarks"]:
+        assert got["landmarks"][e["id"]]["id"] == e["id"] and got["landmarks"][e["id"]]["X"] == e["X"]
+
+
+def test_alembic_writer_equals_the_reference_file_entry_by_entry(tmp_path):
+    """scene_v1.2.11.abc -> SfMData -> saveSfMDataAlembic: every object, property header, metadata string and sample blob (digest
+    included) of the archive written here equals the reference's own file — read back by a second, independent parser
+    (tests/abc_explorer.py) — except the camera transforms' values, which differ by signed zeros / the last ulp of the 4 x 4 inverse."""
+    import abc_explorer
+    src = _gunzip("scene_v1.2.11.abc.gz", tmp_path)
+    out = str(tmp_path / "written.abc")
+    run([TOOL, "sfm-to-abc", src, out])
+    ref, mine = abc_explorer.flatten(open(src, "rb").read()), abc_explorer.flatten(open(out, "rb").read())
+    assert set(ref) == set(mine)
+    differing = [k for k in ref if ref[k] != mine[k]]
+    assert differing and all(k.endswith("/.xform/.vals") for k in differing), differing[:5]
+    for k in differing:
+        assert ref[k][:5] == mine[k][:5]
+        a, b = (np.frombuffer(x[5][0][16:], dtype="<f8") for x in (ref[k], mine[k]))
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-14)
+
+
+def test_alembic_round_trip_with_observations_and_cli_plan(scene, tmp_path):
+    """a scene WITH observations and image paths: .sfm -> .abc -> the same SfMData (positions and observations to float precision — the
+    archive holds them as float32 like the reference's exporter), and the program plans the same work from either file"""
+    sc, lms, sfm, img, d = scene
+    abc_path = str(tmp_path / "scene.abc")
+    run([TOOL, "sfm-to-abc", sfm, abc_path])
+    a, b = _sfm_dump(sfm), _sfm_dump(abc_path)
+    assert a["views"] == b["views"] and [p["poseId"] for p in a["poses"]] == [p["poseId"] for p in b["poses"]]
+    for ia, ib in zip(a["intrinsics"], b["intrinsics"]):
+        assert {k: v for k, v in ia.items() if k not in ("scale", "offset")} == {k: v for k, v in ib.items() if k not in ("scale", "offset")}
+        np.testing.assert_allclose(ia["scale"] + ia["offset"], ib["scale"] + ib["offset"], rtol=1e-15)
+    for pa, pb in zip(a["poses"], b["poses"]):
+        np.testing.assert_allclose(pa["rotation"] + pa["center"], pb["rotation"] + pb["center"], rtol=0, atol=1e-13)
+    assert len(a["landmarks"]) == len(b["landmarks"]) > 100 and sum(len(l["obs"]) for l in a["landmarks"]) > 1000
+    for la, lb in zip(a["landmarks"], b["landmarks"]):
+        np.testing.assert_allclose(la["X"], lb["X"], rtol=2e-7)
+        assert [o[0] for o in la["obs"]] == [o[0] for o in lb["obs"]]
+        np.testing.assert_allclose([o[1:] for o in la["obs"]], [o[1:] for o in lb["obs"]], rtol=2e-7)
+    ref = plan_of(sfm, img, str(tmp_path / "o_sfm"), ["--sgmMaxDepths", 48])
+    got = plan_of(abc_path, img, str(tmp_path / "o_abc"), ["--sgmMaxDepths", 48])
+    assert len(ref["tiles"]) == len(got["tiles"]) > 0
+    for ta, tb in zip(ref["tiles"], got["tiles"]):
+        assert ta["sgmTCams"] == tb["sgmTCams"] and np.allclose(ta["depths"], tb["depths"], rtol=1e-5)
+
+
+def test_alembic_reader_rejects_what_it_cannot_read(tmp_path):
+    bad = str(tmp_path / "bad.abc")
+    open(bad, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    r = run([TOOL, "sfm-dump", bad], check=False)
+    assert r.returncode == 1 and "HDF5" in r.stderr
+    src = _gunzip("scene_v1.2.11.abc.gz", tmp_path)
+    data = open(src, "rb").read()
+    open(bad, "wb").write(data[:len(data) // 2])  # truncated: the root group position points past the end
+    assert run([TOOL, "sfm-dump", bad], check=False).returncode == 1
+    open(bad, "wb").write(data[:5] + b"\x00" + data[6:])  # not frozen
+    r = run([TOOL, "sfm-dump", bad], check=False)
+    assert r.returncode == 1 and "frozen" in r.stderr
+
+
+def test_jet_colour_map_of_the_volume_exports():
+    """image/jetColorMap.cpp holds MATLAB's jet(64) as three tables; jet's closed form is entry i = clamp(1.5 - |4 (i + 1) / 64 - c|, 0, 1)
+    with c = 3, 2, 1 for red, green, blue.  The reference interpolates the table linearly at value * 63 and truncates to 8 bits."""
+    table = np.stack([np.clip(1.5 - np.abs(4.0 * (np.arange(64) + 1) / 64.0 - c), 0.0, 1.0) for c in (3.0, 2.0, 1.0)], axis=1).astype(np.float32)
+    values = np.concatenate([[-0.5, 0.0, 1.0, 1.5], np.linspace(0.001, 0.999, 97)]).astype(np.float32)
+    got = np.array([[int(t) for t in l.split()] for l in run([TOOL, "jet"] + ["%.9g" % v for v in values]).stdout.strip().splitlines()])
+    for v, g in zip(values, got):
+        if v <= 0:
+            want = [0, 0, 0]
+        elif v >= 1:
+            want = [255, 255, 255]
+        else:
+            f = np.float32(v) * np.float32(63.0)
+            i = int(np.floor(f))
+            b = np.float32(f - np.float32(i))
+            a = np.float32(1.0) - b
+            want = [int(np.float32(np.float32(table[i, k] * a + table[i + 1, k] * b) * np.float32(255.0))) for k in range(3)]
+        assert list(g) == want, (v, g, want)
