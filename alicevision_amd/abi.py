@@ -98,6 +98,12 @@ class PatchPattern(C.Structure):
     _fields_ = [("subparts", PatchPatternSubpart * 4), ("nbSubparts", C.c_int)]
 
 
+class JpegComponent(C.Structure):
+    """avdm_jpeg_component_t"""
+    _fields_ = [("coef", C.c_void_p), ("blocks_w", C.c_int), ("blocks_h", C.c_int), ("width", C.c_int), ("height", C.c_int), ("h_samp", C.c_int),
+                ("v_samp", C.c_int), ("quant", C.c_uint16 * 64)]
+
+
 class SgmTile(C.Structure):
     """avdm_sgm_tile_t"""
     _fields_ = [("out_vol", C.c_void_p), ("in_vol", C.c_void_p), ("pitch_y", C.c_longlong), ("pitch_x", C.c_int), ("last_depth_index", C.c_int),
@@ -122,6 +128,8 @@ SIGNATURES = {
     "avdm_pyramid_build_levels": (i32, [P(Pyramid), vp]),
     "avdm_image_resize": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, vp]),
     "avdm_image_decode_integer": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "avdm_image_decode_jpeg_scratch_bytes": (C.c_size_t, [P(JpegComponent), i32]),
+    "avdm_image_decode_jpeg": (i32, [vp, i32, i32, i32, P(JpegComponent), i32, i32, i32, i32, vp, vp]),
     "avdm_image_undistort": (i32, [vp, i32, vp, i32, P(Intrinsic), P(C.c_float * 4), vp]),
     "avdm_pyramid_fill": (i32, [P(Pyramid), vp, i32, vp, vp]),
     "avdm_tex2dlod": (i32, [vp, P(Pyramid), vp, i32, vp]),

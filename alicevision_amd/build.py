@@ -22,6 +22,7 @@ SOURCES = {
     "avdm_sgm.hip": ["-ffp-contract=off"],           # bit-exact class
     "avdm_maps.hip": ["-ffp-contract=off"],          # bit-exact / order-preserving class
     "avdm_fuse.hip": ["-ffp-contract=off"],          # bit-exact class (double arithmetic in the reference's order)
+    "avdm_jpeg.hip": ["-ffp-contract=off"],          # bit-exact class (integers only)
     "avdm_literal.hip": ["-ffp-contract=off"],       # AVDM_SIM_LITERAL=1: the reference's similarity arithmetic as written (attribution switch)
 }
 

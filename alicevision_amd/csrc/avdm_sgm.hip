@@ -27,6 +27,8 @@
 //   * a 4-slot register ring keeps the loads of the next 24-32 slices in flight; the recurrence depends on registers only.
 #include "avdm_device.h"
 
+#include <hip/hip_ext.h>
+
 #include <math.h>
 #include <stdlib.h>
 
@@ -777,10 +779,20 @@ __device__ __forceinline__ float avg_f32(float o, float lc)
 #define AVDM_SGM_AUX_LD 2 // cache policy of the ring loads / the stores: 0 = default, 2 = non-temporal (gfx94x/95x aux bit 1)
 #endif
 #ifndef AVDM_SGM_AUX_ST
-#define AVDM_SGM_AUX_ST 2
+#define AVDM_SGM_AUX_ST 0 // plain stores: 2-3 % faster than non-temporal ones on both kinds of box (profiles/r03_w_sgm_ring_variants.txt)
 #endif
 #ifndef AVDM_SGM_SLOTS_1LD
 #define AVDM_SGM_SLOTS_1LD 4 // ring slots of the walks that load one dword per step (the others use 4)
+#endif
+#ifndef AVDM_SGM_PAIR_PF1
+// steps per ring slot of the 256-plane instantiations: 4 slots x 4 steps = loads 12-16 steps ahead.  Twice that depth (8 steps per slot, the
+// setting of rounds 1-3) costs nothing on the boxes where this kernel runs at 0.57-0.59 of the HBM peak, but 12-14 % on the other kind
+// (0.46 -> 0.52: SQ_WAIT_ANY doubles there with the same instructions at the same clock — more rows in flight than that memory system
+// serves well), and half of it (2 steps per slot) is no better: profiles/r03_w_sgm_ring_variants.txt, r03_t_sgm_clock_pmc.txt
+#define AVDM_SGM_PAIR_PF1 4
+#endif
+#ifndef AVDM_SGM_PAIR_NSETS
+#define AVDM_SGM_PAIR_NSETS 4
 #endif
 #ifndef AVDM_SGM_PROLOGUE_DRAIN
 #define AVDM_SGM_PROLOGUE_DRAIN 0
@@ -835,8 +847,8 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
 {
     constexpr int ZL = 4 * NW;
     constexpr int NR = 2 * NW;
-    constexpr int PF = NW == 1 ? 8 : (NW == 2 ? 4 : 2);
-    constexpr int NSETS = 4;
+    constexpr int PF = NW == 1 ? AVDM_SGM_PAIR_PF1 : (NW == 2 ? 4 : 2); // steps per ring slot
+    constexpr int NSETS = AVDM_SGM_PAIR_NSETS;                           // ring slots: the loads run (NSETS - 1) * PF .. NSETS * PF steps ahead
     // Stash (LDS): on a step whose P2 fraction is within 2^-13 of 1 the reference's running average sees the un-truncated clamped cost
     // (kernels.cuh:733-743) and its fraction can carry.  Three of the four roles have that cost in registers when they average; the
     // reverse wave of phase 1 only STORES a byte that the forward wave averages in phase 2 — so on such a step it also leaves the 256 * NW
@@ -1292,8 +1304,13 @@ __global__ void __launch_bounds__(128 * AVDM_SGM_PAIR_WPB) sgm_pair_kernel(SgmPa
     }
 }
 
-// Opt-in timing of the path kernels alone (avdm_debug_sgm_kernel_timing): a pair of HIP events on the launch stream around every launch,
-// read back (and recycled) by avdm_debug_sgm_kernel_timing_read.  Off by default: no events, no synchronisation.
+// Opt-in timing of the path kernels alone (avdm_debug_sgm_kernel_timing): a pair of HIP events per launch on the launch stream, read back
+// (and recycled) by avdm_debug_sgm_kernel_timing_read.  Off by default: no events, no synchronisation.
+// The events are handed to the launch itself (hipExtLaunchKernelGGL: "startEvent / stopEvent track the start / stop time of the kernel
+// launch"), so their difference is the kernel's execution — what rocprofv3's kernel trace reports.  Events recorded with hipEventRecord
+// before and after the launch also time the two command-processor hops around it: 8-9 us per launch here, 3.6 % of a 0.23 ms kernel
+// (profiles/r03_r_*: 475 us by events against 459 us in the trace for the two launches of one volume).  AVDM_SGM_TIMER=record selects that
+// older bracketing for comparison.
 struct SgmKernelTimer
 {
     std::mutex m;
@@ -1307,12 +1324,22 @@ struct SgmKernelTimer
 };
 static SgmKernelTimer g_sgmTimer;
 
+static bool sgm_timer_brackets()
+{
+    static const bool v = [] {
+        const char* e = getenv("AVDM_SGM_TIMER");
+        return e && e[0] == 'r';
+    }();
+    return v;
+}
+
 struct SgmKernelTimerScope
 {
     hipStream_t st;
     int path;
+    bool brackets;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    explicit SgmKernelTimerScope(hipStream_t s, int path_ = 0) : st(s), path(path_ & 3)
+    explicit SgmKernelTimerScope(hipStream_t s, int path_ = 0) : st(s), path(path_ & 3), brackets(sgm_timer_brackets())
     {
         std::lock_guard<std::mutex> lock(g_sgmTimer.m);
         if(!g_sgmTimer.enabled)
@@ -1327,13 +1354,24 @@ struct SgmKernelTimerScope
             ev = {nullptr, nullptr};
             return;
         }
-        (void)hipEventRecord(ev.first, st);
+        if(brackets)
+            (void)hipEventRecord(ev.first, st);
+    }
+    // the ONE launch of this scope
+    template <typename Kernel, typename Arg>
+    void launch(Kernel kernel, dim3 grid, dim3 block, size_t lds, const Arg& arg)
+    {
+        if(ev.first != nullptr && !brackets)
+            hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, ev.first, ev.second, 0, arg);
+        else
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, arg);
     }
     ~SgmKernelTimerScope()
     {
         if(ev.first == nullptr)
             return;
-        (void)hipEventRecord(ev.second, st);
+        if(brackets)
+            (void)hipEventRecord(ev.second, st);
         std::lock_guard<std::mutex> lock(g_sgmTimer.m);
         g_sgmTimer.pending.push_back(ev);
         g_sgmTimer.pendingPath.push_back(path);
@@ -1368,16 +1406,16 @@ static void launch_pair(const SgmPathBatch& S, int nWorkgroups, int K, bool full
     if(K == 0)
     {
         if(full)
-            hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, HAS_FULL>), grid, block, lds, st, S);
+            timing.launch(sgm_pair_kernel<NW, 0, HAS_FULL>, grid, block, lds, S);
         else
-            hipLaunchKernelGGL((sgm_pair_kernel<NW, 0, false>), grid, block, lds, st, S);
+            timing.launch(sgm_pair_kernel<NW, 0, false>, grid, block, lds, S);
     }
     else
     {
         if(full)
-            hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, HAS_FULL>), grid, block, lds, st, S);
+            timing.launch(sgm_pair_kernel<NW, 2, HAS_FULL>, grid, block, lds, S);
         else
-            hipLaunchKernelGGL((sgm_pair_kernel<NW, 2, false>), grid, block, lds, st, S);
+            timing.launch(sgm_pair_kernel<NW, 2, false>, grid, block, lds, S);
     }
 }
 
@@ -1386,7 +1424,7 @@ static void launch_path(const SgmPathBatch& S, int ncols, int K, bool full, bool
 {
     dim3 grid(ncols);
     SgmKernelTimerScope timing(st, K);
-#define AVDM_SGM_LAUNCH2(KK, FF, II) hipLaunchKernelGGL((sgm_path_kernel<NW, KK, FF, II>), grid, dim3(64 * AVDM_SGM_WPB), 0, st, S)
+#define AVDM_SGM_LAUNCH2(KK, FF, II) timing.launch(sgm_path_kernel<NW, KK, FF, II>, grid, dim3(64 * AVDM_SGM_WPB), 0, S)
     // the fp32 kernel (non-integer P1) is only instantiated in its general form: FULL shapes run it with FULL = false
 #define AVDM_SGM_LAUNCH(KK)                                                                                                                           \
     if(full && int16)                                                                                                                                 \

@@ -33,14 +33,19 @@ struct SortedId
     int id;
     float value;
 };
-bool isPngPath(const std::string& path)
+std::string lowerExtension(const std::string& path)
 {
-    if(path.size() < 4)
-        return false;
-    std::string e = path.substr(path.size() - 4);
+    const size_t dot = path.rfind('.');
+    std::string e = dot == std::string::npos ? "" : path.substr(dot);
     for(char& c : e)
         c = (char)std::tolower((unsigned char)c);
-    return e == ".png";
+    return e;
+}
+bool isPngPath(const std::string& path) { return lowerExtension(path) == ".png"; }
+bool isJpegPath(const std::string& path)
+{
+    const std::string e = lowerExtension(path);
+    return e == ".jpg" || e == ".jpeg";
 }
 } // namespace
 
@@ -75,9 +80,9 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
             else if(_imagesFolder != "/" && dirExists(_imagesFolder))
             {
                 // one file per view named <viewId>.<ext> (MultiViewParams.cpp:83-103: exactly one file with a supported extension); this build
-                // decodes OpenEXR (PrepareDenseScene's output format) and PNG
+                // decodes OpenEXR (PrepareDenseScene's output format), PNG and JPEG
                 std::string candidate;
-                for(const char* ext : {".exr", ".png"})
+                for(const char* ext : {".exr", ".png", ".jpg", ".jpeg", ".JPG"})
                 {
                     const std::string c = _imagesFolder + std::to_string(view.viewId) + ext;
                     if(!fileExists(c))
@@ -89,7 +94,7 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
                 }
                 if(candidate.empty())
                     throw std::runtime_error("Cannot find image file coresponding to the view '" + std::to_string(view.viewId) + "' in folder '" +
-                                             _imagesFolder + "' (expected " + std::to_string(view.viewId) + ".exr or .png).");
+                                             _imagesFolder + "' (expected " + std::to_string(view.viewId) + ".exr, .png or .jpg).");
                 path = candidate;
             }
             dimensions.emplace(view.width, view.height);
@@ -129,6 +134,13 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
             readPng(imgParams.path, png, true);
             header.width = png.width;
             header.height = png.height;
+        }
+        else if(exists && isJpegPath(imgParams.path))
+        {
+            JpegImage jpeg;
+            readJpeg(imgParams.path, jpeg, true);
+            header.width = jpeg.width;
+            header.height = jpeg.height;
         }
         else if(exists)
         {
@@ -456,7 +468,8 @@ bool triangulateMatch(Point3d& out, const Point2d& refpix, const Point2d& tarpix
     return lineLineIntersect(out, mp.CArr[refCam], refpoint, mp.CArr[tarCam], tarpoint);
 }
 
-// mvsUtils/fileIO.cpp:389-443.  Decoding is OpenEXR only; the --downscale resize happens on the device (see below).
+// mvsUtils/fileIO.cpp:389-443.  OpenEXR is decoded on the host; PNG and JPEG leave it as integer samples / DCT coefficients and become
+// linear float RGBA on the device; the --downscale resize happens on the device (see below).
 std::shared_ptr<const HostImage> ImagesCache::getImg_sync(int camId)
 {
     {
@@ -489,6 +502,35 @@ std::shared_ptr<const HostImage> ImagesCache::getImg_sync(int camId)
         full->srcHeight = png.height;
         full->width = s > 1 ? png.width / s : png.width;
         full->height = s > 1 ? png.height / s : png.height;
+        std::shared_ptr<const HostImage> result = full;
+        std::lock_guard<std::mutex> lock(_mutex);
+        if(_cache.size() >= _max)
+        {
+            auto oldest = _cache.begin();
+            for(auto i = _cache.begin(); i != _cache.end(); ++i)
+                if(i->second.first < oldest->second.first)
+                    oldest = i;
+            _cache.erase(oldest);
+        }
+        _cache[camId] = {++_tick, result};
+        return result;
+    }
+    if(isJpegPath(path))
+    {
+        // markers and Huffman decoding on the host (sequential by nature); the coefficients go to the device, which does the rest of the decode
+        auto jpeg = std::make_shared<JpegImage>();
+        readJpeg(path, *jpeg);
+        if(_mp.getOriginalWidth(camId) != jpeg->width || _mp.getOriginalHeight(camId) != jpeg->height)
+            throw std::runtime_error("Bad image dimension for camera : " + std::to_string(camId) + "\n\t- image path : " + path + "\n\t- expected dimension : " +
+                                     std::to_string(_mp.getOriginalWidth(camId)) + "x" + std::to_string(_mp.getOriginalHeight(camId)) +
+                                     "\n\t- real dimension : " + std::to_string(jpeg->width) + "x" + std::to_string(jpeg->height));
+        auto full = std::make_shared<HostImage>();
+        const int s = _mp.getProcessDownscale();
+        full->srcWidth = jpeg->width;
+        full->srcHeight = jpeg->height;
+        full->width = s > 1 ? jpeg->width / s : jpeg->width;
+        full->height = s > 1 ? jpeg->height / s : jpeg->height;
+        full->jpeg = jpeg;
         std::shared_ptr<const HostImage> result = full;
         std::lock_guard<std::mutex> lock(_mutex);
         if(_cache.size() >= _max)

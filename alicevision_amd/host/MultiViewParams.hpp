@@ -5,6 +5,7 @@
 #pragma once
 
 #include "exr.hpp"
+#include "jpeg.hpp"
 #include "mvsData.hpp"
 #include "sfmData.hpp"
 
@@ -139,6 +140,9 @@ struct HostImage
     // and converts them to linear float RGBA on the device (avdm_image_decode_integer).  `rgba` is empty then.
     std::vector<unsigned char> raw;
     int rawChannels = 0, rawBits = 0;
+    // a JPEG file: the entropy-decoded coefficients (host/jpeg.cpp); the inverse DCT, up-sampling, colour conversion and the sRGB decoding run
+    // on the device (avdm_image_decode_jpeg + avdm_image_decode_integer).  `rgba` and `raw` are empty then.
+    std::shared_ptr<const JpegImage> jpeg;
 };
 // mvsUtils/fileIO.cpp:389-443 loadImage + mvsUtils/ImagesCache.hpp: a small thread-safe RAM cache keyed by camera index
 class ImagesCache

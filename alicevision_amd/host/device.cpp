@@ -1,6 +1,7 @@
 // device.cpp — see device.hpp.
 #include "device.hpp"
 
+#include "jpeg.hpp"
 #include "log.hpp"
 
 namespace avdm_host {
@@ -22,6 +23,32 @@ DeviceStreamManager::~DeviceStreamManager()
     }
 }
 
+void decodeJpegToLinearRgba(const JpegImage& jpeg, float* rgba_d, hipStream_t stream)
+{
+    const int nc = (int)jpeg.components.size();
+    if(jpeg.exifOrientation == 2 || jpeg.exifOrientation == 4 || jpeg.exifOrientation == 5 || jpeg.exifOrientation == 7)
+        AVDM_LOG_WARNING("JPEG with a mirrored EXIF orientation (" << jpeg.exifOrientation << "): the reference mirrors it back (image/io.cpp:752-761); not done here.");
+    avdm_jpeg_component_t comps[3] = {};
+    std::vector<DeviceBuffer> coefs((size_t)nc);
+    for(int i = 0; i < nc; ++i)
+    {
+        const JpegComponent& c = jpeg.components[(size_t)i];
+        coefs[(size_t)i].allocate(c.coef.size() * sizeof(int16_t));
+        AVDM_HIP_CHECK(hipMemcpyAsync(coefs[(size_t)i].ptr(), c.coef.data(), c.coef.size() * sizeof(int16_t), hipMemcpyHostToDevice, stream));
+        comps[i].coef = coefs[(size_t)i].as<int16_t>();
+        comps[i].blocks_w = c.blocksW, comps[i].blocks_h = c.blocksH, comps[i].width = c.width, comps[i].height = c.height;
+        comps[i].h_samp = c.h, comps[i].v_samp = c.v;
+        for(int k = 0; k < 64; ++k)
+            comps[i].quant[k] = jpeg.quant[c.tq][k];
+    }
+    DeviceBuffer scratch(avdm_image_decode_jpeg_scratch_bytes(comps, nc)), rgb((size_t)jpeg.width * jpeg.height * 3);
+    avdmCheck(avdm_image_decode_jpeg(rgb.as<uint8_t>(), jpeg.width * 3, jpeg.width, jpeg.height, comps, nc, jpeg.hmax, jpeg.vmax, jpeg.storedAsRgb() ? 0 : 1,
+                                     scratch.ptr(), stream),
+              "avdm_image_decode_jpeg");
+    avdmCheck(avdm_image_decode_integer(rgba_d, jpeg.width * 16, rgb.ptr(), jpeg.width * 3, jpeg.width, jpeg.height, 3, 8, 1, stream), "avdm_image_decode_integer");
+    AVDM_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
 void DeviceMipmapImage::fill(const HostImage& img, int minDownscale, int maxDownscale, int filterMode, hipStream_t stream)
 {
     avdm_pyramid_t p;
@@ -35,7 +62,9 @@ void DeviceMipmapImage::fill(const HostImage& img, int minDownscale, int maxDown
     DeviceBuffer rgba(srcBytes), resized, scratch, samples;
     if(minDownscale > 1)
         scratch.allocate((size_t)img.width * img.height * 8);
-    if(!img.raw.empty())
+    if(img.jpeg)
+        decodeJpegToLinearRgba(*img.jpeg, rgba.as<float>(), stream);
+    else if(!img.raw.empty())
     {
         // an integer file (PNG): upload the decoder's samples, make the linear float RGBA image on the device
         samples.allocate(img.raw.size());

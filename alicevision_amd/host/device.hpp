@@ -42,6 +42,11 @@ inline void avdmCheck(int status, const char* what)
         throw std::runtime_error(std::string(what) + " failed (" + std::to_string(status) + "): " + avdm_last_error());
 }
 
+struct JpegImage;
+// a JPEG's coefficients -> linear float RGBA (pitch width * 16) on the device: avdm_image_decode_jpeg, then avdm_image_decode_integer with the
+// sRGB decoding (image::readImage(path, img, LINEAR) for an 8-bit file).  Synchronises `stream` (its temporaries die on return).
+void decodeJpegToLinearRgba(const JpegImage& jpeg, float* rgba_d, hipStream_t stream);
+
 class DeviceBuffer
 {
   public:

@@ -16,6 +16,8 @@
 #include "log.hpp"
 #include "mvsData.hpp"
 #include "sfmData.hpp"
+#include "png.hpp"
+#include "jpeg.hpp"
 
 #include <avdm.h>
 #include <hip/hip_runtime.h>
@@ -55,11 +57,12 @@ std::vector<std::string> viewPathsFromFolders(const View& view, const std::vecto
     std::vector<std::string> out;
     for(const std::string& folder : folders)
         for(const std::string& base : {std::to_string(view.viewId), stem})
-        {
-            const std::string p = folder + "/" + base + ".exr";
-            if(fileExists(p) && std::find(out.begin(), out.end(), p) == out.end())
-                out.push_back(p);
-        }
+            for(const char* ext : {".exr", ".png", ".jpg", ".jpeg", ".JPG", ".JPEG", ".PNG"}) // the formats this build decodes
+            {
+                const std::string p = folder + "/" + base + ext;
+                if(fileExists(p) && std::find(out.begin(), out.end(), p) == out.end())
+                    out.push_back(p);
+            }
     return out;
 }
 
@@ -209,17 +212,47 @@ static int aliceVision_main(int argc, char* argv[])
                     throw std::runtime_error("Ambiguous case: Multiple source image files found in given folder(s) for the view '" + baseFilename + "'.");
                 srcImage = paths.front();
             }
-            ExrImage exr;
-            readExr(srcImage, exr);
+            // image::readImage(srcImage, image, LINEAR) (main_prepareDenseScene.cpp:55): OpenEXR is decoded on the host; a PNG or a JPEG
+            // leaves the host as integer samples / DCT coefficients and becomes linear float RGBA on the device
+            ExrImage exr; // (size and metadata of the source; pixels only for an OpenEXR source)
+            std::vector<float> rgba;
+            DeviceBuffer deviceSource;
+            std::string ext = srcImage.rfind('.') == std::string::npos ? "" : srcImage.substr(srcImage.rfind('.'));
+            for(char& ch : ext)
+                ch = (char)std::tolower((unsigned char)ch);
+            if(ext == ".jpg" || ext == ".jpeg")
+            {
+                JpegImage jpeg;
+                readJpeg(srcImage, jpeg);
+                exr.width = jpeg.width, exr.height = jpeg.height;
+                deviceSource.allocate((size_t)jpeg.width * jpeg.height * 16);
+                decodeJpegToLinearRgba(jpeg, deviceSource.as<float>(), stream);
+            }
+            else if(ext == ".png")
+            {
+                PngImage png;
+                readPng(srcImage, png);
+                exr.width = png.width, exr.height = png.height;
+                DeviceBuffer samples(png.samples.size());
+                deviceSource.allocate((size_t)png.width * png.height * 16);
+                AVDM_HIP_CHECK(hipMemcpyAsync(samples.ptr(), png.samples.data(), png.samples.size(), hipMemcpyHostToDevice, stream));
+                avdmCheck(avdm_image_decode_integer(deviceSource.as<float>(), png.width * 16, samples.ptr(), png.width * png.channels * (png.bits / 8), png.width,
+                                                    png.height, png.channels, png.bits, 1, stream),
+                          "avdm_image_decode_integer");
+                AVDM_HIP_CHECK(hipStreamSynchronize(stream));
+            }
+            else
+                readExr(srcImage, exr);
             if(exr.width != intr.width || exr.height != intr.height)
                 throw std::runtime_error("image '" + srcImage + "' is " + std::to_string(exr.width) + "x" + std::to_string(exr.height) + ", its intrinsic " +
                                          std::to_string(intr.width) + "x" + std::to_string(intr.height));
-            const int iR = exr.channelIndex("R"), iG = exr.channelIndex("G"), iB = exr.channelIndex("B"), iA = exr.channelIndex("A"), iY = exr.channelIndex("Y");
-            if(!((iR >= 0 && iG >= 0 && iB >= 0) || iY >= 0))
-                throw std::runtime_error("image '" + srcImage + "' has neither R,G,B nor Y channels");
             const size_t n = (size_t)exr.width * exr.height;
-            std::vector<float> rgba(n * 4);
+            rgba.resize(n * 4);
+            if(deviceSource.bytes() == 0)
             {
+                const int iR = exr.channelIndex("R"), iG = exr.channelIndex("G"), iB = exr.channelIndex("B"), iA = exr.channelIndex("A"), iY = exr.channelIndex("Y");
+                if(!((iR >= 0 && iG >= 0 && iB >= 0) || iY >= 0))
+                    throw std::runtime_error("image '" + srcImage + "' has neither R,G,B nor Y channels");
                 const float* r = exr.channels[iR >= 0 ? iR : iY].data();
                 const float* g = exr.channels[iG >= 0 ? iG : iY].data();
                 const float* b = exr.channels[iB >= 0 ? iB : iY].data();
@@ -254,13 +287,23 @@ static int aliceVision_main(int argc, char* argv[])
                 cam.distortion_model = model;
                 for(int k = 0; k < 3; ++k)
                     cam.k[k] = k < (int)intr.distortionParams.size() ? intr.distortionParams[k] : 0.0;
-                DeviceBuffer src(n * 16), dst(n * 16);
-                AVDM_HIP_CHECK(hipMemcpyAsync(src.ptr(), rgba.data(), n * 16, hipMemcpyHostToDevice, stream));
+                DeviceBuffer src, dst(n * 16);
+                if(deviceSource.bytes() == 0)
+                {
+                    src.allocate(n * 16);
+                    AVDM_HIP_CHECK(hipMemcpyAsync(src.ptr(), rgba.data(), n * 16, hipMemcpyHostToDevice, stream));
+                }
+                const float* source = deviceSource.bytes() ? deviceSource.as<float>() : src.as<float>();
                 const float fill[4] = {0.f, 0.f, 0.f, 0.f}; // Pix::Zero()
-                avdmCheck(avdm_image_undistort(dst.as<float>(), exr.width * 16, src.as<float>(), exr.width * 16, &cam, fill, stream), "avdm_image_undistort");
+                avdmCheck(avdm_image_undistort(dst.as<float>(), exr.width * 16, source, exr.width * 16, &cam, fill, stream), "avdm_image_undistort");
                 AVDM_HIP_CHECK(hipMemcpyAsync(rgba.data(), dst.ptr(), n * 16, hipMemcpyDeviceToHost, stream));
                 AVDM_HIP_CHECK(hipStreamSynchronize(stream));
                 ++nbUndistorted;
+            }
+            else if(deviceSource.bytes())
+            {
+                AVDM_HIP_CHECK(hipMemcpyAsync(rgba.data(), deviceSource.ptr(), n * 16, hipMemcpyDeviceToHost, stream));
+                AVDM_HIP_CHECK(hipStreamSynchronize(stream));
             }
 
             // camera: Pinhole::getProjectiveEquivalent(pose) = K [R | t], t = -R C (camera/Pinhole.cpp:277-283)

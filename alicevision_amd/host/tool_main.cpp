@@ -9,6 +9,7 @@
 //   fuse-cameras sfm depthMapsFolder filterFolder n     cameras as aliceVision_depthMapFiltering sees them (from the depth maps' metadata)
 //                                                       and the n nearest cameras of each, as JSON with round-trip precision
 //   sfm-dump scene.(sfm|json|abc)                      the loaded SfMData as JSON with round-trip precision (views, intrinsics, poses, landmarks)
+//   jpeg-dump in.jpg out.bin                           entropy-decode a JPEG (host/jpeg.cpp) and dump geometry, tables and coefficients
 //   jet v0 v1 ...                                      the reference's jet colour map (debug volume exports) at the given values
 //   sfm-to-abc scene.(sfm|json|abc) out.abc            write the loaded SfMData as an Alembic archive (AlembicExporter's layout)
 #include "DepthMapEstimator.hpp"
@@ -20,6 +21,7 @@
 #include "png.hpp"
 #include "sfmData.hpp"
 #include "alembic.hpp"
+#include "jpeg.hpp"
 
 #include <chrono>
 #include <cstdlib>
@@ -231,6 +233,25 @@ int main(int argc, char** argv)
                 std::cout << "]}";
             }
             std::cout << "]}" << std::endl;
+            return 0;
+        }
+        if(cmd == "jpeg-dump" && argc == 4)
+        { // the entropy-decoded image: int32 header { width, height, components, hmax, vmax, storedAsRgb, progressive, exifOrientation },
+          // then per component int32 { h, v, blocksW, blocksH, width, height }, uint16 quant[64], int16 coefficients
+            JpegImage j;
+            readJpeg(argv[2], j);
+            std::ofstream f(argv[3], std::ios::binary);
+            const int32_t hdr[8] = {j.width, j.height, (int32_t)j.components.size(), j.hmax, j.vmax, j.storedAsRgb() ? 1 : 0, j.progressive ? 1 : 0,
+                                    j.exifOrientation};
+            f.write(reinterpret_cast<const char*>(hdr), sizeof(hdr));
+            for(const JpegComponent& c : j.components)
+            {
+                const int32_t ch[6] = {c.h, c.v, c.blocksW, c.blocksH, c.width, c.height};
+                f.write(reinterpret_cast<const char*>(ch), sizeof(ch));
+                f.write(reinterpret_cast<const char*>(j.quant[c.tq]), 128);
+                f.write(reinterpret_cast<const char*>(c.coef.data()), (std::streamsize)(c.coef.size() * 2));
+            }
+            std::cout << j.width << " " << j.height << " " << j.components.size() << std::endl;
             return 0;
         }
         if(cmd == "jet" && argc >= 3)

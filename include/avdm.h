@@ -189,6 +189,20 @@ int avdm_image_resize(float* dst_rgba, int dst_pitch, int dst_w, int dst_h, cons
  * host-evaluated table (C library powf): the device result is a look-up, bit-identical to the oracle's. */
 int avdm_image_decode_integer(float* dst_rgba, int dst_pitch, const void* src, int src_pitch, int width, int height, int channels, int bits,
                               int srgb_to_linear, void* stream);
+/* one component of a JPEG frame as the host's entropy decoder leaves it (avdm_image_decode_jpeg below) */
+typedef struct avdm_jpeg_component
+{
+    const int16_t* coef; /* device memory: blocks_h x blocks_w blocks of 64 quantised coefficients, natural (row-major) order */
+    int blocks_w, blocks_h, width, height, h_samp, v_samp; /* width / height in samples: ceil(image * samp / max samp) */
+    uint16_t quant[64]; /* natural order */
+} avdm_jpeg_component_t;
+/* JPEG (image ingest): quantised DCT coefficients -> 8-bit RGB on the device, exactly as libjpeg(-turbo) decodes with its
+ * defaults (JDCT_ISLOW inverse DCT, fancy up-sampling, YCbCr -> RGB): what OpenImageIO's JPEG reader hands image::readImage
+ * (image/io.cpp:571-760) of the reference.  Entropy decoding stays on the host (host/jpeg.cpp).  4:4:4, 4:2:2 (h2v1), 4:2:0 (h2v2).
+ * `scratch`: avdm_image_decode_jpeg_scratch_bytes bytes of device memory. */
+size_t avdm_image_decode_jpeg_scratch_bytes(const avdm_jpeg_component_t* comps, int n_comps);
+int avdm_image_decode_jpeg(uint8_t* dst_rgb, int dst_pitch, int width, int height, const avdm_jpeg_component_t* comps, int n_comps, int hmax, int vmax,
+                           int ycc_to_rgb, void* scratch, void* stream);
 /* Undistortion of an input image (second slice of the image ingest): camera::UndistortImage(imageIn, intrinsic, image_ud,
  * fillcolor) (camera/cameraUndistortImage.hpp:81-139) as software/pipeline/main_prepareDenseScene.cpp:71-79 calls it — for every pixel of
  * the undistorted image the distorted position  cam2ima(addDistortion(ima2cam(p)))  (camera/IntrinsicScaleOffsetDisto.cpp:80,

@@ -627,6 +627,213 @@ int avo_image_decode_integer(float* dst, int dst_pitch, const void* src, int src
     return 0;
 }
 
+/* ---- JPEG: coefficients -> RGB, as libjpeg / libjpeg-turbo decode with their defaults -----------------------------------------------
+ * The library behind OpenImageIO's JPEG reader is not part of /root/reference; this restates its published arithmetic in the library's own
+ * order of work (a block at a time, then a row at a time with the context rows its main controller provides) and is pinned to golden
+ * vectors decoded by libjpeg-turbo (tests/golden/jpeg, made with Pillow).
+ *   jidctint.c  jpeg_idct_islow: the Loeffler-Ligtenberg-Moschytz inverse DCT with 13-bit constants; pass 1 over columns keeps 2 extra bits,
+ *               pass 2 over rows removes 2 + 13 + 3 bits, adds 128 and range-limits through the 1024-entry wrap-around table;
+ *   jdsample.c  h2v1_fancy_upsample / h2v2_fancy_upsample (triangle filters), fullsize_upsample; replication for <= 2 input columns;
+ *   jdmainct.c  context rows: the row above the first row and the row below the last REAL row (downsampled_height) are those rows again;
+ *   jdcolor.c   ycc_rgb_convert with the tables of build_ycc_rgb_table (16 fractional bits). */
+static int jdescale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+static void jidct_1d(const int in[8], int out[8])
+{
+    /* even part */
+    int z2 = in[2], z3 = in[6];
+    int z1 = (z2 + z3) * 4433;
+    int tmp2 = z1 + z3 * (-15137);
+    int tmp3 = z1 + z2 * 6270;
+    int tmp0 = (in[0] + in[4]) * 8192;
+    int tmp1 = (in[0] - in[4]) * 8192;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    /* odd part */
+    tmp0 = in[7], tmp1 = in[5], tmp2 = in[3], tmp3 = in[1];
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * 9633;
+    tmp0 *= 2446;
+    tmp1 *= 16819;
+    tmp2 *= 25172;
+    tmp3 *= 12299;
+    z1 *= -7373;
+    z2 *= -20995;
+    z3 *= -16069;
+    z4 *= -3196;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    out[0] = tmp10 + tmp3, out[7] = tmp10 - tmp3;
+    out[1] = tmp11 + tmp2, out[6] = tmp11 - tmp2;
+    out[2] = tmp12 + tmp1, out[5] = tmp12 - tmp1;
+    out[3] = tmp13 + tmp0, out[4] = tmp13 - tmp0;
+}
+
+static void jidct_block(const int16_t* coef, const uint16_t* quant, uint8_t* out, int out_pitch, const uint8_t* range_limit /* centred */)
+{
+    int ws[64];
+    for(int c = 0; c < 8; ++c)
+    {
+        int in[8], o[8];
+        for(int r = 0; r < 8; ++r)
+            in[r] = (int)coef[8 * r + c] * (int)quant[8 * r + c];
+        jidct_1d(in, o);
+        for(int r = 0; r < 8; ++r)
+            ws[8 * r + c] = jdescale(o[r], 13 - 2);
+    }
+    for(int r = 0; r < 8; ++r)
+    {
+        int o[8];
+        jidct_1d(ws + 8 * r, o);
+        for(int c = 0; c < 8; ++c)
+            out[(long long)r * out_pitch + c] = range_limit[jdescale(o[c], 13 + 2 + 3) & 1023];
+    }
+}
+
+int avo_image_decode_jpeg(uint8_t* dst_rgb, int dst_pitch, int width, int height, const avdm_jpeg_component_t* comps, int n_comps, int hmax, int vmax,
+                          int ycc_to_rgb)
+{
+    if(comps == NULL || (n_comps != 1 && n_comps != 3) || width <= 0 || height <= 0 || hmax < 1 || vmax < 1 || dst_pitch < 3 * width)
+        return 1;
+    /* the post-IDCT range-limit table (prepare_range_limit_table): indices 0..127 -> 128..255, ..511 -> 255, ..895 -> 0, ..1023 -> 0..127 */
+    uint8_t limit[1024];
+    for(int i = 0; i < 1024; ++i)
+        limit[i] = (uint8_t)(i < 128 ? i + 128 : (i < 512 ? 255 : (i < 896 ? 0 : i - 896)));
+    uint8_t* planes[3] = {NULL, NULL, NULL};
+    uint8_t* full[3] = {NULL, NULL, NULL}; /* components at full resolution (up-sampled), width x height */
+    int rc = 0;
+    for(int i = 0; i < n_comps && rc == 0; ++i)
+    {
+        const avdm_jpeg_component_t* c = &comps[i];
+        const int he = (c->h_samp > 0 && hmax % c->h_samp == 0) ? hmax / c->h_samp : 0, ve = (c->v_samp > 0 && vmax % c->v_samp == 0) ? vmax / c->v_samp : 0;
+        if(c->coef == NULL || c->blocks_w <= 0 || c->blocks_h <= 0 || c->width <= 0 || c->height <= 0 || c->width > 8 * c->blocks_w ||
+           c->height > 8 * c->blocks_h || !((he == 1 && ve == 1) || (he == 2 && ve == 1) || (he == 2 && ve == 2)) || c->width * he < width ||
+           c->height * ve < height)
+        {
+            rc = 1;
+            break;
+        }
+        const int pitch = 8 * c->blocks_w;
+        planes[i] = (uint8_t*)malloc((size_t)pitch * 8 * c->blocks_h);
+        for(int by = 0; by < c->blocks_h; ++by)
+            for(int bx = 0; bx < c->blocks_w; ++bx)
+                jidct_block(c->coef + ((size_t)by * c->blocks_w + bx) * 64, c->quant, planes[i] + (size_t)8 * by * pitch + 8 * bx, pitch, limit);
+        /* up-sampling, an output row pair at a time */
+        const int ow = c->width * he;
+        full[i] = (uint8_t*)malloc((size_t)ow * c->height * ve);
+        for(int inrow = 0; inrow < c->height; ++inrow)
+        {
+            const uint8_t* in0 = planes[i] + (size_t)inrow * pitch;
+            if(he == 1)
+                memcpy(full[i] + (size_t)inrow * ow, in0, (size_t)ow);
+            else if(ve == 1)
+            {
+                uint8_t* o = full[i] + (size_t)inrow * ow;
+                if(c->width <= 2) /* h2v1_upsample */
+                    for(int x = 0; x < c->width; ++x)
+                        o[2 * x] = o[2 * x + 1] = in0[x];
+                else
+                {
+                    int x = 0;
+                    o[0] = in0[0];
+                    o[1] = (uint8_t)((in0[0] * 3 + in0[1] + 2) >> 2);
+                    for(x = 1; x < c->width - 1; ++x)
+                    {
+                        const int v3 = in0[x] * 3;
+                        o[2 * x] = (uint8_t)((v3 + in0[x - 1] + 1) >> 2);
+                        o[2 * x + 1] = (uint8_t)((v3 + in0[x + 1] + 2) >> 2);
+                    }
+                    o[2 * x] = (uint8_t)((in0[x] * 3 + in0[x - 1] + 1) >> 2);
+                    o[2 * x + 1] = in0[x];
+                }
+            }
+            else
+                for(int v = 0; v < 2; ++v)
+                {
+                    /* the nearer neighbour row: above for the upper output row, below for the lower; the image edges provide themselves */
+                    int nrow = v == 0 ? inrow - 1 : inrow + 1;
+                    nrow = nrow < 0 ? 0 : (nrow > c->height - 1 ? c->height - 1 : nrow);
+                    const uint8_t* in1 = planes[i] + (size_t)nrow * pitch;
+                    uint8_t* o = full[i] + (size_t)(2 * inrow + v) * ow;
+                    if(c->width <= 2) /* h2v2_upsample */
+                    {
+                        for(int x = 0; x < c->width; ++x)
+                            o[2 * x] = o[2 * x + 1] = in0[x];
+                        continue;
+                    }
+                    int thiscolsum = in0[0] * 3 + in1[0], nextcolsum = in0[1] * 3 + in1[1], lastcolsum;
+                    o[0] = (uint8_t)((thiscolsum * 4 + 8) >> 4);
+                    o[1] = (uint8_t)((thiscolsum * 3 + nextcolsum + 7) >> 4);
+                    lastcolsum = thiscolsum;
+                    thiscolsum = nextcolsum;
+                    int x;
+                    for(x = 1; x < c->width - 1; ++x)
+                    {
+                        nextcolsum = in0[x + 1] * 3 + in1[x + 1];
+                        o[2 * x] = (uint8_t)((thiscolsum * 3 + lastcolsum + 8) >> 4);
+                        o[2 * x + 1] = (uint8_t)((thiscolsum * 3 + nextcolsum + 7) >> 4);
+                        lastcolsum = thiscolsum;
+                        thiscolsum = nextcolsum;
+                    }
+                    o[2 * x] = (uint8_t)((thiscolsum * 3 + lastcolsum + 8) >> 4);
+                    o[2 * x + 1] = (uint8_t)((thiscolsum * 4 + 7) >> 4);
+                }
+        }
+    }
+    if(rc == 0)
+    {
+        /* build_ycc_rgb_table */
+        int cr_r[256], cb_b[256], cr_g[256], cb_g[256];
+        for(int i = 0; i < 256; ++i)
+        {
+            const int x = i - 128;
+            cr_r[i] = (91881 * x + 32768) >> 16;
+            cb_b[i] = (116130 * x + 32768) >> 16;
+            cr_g[i] = -46802 * x;
+            cb_g[i] = -22554 * x + 32768;
+        }
+        const int ow0 = comps[0].width * (hmax / comps[0].h_samp);
+        for(int y = 0; y < height; ++y)
+        {
+            uint8_t* o = dst_rgb + (long long)y * dst_pitch;
+            for(int x = 0; x < width; ++x)
+            {
+                const int c0 = full[0][(size_t)y * ow0 + x];
+                int r = c0, g = c0, b = c0;
+                if(n_comps == 3)
+                {
+                    const int c1 = full[1][(size_t)y * (comps[1].width * (hmax / comps[1].h_samp)) + x];
+                    const int c2 = full[2][(size_t)y * (comps[2].width * (hmax / comps[2].h_samp)) + x];
+                    if(ycc_to_rgb)
+                    {
+                        r = c0 + cr_r[c2];
+                        g = c0 + ((cb_g[c1] + cr_g[c2]) >> 16);
+                        b = c0 + cb_b[c1];
+                        r = r < 0 ? 0 : (r > 255 ? 255 : r);
+                        g = g < 0 ? 0 : (g > 255 ? 255 : g);
+                        b = b < 0 ? 0 : (b > 255 ? 255 : b);
+                    }
+                    else
+                        g = c1, b = c2;
+                }
+                o[3 * x] = (uint8_t)r, o[3 * x + 1] = (uint8_t)g, o[3 * x + 2] = (uint8_t)b;
+            }
+        }
+    }
+    for(int i = 0; i < 3; ++i)
+    {
+        free(planes[i]);
+        free(full[i]);
+    }
+    return rc;
+}
+
 int avo_image_resize(float* dst, int dst_pitch, int dst_w, int dst_h, const float* src, int src_pitch, int src_w, int src_h, int nchannels)
 {
     if(dst_w <= 0 || dst_h <= 0 || src_w <= 0 || src_h <= 0 || nchannels < 1 || nchannels > 4 || dst_w > src_w || dst_h > src_h)

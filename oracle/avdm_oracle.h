@@ -28,6 +28,9 @@ int avo_pyramid_fill(const avdm_pyramid_t* p, const float* rgba, int in_pitch);
 /* imageAlgo::resizeImage(downscale, in, out) -> oiio::ImageBufAlgo::resize with the default filter (see avdm_oracle.c) */
 int avo_image_resize(float* dst, int dst_pitch, int dst_w, int dst_h, const float* src, int src_pitch, int src_w, int src_h, int nchannels);
 int avo_image_decode_integer(float* dst, int dst_pitch, const void* src, int src_pitch, int width, int height, int channels, int bits, int srgb_to_linear);
+/* libjpeg(-turbo)'s default decode of one image from its quantised coefficients (host memory): jidctint.c, jdsample.c, jdcolor.c */
+int avo_image_decode_jpeg(uint8_t* dst_rgb, int dst_pitch, int width, int height, const avdm_jpeg_component_t* comps, int n_comps, int hmax, int vmax,
+                          int ycc_to_rgb);
 int avo_image_resize_taps(int dst_n, int src_n, float* weights /* [dst_n][taps] or NULL */, int* first /* [dst_n] or NULL */);
 /* camera::UndistortImage (camera/cameraUndistortImage.hpp:81-139) */
 int avo_image_undistort(float* dst, int dst_pitch, const float* src, int src_pitch, const avdm_intrinsic_t* cam, const float fill[4]);

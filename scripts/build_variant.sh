@@ -14,7 +14,7 @@ case $SRC in avdm_sgm.hip|avdm_maps.hip|avdm_fuse.hip|avdm_literal.hip) EXTRA="-
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I $ROOT/include $EXTRA "$@" \
    -Rpass-analysis=kernel-resource-usage -c $CS/$SRC -o $OUT/${SRC%.hip}.o 2> $OUT/remarks.txt
 OBJS=""
-for f in avdm_image avdm_similarity avdm_sgm avdm_maps avdm_fuse avdm_literal; do
+for f in avdm_image avdm_similarity avdm_sgm avdm_maps avdm_fuse avdm_jpeg avdm_literal; do
   if [ -f $OUT/$f.o ]; then OBJS="$OBJS $OUT/$f.o"; else OBJS="$OBJS $CS/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libavdm.so $OBJS

@@ -135,6 +135,71 @@ def test_image_decode_integer_bit_exact(bits, ch):
     assert lib.avdm_image_decode_integer(_ptr(tdst), (W + 3) * 16, _ptr(tsrc), W * bpp + pad, W, H, 5, bits, 1, _st()) != 0
 
 
+def _jpeg_device_and_oracle(path):
+    import ctypes as C
+    torch = _torch()
+    from alicevision_amd import jpeg_io
+    from oracle import oracle
+    lib, olib = abi.load(), oracle.load()
+    j = jpeg_io.read_coefficients(path)
+    nc = len(j.components)
+    host = j.descriptors([c["coef"].ctypes.data for c in j.components])
+    want = np.zeros((j.height, j.width, 3), np.uint8)
+    olib.avo_image_decode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(abi.JpegComponent), C.c_int, C.c_int, C.c_int, C.c_int]
+    assert olib.avo_image_decode_jpeg(want.ctypes.data, 3 * j.width, j.width, j.height, host, nc, j.hmax, j.vmax, 0 if j.stored_as_rgb else 1) == 0
+    tcoef = [torch.from_numpy(c["coef"]).cuda() for c in j.components]
+    dev = j.descriptors([t.data_ptr() for t in tcoef])
+    scratch = torch.empty(int(lib.avdm_image_decode_jpeg_scratch_bytes(dev, nc)), dtype=torch.uint8, device="cuda")
+    pitch = 3 * j.width + 5  # an unaligned pitch: the byte-wise store path
+    for pitch in (3 * j.width + 5, (3 * j.width + 3) // 4 * 4 + 8):
+        tdst = torch.full((j.height, pitch), 77, dtype=torch.uint8, device="cuda")
+        abi.check(lib.avdm_image_decode_jpeg(_ptr(tdst), pitch, j.width, j.height, dev, nc, j.hmax, j.vmax, 0 if j.stored_as_rgb else 1, _ptr(scratch), _st()))
+        torch.cuda.synchronize()
+        got = tdst.cpu().numpy()
+        assert np.array_equal(got[:, :3 * j.width].reshape(j.height, j.width, 3), want), (path, pitch)
+        assert np.all(got[:, 3 * j.width:] == 77)
+    return want, j
+
+
+def test_jpeg_decode_bit_exact_on_the_golden_files():
+    """avdm_image_decode_jpeg (dequantisation, libjpeg's integer inverse DCT, fancy up-sampling, YCbCr -> RGB on the device) == the oracle ==
+    the pixels libjpeg-turbo decoded, for every golden file (all sampling modes, baseline / progressive, grey, RGB-stored, 1 x 1 ... )"""
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg")
+    exp = np.load(os.path.join(golden, "expected.npz"))
+    for name in exp.files:
+        want, j = _jpeg_device_and_oracle(os.path.join(golden, name + ".jpg"))
+        assert np.array_equal(want, exp[name]), name
+    lib = abi.load()
+    bad = (abi.JpegComponent * 3)()
+    assert lib.avdm_image_decode_jpeg(None, 0, 8, 8, bad, 2, 1, 1, 1, None, _st()) != 0  # two components
+
+
+def test_jpeg_decode_full_size(tmp_path):
+    """a 12 MP 4:2:0 photograph-sized file (and 4:2:2 progressive at 3000 x 2000): device == oracle == libjpeg-turbo, and the decoded image
+    goes through avdm_image_decode_integer to the linear float RGBA the pyramids are built from"""
+    Image = pytest.importorskip("PIL.Image")
+    torch = _torch()
+    rng = np.random.default_rng(12)
+    for (w, h, sub, prog) in ((4000, 3000, 2, False), (3001, 1999, 1, True)):
+        y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+        a = np.stack([128 + 100 * np.sin(x / 37.0) * np.cos(y / 25.0), 128 + 90 * np.cos(x / 13.0 + y / 19.0), 60 + x * (150.0 / w) + 20 * np.sin(y / 7.0)], -1)
+        a = np.clip(a + rng.normal(0, 5, a.shape).astype(np.float32), 0, 255).astype(np.uint8)
+        p = str(tmp_path / "big.jpg")
+        Image.fromarray(a).save(p, quality=92, subsampling=sub, progressive=prog)
+        want, j = _jpeg_device_and_oracle(p)
+        assert np.array_equal(want, np.array(Image.open(p)))
+    # RGB8 -> linear float RGBA (the existing path of 8-bit input)
+    from oracle import oracle
+    lib, olib = abi.load(), oracle.load()
+    lin = np.zeros((h, w, 4), np.float32)
+    assert olib.avo_image_decode_integer(oracle.ptr(lin), w * 16, oracle.ptr(want), w * 3, w, h, 3, 8, 1) == 0
+    trgb = torch.from_numpy(want).cuda()
+    tlin = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    abi.check(lib.avdm_image_decode_integer(_ptr(tlin), w * 16, _ptr(trgb), w * 3, w, h, 3, 8, 1, _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(tlin.cpu().numpy().view(np.uint32), lin.view(np.uint32))
+
+
 @pytest.mark.parametrize("model,k", [(0, (0.0, 0.0, 0.0)), (1, (0.08, 0.0, 0.0)), (2, (0.1, -0.05, 0.01)), (2, (-0.3, 0.1, 0.0)), (3, (0.05, 0.02, -0.01))])
 def test_image_undistort_bit_exact(model, k):
     """camera::UndistortImage (PrepareDenseScene): the device kernel against the oracle — double-precision geometry, float sample position,

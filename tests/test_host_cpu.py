@@ -560,3 +560,24 @@ def test_jet_colour_map_of_the_volume_exports():
             a = np.float32(1.0) - b
             want = [int(np.float32(np.float32(table[i, k] * a + table[i + 1, k] * b) * np.float32(255.0))) for k in range(3)]
         assert list(g) == want, (v, g, want)
+
+
+def test_jpeg_images_folder_is_planned_like_the_exr_folder(scene, tmp_path):
+    """<viewId>.jpg in --imagesFolder: the program finds the files, reads their size from the frame header and plans the same work; a
+    second file for a view is refused like in the reference (MultiViewParams.cpp:96-100)"""
+    Image = pytest.importorskip("PIL.Image")
+    sc, lms, sfm, img, d = scene
+    jpg = str(tmp_path / "jpg")
+    os.makedirs(jpg)
+    for i in range(6):
+        a = np.clip(sc.images[i].numpy()[..., :3] * 255.0, 0, 255).astype(np.uint8)
+        Image.fromarray(a).save(os.path.join(jpg, "%d.jpg" % scene_io.view_id(i)), quality=90, progressive=bool(i % 2))
+    ref = plan_of(sfm, img, str(tmp_path / "o_exr"), ["--sgmMaxDepths", 48])
+    got = plan_of(sfm, jpg, str(tmp_path / "o_jpg"), ["--sgmMaxDepths", 48])
+    assert len(ref["tiles"]) == len(got["tiles"]) > 0
+    for ta, tb in zip(ref["tiles"], got["tiles"]):
+        assert ta["sgmTCams"] == tb["sgmTCams"] and ta["depths"] == tb["depths"]
+    import shutil
+    shutil.copy(os.path.join(img, "%d.exr" % scene_io.view_id(0)), jpg)
+    r = run([CLI, "-i", sfm, "--imagesFolder", jpg, "-o", str(tmp_path / "o_x"), "--downscale", 1, "--dryRun", 1, "-v", "error"], check=False)
+    assert r.returncode == 1 and "Ambiguous" in (r.stdout + r.stderr)

@@ -6,6 +6,7 @@ pins the oracle bit for bit to the reference's own kernels compiled for the CPU 
 import ctypes as C
 import math
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -477,3 +478,61 @@ def test_image_decode_integer_oracle(bits):
         assert lib.avo_image_decode_integer(oracle.ptr(dst), n * 16, oracle.ptr(src), n * ch * (bits // 8), n, h, ch, bits, 0) == 0
         assert np.array_equal(dst[..., 0], src[..., 0].astype(np.float32) * np.float32(1.0 / (n - 1)))
     assert lib.avo_image_decode_integer(oracle.ptr(dst), n * 16, oracle.ptr(src), n, n, 1, 5, bits, 1) != 0
+
+
+# ------------------------------------------------------------------------------------------------ JPEG (image ingest)
+JPEG_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg")
+
+
+def _jpeg_oracle_decode(path):
+    import ctypes as C
+    from alicevision_amd import abi, jpeg_io
+    from oracle import oracle
+    j = jpeg_io.read_coefficients(path)
+    comps = j.descriptors([c["coef"].ctypes.data for c in j.components])
+    out = np.zeros((j.height, j.width, 3), np.uint8)
+    olib = oracle.load()
+    olib.avo_image_decode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(abi.JpegComponent), C.c_int, C.c_int, C.c_int, C.c_int]
+    rc = olib.avo_image_decode_jpeg(out.ctypes.data, 3 * j.width, j.width, j.height, comps, len(j.components), j.hmax, j.vmax, 0 if j.stored_as_rgb else 1)
+    assert rc == 0
+    return out, j
+
+
+def test_jpeg_entropy_decoder_and_oracle_equal_libjpeg_turbo_on_the_golden_files():
+    """host/jpeg.cpp (markers, Huffman, sequential and progressive scans, restart markers) + the oracle's restatement of libjpeg's inverse
+    DCT, fancy up-sampling and colour conversion == the pixels libjpeg-turbo decoded from the same files (tests/golden/jpeg: 4:4:4 /
+    4:2:2 / 4:2:0, baseline / progressive, restarts, optimised tables, grey, RGB-stored, sizes down to 1 x 1, quality 1 .. 100)."""
+    subprocess.run(["make", "-C", os.path.join(os.path.dirname(JPEG_GOLDEN), "..", "..", "alicevision_amd", "host"), "-s", "-j8"], check=True)
+    exp = np.load(os.path.join(JPEG_GOLDEN, "expected.npz"))
+    assert len(exp.files) >= 17
+    seen_progressive = seen_rgb = 0
+    for name in exp.files:
+        got, j = _jpeg_oracle_decode(os.path.join(JPEG_GOLDEN, name + ".jpg"))
+        assert np.array_equal(got, exp[name]), name
+        seen_progressive += j.progressive
+        seen_rgb += j.stored_as_rgb
+    assert seen_progressive >= 3 and seen_rgb == 1
+
+
+def test_jpeg_decoder_against_pillow_when_available(tmp_path):
+    """the same comparison on files made now (when this host has Pillow): a larger image per sampling mode, and malformed input"""
+    Image = pytest.importorskip("PIL.Image")
+    subprocess.run(["make", "-C", os.path.join(os.path.dirname(JPEG_GOLDEN), "..", "..", "alicevision_amd", "host"), "-s", "-j8"], check=True)
+    rng = np.random.default_rng(5)
+    y, x = np.mgrid[0:301, 0:413]
+    a = np.clip(np.stack([128 + 100 * np.sin(x / 17.0) * np.cos(y / 11.0), 128 + 90 * np.cos(x / 13.0 + y / 9.0), 60 + x * 0.4 + 20 * np.sin(y / 2.0)], -1) +
+                rng.normal(0, 6, (301, 413, 3)), 0, 255).astype(np.uint8)
+    for sub, prog in ((0, False), (1, True), (2, False), (2, True)):
+        p = str(tmp_path / "t.jpg")
+        Image.fromarray(a).save(p, quality=88, subsampling=sub, progressive=prog)
+        got, j = _jpeg_oracle_decode(p)
+        assert np.array_equal(got, np.array(Image.open(p))) and j.progressive == prog
+    from alicevision_amd import jpeg_io
+    data = open(p, "rb").read()
+    open(p, "wb").write(b"\x89PNG" + data[4:])
+    with pytest.raises(RuntimeError, match="not a JPEG"):
+        jpeg_io.read_coefficients(p)
+    sof = data.index(b"\xff\xc2")
+    open(p, "wb").write(data[:sof + 1] + b"\xc9" + data[sof + 2:])  # SOF9: arithmetic coding
+    with pytest.raises(RuntimeError, match="arithmetic"):
+        jpeg_io.read_coefficients(p)
