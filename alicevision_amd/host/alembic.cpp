@@ -914,7 +914,7 @@ public:
         }
         if(kIoVersion < _version)
             throw std::runtime_error("Alembic: file has a version more recent than this reader (1.2.11)");
-        visit(_a.top(), M44(), true);
+        visit(_a.top(), M44(), true, 0);
     }
 
 private:
@@ -1061,9 +1061,11 @@ private:
         return true;
     }
 
-    void visit(const Object& o, M44 mat, bool isReconstructed)
+    void visit(const Object& o, M44 mat, bool isReconstructed, int depth)
     {
         // AlembicImporter.cpp:982-1027 visitObject
+        if(depth > 64)
+            throw std::runtime_error("Alembic: object hierarchy deeper than 64 levels (a cycle in a damaged file?)");
         if(o.name == "mvgCamerasUndefined")
             isReconstructed = false;
         const std::string schema = o.meta("schema");
@@ -1082,7 +1084,7 @@ private:
                 readCamera(g, mat, 0, isReconstructed);
         }
         for(const Object& c : kids)
-            visit(c, mat, isReconstructed);
+            visit(c, mat, isReconstructed, depth + 1);
     }
 
     // AlembicImporter.cpp:860-980 readXform: accumulates the transform; a node with mvg_rigId / mvg_poseId is a pose (rig) node

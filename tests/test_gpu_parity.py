@@ -7,6 +7,7 @@ Parity classes:
                 homogeneous patch projection), Refine volume, colour optimisation — tolerances stated in each test.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
