@@ -201,7 +201,7 @@ void MultiViewParams::loadMatricesFromSfM(int index)
 {
     const View& view = _sfmData.views.at(getViewId(index));
     const Intrinsic& intr = _sfmData.getIntrinsic(view);
-    const Pose& pose = _sfmData.getPose(view);
+    const Pose pose = _sfmData.getPose(view);
     const Point3d t = (pose.rotation * pose.center) * -1.0;
     Matrix3x4 P;
     if(intr.isPinhole)
@@ -290,7 +290,7 @@ std::vector<int> MultiViewParams::findNearestCamsFromLandmarks(int rc, int nbNea
 
     const IndexT viewId = getViewId(rc);
     const View& view = _sfmData.views.at(viewId);
-    const Pose& pose = _sfmData.getPose(view);
+    const Pose pose = _sfmData.getPose(view);
     const Intrinsic& intr = _sfmData.getIntrinsic(view);
 
     for(const auto& landmarkPair : _sfmData.landmarks)
@@ -346,7 +346,7 @@ std::vector<int> MultiViewParams::findTileNearestCams(int rc, int nbNearestCams,
 
     const IndexT viewId = getViewId(rc);
     const View& view = _sfmData.views.at(viewId);
-    const Pose& pose = _sfmData.getPose(view);
+    const Pose pose = _sfmData.getPose(view);
     const Intrinsic& intr = _sfmData.getIntrinsic(view);
     const ROI fullsizeRoi = upscaleROI(roi, (float)getProcessDownscale());
 

@@ -700,6 +700,10 @@ OutProperty OutProperty::scalarUInt32(const std::string& name, uint32_t v)
 {
     return leaf(PropertyHeader::Scalar, Pod::UInt32, 1, name, rawBytes(std::vector<uint32_t>{v}), 1);
 }
+OutProperty OutProperty::scalarUInt16(const std::string& name, uint16_t v)
+{
+    return leaf(PropertyHeader::Scalar, Pod::UInt16, 1, name, rawBytes(std::vector<uint16_t>{v}), 1);
+}
 OutProperty OutProperty::scalarDouble(const std::string& name, double v)
 {
     return leaf(PropertyHeader::Scalar, Pod::Float64, 1, name, rawBytes(std::vector<double>{v}), 1);
@@ -1121,11 +1125,15 @@ private:
         indexProp(up, "mvg_poseId", 0, poseId);
         if(rigId == UndefinedIndexT && poseId == UndefinedIndexT)
             return; // not a rig
-        if(rigId != UndefinedIndexT)
-            throw std::runtime_error("Alembic: rigs are not supported (rig " + std::to_string(rigId) + ")");
         if(isReconstructed && !_out.poses.count(poseId))
             _out.poses[poseId] = poseFromMatrix(mat, _version, false);
-        mat = M44();
+        if(rigId != UndefinedIndexT && !_out.rigs.count(rigId))
+        {
+            uint64_t nbSubPoses = 0;
+            uintProp(up, "mvg_nbSubPoses", 0, nbSubPoses);
+            _out.rigs[rigId].subPoses.resize((size_t)nbSubPoses);
+        }
+        mat = M44(); // the cameras below a rig node carry their sub-poses
     }
 
     // AlembicImporter.cpp:375-812 readCamera (`g` = the properties of the camera's ".geom" compound)
@@ -1136,7 +1144,6 @@ private:
         v.viewId = (IndexT)_out.views.size();
         v.poseId = (IndexT)_out.views.size();
         v.intrinsicId = (IndexT)_out.intrinsics.size();
-        IndexT rigId = UndefinedIndexT;
         bool poseIndependant = true;
         std::string intrinsicType = "pinhole", distortionType = "none", undistortionType = "none";
         std::vector<double> sensorPix = {0, 0}, sensorMm = {0, 0};
@@ -1145,8 +1152,10 @@ private:
         indexProp(up, "mvg_viewId", frame, v.viewId);
         indexProp(up, "mvg_poseId", frame, v.poseId);
         indexProp(up, "mvg_intrinsicId", frame, v.intrinsicId);
-        indexProp(up, "mvg_rigId", frame, rigId);
+        indexProp(up, "mvg_rigId", frame, v.rigId);
+        indexProp(up, "mvg_subPoseId", frame, v.subPoseId);
         boolProp(up, "mvg_poseIndependant", frame, poseIndependant);
+        v.independantPose = poseIndependant;
         if(const PropertyHeader* p = Archive::find(up, "mvg_metadata"))
         {
             const std::vector<std::string> raw = _a.readStrings(*p, std::min(frame, p->numSamples() ? p->numSamples() - 1 : 0));
@@ -1239,13 +1248,29 @@ private:
             _out.intrinsics.emplace(I.intrinsicId, std::move(I)); // the first definition of an id stays (std::map::emplace in the importer)
         }
 
-        const bool partOfRig = rigId != UndefinedIndexT;
-        if(partOfRig && !poseIndependant)
-            throw std::runtime_error("Alembic: rigs are not supported (view " + std::to_string(v.viewId) + ")");
-        const IndexT poseId = v.poseId;
+        const View key = v; // (ids for the pose bookkeeping below)
         _out.views.emplace(v.viewId, std::move(v));
         if(isReconstructed)
-            _out.poses[poseId] = poseFromMatrix(mat, _version, true); // SfMData::setPose: a view's own pose replaces what is there
+        {
+            const Pose pose = poseFromMatrix(mat, _version, true);
+            if(key.isPartOfRig() && !key.isPoseIndependant())
+            {
+                // AlembicImporter.cpp:783-795: below a rig node the camera's transform is its sub-pose; the first one read for an index stays
+                Rig& rig = _out.rigs[key.rigId];
+                if(key.subPoseId == UndefinedIndexT)
+                    throw std::runtime_error("Alembic: rig camera of view " + std::to_string(key.viewId) + " has no sub-pose index");
+                if(key.subPoseId >= rig.subPoses.size())
+                    rig.subPoses.resize((size_t)key.subPoseId + 1);
+                RigSubPose& sp = rig.subPoses[key.subPoseId];
+                if(!sp.initialized)
+                {
+                    sp.initialized = true;
+                    sp.pose = pose;
+                }
+            }
+            else
+                _out.poses[key.poseId] = pose; // SfMData::setPose: a view's own pose replaces what is there
+        }
     }
 
     // AlembicImporter.cpp:153-373 readPointCloud
@@ -1400,14 +1425,30 @@ void saveSfMDataAlembic(const SfMData& in, const std::string& filename, bool wit
     OutObject cameras = xformObject("mvgCameras", nullptr), undefined = xformObject("mvgCamerasUndefined", nullptr);
     undefined.properties.add(hidden());
 
-    // AlembicExporter.cpp:93-312 addCamera, :395-409 addSfMSingleCamera
-    for(const auto& kv : in.views)
-    {
-        if(!withViews)
-            break;
-        const View& v = kv.second;
-        const bool hasPose = v.poseId != UndefinedIndexT && in.poses.count(v.poseId);
+    // the 4 x 4 an exporter node stores for a pose: T = [R | -R C], T2 = (M T M)^-1, transposed to Imath's row-vector convention
+    auto poseMatrix = [](const Pose& p, IndexT viewId, double xm[16]) {
+        const Point3d t = p.rotation * p.center * -1.0;
+        const double sgn[4] = {1.0, -1.0, -1.0, 1.0};
+        double A[16] = {0}, T2[16];
+        for(int i = 0; i < 3; ++i)
+        {
+            for(int j = 0; j < 3; ++j)
+                A[4 * i + j] = sgn[i] * p.rotation(i, j) * sgn[j];
+            A[4 * i + 3] = sgn[i] * (i == 0 ? t.x : (i == 1 ? t.y : t.z));
+        }
+        A[15] = 1.0;
+        if(!invert4(A, T2))
+            throw std::runtime_error("Alembic: singular pose of view " + std::to_string(viewId));
+        for(int i = 0; i < 4; ++i)
+            for(int j = 0; j < 4; ++j)
+                xm[4 * j + i] = T2[4 * i + j];
+    };
+    // AlembicExporter.cpp:93-312 addCamera: the transform node of a view with its camera below; `pose` = what the node's matrix states (the
+    // view's own pose, or its sub-pose below a rig node), nullptr = none
+    auto cameraNode = [&](const View& v, const Pose* pose, bool& complete) -> OutObject {
+        const bool hasPose = pose != nullptr;
         const bool hasIntrinsic = v.intrinsicId != UndefinedIndexT && in.intrinsics.count(v.intrinsicId);
+        complete = hasPose && hasIntrinsic;
         std::string stem = v.path;
         const size_t slash = stem.find_last_of("/\\");
         if(slash != std::string::npos)
@@ -1419,25 +1460,7 @@ void saveSfMDataAlembic(const SfMData& in, const std::string& filename, bool wit
         label << "camxform_" << std::setfill('0') << std::setw(5) << UndefinedIndexT << "_" << v.poseId << "_" << stem << "_" << v.viewId;
         double xm[16];
         if(hasPose)
-        {
-            // T = [R | -R C]; T2 = (M T M)^-1; stored transposed (row-vector convention)
-            const Pose& p = in.poses.at(v.poseId);
-            const Point3d t = p.rotation * p.center * -1.0;
-            const double sgn[4] = {1.0, -1.0, -1.0, 1.0};
-            double A[16] = {0}, T2[16];
-            for(int i = 0; i < 3; ++i)
-            {
-                for(int j = 0; j < 3; ++j)
-                    A[4 * i + j] = sgn[i] * p.rotation(i, j) * sgn[j];
-                A[4 * i + 3] = sgn[i] * (i == 0 ? t.x : (i == 1 ? t.y : t.z));
-            }
-            A[15] = 1.0;
-            if(!invert4(A, T2))
-                throw std::runtime_error("Alembic: singular pose of view " + std::to_string(v.viewId));
-            for(int i = 0; i < 4; ++i)
-                for(int j = 0; j < 4; ++j)
-                    xm[4 * j + i] = T2[4 * i + j];
-        }
+            poseMatrix(*pose, v.viewId, xm);
         OutObject xf = xformObject(label.str(), hasPose ? xm : nullptr);
         OutObject cam("camera_" + label.str(), kCameraMeta);
         OutProperty geom = OutProperty::compound(".geom", "schema=AbcGeom_Camera_v1");
@@ -1450,6 +1473,13 @@ void saveSfMDataAlembic(const SfMData& in, const std::string& filename, bool wit
         up.add(OutProperty::scalarUInt32("mvg_poseId", v.poseId));
         up.add(OutProperty::scalarUInt32("mvg_intrinsicId", v.intrinsicId));
         up.add(OutProperty::scalarUInt32("mvg_resectionId", UndefinedIndexT));
+        if(v.isPartOfRig())
+        {
+            up.add(OutProperty::scalarUInt32("mvg_rigId", v.rigId));
+            up.add(OutProperty::scalarUInt32("mvg_subPoseId", v.subPoseId));
+        }
+        if(!v.isPoseIndependant())
+            up.add(OutProperty::scalarBool("mvg_poseIndependant", false));
         {
             std::vector<std::string> raw;
             for(const auto& m : v.metadata)
@@ -1500,8 +1530,65 @@ void saveSfMDataAlembic(const SfMData& in, const std::string& filename, bool wit
         if(!hasPose || !hasIntrinsic)
             xf.properties.add(hidden());
         xf.add(std::move(cam));
-        (hasPose && hasIntrinsic ? cameras : undefined).add(std::move(xf));
+        return xf;
+    };
+
+    // AlembicExporter.cpp:364-393 addSfM: single cameras, then one rig node per (rig, rig pose)
+    std::map<IndexT, std::map<IndexT, std::vector<IndexT>>> rigsViewIds;
+    for(const auto& kv : in.views)
+    {
+        if(!withViews)
+            break;
+        const View& v = kv.second;
+        if(v.isPartOfRig() && !v.isPoseIndependant())
+        {
+            rigsViewIds[v.rigId][v.poseId].push_back(v.viewId);
+            continue;
+        }
+        // AlembicExporter.cpp:395-409 addSfMSingleCamera
+        const bool posed = v.poseId != UndefinedIndexT && in.poses.count(v.poseId);
+        const Pose own = posed ? in.poses.at(v.poseId) : Pose();
+        bool complete = false;
+        OutObject xf = cameraNode(v, posed ? &own : nullptr, complete);
+        (complete && in.isPoseAndIntrinsicDefined(v) ? cameras : undefined).add(std::move(xf));
     }
+    // AlembicExporter.cpp:411-486 addSfMCameraRig
+    for(const auto& rigPair : rigsViewIds)
+        for(const auto& poseViews : rigPair.second)
+        {
+            const IndexT rigId = rigPair.first, rigPoseId = poseViews.first;
+            const auto rigIt = in.rigs.find(rigId);
+            if(rigIt == in.rigs.end())
+                throw std::runtime_error("Alembic: view of rig " + std::to_string(rigId) + " but no such rig");
+            double xm[16];
+            const bool rigPosed = in.poses.count(rigPoseId) != 0;
+            if(rigPosed)
+                poseMatrix(in.poses.at(rigPoseId), poseViews.second.front(), xm);
+            std::ostringstream label;
+            label << "rigxform_" << std::setfill('0') << std::setw(5) << rigId << "_" << rigPoseId;
+            std::map<bool, OutObject> rigObj; // one node among the reconstructed cameras, one among the undefined ones
+            for(const IndexT viewId : poseViews.second)
+            {
+                const View& v = in.views.at(viewId);
+                const RigSubPose* sp = in.rigSubPose(v);
+                const bool isReconstructed = sp != nullptr && sp->initialized;
+                if(!rigObj.count(isReconstructed))
+                {
+                    OutObject node = xformObject(label.str(), rigPosed ? xm : nullptr);
+                    OutProperty up = OutProperty::compound(".userProperties");
+                    up.add(OutProperty::scalarUInt32("mvg_rigId", rigId));
+                    up.add(OutProperty::scalarUInt32("mvg_poseId", rigPoseId));
+                    up.add(OutProperty::scalarUInt16("mvg_nbSubPoses", (uint16_t)rigIt->second.subPoses.size()));
+                    up.add(OutProperty::scalarBool("mvg_rigPoseLocked", false));
+                    node.properties.children.front().add(std::move(up)); // under ".xform"
+                    rigObj.emplace(isReconstructed, std::move(node));
+                }
+                bool complete = false;
+                rigObj.at(isReconstructed).add(cameraNode(v, isReconstructed ? &sp->pose : nullptr, complete));
+            }
+            for(auto& kv : rigObj)
+                (kv.first ? cameras : undefined).add(std::move(kv.second));
+        }
 
     // AlembicExporter.cpp:488-600 addLandmarks
     OutObject cloud = xformObject("mvgCloud", nullptr), pointCloud = xformObject("mvgPointCloud", nullptr);

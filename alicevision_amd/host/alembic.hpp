@@ -140,6 +140,7 @@ public:
     }
     static OutProperty scalarBool(const std::string& name, bool v);
     static OutProperty scalarUInt32(const std::string& name, uint32_t v);
+    static OutProperty scalarUInt16(const std::string& name, uint16_t v);
     static OutProperty scalarDouble(const std::string& name, double v);
     static OutProperty scalarString(const std::string& name, const std::string& v);
     static OutProperty scalarDoubles(const std::string& name, const std::vector<double>& v, const std::string& metadata = "");  // extent = size

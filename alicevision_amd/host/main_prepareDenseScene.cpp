@@ -194,7 +194,7 @@ static int aliceVision_main(int argc, char* argv[])
         for(const View* view : todo)
         {
             const Intrinsic& intr = sfmData.getIntrinsic(*view);
-            const Pose& pose = sfmData.getPose(*view);
+            const Pose pose = sfmData.getPose(*view);
             const std::string baseFilename = std::to_string(view->viewId);
             if(!intr.isPinhole)
             {

@@ -193,8 +193,13 @@ void loadSfMData(SfMData& out, const std::string& filename)
             v.viewId = (IndexT)n.getUInt("viewId", UndefinedIndexT);
             v.poseId = (IndexT)n.getUInt("poseId", UndefinedIndexT);
             v.intrinsicId = (IndexT)n.getUInt("intrinsicId", UndefinedIndexT);
-            if(n.has("rigId") && (IndexT)n.getUInt("rigId", UndefinedIndexT) != UndefinedIndexT)
-                throw std::runtime_error("SfMData: rigs are not supported (view " + std::to_string(v.viewId) + ")");
+            if(n.has("rigId"))
+            { // jsonIO.cpp:84-91
+                v.rigId = (IndexT)n.getUInt("rigId", UndefinedIndexT);
+                v.subPoseId = (IndexT)n.getUInt("subPoseId", UndefinedIndexT);
+            }
+            if(const JsonValue* ind = n.find("isPoseIndependant"))
+                v.independantPose = ind->asBool();
             v.path = n.getString("path", "");
             v.width = (int)n.getUInt("width", 0);
             v.height = (int)n.getUInt("height", 0);
@@ -219,6 +224,32 @@ void loadSfMData(SfMData& out, const std::string& filename)
                     p.rotation(row, col) = r[3 * col + row];
             p.center = Point3d(c[0], c[1], c[2]);
             out.poses[poseId] = p;
+        }
+
+    if(const JsonValue* rigs = root.find("rigs"))
+        for(const JsonValue& n : rigs->items)
+        { // jsonIO.cpp:472-489 loadRig
+            Rig rig;
+            if(const JsonValue* sps = n.find("subPoses"))
+                for(const JsonValue& spn : sps->items)
+                {
+                    RigSubPose sp;
+                    std::string status = spn.getString("status", "uninitialized");
+                    std::transform(status.begin(), status.end(), status.begin(), ::tolower);
+                    if(status != "uninitialized" && status != "estimated" && status != "constant")
+                        throw std::runtime_error("SfMData: invalid rigSubPoseStatus '" + status + "'");
+                    sp.initialized = status != "uninitialized";
+                    const JsonValue& pn = spn.at("pose");
+                    double r[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, c[3] = {0, 0, 0};
+                    loadVector(pn.at("rotation"), r, 9);
+                    loadVector(pn.at("center"), c, 3);
+                    for(int col = 0; col < 3; ++col)
+                        for(int row = 0; row < 3; ++row)
+                            sp.pose.rotation(row, col) = r[3 * col + row];
+                    sp.pose.center = Point3d(c[0], c[1], c[2]);
+                    rig.subPoses.push_back(sp);
+                }
+            out.rigs.emplace((IndexT)n.at("rigId").asUInt(), std::move(rig));
         }
 
     if(const JsonValue* st = root.find("structure"))

@@ -2,13 +2,14 @@
 // landmarks with their 2-D observations.  Restates sfmData/{SfMData,View,Landmark,CameraPose}.hpp and the JSON reader
 // sfmDataIO/jsonIO.cpp:76-111 (views), :244-449 (intrinsics), :533-566 (landmarks), :707-860 (file) of the reference.
 // Alembic (.abc) scenes — what Meshroom's StructureFromMotion node writes — are read by alembic.cpp (no Alembic library needed).
-// Not read: rigs, ancestors, features/matches folders, constraints.
+// Rigs are read (a rig camera's pose = its sub-pose composed with the rig's pose).  Not read: ancestors, features/matches folders, constraints.
 #pragma once
 
 #include "mvsData.hpp"
 
 #include <cstdint>
 #include <map>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,12 @@ static constexpr IndexT UndefinedIndexT = 0xffffffffu;
 struct View
 {
     IndexT viewId = UndefinedIndexT, poseId = UndefinedIndexT, intrinsicId = UndefinedIndexT;
+    // a camera of a rig (sfmData/View.hpp:150-190): its pose is the rig's sub-pose composed with the rig's pose unless it was
+    // estimated on its own ("independant")
+    IndexT rigId = UndefinedIndexT, subPoseId = UndefinedIndexT;
+    bool independantPose = true;
+    bool isPartOfRig() const { return rigId != UndefinedIndexT; }
+    bool isPoseIndependant() const { return !isPartOfRig() || independantPose; }
     std::string path;
     int width = 0, height = 0;
     std::map<std::string, std::string> metadata;
@@ -61,6 +68,17 @@ struct Pose
     Point3d center;
 };
 
+// sfmData/Rig.hpp: the relative poses of a rig's cameras
+struct RigSubPose
+{
+    bool initialized = false;  // ERigSubPoseStatus != UNINITIALIZED (ESTIMATED and CONSTANT are the same to this stage)
+    Pose pose;
+};
+struct Rig
+{
+    std::vector<RigSubPose> subPoses;
+};
+
 struct Observation
 {
     double x = 0.0, y = 0.0;  // full-size image pixels
@@ -80,12 +98,41 @@ struct SfMData
     std::map<IndexT, Pose> poses;
     std::map<IndexT, Landmark> landmarks;
 
-    // sfmData/SfMData.hpp: isPoseAndIntrinsicDefined
+    std::map<IndexT, Rig> rigs;
+
+    const RigSubPose* rigSubPose(const View& v) const
+    {
+        const auto it = rigs.find(v.rigId);
+        return it != rigs.end() && v.subPoseId < it->second.subPoses.size() ? &it->second.subPoses[v.subPoseId] : nullptr;
+    }
+    // sfmData/SfMData.hpp:288-295 isPoseAndIntrinsicDefined
     bool isPoseAndIntrinsicDefined(const View& v) const
     {
-        return v.intrinsicId != UndefinedIndexT && v.poseId != UndefinedIndexT && intrinsics.count(v.intrinsicId) && poses.count(v.poseId);
+        if(!(v.intrinsicId != UndefinedIndexT && v.poseId != UndefinedIndexT && intrinsics.count(v.intrinsicId) && poses.count(v.poseId)))
+            return false;
+        if(v.isPoseIndependant())
+            return true;
+        const RigSubPose* sp = rigSubPose(v);
+        return sp != nullptr && sp->initialized;
     }
-    const Pose& getPose(const View& v) const { return poses.at(v.poseId); }
+    // sfmData/SfMData.cpp getPose: the view's own pose, or rig sub-pose * rig pose (geometry::Pose3 composition of [R | -R C] blocks)
+    Pose getPose(const View& v) const
+    {
+        const Pose& base = poses.at(v.poseId);
+        if(v.isPoseIndependant())
+            return base;
+        const RigSubPose* sp = rigSubPose(v);
+        if(sp == nullptr)
+            throw std::out_of_range("SfMData::getPose: view " + std::to_string(v.viewId) + " names a rig sub-pose that does not exist");
+        const Matrix3x3 R = sp->pose.rotation * base.rotation;
+        const Point3d tRig = (base.rotation * base.center) * -1.0, tSub = (sp->pose.rotation * sp->pose.center) * -1.0;
+        const Point3d t = sp->pose.rotation * tRig + tSub;
+        Pose out;
+        out.rotation = R;
+        out.center = Point3d(-(R(0, 0) * t.x + R(1, 0) * t.y + R(2, 0) * t.z), -(R(0, 1) * t.x + R(1, 1) * t.y + R(2, 1) * t.z),
+                             -(R(0, 2) * t.x + R(1, 2) * t.y + R(2, 2) * t.z));
+        return out;
+    }
     const Intrinsic& getIntrinsic(const View& v) const { return intrinsics.at(v.intrinsicId); }
 };
 

@@ -299,7 +299,17 @@ int main(int argc, char** argv)
                     os << (f2 ? "" : ", ") << str(m.first) << ": " << str(m.second);
                     f2 = false;
                 }
-                os << "}}";
+                os << "}, \"rigId\": " << (long long)(v.isPartOfRig() ? (long long)v.rigId : -1) << ", \"subPoseId\": "
+                   << (long long)(v.isPartOfRig() ? (long long)v.subPoseId : -1) << ", \"independantPose\": " << (v.isPoseIndependant() ? 1 : 0);
+                if(sfm.isPoseAndIntrinsicDefined(v))
+                {
+                    const Pose ap = sfm.getPose(v);
+                    os << ", \"absRotation\": [";
+                    for(int i = 0; i < 9; ++i)
+                        os << (i ? ", " : "") << ap.rotation.m[i];
+                    os << "], \"absCenter\": [" << ap.center.x << ", " << ap.center.y << ", " << ap.center.z << "]";
+                }
+                os << "}";
                 first = false;
             }
             os << "], \"intrinsics\": [";

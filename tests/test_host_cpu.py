@@ -510,7 +510,10 @@ def test_alembic_round_trip_with_observations_and_cli_plan(scene, tmp_path):
     abc_path = str(tmp_path / "scene.abc")
     run([TOOL, "sfm-to-abc", sfm, abc_path])
     a, b = _sfm_dump(sfm), _sfm_dump(abc_path)
-    assert a["views"] == b["views"] and [p["poseId"] for p in a["poses"]] == [p["poseId"] for p in b["poses"]]
+    strip = lambda vs: [{k: x for k, x in v.items() if not k.startswith("abs")} for v in vs]
+    assert strip(a["views"]) == strip(b["views"]) and [p["poseId"] for p in a["poses"]] == [p["poseId"] for p in b["poses"]]
+    for va, vb in zip(a["views"], b["views"]):
+        np.testing.assert_allclose(va["absRotation"] + va["absCenter"], vb["absRotation"] + vb["absCenter"], rtol=0, atol=1e-13)
     for ia, ib in zip(a["intrinsics"], b["intrinsics"]):
         assert {k: v for k, v in ia.items() if k not in ("scale", "offset")} == {k: v for k, v in ib.items() if k not in ("scale", "offset")}
         np.testing.assert_allclose(ia["scale"] + ia["offset"], ib["scale"] + ib["offset"], rtol=1e-15)
@@ -581,3 +584,48 @@ def test_jpeg_images_folder_is_planned_like_the_exr_folder(scene, tmp_path):
     shutil.copy(os.path.join(img, "%d.exr" % scene_io.view_id(0)), jpg)
     r = run([CLI, "-i", sfm, "--imagesFolder", jpg, "-o", str(tmp_path / "o_x"), "--downscale", 1, "--dryRun", 1, "-v", "error"], check=False)
     assert r.returncode == 1 and "Ambiguous" in (r.stdout + r.stderr)
+
+
+def test_rig_scene_equals_the_scene_with_absolute_poses(scene, tmp_path):
+    """a scene whose cameras hang on a rig (sfmData/Rig.hpp: pose of a view = sub-pose composed with the rig's pose, SfMData::getPose) read from
+    .sfm and — written with the rig structure of AlembicExporter.cpp:411-486 and read back — from .abc: the same absolute cameras and the same
+    plan as the scene that states every pose on its own; a view with an uninitialised sub-pose is not a camera of the stage"""
+    sc, lms, sfm, img, d = scene
+    doc = json.load(open(sfm))
+    R = [np.asarray(sc.R[i], np.float64) for i in range(6)]
+    C = [np.asarray(sc.C[i], np.float64) for i in range(6)]
+    H = [np.block([[R[i], (-R[i] @ C[i])[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]]) for i in range(6)]
+    rig = json.loads(json.dumps(doc))
+    rig_pose_id = doc["views"][0]["poseId"]
+    sub = []
+    for i, v in enumerate(rig["views"]):
+        v["rigId"], v["subPoseId"], v["isPoseIndependant"], v["poseId"] = "7", str(i), "false", rig_pose_id
+        Hs = H[i] @ np.linalg.inv(H[0])  # H_i = H_sub * H_rig
+        Rs, ts = Hs[:3, :3], Hs[:3, 3]
+        Cs = -Rs.T @ ts
+        sub.append({"status": "estimated", "pose": {"rotation": ["%.17g" % x for x in Rs.T.reshape(-1)], "center": ["%.17g" % x for x in Cs]}})
+    rig["poses"] = [p for p in doc["poses"] if p["poseId"] == rig_pose_id]
+    rig["rigs"] = [{"rigId": "7", "subPoses": sub}]
+    rig_sfm = str(tmp_path / "rig.sfm")
+    json.dump(rig, open(rig_sfm, "w"))
+    rig_abc = str(tmp_path / "rig.abc")
+    run([TOOL, "sfm-to-abc", rig_sfm, rig_abc])
+    plain = _sfm_dump(sfm)
+    for path in (rig_sfm, rig_abc):
+        got = _sfm_dump(path)
+        assert len(got["poses"]) == 1 and [v["rigId"] for v in got["views"]] == [7] * 6 and [v["subPoseId"] for v in got["views"]] == list(range(6))
+        for a, b in zip(plain["views"], got["views"]):
+            np.testing.assert_allclose(b["absRotation"], a["absRotation"], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(b["absCenter"], a["absCenter"], rtol=0, atol=1e-11)
+        ref = plan_of(sfm, img, str(tmp_path / "o_plain"), ["--sgmMaxDepths", 48])
+        out = plan_of(path, img, str(tmp_path / "o_rig"), ["--sgmMaxDepths", 48])
+        for ta, tb in zip(ref["tiles"], out["tiles"]):
+            assert ta["sgmTCams"] == tb["sgmTCams"] and np.allclose(ta["depths"], tb["depths"], rtol=1e-5)
+    # an uninitialised sub-pose: that view has no pose (SfMData.hpp:288-295), the others keep theirs
+    rig["rigs"][0]["subPoses"][2]["status"] = "uninitialized"
+    json.dump(rig, open(rig_sfm, "w"))
+    got = _sfm_dump(rig_sfm)
+    assert ["absCenter" in v for v in got["views"]] == [True, True, False, True, True, True]
+    run([TOOL, "sfm-to-abc", rig_sfm, rig_abc])
+    got = _sfm_dump(rig_abc)
+    assert ["absCenter" in v for v in got["views"]] == [True, True, False, True, True, True]
