@@ -115,6 +115,89 @@ __global__ void __launch_bounds__(256) sgm_p2_map_kernel(SgmP2Batch S)
     T.p2[(long long)a * T.B + b] = P2;
 }
 
+// The maps of BOTH filtering axes of a tile in one pass over its pixels.  A lane owns stage pixel (x, y): the colour step to its left
+// neighbour is the X-axis map's entry [y][x], the one to the neighbour above the Y-axis map's [x][y] — three texel fetches instead of
+// four (the centre is shared whenever both axes apply the same ROI offsets, i.e. always but in strictRoiQuirk mode on an offset tile),
+// lanes along x for both fetch patterns, and the Y-axis map — whose rows run along y — stored through a 16 x 16 LDS transpose so that
+// its stores are runs of 16 floats too.  Same expressions as sgm_p2_map_kernel, entry by entry (the A/B is AVDM_SGM_P2_MAP=legacy).
+struct SgmP2Tile2
+{
+    TexLod L;
+    float rcW, rcH;
+    int dimX, dimY;
+    int beginX[2], beginY[2]; // per filtering axis (slot): ROI offsets as the reference applies them to (v.x, v.y)
+    int scanIsX[2];
+    float* p2[2];             // slot's map: [dimY][dimX] when it scans along x, [dimX][dimY] when along y; nullptr: no such slot
+};
+struct SgmP2Batch2
+{
+    float step;
+    float P2w;
+    int fixed8;
+    SgmP2Tile2 t[AVDM_SGM_MAX_TILES];
+};
+
+__device__ __forceinline__ float4 sgm_p2_texel(const SgmP2Batch2& S, const SgmP2Tile2& T, int imX, int imY)
+{
+    const float u = ((float)imX + 0.5f) / T.rcW, v = ((float)imY + 0.5f) / T.rcH;
+    return S.fixed8 ? tex2D_lod<true>(T.L, u, v) : tex2D_lod<false>(T.L, u, v);
+}
+
+__global__ void __launch_bounds__(256) sgm_p2_map2_kernel(SgmP2Batch2 S)
+{
+    __shared__ float tile[16][17];
+    const SgmP2Tile2& T = S.t[blockIdx.z];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = blockIdx.x * 16 + tx, y = blockIdx.y * 16 + ty;
+    if((int)(blockIdx.x * 16) >= T.dimX || (int)(blockIdx.y * 16) >= T.dimY)
+        return; // (whole workgroup outside this tile: the grid is sized for the largest tile of the batch)
+    const bool inside = x < T.dimX && y < T.dimY;
+    const bool shared0 = T.p2[0] != nullptr && T.p2[1] != nullptr && T.beginX[0] == T.beginX[1] && T.beginY[0] == T.beginY[1];
+    float4 c0shared = make_float4(0.f, 0.f, 0.f, 0.f);
+    if(inside && shared0 && !(S.P2w < 0))
+        c0shared = sgm_p2_texel(S, T, (int)((float)(T.beginX[0] + x) * S.step), (int)((float)(T.beginY[0] + y) * S.step));
+    for(int s = 0; s < 2; ++s)
+    {
+        if(T.p2[s] == nullptr)
+            continue;
+        float P2 = 80.0f;
+        if(inside)
+        {
+            const int b = T.scanIsX[s] ? x : y;
+            if(S.P2w < 0)
+                P2 = fabsf(S.P2w);
+            else if(b == 0)
+                P2 = 80.0f; // never read
+            else
+            {
+                const int imX0 = (int)((float)(T.beginX[s] + x) * S.step);
+                const int imY0 = (int)((float)(T.beginY[s] + y) * S.step);
+                const int imX1 = (int)((float)imX0 - S.step * (float)(T.scanIsX[s] ? 1 : 0));
+                const int imY1 = (int)((float)imY0 - S.step * (float)(T.scanIsX[s] ? 0 : 1));
+                const float4 c0 = shared0 ? c0shared : sgm_p2_texel(S, T, imX0, imY0);
+                const float4 c1 = sgm_p2_texel(S, T, imX1, imY1);
+                const float dx = c0.x - c1.x, dy = c0.y - c1.y, dz = c0.z - c1.z;
+                const float deltaC = sqrtf(dx * dx + dy * dy + dz * dz);
+                P2 = 80.f + (255.f - 80.f) * (1.0f / (1.0f + exp_p2(10.0f * ((deltaC - S.P2w) / 80.f))));
+            }
+        }
+        if(T.scanIsX[s])
+        {
+            if(inside)
+                T.p2[s][(long long)y * T.dimX + x] = P2;
+        }
+        else
+        {
+            __syncthreads(); // (the tile may still be read by the previous slot)
+            tile[ty][tx] = P2;
+            __syncthreads();
+            const int ox = blockIdx.x * 16 + ty, oy = blockIdx.y * 16 + tx; // roles swapped: consecutive lanes = consecutive y
+            if(ox < T.dimX && oy < T.dimY)
+                T.p2[s][(long long)ox * T.dimY + oy] = tile[tx][ty];
+        }
+    }
+}
+
 // ---- one aggregation path over a batch of tiles -----------------------------------------------------------------------
 struct SgmPathTile
 {
@@ -1491,11 +1574,50 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
             return set_error_msg(1, "avdm_volume_optimize: at most 2 filtering axes (the reference runs two paths per character for any length)");
         axisIsX[nAxes++] = (*ax == 'X');
     }
-    // pass 1: the adaptive-P2 map of every (axis, tile) — ONE launch for all of them when they fit the kernel-argument table
-    // (the maps only depend on the R image), otherwise one launch per axis
+    // pass 1: the adaptive-P2 maps.  Default: both axes of every tile in one pass over the tile's pixels (sgm_p2_map2_kernel)
+    static const bool legacyP2 = [] {
+        const char* e = getenv("AVDM_SGM_P2_MAP");
+        return e && e[0] == 'l';
+    }();
+    if(!legacyP2)
+    {
+        SgmP2Batch2 Q2;
+        Q2.step = (float)sp->stepXY;
+        Q2.P2w = (float)sp->p2Weighting;
+        Q2.fixed8 = 0;
+        int maxX = 0, maxY = 0;
+        for(int i = 0; i < n; ++i)
+        {
+            const avdm_sgm_tile_t& t = tiles[idx[i]];
+            const int dimX = (int)(t.roi.x.end - t.roi.x.begin), dimY = (int)(t.roi.y.end - t.roi.y.begin);
+            SgmP2Tile2& R = Q2.t[i];
+            R.L = make_tex_lod(t.rc_pyr, sp->scale);
+            R.rcW = (float)tex_dim_w(t.rc_pyr, sp->scale);
+            R.rcH = (float)tex_dim_h(t.rc_pyr, sp->scale);
+            R.dimX = dimX, R.dimY = dimY;
+            for(int ai = 0; ai < 2; ++ai)
+            {
+                const bool scanX = ai < nAxes ? axisIsX[ai] : true;
+                // deviceSimilarityVolumeKernels.cuh:688-689: beginX = (axisT.x == 0) ? roi.x.begin : roi.y.begin, applied to v.x (sic)
+                const bool swap = sp->strictRoiQuirk && scanX;
+                R.beginX[ai] = swap ? (int)t.roi.y.begin : (int)t.roi.x.begin;
+                R.beginY[ai] = swap ? (int)t.roi.x.begin : (int)t.roi.y.begin;
+                R.scanIsX[ai] = scanX ? 1 : 0;
+                R.p2[ai] = ai < nAxes ? (float*)((char*)scratch + p2off[idx[i]] + (size_t)ai * p2_map_bytes(dimX, dimY)) : nullptr;
+            }
+            Q2.fixed8 = t.rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
+            maxX = dimX > maxX ? dimX : maxX;
+            maxY = dimY > maxY ? dimY : maxY;
+        }
+        for(int i = n; i < AVDM_SGM_MAX_TILES; ++i)
+            Q2.t[i] = Q2.t[n - 1];
+        hipLaunchKernelGGL(sgm_p2_map2_kernel, dim3(divUp(maxX, 16), divUp(maxY, 16), n), dim3(256), 0, st, Q2);
+    }
+    // (AVDM_SGM_P2_MAP=legacy) one map per (axis, tile) — ONE launch for all of them when they fit the kernel-argument table, otherwise
+    // one launch per axis
     const bool oneP2Launch = nAxes * n <= AVDM_SGM_MAX_TILES;
     int maxA = 0, maxB = 0, nq = 0;
-    for(int ai = 0; ai < nAxes; ++ai)
+    for(int ai = 0; legacyP2 && ai < nAxes; ++ai)
     {
         const bool scanX = axisIsX[ai];
         if(!oneP2Launch)
