@@ -1,6 +1,7 @@
 // MultiViewParams.cpp — see MultiViewParams.hpp for the reference lines restated.
 #include "MultiViewParams.hpp"
 #include "png.hpp"
+#include "tiff.hpp"
 
 #include <cctype>
 
@@ -42,6 +43,11 @@ std::string lowerExtension(const std::string& path)
     return e;
 }
 bool isPngPath(const std::string& path) { return lowerExtension(path) == ".png"; }
+bool isTiffPath(const std::string& path)
+{
+    const std::string e = lowerExtension(path);
+    return e == ".tif" || e == ".tiff";
+}
 bool isJpegPath(const std::string& path)
 {
     const std::string e = lowerExtension(path);
@@ -80,9 +86,9 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
             else if(_imagesFolder != "/" && dirExists(_imagesFolder))
             {
                 // one file per view named <viewId>.<ext> (MultiViewParams.cpp:83-103: exactly one file with a supported extension); this build
-                // decodes OpenEXR (PrepareDenseScene's output format), PNG and JPEG
+                // decodes OpenEXR (PrepareDenseScene's output format), PNG, JPEG and TIFF
                 std::string candidate;
-                for(const char* ext : {".exr", ".png", ".jpg", ".jpeg", ".JPG"})
+                for(const char* ext : {".exr", ".png", ".jpg", ".jpeg", ".JPG", ".tif", ".tiff"})
                 {
                     const std::string c = _imagesFolder + std::to_string(view.viewId) + ext;
                     if(!fileExists(c))
@@ -94,7 +100,7 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
                 }
                 if(candidate.empty())
                     throw std::runtime_error("Cannot find image file coresponding to the view '" + std::to_string(view.viewId) + "' in folder '" +
-                                             _imagesFolder + "' (expected " + std::to_string(view.viewId) + ".exr, .png or .jpg).");
+                                             _imagesFolder + "' (expected " + std::to_string(view.viewId) + ".exr, .png, .jpg or .tif).");
                 path = candidate;
             }
             dimensions.emplace(view.width, view.height);
@@ -134,6 +140,13 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
             readPng(imgParams.path, png, true);
             header.width = png.width;
             header.height = png.height;
+        }
+        else if(exists && isTiffPath(imgParams.path))
+        {
+            TiffImage tiff;
+            readTiff(imgParams.path, tiff, true);
+            header.width = tiff.width;
+            header.height = tiff.height;
         }
         else if(exists && isJpegPath(imgParams.path))
         {
@@ -483,25 +496,40 @@ std::shared_ptr<const HostImage> ImagesCache::getImg_sync(int camId)
     }
     // decode outside the lock: several images can be read at once (DepthMapEstimator pre-warms the cache of a batch in parallel)
     const std::string& path = _mp.getImagePath(camId);
-    if(isPngPath(path))
+    if(isPngPath(path) || isTiffPath(path))
     {
-        // inflate + scan-line filters on the host (sequential by nature); the integer samples go to the device as they are and become linear
-        // float RGBA there (avdm_image_decode_integer: image::readImage(..., LINEAR) for an 8- / 16-bit sRGB file)
-        PngImage png;
-        readPng(path, png);
-        if(_mp.getOriginalWidth(camId) != png.width || _mp.getOriginalHeight(camId) != png.height)
+        // the container's own decoding on the host (inflate + scan-line filters / strips, LZW, predictor: sequential by nature); the
+        // integer samples go to the device as they are and become linear float RGBA there (avdm_image_decode_integer:
+        // image::readImage(..., LINEAR) for an 8- / 16-bit sRGB file)
+        int w = 0, h = 0, channels = 0, bits = 0;
+        std::vector<unsigned char> samples;
+        if(isPngPath(path))
+        {
+            PngImage png;
+            readPng(path, png);
+            w = png.width, h = png.height, channels = png.channels, bits = png.bits;
+            samples.swap(png.samples);
+        }
+        else
+        {
+            TiffImage tiff;
+            readTiff(path, tiff);
+            w = tiff.width, h = tiff.height, channels = tiff.channels, bits = tiff.bits;
+            samples.swap(tiff.samples);
+        }
+        if(_mp.getOriginalWidth(camId) != w || _mp.getOriginalHeight(camId) != h)
             throw std::runtime_error("Bad image dimension for camera : " + std::to_string(camId) + "\n\t- image path : " + path + "\n\t- expected dimension : " +
                                      std::to_string(_mp.getOriginalWidth(camId)) + "x" + std::to_string(_mp.getOriginalHeight(camId)) +
-                                     "\n\t- real dimension : " + std::to_string(png.width) + "x" + std::to_string(png.height));
+                                     "\n\t- real dimension : " + std::to_string(w) + "x" + std::to_string(h));
         auto full = std::make_shared<HostImage>();
-        full->raw.swap(png.samples);
-        full->rawChannels = png.channels;
-        full->rawBits = png.bits;
+        full->raw.swap(samples);
+        full->rawChannels = channels;
+        full->rawBits = bits;
         const int s = _mp.getProcessDownscale();
-        full->srcWidth = png.width;
-        full->srcHeight = png.height;
-        full->width = s > 1 ? png.width / s : png.width;
-        full->height = s > 1 ? png.height / s : png.height;
+        full->srcWidth = w;
+        full->srcHeight = h;
+        full->width = s > 1 ? w / s : w;
+        full->height = s > 1 ? h / s : h;
         std::shared_ptr<const HostImage> result = full;
         std::lock_guard<std::mutex> lock(_mutex);
         if(_cache.size() >= _max)

@@ -17,6 +17,7 @@
 #include "mvsData.hpp"
 #include "sfmData.hpp"
 #include "png.hpp"
+#include "tiff.hpp"
 #include "jpeg.hpp"
 
 #include <avdm.h>
@@ -57,7 +58,7 @@ std::vector<std::string> viewPathsFromFolders(const View& view, const std::vecto
     std::vector<std::string> out;
     for(const std::string& folder : folders)
         for(const std::string& base : {std::to_string(view.viewId), stem})
-            for(const char* ext : {".exr", ".png", ".jpg", ".jpeg", ".JPG", ".JPEG", ".PNG"}) // the formats this build decodes
+            for(const char* ext : {".exr", ".png", ".jpg", ".jpeg", ".tif", ".tiff", ".JPG", ".JPEG", ".PNG", ".TIF", ".TIFF"}) // the formats this build decodes
             {
                 const std::string p = folder + "/" + base + ext;
                 if(fileExists(p) && std::find(out.begin(), out.end(), p) == out.end())
@@ -228,16 +229,29 @@ static int aliceVision_main(int argc, char* argv[])
                 deviceSource.allocate((size_t)jpeg.width * jpeg.height * 16);
                 decodeJpegToLinearRgba(jpeg, deviceSource.as<float>(), stream);
             }
-            else if(ext == ".png")
+            else if(ext == ".png" || ext == ".tif" || ext == ".tiff")
             {
-                PngImage png;
-                readPng(srcImage, png);
-                exr.width = png.width, exr.height = png.height;
-                DeviceBuffer samples(png.samples.size());
-                deviceSource.allocate((size_t)png.width * png.height * 16);
-                AVDM_HIP_CHECK(hipMemcpyAsync(samples.ptr(), png.samples.data(), png.samples.size(), hipMemcpyHostToDevice, stream));
-                avdmCheck(avdm_image_decode_integer(deviceSource.as<float>(), png.width * 16, samples.ptr(), png.width * png.channels * (png.bits / 8), png.width,
-                                                    png.height, png.channels, png.bits, 1, stream),
+                int w = 0, h = 0, channels = 0, bits = 0;
+                std::vector<unsigned char> samplesHost;
+                if(ext == ".png")
+                {
+                    PngImage png;
+                    readPng(srcImage, png);
+                    w = png.width, h = png.height, channels = png.channels, bits = png.bits;
+                    samplesHost.swap(png.samples);
+                }
+                else
+                {
+                    TiffImage tiff;
+                    readTiff(srcImage, tiff);
+                    w = tiff.width, h = tiff.height, channels = tiff.channels, bits = tiff.bits;
+                    samplesHost.swap(tiff.samples);
+                }
+                exr.width = w, exr.height = h;
+                DeviceBuffer samples(samplesHost.size());
+                deviceSource.allocate((size_t)w * h * 16);
+                AVDM_HIP_CHECK(hipMemcpyAsync(samples.ptr(), samplesHost.data(), samplesHost.size(), hipMemcpyHostToDevice, stream));
+                avdmCheck(avdm_image_decode_integer(deviceSource.as<float>(), w * 16, samples.ptr(), w * channels * (bits / 8), w, h, channels, bits, 1, stream),
                           "avdm_image_decode_integer");
                 AVDM_HIP_CHECK(hipStreamSynchronize(stream));
             }

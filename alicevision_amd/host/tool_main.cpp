@@ -9,6 +9,7 @@
 //   fuse-cameras sfm depthMapsFolder filterFolder n     cameras as aliceVision_depthMapFiltering sees them (from the depth maps' metadata)
 //                                                       and the n nearest cameras of each, as JSON with round-trip precision
 //   sfm-dump scene.(sfm|json|abc)                      the loaded SfMData as JSON with round-trip precision (views, intrinsics, poses, landmarks)
+//   tiff-dump in.tif out.raw                           decode a TIFF to its interleaved integer samples (host/tiff.cpp)
 //   jpeg-dump in.jpg out.bin                           entropy-decode a JPEG (host/jpeg.cpp) and dump geometry, tables and coefficients
 //   jet v0 v1 ...                                      the reference's jet colour map (debug volume exports) at the given values
 //   sfm-to-abc scene.(sfm|json|abc) out.abc            write the loaded SfMData as an Alembic archive (AlembicExporter's layout)
@@ -22,6 +23,7 @@
 #include "sfmData.hpp"
 #include "alembic.hpp"
 #include "jpeg.hpp"
+#include "tiff.hpp"
 
 #include <chrono>
 #include <cstdlib>
@@ -233,6 +235,15 @@ int main(int argc, char** argv)
                 std::cout << "]}";
             }
             std::cout << "]}" << std::endl;
+            return 0;
+        }
+        if(cmd == "tiff-dump" && argc == 4)
+        { // decode a TIFF to its integer samples: prints "width height channels bits orientation", writes the samples (host byte order)
+            TiffImage t;
+            readTiff(argv[2], t);
+            std::ofstream f(argv[3], std::ios::binary);
+            f.write(reinterpret_cast<const char*>(t.samples.data()), (std::streamsize)t.samples.size());
+            std::cout << t.width << " " << t.height << " " << t.channels << " " << t.bits << " " << t.orientation << std::endl;
             return 0;
         }
         if(cmd == "jpeg-dump" && argc == 4)

@@ -790,3 +790,42 @@ def test_prepare_dense_scene_reads_jpeg_sources(tmp_path):
         want = np.zeros_like(src)
         assert olib.avo_image_undistort(oracle.ptr(want), w * 16, oracle.ptr(src), w * 16, C.byref(cam), C.byref(fill)) == 0
         assert np.array_equal(got, want), (i, float(np.abs(got - want).max()))
+
+
+def test_tiff_input_is_decoded_on_the_device(dataset, tmp_path):
+    """<viewId>.tif in --imagesFolder (16-bit RGB, tiled and big-endian for the odd views): strips / tiles on the host, the integer samples
+    to linear float RGBA on the device (avdm_image_decode_integer) — the program's maps equal, bit for bit, the harness run on the images
+    the ORACLE decodes from the same samples"""
+    import torch
+    from test_host_cpu import _write_tiff
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    from oracle import oracle
+    sc, sfm, img, d = dataset
+    tif_dir = str(tmp_path / "tif")
+    os.makedirs(tif_dir)
+    olib = oracle.load()
+    decoded = []
+    for i in range(NVIEWS):
+        lin = sc.images[i].numpy()[..., :3].astype(np.float64)
+        enc = np.where(lin <= 0.0031308, lin * 12.92, 1.055 * np.power(lin, 1.0 / 2.4) - 0.055)
+        q = np.clip(np.rint(enc * 65535.0), 0, 65535).astype(np.uint16)
+        _write_tiff(os.path.join(tif_dir, "%d.tif" % scene_io.view_id(i)), q, big_endian=bool(i % 2), tile=(128, 96) if i % 2 else None)
+        out = np.zeros((H, W, 4), np.float32)
+        assert olib.avo_image_decode_integer(oracle.ptr(out), W * 16, oracle.ptr(q), W * 6, W, H, 3, 16, 1) == 0
+        decoded.append(out)
+    out_dir = str(tmp_path / "out_tif")
+    args = ["-i", sfm, "--imagesFolder", tif_dir, "-o", out_dir, "--downscale", 1, "--rangeStart", 0, "--rangeSize", 1, "--sgmMaxDepths", 64,
+            "--colorOptimizationNbIterations", 5, "-v", "warning"]
+    plan = json.loads(run_cli(args + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
+    t0 = plan["tiles"][0]
+    run_cli(args)
+    depth, sim, _, _ = read_maps(out_dir)
+    sgm = abi.SgmParams.default(scale=plan["sgmScale"], stepXY=plan["sgmStepXY"])
+    ref = abi.RefineParams.default(optimizationNbIterations=5)
+    torch.cuda.set_device(0)
+    pyr = [DevicePyramid(torch.from_numpy(decoded[i]).cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(NVIEWS)]
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+    h.run_sgm(0, t0["sgmTCams"], np.asarray(t0["depths"], np.float32), tc_ranges=[(a, a + n) for a, n in t0["depthsTcLimits"]])
+    got = h.run_refine(0, t0["refineTCams"]).cpu().numpy()
+    assert np.array_equal(got[..., 0], depth), float(np.abs(got[..., 0] - depth).max())
+    assert np.array_equal(got[..., 1].astype(np.float16).astype(np.float32), sim)

@@ -629,3 +629,140 @@ def test_rig_scene_equals_the_scene_with_absolute_poses(scene, tmp_path):
     run([TOOL, "sfm-to-abc", rig_sfm, rig_abc])
     got = _sfm_dump(rig_abc)
     assert ["absCenter" in v for v in got["views"]] == [True, True, False, True, True, True]
+
+
+# ------------------------------------------------------------------------------------------------ TIFF
+def _write_tiff(path, a, big_endian=False, tile=None, planar=False, white_is_zero=False):
+    """a minimal classic-TIFF writer for the layouts Pillow cannot produce: a (H, W, C) uint8 / uint16 array, uncompressed, in strips of 7
+    rows or in tiles, chunky or planar, either byte order"""
+    import struct
+    H, W, C = a.shape
+    bits = 8 * a.dtype.itemsize
+    e = ">" if big_endian else "<"
+    data = a.astype(a.dtype.newbyteorder(e))
+    chunks = []
+    planes = [data[..., c:c + 1] for c in range(C)] if planar else [data]
+    if tile:
+        tw, th = tile
+        for pl in planes:
+            for y0 in range(0, H, th):
+                for x0 in range(0, W, tw):
+                    t = np.zeros((th, tw, pl.shape[2]), pl.dtype)
+                    blk = pl[y0:y0 + th, x0:x0 + tw]
+                    t[:blk.shape[0], :blk.shape[1]] = blk
+                    chunks.append(t.tobytes())
+    else:
+        rps = 7
+        for pl in planes:
+            for y0 in range(0, H, rps):
+                chunks.append(pl[y0:y0 + rps].tobytes())
+    entries = []
+
+    def ent(tag, typ, vals):
+        entries.append((tag, typ, list(vals)))
+
+    ent(256, 4, [W]), ent(257, 4, [H]), ent(258, 3, [bits] * C), ent(259, 3, [1])
+    ent(262, 3, [2 if C >= 3 else (0 if white_is_zero else 1)]), ent(277, 3, [C]), ent(284, 3, [2 if planar else 1])
+    if C in (2, 4):
+        ent(338, 3, [2])
+    if tile:
+        ent(322, 4, [tile[0]]), ent(323, 4, [tile[1]])
+    else:
+        ent(278, 4, [7])
+    off_tag, cnt_tag = (324, 325) if tile else (273, 279)
+    ent(off_tag, 4, [0] * len(chunks)), ent(cnt_tag, 4, [len(c) for c in chunks])
+    entries.sort()
+    ifd_size = 2 + 12 * len(entries) + 4
+    ext_off = 8 + ifd_size
+    blobs, body = [], b""
+    for tag, typ, vals in entries:
+        fmt = {3: "H", 4: "I"}[typ]
+        raw = struct.pack(e + fmt * len(vals), *vals)
+        blobs.append(raw)
+    # layout: header, IFD, out-of-line values, pixel data
+    pos = ext_off
+    where = []
+    for raw in blobs:
+        if len(raw) > 4:
+            where.append(pos)
+            pos += len(raw) + (len(raw) & 1)
+        else:
+            where.append(None)
+    data_off = pos
+    offs = []
+    for c in chunks:
+        offs.append(data_off)
+        data_off += len(c)
+    out = (b"MM" if big_endian else b"II") + struct.pack(e + "HI", 42, 8) + struct.pack(e + "H", len(entries))
+    ext = b""
+    for (tag, typ, vals), raw, w in zip(entries, blobs, where):
+        if tag == off_tag:
+            raw = struct.pack(e + "I" * len(offs), *offs)
+        if w is None:
+            out += struct.pack(e + "HHI", tag, typ, len(vals)) + raw.ljust(4, b"\0")
+        else:
+            out += struct.pack(e + "HHII", tag, typ, len(vals), w)
+            ext += raw + (b"\0" if len(raw) & 1 else b"")
+    out += struct.pack(e + "I", 0) + ext + b"".join(chunks)
+    open(path, "wb").write(out)
+
+
+def _tiff_dump(path, tmp_path):
+    raw = str(tmp_path / "tiff.raw")
+    r = run([TOOL, "tiff-dump", path, raw])
+    w, h, c, b, o = (int(v) for v in r.stdout.split())
+    return np.fromfile(raw, np.uint8 if b == 8 else np.uint16).reshape(h, w, c)
+
+
+def test_tiff_reader_layouts(tmp_path):
+    """strips and tiles, chunky and planar, both byte orders, 8 and 16 bits, 1 to 4 channels, WhiteIsZero: the samples as stored"""
+    rng = np.random.default_rng(8)
+    p = str(tmp_path / "t.tif")
+    for dt in (np.uint8, np.uint16):
+        for C in (1, 2, 3, 4):
+            a = rng.integers(0, np.iinfo(dt).max, size=(45, 67, C)).astype(dt)
+            for kw in ({}, {"big_endian": True}, {"tile": (32, 16)}, {"planar": True}, {"tile": (16, 32), "planar": True, "big_endian": True}):
+                _write_tiff(p, a, **kw)
+                assert np.array_equal(_tiff_dump(p, tmp_path), a), (dt, C, kw)
+    a = rng.integers(0, 255, size=(9, 11, 1)).astype(np.uint8)
+    _write_tiff(p, a, white_is_zero=True)
+    assert np.array_equal(_tiff_dump(p, tmp_path), 255 - a)
+    open(p, "wb").write(b"II+\0" + b"\0" * 32)
+    r = run([TOOL, "tiff-dump", p, str(tmp_path / "x.raw")], check=False)
+    assert r.returncode == 1 and "BigTIFF" in r.stderr
+
+
+@pytest.mark.parametrize("compression", [None, "tiff_lzw", "tiff_adobe_deflate", "packbits"])
+def test_tiff_reader_against_pillow(tmp_path, compression):
+    """files written by Pillow / libtiff: LZW, Deflate, PackBits, with and without the horizontal predictor, 8-bit RGB(A) / grey and 16-bit grey"""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(9)
+    y, x = np.mgrid[0:211, 0:300]
+    base = (np.sin(x / 9.0) * np.cos(y / 7.0) * 0.4 + 0.5)
+    for mode, C, dt in (("RGB", 3, np.uint8), ("RGBA", 4, np.uint8), ("L", 1, np.uint8), ("I;16", 1, np.uint16)):
+        mx = np.iinfo(dt).max
+        a = np.clip(np.stack([base * mx + rng.normal(0, mx * 0.01, base.shape) for _ in range(C)], -1), 0, mx).astype(dt)
+        for predictor in ((1,) if compression in (None, "packbits") else (1, 2)):
+            p = str(tmp_path / "p.tif")
+            kw = {"compression": compression} if compression else {}
+            if predictor == 2:
+                kw["tiffinfo"] = {317: 2}
+            Image.fromarray(a[..., 0] if C == 1 else a).save(p, **kw)
+            ref = np.array(Image.open(p))
+            got = _tiff_dump(p, tmp_path)
+            assert np.array_equal(got, ref.reshape(got.shape)), (mode, compression, predictor)
+
+
+def test_tiff_images_folder_is_planned_like_the_exr_folder(scene, tmp_path):
+    """<viewId>.tif in --imagesFolder: found, sized from the directory, the same plan"""
+    sc, lms, sfm, img, d = scene
+    tif = str(tmp_path / "tif")
+    os.makedirs(tif)
+    for i in range(6):
+        a = np.clip(sc.images[i].numpy()[..., :3] * 65535.0, 0, 65535).astype(np.uint16)
+        _write_tiff(os.path.join(tif, "%d.tif" % scene_io.view_id(i)), a, tile=(128, 64) if i % 2 else None)
+    ref = plan_of(sfm, img, str(tmp_path / "o_exr"), ["--sgmMaxDepths", 48])
+    got = plan_of(sfm, tif, str(tmp_path / "o_tif"), ["--sgmMaxDepths", 48])
+    assert len(ref["tiles"]) == len(got["tiles"]) > 0
+    for ta, tb in zip(ref["tiles"], got["tiles"]):
+        assert ta["sgmTCams"] == tb["sgmTCams"] and ta["depths"] == tb["depths"]
