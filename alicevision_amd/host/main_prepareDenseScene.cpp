@@ -4,7 +4,8 @@
 // a distortion model, copied otherwise — with the camera in the image metadata (AliceVision:downscale / P / K / R / t, which
 // aliceVision_depthMapEstimation prefers over the SfMData: mvsUtils/MultiViewParams.cpp:164-186) and, with --saveMatricesTxtFiles 1,
 // <viewId>_P.txt / <viewId>_KRt.txt.
-// Not built: image formats other than OpenEXR in and out (the reference decodes through OpenImageIO), masks (--masksFolders), exposure
+// Sources: OpenEXR, PNG, TIFF and JPEG (PNG / TIFF / JPEG become linear float RGBA on the device); masks (--masksFolders, PNG or TIFF).
+// Not built: output formats other than OpenEXR, exposure
 // compensation (--evCorrection needs the EXIF exposure of every view; for the same reason the AliceVision:EV / AliceVision:EVComp entries of
 // main_prepareDenseScene.cpp:243-247 are not written: the .sfm reader does not keep the views' EXIF metadata — aliceVision_depthMapEstimation
 // reads them only under --correctEV, which this build does not offer either).  Asking for either is an error, not a silent no-op.
@@ -26,6 +27,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <chrono>
 #include <cstdlib>
 #include <fstream>
@@ -65,6 +67,65 @@ std::vector<std::string> viewPathsFromFolders(const View& view, const std::vecto
                     out.push_back(p);
             }
     return out;
+}
+
+// image::tryLoadMask (image/io.cpp:1357-1386): <folder>/<viewId>.<ext>, else <folder>/<file name of the source image with that extension>; the
+// mask is read as ONE 8-bit channel (readImageNoFloat, io.cpp:955-984: any other channel count is an error; 16-bit samples are converted the
+// way OpenImageIO converts types: v / 65535 * 255, rounded).  PNG and TIFF masks are decoded here.
+bool tryLoadMask(std::vector<unsigned char>& mask, int& mw, int& mh, const std::vector<std::string>& masksFolders, IndexT viewId, const std::string& srcImage,
+                 const std::string& fileExtension)
+{
+    std::string ext = fileExtension;
+    if(!ext.empty() && ext[0] != '.')
+        ext = "." + ext;
+    std::string name = srcImage;
+    const size_t slash = name.find_last_of('/');
+    if(slash != std::string::npos)
+        name = name.substr(slash + 1);
+    const size_t dot = name.find_last_of('.');
+    if(dot != std::string::npos)
+        name = name.substr(0, dot);
+    for(const std::string& folder : masksFolders)
+    {
+        if(folder.empty())
+            continue;
+        for(const std::string& candidate : {folder + "/" + std::to_string(viewId) + ext, folder + "/" + name + ext})
+        {
+            if(!fileExists(candidate))
+                continue;
+            std::string e = ext;
+            for(char& ch : e)
+                ch = (char)std::tolower((unsigned char)ch);
+            int channels = 0, bits = 0;
+            std::vector<unsigned char> samples;
+            if(e == ".png")
+            {
+                PngImage png;
+                readPng(candidate, png);
+                mw = png.width, mh = png.height, channels = png.channels, bits = png.bits;
+                samples.swap(png.samples);
+            }
+            else if(e == ".tif" || e == ".tiff")
+            {
+                TiffImage tiff;
+                readTiff(candidate, tiff);
+                mw = tiff.width, mh = tiff.height, channels = tiff.channels, bits = tiff.bits;
+                samples.swap(tiff.samples);
+            }
+            else
+                throw std::runtime_error("mask '" + candidate + "': only .png and .tif masks are decoded by this build");
+            if(channels != 1)
+                throw std::runtime_error("Can't load channels of image file '" + candidate + "'.");
+            mask.resize((size_t)mw * mh);
+            if(bits == 8)
+                mask = samples;
+            else
+                for(size_t i = 0; i < mask.size(); ++i)
+                    mask[i] = (unsigned char)((float)reinterpret_cast<const uint16_t*>(samples.data())[i] / 65535.0f * 255.0f + 0.5f);
+            return true;
+        }
+    }
+    return false;
 }
 
 int distortionModelOf(const Intrinsic& I)
@@ -123,11 +184,6 @@ static int aliceVision_main(int argc, char* argv[])
     if(outImageFileTypeName != "exr" && outImageFileTypeName != "EXR")
     {
         AVDM_LOG_ERROR("outputFileType '" << outImageFileTypeName << "' is not supported by this implementation: exr only.");
-        return EXIT_FAILURE;
-    }
-    if(!masksFolders.empty())
-    {
-        AVDM_LOG_ERROR("masksFolders is not supported by this implementation.");
         return EXIT_FAILURE;
     }
     if(evCorrection)
@@ -278,6 +334,29 @@ static int aliceVision_main(int argc, char* argv[])
                     rgba[4 * i + 1] = g[i];
                     rgba[4 * i + 2] = b[i];
                     rgba[4 * i + 3] = a ? a[i] : 1.0f;
+                }
+            }
+
+            // mask (main_prepareDenseScene.cpp:68-69, 255-273): BEFORE the undistortion, alpha = 0 where the mask is 0 and 1 elsewhere
+            {
+                std::vector<unsigned char> mask;
+                int mw = 0, mh = 0;
+                if(!masksFolders.empty() && tryLoadMask(mask, mw, mh, masksFolders, view->viewId, srcImage, maskExtension))
+                {
+                    if((size_t)mw * mh != n)
+                        AVDM_LOG_WARNING("Invalid image mask size: mask is ignored.");
+                    else
+                    {
+                        if(deviceSource.bytes())
+                        { // (a source decoded on the device comes back for the mask; masks are the exception, not the hot path)
+                            AVDM_HIP_CHECK(hipMemcpyAsync(rgba.data(), deviceSource.ptr(), n * 16, hipMemcpyDeviceToHost, stream));
+                            AVDM_HIP_CHECK(hipStreamSynchronize(stream));
+                            deviceSource.release();
+                        }
+#pragma omp parallel for
+                        for(long long i = 0; i < (long long)n; ++i)
+                            rgba[4 * i + 3] = mask[(size_t)i] == 0 ? 0.f : 1.f;
+                    }
                 }
             }
 

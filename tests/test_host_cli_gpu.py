@@ -829,3 +829,54 @@ def test_tiff_input_is_decoded_on_the_device(dataset, tmp_path):
     got = h.run_refine(0, t0["refineTCams"]).cpu().numpy()
     assert np.array_equal(got[..., 0], depth), float(np.abs(got[..., 0] - depth).max())
     assert np.array_equal(got[..., 1].astype(np.float16).astype(np.float32), sim)
+
+
+def test_prepare_dense_scene_applies_masks(tmp_path):
+    """--masksFolders (main_prepareDenseScene.cpp:255-273, image::tryLoadMask): <viewId>.png or <image name>.png, one 8-bit channel; alpha = 0
+    where the mask is 0, 1 elsewhere, applied BEFORE the undistortion (so the alpha is resampled with the colours); a mask of another size
+    is ignored with a warning, a multi-channel mask is an error like in the reference"""
+    import ctypes as C
+    from png_util import write_png
+    from oracle import oracle
+    exe = os.path.join(ROOT, "alicevision_amd", "bin", "aliceVision_prepareDenseScene")
+    w, h = 160, 120
+    sc = make_scene(3, w, h, seed=12, baseline=0.9, amp=0.6)
+    d = str(tmp_path)
+    sfm, img = scene_io.write_scene(sc, d, n_landmarks=10, compression=0)
+    sd = scene_io.sfm_dict(sc, scene_io.sample_landmarks(sc, 50, amp=0.6), img)
+    k = (0.08, -0.03, 0.01)
+    sd["intrinsics"][0]["distortionType"] = "radialk3"
+    sd["intrinsics"][0]["distortionParams"] = ["%.17g" % v for v in k]
+    with open(sfm, "w") as f:
+        json.dump(sd, f)
+    masks = os.path.join(d, "masks")
+    os.makedirs(masks)
+    yy, xx = np.mgrid[0:h, 0:w]
+    m0 = (((xx - 80) ** 2 + (yy - 60) ** 2) < 50 ** 2).astype(np.uint8) * 255   # view 0: a disc, by view id
+    m1 = ((xx // 16 + yy // 16) % 2).astype(np.uint8) * 200                       # view 1: a checker board, by image name
+    write_png(os.path.join(masks, "%d.png" % scene_io.view_id(0)), m0)
+    write_png(os.path.join(masks, "%d.png" % scene_io.view_id(1)), m1)
+    write_png(os.path.join(masks, "%d.png" % scene_io.view_id(2)), np.zeros((8, 8), np.uint8))  # wrong size: ignored
+    out = os.path.join(d, "prepared")
+    r = subprocess.run([exe, "-i", sfm, "-o", out, "--masksFolders", masks, "-v", "info"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mask is ignored" in r.stdout + r.stderr
+    olib = oracle.load()
+    fx = float(sc.K[0, 0])
+    cam = abi.Intrinsic(width=w, height=h, scale_x=fx, scale_y=fx, offset_x=float(sc.K[0, 2]) - w / 2.0, offset_y=float(sc.K[1, 2]) - h / 2.0,
+                        distortion_model=abi.DISTORTION_RADIALK3, k=(C.c_double * 3)(*k))
+    fill = (C.c_float * 4)(0, 0, 0, 0)
+    for i, m in enumerate((m0, m1, None)):
+        ch, info = exr_io.read_exr(os.path.join(out, "%d.exr" % scene_io.view_id(i)))
+        got = np.stack([ch["R"], ch["G"], ch["B"], ch["A"]], -1)
+        src = np.ascontiguousarray(sc.images[i].numpy()).copy()
+        if m is not None:
+            src[..., 3] = np.where(m == 0, 0.0, 1.0)
+        want = np.zeros_like(src)
+        assert olib.avo_image_undistort(oracle.ptr(want), w * 16, oracle.ptr(src), w * 16, C.byref(cam), C.byref(fill)) == 0
+        assert np.array_equal(got, want), (i, float(np.abs(got - want).max()))
+        if m is not None:
+            assert 0.05 < float((got[..., 3] == 0).mean()) < 0.95
+    write_png(os.path.join(masks, "%d.png" % scene_io.view_id(2)), np.zeros((h, w, 3), np.uint8))  # three channels
+    r = subprocess.run([exe, "-i", sfm, "-o", out, "--masksFolders", masks], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Can't load channels" in r.stdout + r.stderr

@@ -393,7 +393,6 @@ def test_prepare_dense_scene_cli_argument_errors(scene, tmp_path):
     assert run([exe, "--help"], check=False).returncode == 0
     assert run([exe, "-i", sfm], check=False).returncode == 1                                  # --output is required
     assert run(base + ["--outputFileType", "jpg"], check=False).returncode == 1               # exr only
-    assert run(base + ["--masksFolders", str(tmp_path)], check=False).returncode == 1
     assert run(base + ["--evCorrection", 1], check=False).returncode == 1
     assert run(base + ["--rangeStart", 2, "--rangeSize", -1], check=False).returncode == 1   # Range is incorrect
     r = run([exe, "-i", str(tmp_path / "nope.sfm"), "-o", str(tmp_path / "prep")], check=False)
