@@ -5,10 +5,8 @@
 // aliceVision_depthMapEstimation prefers over the SfMData: mvsUtils/MultiViewParams.cpp:164-186) and, with --saveMatricesTxtFiles 1,
 // <viewId>_P.txt / <viewId>_KRt.txt.
 // Sources: OpenEXR, PNG, TIFF and JPEG (PNG / TIFF / JPEG become linear float RGBA on the device); masks (--masksFolders, PNG or TIFF).
-// Not built: output formats other than OpenEXR, exposure
-// compensation (--evCorrection needs the EXIF exposure of every view; for the same reason the AliceVision:EV / AliceVision:EVComp entries of
-// main_prepareDenseScene.cpp:243-247 are not written: the .sfm reader does not keep the views' EXIF metadata — aliceVision_depthMapEstimation
-// reads them only under --correctEV, which this build does not offer either).  Asking for either is an error, not a silent no-op.
+// Exposure: AliceVision:EV / AliceVision:EVComp from the views' EXIF metadata, --evCorrection scales the colours (sfmData.cpp: ExposureSetting).
+// Not built: output formats other than OpenEXR (asking for one is an error, not a silent no-op).
 // The range is taken over the views in id order (the reference iterates its hash container's order: chunk MEMBERSHIP may differ, the union
 // over all chunks does not).
 #include "cmdline.hpp"
@@ -27,6 +25,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <chrono>
 #include <cstdlib>
@@ -186,11 +185,6 @@ static int aliceVision_main(int argc, char* argv[])
         AVDM_LOG_ERROR("outputFileType '" << outImageFileTypeName << "' is not supported by this implementation: exr only.");
         return EXIT_FAILURE;
     }
-    if(evCorrection)
-    {
-        AVDM_LOG_ERROR("evCorrection is not supported by this implementation.");
-        return EXIT_FAILURE;
-    }
 
     SfMData sfmData;
     try
@@ -246,6 +240,9 @@ static int aliceVision_main(int argc, char* argv[])
     AVDM_LOG_INFO("Exporting Scene Undistorted Images: " << todo.size() << " view(s).");
 
     int nbUndistorted = 0;
+    // for the exposure metadata / correction (main_prepareDenseScene.cpp:127-129)
+    const double medianCameraExposure = sfmData.medianCameraExposure();
+    AVDM_LOG_INFO("Median Camera Exposure: " << medianCameraExposure << ", Median EV: " << std::log2(1.0 / medianCameraExposure));
     try
     {
         for(const View* view : todo)
@@ -337,6 +334,29 @@ static int aliceVision_main(int argc, char* argv[])
                 }
             }
 
+            // exposure (main_prepareDenseScene.cpp:241-252, 58-66): EV and the compensation towards the scene's median exposure go into the
+            // metadata; with --evCorrection the colours are scaled by the compensation (before the mask and the undistortion)
+            const double cameraExposure = cameraExposureSetting(view->metadata).getExposure();
+            const double ev = std::log2(1.0 / cameraExposure);
+            const float exposureCompensation = float(medianCameraExposure / cameraExposure);
+            if(evCorrection)
+            {
+                AVDM_LOG_INFO("image " << view->viewId << ", exposure: " << cameraExposure << ", Ev " << ev << " Ev compensation: " << exposureCompensation);
+                if(deviceSource.bytes())
+                { // (like the mask: a device-decoded source comes back for this optional step)
+                    AVDM_HIP_CHECK(hipMemcpyAsync(rgba.data(), deviceSource.ptr(), n * 16, hipMemcpyDeviceToHost, stream));
+                    AVDM_HIP_CHECK(hipStreamSynchronize(stream));
+                    deviceSource.release();
+                }
+#pragma omp parallel for
+                for(long long i = 0; i < (long long)n; ++i)
+                {
+                    rgba[4 * i + 0] *= exposureCompensation;
+                    rgba[4 * i + 1] *= exposureCompensation;
+                    rgba[4 * i + 2] *= exposureCompensation;
+                }
+            }
+
             // mask (main_prepareDenseScene.cpp:68-69, 255-273): BEFORE the undistortion, alpha = 0 where the mask is 0 and 1 elsewhere
             {
                 std::vector<unsigned char> mask;
@@ -415,6 +435,8 @@ static int aliceVision_main(int argc, char* argv[])
                         vK[3 * r + c] = K(r, c);
                         vR[3 * r + c] = R(r, c);
                     }
+                metadata.setFloat("AliceVision:EV", float(ev));
+                metadata.setFloat("AliceVision:EVComp", exposureCompensation);
                 metadata.setInt("AliceVision:downscale", 1);
                 metadata.setM44d("AliceVision:P", vP);
                 metadata.setM33d("AliceVision:K", vK);

@@ -6,6 +6,8 @@
 #include "json.hpp"
 
 #include <algorithm>
+#include <cctype>
+#include <cmath>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -86,6 +88,148 @@ double angleBetweenRays(const Pose& pose1, const Intrinsic& intr1, const Pose& p
     const double mag = r1.size() * r2.size();
     const double c = std::min(std::max(dot(r1, r2) / mag, -1.0 + 1.e-8), 1.0 - 1.e-8);
     return std::acos(c) * 180.0 / M_PI;
+}
+
+bool ExposureSetting::hasShutter() const { return shutter > 0.0 && std::isnormal(shutter); }
+bool ExposureSetting::hasFNumber() const { return fnumber > 0.0 && std::isnormal(fnumber); }
+
+double ExposureSetting::getExposure() const
+{
+    // sfmData/ExposureSetting.hpp:37-112 with referenceISO = 100, referenceFNumber = 1
+    const double referenceISO = 100.0, referenceFNumber = 1.0;
+    if(!hasShutter() && !hasFNumber())
+        return -1.0;
+    const double sh = hasShutter() ? shutter : 1.0 / 200.0;
+    const double fn = hasFNumber() ? fnumber : referenceFNumber;
+    double iso2Aperture = 1.0;
+    if(iso > 1e-6 && referenceISO > 1e-6)
+        iso2Aperture = std::sqrt(iso / referenceISO);
+    const double newFnumber = fn * iso2Aperture;
+    const double expIncrease = (referenceFNumber / newFnumber) * (referenceFNumber / newFnumber);
+    return sh * expIncrease;
+}
+
+namespace {
+const std::string* findMetadata(const std::map<std::string, std::string>& md, const std::string& name)
+{
+    const auto it = md.find(name);
+    if(it != md.end())
+        return &it->second;
+    std::string nameLower = name;
+    std::transform(nameLower.begin(), nameLower.end(), nameLower.begin(), ::tolower);
+    for(const auto& kv : md)
+    {
+        std::string key = kv.first;
+        std::transform(key.begin(), key.end(), key.begin(), ::tolower);
+        if(key.size() > name.size())
+        {
+            const size_t d = key.find_last_of("/:");
+            if(d != std::string::npos)
+                key = key.substr(d + 1);
+        }
+        if(key == nameLower)
+            return &kv.second;
+    }
+    return nullptr;
+}
+const std::string* findMetadata(const std::map<std::string, std::string>& md, std::initializer_list<const char*> names)
+{
+    for(const char* n : names)
+        if(const std::string* v = findMetadata(md, n))
+            return v;
+    return nullptr;
+}
+// ImageInfo::readRealNumber: "num/den" anywhere in the text, else std::stod; -1 on failure
+double readRealNumber(const std::string& str)
+{
+    try
+    {
+        size_t i = 0;
+        while(i < str.size())
+        {
+            // the first run of digits directly followed by '/' and a digit
+            if(std::isdigit((unsigned char)str[i]))
+            {
+                size_t j = i;
+                while(j < str.size() && std::isdigit((unsigned char)str[j]))
+                    ++j;
+                if(j + 1 < str.size() && str[j] == '/' && std::isdigit((unsigned char)str[j + 1]))
+                {
+                    size_t k = j + 1;
+                    while(k < str.size() && std::isdigit((unsigned char)str[k]))
+                        ++k;
+                    // std::regex_search finds the leftmost match; with greedy digit runs that is this one, except that the numerator may
+                    // start inside a longer digit run only at its beginning — which is where we are
+                    const int num = std::stoi(str.substr(i, j - i)), den = std::stoi(str.substr(j + 1, k - j - 1));
+                    return den != 0 ? double(num) / double(den) : 0.0;
+                }
+                i = j;
+            }
+            else
+                ++i;
+        }
+        return std::stod(str);
+    }
+    catch(const std::exception&)
+    {
+        return -1.0;
+    }
+}
+// ImageInfo::hasDigitMetadata(names, isPositive = true): the first of the names whose value parses as a number decides
+bool hasDigitMetadata(const std::map<std::string, std::string>& md, std::initializer_list<const char*> names)
+{
+    for(const char* n : names)
+    {
+        const std::string* v = findMetadata(md, n);
+        if(v == nullptr || v->empty())
+            continue;
+        try
+        {
+            return std::stod(*v) > 0.0;
+        }
+        catch(const std::exception&)
+        {
+        }
+    }
+    return false;
+}
+// ImageInfo::getDoubleMetadata(names): the first of the names that exists; -1 when none does or its value is empty
+double getDoubleMetadata(const std::map<std::string, std::string>& md, std::initializer_list<const char*> names)
+{
+    const std::string* v = findMetadata(md, names);
+    return v == nullptr || v->empty() ? -1.0 : readRealNumber(*v);
+}
+} // namespace
+
+ExposureSetting cameraExposureSetting(const std::map<std::string, std::string>& md)
+{
+    ExposureSetting e;
+    e.shutter = getDoubleMetadata(md, {"ExposureTime", "Shutter Speed Value"});
+    // ImageInfo.hpp:213-226
+    if(hasDigitMetadata(md, {"FNumber"}))
+        e.fnumber = getDoubleMetadata(md, {"FNumber"});
+    else if(hasDigitMetadata(md, {"ApertureValue", "Aperture Value"}))
+        e.fnumber = std::pow(2.0, getDoubleMetadata(md, {"ApertureValue", "Aperture Value"}) / 2.0);
+    e.iso = getDoubleMetadata(md, {"Exif:PhotographicSensitivity", "PhotographicSensitivity", "Photographic Sensitivity", "ISO"});
+    return e;
+}
+
+double SfMData::medianCameraExposure() const
+{
+    std::vector<double> exposures; // distinct by value: ExposureSetting::operator== compares getExposure()
+    for(const auto& kv : views)
+    {
+        const ExposureSetting ce = cameraExposureSetting(kv.second.metadata);
+        if(!ce.isPartiallyDefined())
+            continue;
+        const double x = ce.getExposure();
+        if(std::find(exposures.begin(), exposures.end(), x) == exposures.end())
+            exposures.push_back(x);
+    }
+    if(exposures.empty())
+        return -1.0;
+    std::nth_element(exposures.begin(), exposures.begin() + exposures.size() / 2, exposures.end());
+    return exposures[exposures.size() / 2];
 }
 
 void loadSfMData(SfMData& out, const std::string& filename)

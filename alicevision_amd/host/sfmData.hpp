@@ -32,6 +32,20 @@ struct View
     std::map<std::string, std::string> metadata;
 };
 
+// sfmData/ExposureSetting.hpp: shutter [s], relative aperture, ISO of a view (from its EXIF metadata); -1 = not stated
+struct ExposureSetting
+{
+    double shutter = -1.0, fnumber = -1.0, iso = -1.0;
+    bool hasShutter() const;
+    bool hasFNumber() const;
+    bool isPartiallyDefined() const { return hasShutter() || hasFNumber(); }
+    // ExposureSetting::getExposure(referenceISO = 100, referenceFNumber = 1): the exposure time that gives the same light at ISO 100, f/1
+    double getExposure() const;
+};
+// sfmData/ImageInfo.{hpp,cpp}: getCameraExposureSetting() from a view's metadata (keys matched like findMetadataIterator: exact, else
+// case-insensitive on the part behind the last '/' or ':'; "1/200"-style fractions)
+ExposureSetting cameraExposureSetting(const std::map<std::string, std::string>& metadata);
+
 // camera::Pinhole with camera::IntrinsicScaleOffsetDisto (camera/Pinhole.hpp, IntrinsicScaleOffset.cpp:55-66)
 struct Intrinsic
 {
@@ -133,6 +147,9 @@ struct SfMData
                              -(R(0, 2) * t.x + R(1, 2) * t.y + R(2, 2) * t.z));
         return out;
     }
+    // sfmData/SfMData.hpp:406-426 getMedianCameraExposureSetting().getExposure(): the median over the DISTINCT exposures of the views that state
+    // one (-1 when none does: the reference indexes an empty list there)
+    double medianCameraExposure() const;
     const Intrinsic& getIntrinsic(const View& v) const { return intrinsics.at(v.intrinsicId); }
 };
 

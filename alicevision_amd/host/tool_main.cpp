@@ -12,6 +12,7 @@
 //   tiff-dump in.tif out.raw                           decode a TIFF to its interleaved integer samples (host/tiff.cpp)
 //   jpeg-dump in.jpg out.bin                           entropy-decode a JPEG (host/jpeg.cpp) and dump geometry, tables and coefficients
 //   jet v0 v1 ...                                      the reference's jet colour map (debug volume exports) at the given values
+//   exposures scene.(sfm|abc)                          every view's exposure setting from its metadata and the scene's median exposure
 //   sfm-to-abc scene.(sfm|json|abc) out.abc            write the loaded SfMData as an Alembic archive (AlembicExporter's layout)
 #include "DepthMapEstimator.hpp"
 #include "MultiViewParams.hpp"
@@ -273,6 +274,30 @@ int main(int argc, char** argv)
                 jetColor((float)std::atof(argv[i]), c);
                 std::cout << (int)c[0] << " " << (int)c[1] << " " << (int)c[2] << "\n";
             }
+            return 0;
+        }
+        if(cmd == "exposure-of" && argc >= 5 && (argc - 2) % 3 == 0)
+        { // ExposureSetting(shutter, fnumber, iso).getExposure() for every triple given
+            std::cout << std::setprecision(17);
+            for(int i = 2; i + 2 < argc; i += 3)
+            {
+                ExposureSetting e;
+                e.shutter = std::atof(argv[i]), e.fnumber = std::atof(argv[i + 1]), e.iso = std::atof(argv[i + 2]);
+                std::cout << e.getExposure() << " " << (e.isPartiallyDefined() ? 1 : 0) << "\n";
+            }
+            return 0;
+        }
+        if(cmd == "exposures" && argc == 3)
+        { // per view: id, shutter, fnumber, iso, exposure; last line: the median exposure (ExposureSetting / getMedianCameraExposureSetting)
+            SfMData sfm;
+            loadSfMData(sfm, argv[2]);
+            std::cout << std::setprecision(17);
+            for(const auto& kv : sfm.views)
+            {
+                const ExposureSetting e = cameraExposureSetting(kv.second.metadata);
+                std::cout << kv.first << " " << e.shutter << " " << e.fnumber << " " << e.iso << " " << e.getExposure() << "\n";
+            }
+            std::cout << "median " << sfm.medianCameraExposure() << std::endl;
             return 0;
         }
         if(cmd == "sfm-to-abc" && argc == 4)

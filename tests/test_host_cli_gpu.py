@@ -880,3 +880,37 @@ def test_prepare_dense_scene_applies_masks(tmp_path):
     write_png(os.path.join(masks, "%d.png" % scene_io.view_id(2)), np.zeros((h, w, 3), np.uint8))  # three channels
     r = subprocess.run([exe, "-i", sfm, "-o", out, "--masksFolders", masks], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "Can't load channels" in r.stdout + r.stderr
+
+
+def test_prepare_dense_scene_exposure_metadata_and_correction(tmp_path):
+    """AliceVision:EV / AliceVision:EVComp (main_prepareDenseScene.cpp:241-247) from the views' EXIF metadata, and --evCorrection: the
+    colours scaled by the compensation towards the scene's median exposure (alpha untouched), before the undistortion"""
+    exe = os.path.join(ROOT, "alicevision_amd", "bin", "aliceVision_prepareDenseScene")
+    w, h = 160, 120
+    sc = make_scene(3, w, h, seed=13, baseline=0.9, amp=0.6)
+    d = str(tmp_path)
+    sfm, img = scene_io.write_scene(sc, d, n_landmarks=10, compression=0)
+    sd = scene_io.sfm_dict(sc, scene_io.sample_landmarks(sc, 50, amp=0.6), img)
+    metas = [{"ExposureTime": "1/100", "FNumber": "2", "ISO": "100"}, {"ExposureTime": "1/200", "FNumber": "2", "ISO": "100"},
+             {"ExposureTime": "1/400", "FNumber": "2", "ISO": "100"}]
+    for v, m in zip(sd["views"], metas):
+        v["metadata"] = m
+    with open(sfm, "w") as f:
+        json.dump(sd, f)
+    exposures = [0.01 / 4, 0.005 / 4, 0.0025 / 4]  # shutter * (1 / fnumber)^2 at ISO 100
+    median = exposures[1]
+    for correct in (0, 1):
+        out = os.path.join(d, "prepared%d" % correct)
+        r = subprocess.run([exe, "-i", sfm, "-o", out, "--evCorrection", str(correct)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        for i in range(3):
+            ch, info = exr_io.read_exr(os.path.join(out, "%d.exr" % scene_io.view_id(i)))
+            comp = np.float32(median / exposures[i])
+            assert exr_io.attr_value(info, "AliceVision:EV") == np.float32(np.log2(1.0 / exposures[i]))
+            assert exr_io.attr_value(info, "AliceVision:EVComp") == comp
+            src = sc.images[i].numpy()
+            got = np.stack([ch["R"], ch["G"], ch["B"], ch["A"]], -1)
+            want = src.copy()
+            if correct:
+                want[..., :3] = src[..., :3] * comp
+            assert np.array_equal(got, want), (correct, i)

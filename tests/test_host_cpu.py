@@ -765,3 +765,99 @@ def test_tiff_images_folder_is_planned_like_the_exr_folder(scene, tmp_path):
     assert len(ref["tiles"]) == len(got["tiles"]) > 0
     for ta, tb in zip(ref["tiles"], got["tiles"]):
         assert ta["sgmTCams"] == tb["sgmTCams"] and ta["depths"] == tb["depths"]
+
+
+def test_view_exposures_from_metadata(scene, tmp_path):
+    """ImageInfo::getCameraExposureSetting (sfmData/ImageInfo.{hpp,cpp}: key lookup exact, then case-insensitive on the part behind the last
+    '/' or ':'; "1/200"-style fractions; FNumber else 2^(ApertureValue / 2); four names for the ISO) and the scene's median exposure
+    (SfMData.hpp:406-426: over the DISTINCT exposures), restated here in Python with the formula pinned separately to the reference's own
+    class (test_host_ref.py::test_exposure_setting_equals_reference)"""
+    import re
+    sc, lms, sfm, img, d = scene
+    doc = json.load(open(sfm))
+    metas = [
+        {"ExposureTime": "1/200", "FNumber": "2.8", "Exif:PhotographicSensitivity": "400"},
+        {"Exif:ExposureTime": "0.01", "Exif:FNumber": "4", "ISO": "100"},
+        {"exif/shutter speed value": "1/60", "ApertureValue": "3", "PhotographicSensitivity": "200"},
+        {"ExposureTime": "1/200", "FNumber": "2.8", "Exif:PhotographicSensitivity": "400", "Make": "x"},   # the same exposure as view 0
+        {"FNumber": "abc", "Aperture Value": "5", "Photographic Sensitivity": "800"},                          # no shutter: 1 / 200
+        {"Make": "nothing about exposure"},
+    ]
+    for v, m in zip(doc["views"], metas):
+        v["metadata"] = m
+    p = str(tmp_path / "ev.sfm")
+    json.dump(doc, open(p, "w"))
+    lines = run([TOOL, "exposures", p]).stdout.strip().splitlines()
+
+    def find(md, name):
+        if name in md:
+            return md[name]
+        for k, v in md.items():  # std::map order = sorted keys
+            key = k.lower()
+            if len(key) > len(name):
+                i = max(key.rfind("/"), key.rfind(":"))
+                if i >= 0:
+                    key = key[i + 1:]
+            if key == name.lower():
+                return v
+        return None
+
+    def first(md, names):
+        for n in names:
+            v = find(dict(sorted(md.items())), n)
+            if v is not None:
+                return v
+        return None
+
+    def real(s):
+        m = re.search(r"([0-9]+)/([0-9]+)", s)
+        try:
+            if not m:
+                return float(s)
+            return int(m.group(1)) / int(m.group(2)) if int(m.group(2)) else 0.0
+        except ValueError:
+            return -1.0
+
+    def has_digit(md, names):
+        for n in names:
+            v = find(dict(sorted(md.items())), n)
+            if not v:
+                continue
+            try:
+                return float(v) > 0
+            except ValueError:
+                pass
+        return False
+
+    def get_double(md, names):
+        v = first(md, names)
+        return -1.0 if not v else real(v)
+
+    def exposure(md):
+        sh = get_double(md, ["ExposureTime", "Shutter Speed Value"])
+        fn = -1.0
+        if has_digit(md, ["FNumber"]):
+            fn = get_double(md, ["FNumber"])
+        elif has_digit(md, ["ApertureValue", "Aperture Value"]):
+            fn = 2.0 ** (get_double(md, ["ApertureValue", "Aperture Value"]) / 2.0)
+        iso = get_double(md, ["Exif:PhotographicSensitivity", "PhotographicSensitivity", "Photographic Sensitivity", "ISO"])
+        ok_s, ok_f = sh > 0, fn > 0
+        if not ok_s and not ok_f:
+            return sh, fn, iso, -1.0
+        s_, f_ = (sh if ok_s else 1.0 / 200.0), (fn if ok_f else 1.0)
+        k = np.sqrt(iso / 100.0) if iso > 1e-6 else 1.0
+        return sh, fn, iso, s_ * (1.0 / (f_ * k)) ** 2
+
+    want = [exposure(m) for m in metas]
+    ordered = sorted(zip([int(v["viewId"]) for v in doc["views"]], want))
+    for line, (vid, w) in zip(lines, ordered):
+        got = [float(x) for x in line.split()]
+        assert int(got[0]) == vid
+        np.testing.assert_allclose(got[1:], w, rtol=1e-15)
+    distinct = []
+    for w in want:
+        if w[3] != -1.0 or w[0] > 0 or w[1] > 0:
+            if (w[0] > 0 or w[1] > 0) and w[3] not in distinct:
+                distinct.append(w[3])
+    assert len(distinct) == 4
+    assert float(lines[-1].split()[1]) == sorted(distinct)[len(distinct) // 2]

@@ -5,6 +5,8 @@ oracle/ref/host_driver.cpp): same cameras, landmarks, tile and parameters into b
 The two sides derive K, R, C from the projection matrix with different RQ codes (numpy there, the reference's Matrix3x3::RQ here) and
 the oracle evaluates the geometry in numpy double expressions: the planes agree to fp32 rounding (the bar of test_host_cpu.py, 2e-6
 relative), their NUMBER and the per-T-camera limits agree exactly."""
+import os
+
 import numpy as np
 import pytest
 
@@ -204,3 +206,26 @@ def test_undistort_equals_reference(model, k, size):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (float(np.abs(got - want).max()), float((got != want).mean()))
     if model:
         assert not np.array_equal(got, src)
+
+
+def test_exposure_setting_equals_reference():
+    """ExposureSetting::getExposure / isPartiallyDefined (sfmData/ExposureSetting.hpp, compiled as it lies into oracle/_ref) against the
+    host's restatement (sfmData.cpp) over a grid of shutters, apertures and sensitivities, the undefined ones (-1, 0, nan) included: the
+    quantity behind AliceVision:EV / AliceVision:EVComp and --evCorrection of aliceVision_prepareDenseScene"""
+    import ctypes as C
+    import subprocess
+    lib = C.CDLL(hr.LIB_PATH)
+    lib.avr_exposure.restype = C.c_double
+    lib.avr_exposure.argtypes = [C.c_double] * 3
+    lib.avr_exposure_partially_defined.argtypes = [C.c_double] * 3
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alicevision_amd", "bin", "avdm_host_tool")
+    subprocess.run(["make", "-C", os.path.join(os.path.dirname(tool), "..", "host"), "-s", "-j8"], check=True)
+    triples = [(s, f, i) for s in (-1.0, 0.0, 1.0 / 4000, 1.0 / 200, 0.005, 1.0 / 3, 2.5, float("nan"))
+               for f in (-1.0, 0.0, 1.4, 2.8, 5.6, 22.0, float("inf")) for i in (-1.0, 0.0, 1e-7, 50.0, 100.0, 800.0, 25600.0)]
+    args = [repr(v) for t in triples for v in t]
+    out = subprocess.run([tool, "exposure-of"] + args, capture_output=True, text=True, check=True).stdout.split()
+    got = np.array(out, dtype=np.float64).reshape(-1, 2)
+    for (s, f, i), (e, pd) in zip(triples, got):
+        want = lib.avr_exposure(s, f, i)
+        assert (np.isnan(want) and np.isnan(e)) or want == e, (s, f, i, want, e)
+        assert int(pd) == lib.avr_exposure_partially_defined(s, f, i)
