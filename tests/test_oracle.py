@@ -532,6 +532,9 @@ def test_jpeg_decoder_against_pillow_when_available(tmp_path):
     open(p, "wb").write(b"\x89PNG" + data[4:])
     with pytest.raises(RuntimeError, match="not a JPEG"):
         jpeg_io.read_coefficients(p)
+    Image.new("CMYK", (16, 16), (10, 20, 30, 40)).save(p, quality=90)
+    with pytest.raises(RuntimeError, match="CMYK"):
+        jpeg_io.read_coefficients(p)
     sof = data.index(b"\xff\xc2")
     open(p, "wb").write(data[:sof + 1] + b"\xc9" + data[sof + 2:])  # SOF9: arithmetic coding
     with pytest.raises(RuntimeError, match="arithmetic"):
