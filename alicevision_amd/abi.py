@@ -143,6 +143,8 @@ SIGNATURES = {
     "avdm_volume_optimize_scratch_bytes": (C.c_size_t, [i32, i32, i32]),
     "avdm_volume_optimize": (i32, [vp, vp, i64, i32, vp, P(Pyramid), P(SgmParams), i32, ROI, vp]),
     "avdm_volume_optimize_tiles": (i32, [i32, P(SgmTile), vp, P(SgmParams), vp]),
+    "avdm_volume_optimize_prepare": (i32, [i32, P(SgmTile), vp, P(SgmParams), vp]),
+    "avdm_volume_optimize_tiles_prepared": (i32, [i32, P(SgmTile), vp, P(SgmParams), vp]),
     "avdm_volume_retrieve_best_depth": (i32, [vp, i32, vp, i32, vp, vp, i64, i32, i32, P(Camera), P(SgmParams), Range, ROI, vp]),
     "avdm_volume_refine_best_depth": (i32, [vp, i32, vp, i32, vp, i64, i32, i32, P(RefineParams), ROI, vp]),
     "avdm_depth_sim_map_copy_depth_only": (i32, [vp, i32, vp, i32, i32, i32, f32, vp]),

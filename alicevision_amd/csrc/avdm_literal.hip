@@ -15,6 +15,7 @@
 #include "avdm_device.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace avdm {
 
@@ -52,6 +53,18 @@ __device__ __forceinline__ float cost_yk(int dx, int dy, float4 c1, float4 c2, f
     return expf(-deltaC);
 }
 
+// AVDM_SIM_LITERAL_DEV=<bit mask> (read at each call): the deviations of the default kernels (avdm_similarity.hip) from the reference's
+// arithmetic, introduced into THIS literal evaluation one at a time, so that the distance default <-> reference can be attributed deviation by
+// deviation (scripts/deviation_report.py, tests/test_gpu_parity.py::test_deviation_attribution):
+enum
+{
+    DEV_SHIFTED_SUMS = 1,  // NCC statistics of L(centre) - L(sample) instead of L(sample) (shift invariant; the sums no longer cancel), FMA sums, rcp / rsq finish
+    DEV_MERGED_EXP = 2,    // one hardware exp2 of the summed exponents instead of two expf multiplied; hardware sqrt of the colour distances
+    DEV_HOMOGENEOUS = 4,   // sample positions as h0 + a (M x d) + b (M y d) with v_rcp_f32 instead of a 3-D point through the 3 x 4 matrix and a division
+    DEV_EXACT_PIXEL = 8,   // border test and centre colour of R on the lane's own pixel instead of the re-projected patch centre
+    DEV_SHARED_R = 16,     // R side of a sample (position, taps) from the patch of plane 1 of the aligned group of four planes
+};
+
 struct LitArgs
 {
     Tex rcT, tcT;
@@ -59,13 +72,26 @@ struct LitArgs
     float mipmapLevel;
     float invGammaC, invGammaP;
     int wsh;
+    int dev; // DEV_* bits
 };
 
-// Patch.cuh:466-572 + SimStat.cuh; INFINITY when the patch is invalid
-template <bool TInvert>
-__device__ float ncc_literal(const avdm_camera_t& rc, const avdm_camera_t& tc, const LitArgs& L, f3 pp, f3 px, f3 py, float pd)
+struct LitPatch
 {
-    const float2 rp = project_lit(rc.P, pp), tp = project_lit(tc.P, pp);
+    f3 p, x, y;
+    float d;
+};
+
+// Patch.cuh:466-572 + SimStat.cuh; INFINITY when the patch is invalid.  T = the plane's own patch; Rp = the patch the R side is sampled
+// from (the same one unless DEV_SHARED_R); (x, y) = the lane's pixel (DEV_EXACT_PIXEL).
+template <bool TInvert>
+__device__ float ncc_literal(const avdm_camera_t& rc, const avdm_camera_t& tc, const LitArgs& L, const LitPatch& T, const LitPatch& Rp, float x, float y)
+{
+    const int dev = L.dev;
+    const f3 pp = T.p;
+    float2 rp = project_lit(rc.P, pp);
+    const float2 tp = project_lit(tc.P, pp);
+    if(dev & DEV_EXACT_PIXEL)
+        rp = make_float2(x, y);
     const float dd = (float)L.wsh + 2.0f;
     if((rp.x < dd) || (rp.x > (L.rcW - 1.0f) - dd) || (tp.x < dd) || (tp.x > (L.tcW - 1.0f) - dd) || (rp.y < dd) || (rp.y > (L.rcH - 1.0f) - dd) ||
        (tp.y < dd) || (tp.y > (L.tcH - 1.0f) - dd))
@@ -75,32 +101,91 @@ __device__ float ncc_literal(const avdm_camera_t& rc, const avdm_camera_t& tc, c
     const float4 tcCenter = tex2DLod(L.tcT, (tp.x + 0.5f) * tcIW, (tp.y + 0.5f) * tcIH, L.mipmapLevel);
     if(rcCenter.w < (255.f * 0.9f) || tcCenter.w < (255.f * 0.4f))
         return INFINITY;
+    // DEV_HOMOGENEOUS: P (p + a x d + b y d) = h0 + a (M x d) + b (M y d)
+    const f3 hr0 = M3x4mulV3(rc.P, Rp.p), ht0 = M3x4mulV3(tc.P, T.p);
+    const f3 rax = M3x3mulV3(rc.P, Rp.x * Rp.d), ray = M3x3mulV3(rc.P, Rp.y * Rp.d);
+    const f3 tax = M3x3mulV3(tc.P, T.x * T.d), tay = M3x3mulV3(tc.P, T.y * T.d);
+    const float log2e = 1.44269504088896340736f;
     float xsum = 0.f, ysum = 0.f, xxsum = 0.f, yysum = 0.f, xysum = 0.f, wsum = 0.f;
 #pragma unroll 1
     for(int yp = -L.wsh; yp <= L.wsh; ++yp)
 #pragma unroll 1
         for(int xp = -L.wsh; xp <= L.wsh; ++xp)
         {
-            const f3 p = (pp + px * (pd * (float)xp)) + py * (pd * (float)yp);
-            const float2 rpc = project_lit(rc.P, p), tpc = project_lit(tc.P, p);
+            float2 rpc, tpc;
+            if(dev & DEV_HOMOGENEOUS)
+            {
+                const float fx = (float)xp, fy = (float)yp;
+                const float hrz = fmaf(fx, rax.z, fmaf(fy, ray.z, hr0.z)), htz = fmaf(fx, tax.z, fmaf(fy, tay.z, ht0.z));
+                const float ir = fast_rcp(hrz), it = fast_rcp(htz);
+                rpc = make_float2(fmaf(fx, rax.x, fmaf(fy, ray.x, hr0.x)) * ir, fmaf(fx, rax.y, fmaf(fy, ray.y, hr0.y)) * ir);
+                tpc = make_float2(fmaf(fx, tax.x, fmaf(fy, tay.x, ht0.x)) * it, fmaf(fx, tax.y, fmaf(fy, tay.y, ht0.y)) * it);
+            }
+            else
+            {
+                const f3 pT = (T.p + T.x * (T.d * (float)xp)) + T.y * (T.d * (float)yp);
+                const f3 pR = (Rp.p + Rp.x * (Rp.d * (float)xp)) + Rp.y * (Rp.d * (float)yp);
+                rpc = project_lit(rc.P, pR);
+                tpc = project_lit(tc.P, pT);
+            }
             const float4 rcC = tex2DLod(L.rcT, (rpc.x + 0.5f) * rcIW, (rpc.y + 0.5f) * rcIH, L.mipmapLevel);
             const float4 tcC = tex2DLod(L.tcT, (tpc.x + 0.5f) * tcIW, (tpc.y + 0.5f) * tcIH, L.mipmapLevel);
-            const float wr = cost_yk(xp, yp, rcCenter, rcC, L.invGammaC, L.invGammaP);
-            const float wt = cost_yk(xp, yp, tcCenter, tcC, L.invGammaC, L.invGammaP);
-            const float w = wr * wt;
-            const float gx = rcC.x, gy = tcC.x; // simStat::update
-            wsum += w;
-            xsum += w * gx;
-            ysum += w * gy;
-            xxsum += w * gx * gx;
-            yysum += w * gy * gy;
-            xysum += w * gx * gy;
+            float w;
+            if(dev & DEV_MERGED_EXP)
+            {
+                // exp(-(dCr / gC + dP / gP)) exp(-(dCt / gC + dP / gP)) = exp2((dCr + dCt) (-log2e / gC) - 2 dP log2e / gP)
+                const float drx = rcCenter.x - rcC.x, dry = rcCenter.y - rcC.y, drz = rcCenter.z - rcC.z;
+                const float dtx = tcCenter.x - tcC.x, dty = tcCenter.y - tcC.y, dtz = tcCenter.z - tcC.z;
+                const float dcr = __builtin_amdgcn_sqrtf(fmaf(drx, drx, fmaf(dry, dry, drz * drz)));
+                const float dct = __builtin_amdgcn_sqrtf(fmaf(dtx, dtx, fmaf(dty, dty, dtz * dtz)));
+                const float tabv = 2.0f * sqrtf((float)(xp * xp + yp * yp)) * L.invGammaP * log2e;
+                w = __builtin_amdgcn_exp2f(fmaf(dcr + dct, -L.invGammaC * log2e, -tabv));
+            }
+            else
+            {
+                const float wr = cost_yk(xp, yp, rcCenter, rcC, L.invGammaC, L.invGammaP);
+                const float wt = cost_yk(xp, yp, tcCenter, tcC, L.invGammaC, L.invGammaP);
+                w = wr * wt;
+            }
+            if(dev & DEV_SHIFTED_SUMS)
+            {
+                const float gx = rcCenter.x - rcC.x, gy = tcCenter.x - tcC.x;
+                const float wgx = w * gx, wgy = w * gy;
+                wsum += w;
+                xsum += wgx;
+                ysum += wgy;
+                xxsum = fmaf(wgx, gx, xxsum);
+                yysum = fmaf(wgy, gy, yysum);
+                xysum = fmaf(wgx, gy, xysum);
+            }
+            else
+            {
+                const float gx = rcC.x, gy = tcC.x; // simStat::update
+                wsum += w;
+                xsum += w * gx;
+                ysum += w * gy;
+                xxsum += w * gx * gx;
+                yysum += w * gy * gy;
+                xysum += w * gx * gy;
+            }
         }
-    // simStat::computeWSim
-    const float varXW = (xxsum - xsum * xsum / wsum) / wsum;
-    const float varYW = (yysum - ysum * ysum / wsum) / wsum;
-    const float varXYW = (xysum - xsum * ysum / wsum) / wsum;
-    const float rawSim = varXYW / sqrtf(varXW * varYW);
+    float rawSim;
+    if(dev & DEV_SHIFTED_SUMS)
+    {
+        const float iw = fast_rcp(wsum);
+        const float varXW = (xxsum - xsum * xsum * iw) * iw;
+        const float varYW = (yysum - ysum * ysum * iw) * iw;
+        const float varXYW = (xysum - xsum * ysum * iw) * iw;
+        rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
+    }
+    else
+    {
+        // simStat::computeWSim
+        const float varXW = (xxsum - xsum * xsum / wsum) / wsum;
+        const float varYW = (yysum - ysum * ysum / wsum) / wsum;
+        const float varXYW = (xysum - xsum * ysum / wsum) / wsum;
+        rawSim = varXYW / sqrtf(varXW * varYW);
+    }
     const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
     if(TInvert)
         return sigmoid(0.0f, 1.0f, 0.7f, -0.7f, sim);
@@ -138,14 +223,21 @@ __global__ void __launch_bounds__(256)
         if(vz < zBegin || vz >= zEnd)
             continue;
         // volume_computePatch (kernels.cuh:26-35)
-        const f3 C = ld3(rc.C), Z = ld3(rc.ZVect);
-        const f3 planep = C + Z * depths[vz];
-        const f3 v = normalize_lit(M3x3mulV2(rc.iP, x, y));
-        const f3 p = linePlaneIntersect(C, v, planep, Z);
-        const float pd = pix_size_lit(rc, p);
-        f3 ax, ay;
-        patch_axes_lit(rc, tc, p, nullptr, ax, ay);
-        float fsim = ncc_literal<false>(rc, tc, L, p, ax, ay, pd);
+        auto patch_of = [&](unsigned z) -> LitPatch {
+            const f3 C = ld3(rc.C), Z = ld3(rc.ZVect);
+            const f3 planep = C + Z * depths[z];
+            const f3 v = normalize_lit(M3x3mulV2(rc.iP, x, y));
+            LitPatch q;
+            q.p = linePlaneIntersect(C, v, planep, Z);
+            q.d = pix_size_lit(rc, q.p);
+            patch_axes_lit(rc, tc, q.p, nullptr, q.x, q.y);
+            return q;
+        };
+        const LitPatch T = patch_of(vz);
+        // DEV_SHARED_R: the R side from plane 1 of the aligned group of four (clamped to the T camera's range), like the four-plane pass
+        const unsigned zr = min(max(z0 + 1u, zBegin), zEnd - 1u);
+        const LitPatch Rp = (L.dev & DEV_SHARED_R) ? patch_of(zr) : T;
+        float fsim = ncc_literal<false>(rc, tc, L, T, Rp, x, y);
         if(fsim == INFINITY)
             fsim = 255.0f;
         else
@@ -186,15 +278,21 @@ __global__ void __launch_bounds__(256)
 #pragma unroll 1
     for(unsigned vz = zBegin; vz < zEnd; ++vz)
     {
-        const f3 C = ld3(rc.C);
-        f3 p = C + normalize_lit(M3x3mulV2(rc.iP, x, y)) * dps.x; // get3DPointForPixelAndDepthFromRC
-        const int rel = (int)vz - ((volDimZ - 1) / 2);
-        if(rel != 0)
-            p = p + normalize_lit(p - C) * ((float)rel * dps.y); // move3DPointByRcPixSize (kernels.cuh:17-24)
-        const float pd = pix_size_lit(rc, p);
-        f3 ax, ay;
-        patch_axes_lit(rc, tc, p, nn, ax, ay);
-        const float fsim = ncc_literal<true>(rc, tc, L, p, ax, ay, pd);
+        auto patch_of = [&](unsigned z) -> LitPatch {
+            const f3 C = ld3(rc.C);
+            LitPatch q;
+            q.p = C + normalize_lit(M3x3mulV2(rc.iP, x, y)) * dps.x; // get3DPointForPixelAndDepthFromRC
+            const int rel = (int)z - ((volDimZ - 1) / 2);
+            if(rel != 0)
+                q.p = q.p + normalize_lit(q.p - C) * ((float)rel * dps.y); // move3DPointByRcPixSize (kernels.cuh:17-24)
+            q.d = pix_size_lit(rc, q.p);
+            patch_axes_lit(rc, tc, q.p, nn, q.x, q.y);
+            return q;
+        };
+        const LitPatch T = patch_of(vz);
+        const unsigned zr = min(max((vz & ~3u) + 1u, zBegin), zEnd - 1u);
+        const LitPatch Rp = (L.dev & DEV_SHARED_R) ? patch_of(zr) : T;
+        const float fsim = ncc_literal<true>(rc, tc, L, T, Rp, x, y);
         if(fsim == INFINITY)
             continue;
         pv[vz] = __float2half(__half2float(pv[vz]) + fsim);
@@ -214,6 +312,8 @@ static LitArgs make_args(const avdm_pyramid_t* rcPyr, const avdm_pyramid_t* tcPy
     L.invGammaC = 1.f / (float)gammaC;
     L.invGammaP = 1.f / (float)gammaP;
     L.wsh = wsh;
+    const char* e = getenv("AVDM_SIM_LITERAL_DEV");
+    L.dev = e != nullptr ? atoi(e) : 0;
     return L;
 }
 

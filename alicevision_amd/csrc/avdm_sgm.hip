@@ -1532,8 +1532,10 @@ static size_t p2_map_bytes(int dimX, int dimY) { return ((size_t)dimX * (size_t)
 static size_t tmp_vol_bytes(int dimX, int dimY, int dimZ) { return ((size_t)dimX * (size_t)dimY * (size_t)((dimZ + 3) & ~3) + 255) & ~(size_t)255; }
 
 // all tiles of one launch group share (NW, FULL); `idx` lists their positions in `tiles`
+// phase: 0 = the adaptive-P2 maps, then the paths (avdm_volume_optimize[_tiles]); 1 = the maps only (avdm_volume_optimize_prepare: they depend
+// on nothing but the R pyramid, so a caller computes them beside the similarity sweep); 2 = the paths only, on maps prepared earlier
 static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, const size_t* p2off, void* scratch, const avdm_sgm_params_t* sp,
-                          hipStream_t st)
+                          hipStream_t st, int phase = 0)
 {
     const avdm_sgm_tile_t& t0 = tiles[idx[0]];
     const int NW = (t0.last_depth_index + 255) / 256;
@@ -1579,7 +1581,7 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
         const char* e = getenv("AVDM_SGM_P2_MAP");
         return e && e[0] == 'l';
     }();
-    if(!legacyP2)
+    if(!legacyP2 && phase != 2)
     {
         SgmP2Batch2 Q2;
         Q2.step = (float)sp->stepXY;
@@ -1617,7 +1619,7 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
     // one launch per axis
     const bool oneP2Launch = nAxes * n <= AVDM_SGM_MAX_TILES;
     int maxA = 0, maxB = 0, nq = 0;
-    for(int ai = 0; legacyP2 && ai < nAxes; ++ai)
+    for(int ai = 0; legacyP2 && phase != 2 && ai < nAxes; ++ai)
     {
         const bool scanX = axisIsX[ai];
         if(!oneP2Launch)
@@ -1651,7 +1653,7 @@ static int optimize_group(const avdm_sgm_tile_t* tiles, const int* idx, int n, c
     }
     // pass 2: the paths
     int npaths = 0;
-    for(int ai = 0; ai < nAxes; ++ai)
+    for(int ai = 0; phase != 1 && ai < nAxes; ++ai)
     {
         const bool scanX = axisIsX[ai];
         int cols = 0;
@@ -1795,7 +1797,24 @@ size_t avdm_volume_optimize_scratch_bytes(int dimX, int dimY, int dimZ)
     return 2 * p2_map_bytes(dimX, dimY) + tmp_vol_bytes(dimX, dimY, dimZ);
 }
 
+static int optimize_tiles_phase(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* sp, void* stream, int phase);
+
 int avdm_volume_optimize_tiles(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* sp, void* stream)
+{
+    return optimize_tiles_phase(n_tiles, tiles, scratch, sp, stream, 0);
+}
+
+int avdm_volume_optimize_prepare(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* sp, void* stream)
+{
+    return optimize_tiles_phase(n_tiles, tiles, scratch, sp, stream, 1);
+}
+
+int avdm_volume_optimize_tiles_prepared(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* sp, void* stream)
+{
+    return optimize_tiles_phase(n_tiles, tiles, scratch, sp, stream, 2);
+}
+
+static int optimize_tiles_phase(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* sp, void* stream, int phase)
 {
     if(n_tiles <= 0)
         return 0;
@@ -1812,10 +1831,13 @@ int avdm_volume_optimize_tiles(int n_tiles, const avdm_sgm_tile_t* tiles, void* 
         if(dimX <= 0 || dimY <= 0 || Z <= 0)
             continue; // nothing to do for this tile (cuda_volumeOptimize on an empty ROI)
         off += 2 * p2_map_bytes(dimX, dimY) + tmp_vol_bytes(dimX, dimY, Z);
-        if((t.pitch_x & 3) || (t.pitch_y & 3) || ((uintptr_t)t.out_vol & 3) || ((uintptr_t)t.in_vol & 3))
-            return set_error_msg(1, "avdm_volume_optimize: volume base / pitches must be multiples of 4 bytes");
-        if(((Z + 3) & ~3) > t.pitch_x)
-            return set_error_msg(1, "avdm_volume_optimize: pitch_x must cover the 4-aligned depth count");
+        if(phase != 1)
+        { // (the maps do not touch the volumes)
+            if((t.pitch_x & 3) || (t.pitch_y & 3) || ((uintptr_t)t.out_vol & 3) || ((uintptr_t)t.in_vol & 3))
+                return set_error_msg(1, "avdm_volume_optimize: volume base / pitches must be multiples of 4 bytes");
+            if(((Z + 3) & ~3) > t.pitch_x)
+                return set_error_msg(1, "avdm_volume_optimize: pitch_x must cover the 4-aligned depth count");
+        }
         if(Z > 1536)
             return set_error_msg(1, "avdm_volume_optimize: more than 1536 depth planes are not supported");
         order.push_back(i);
@@ -1841,7 +1863,7 @@ int avdm_volume_optimize_tiles(int n_tiles, const avdm_sgm_tile_t* tiles, void* 
         for(size_t g0 = 0; g0 < grp.size(); g0 += AVDM_SGM_MAX_TILES)
         {
             const int n = (int)std::min<size_t>(AVDM_SGM_MAX_TILES, grp.size() - g0);
-            const int rc = optimize_group(tiles, grp.data() + g0, n, p2off.data(), scratch, sp, (hipStream_t)stream);
+            const int rc = optimize_group(tiles, grp.data() + g0, n, p2off.data(), scratch, sp, (hipStream_t)stream, phase);
             if(rc)
                 return rc;
         }

@@ -75,6 +75,50 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #define AVDM_NCC_PAIR_W3_MODE 1 // 7-tap rows of the plane-pair form: 0 = 3 + 3 + 1 with fences, 1 = 4 + 3, 2 = the whole row unrolled
 #endif
 
+// ---- per-deviation switches (compile time; every default is the product path) ---------------------------------------------------
+// The default kernels deviate from the reference's arithmetic as written in five places; each can be REVERTED on the fast LDS path in a
+// variant build (scripts/build_variant.sh <name> -DAVDM_DEV_...=1, selected with AVDM_LIB) so that the distance default <-> reference is
+// attributed deviation by deviation (scripts/deviation_report.py).  The fifth — the R side shared by the planes of a
+// pass — is the run-time switch AVDM_SIM_PLANE_PAIRS=0; the literal kernel (avdm_literal.hip) has the same five in the other direction.
+#ifndef AVDM_DEV_UNSHIFTED_SUMS
+#define AVDM_DEV_UNSHIFTED_SUMS 0 // 1: the six NCC sums on the UNSHIFTED L values in the reference's order and form (SimStat.cuh:72-155), no FMA contraction
+#endif
+#ifndef AVDM_DEV_TWO_EXP
+#define AVDM_DEV_TWO_EXP 0 // 1: two Yoon-Kweon weights, two expf, multiplied (color.cuh:167-210)
+#endif
+#ifndef AVDM_DEV_IEEE_DIV
+#define AVDM_DEV_IEEE_DIV 0 // 1: IEEE divisions where the projections use v_rcp_f32 (matrix.cuh:117-126 evaluated like the CPU pin evaluates it)
+#endif
+#ifndef AVDM_DEV_REPROJ_BORDER
+#define AVDM_DEV_REPROJ_BORDER 0 // 1: the border test of R on the RE-PROJECTED patch centre (Patch.cuh:486-496) instead of the lane's own pixel
+#endif
+__device__ __forceinline__ float proj_rcp(float x) { return AVDM_DEV_IEEE_DIV ? 1.0f / x : fast_rcp(x); }
+// the reference's weight of one image: exp(-(dC / gammaC + dP / gammaP)) (CostYKfromLab)
+__device__ __forceinline__ float yk_weight(float dC, float dP, float invGammaC) { return expf(-(dC * invGammaC + dP)); }
+// SimStat::update(gx, gy, w) and computeWSim as written (no contraction: the pinned CPU build of the reference has none)
+struct SimStatLit
+{
+    float xsum = 0.f, ysum = 0.f, xxsum = 0.f, yysum = 0.f, xysum = 0.f, wsum = 0.f;
+    __device__ __forceinline__ void update(float gx, float gy, float w)
+    {
+#pragma clang fp contract(off)
+        wsum += w;
+        xsum += w * gx;
+        ysum += w * gy;
+        xxsum += w * gx * gx;
+        yysum += w * gy * gy;
+        xysum += w * gx * gy;
+    }
+    __device__ __forceinline__ float raw_sim() const
+    {
+#pragma clang fp contract(off)
+        const float varXW = (xxsum - xsum * xsum / wsum) / wsum;
+        const float varYW = (yysum - ysum * ysum / wsum) / wsum;
+        const float varXYW = (xysum - xsum * ysum / wsum) / wsum;
+        return varXYW / sqrtf(varXW * varYW);
+    }
+};
+
 struct PatchTable
 {
     float c[81]; // 2 * sqrt(xp^2 + yp^2) * invGammaP * log2(e), row-major over (yp, xp), for wsh <= 4
@@ -342,7 +386,7 @@ __device__ __forceinline__ void sample_pos(const PatchProj& Q, const NccArgs& A,
                                            float& tY)
 {
     const float hrz = fmaf(fx, Q.rax.z, hrRow.z), htz = fmaf(fx, Q.tax.z, htRow.z);
-    const float ir = fast_rcp(hrz), it = fast_rcp(htz);
+    const float ir = proj_rcp(hrz), it = proj_rcp(htz);
     const float rx = fmaf(fx, Q.rax.x, hrRow.x) * ir, ry = fmaf(fx, Q.rax.y, hrRow.y) * ir;
     const float tx = fmaf(fx, Q.tax.x, htRow.x) * it, ty = fmaf(fx, Q.tax.y, htRow.y) * it;
     rX = fmaf(rx, A.rcSx, A.rcOx);
@@ -363,6 +407,7 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
 {
     const int wsh = WSH > 0 ? WSH : A.wsh;
     float xsum = 0.f, ysum = 0.f, xxsum = 0.f, yysum = 0.f, xysum = 0.f, wsum = 0.f;
+    [[maybe_unused]] SimStatLit lit;
     const int n = 2 * wsh + 1;
 
 #pragma unroll 1
@@ -386,7 +431,15 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
             const float dtx = tcCenter.x - tcC.x, dty = tcCenter.y - tcC.y, dtz = tcCenter.z - tcC.z;
             const float dcr = __builtin_amdgcn_sqrtf(fmaf(drx, drx, fmaf(dry, dry, drz * drz)));
             const float dct = __builtin_amdgcn_sqrtf(fmaf(dtx, dtx, fmaf(dty, dty, dtz * dtz)));
+#if AVDM_DEV_TWO_EXP
+            const float dPl = sqrtf((float)(xp * xp + yp * yp)) * A.invGammaP;
+            const float w = yk_weight(dcr, dPl, A.invGammaC) * yk_weight(dct, dPl, A.invGammaC);
+#else
             const float w = __builtin_amdgcn_exp2f(fmaf(dcr + dct, A.negInvGammaC_log2e, -trow[xp]));
+#endif
+#if AVDM_DEV_UNSHIFTED_SUMS
+            lit.update(rcC.x, tcC.x, w);
+#endif
 
             // NCC statistics on L shifted by the centre values (gx = L_r(centre) - L_r(sample), same for T): variances and the
             // covariance are shift- and (joint) sign-invariant, and the shifted sums do not cancel catastrophically in fp32
@@ -406,7 +459,10 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
     const float varXW = (xxsum - xsum * xsum * iw) * iw;
     const float varYW = (yysum - ysum * ysum * iw) * iw;
     const float varXYW = (xysum - xsum * ysum * iw) * iw;
-    const float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
+    float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
+#if AVDM_DEV_UNSHIFTED_SUMS
+    rawSim = lit.raw_sim();
+#endif
     const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
     if(TInvert)
         return sigmoid(0.0f, 1.0f, 0.7f, -0.7f, sim);
@@ -582,6 +638,7 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
     v2f sum1 = {0.f, 0.f}; // {xsum, ysum}
     v2f sum2 = {0.f, 0.f}; // {xxsum, yysum}
     float xysum = 0.f, wsum = 0.f;
+    [[maybe_unused]] SimStatLit lit;
 
 #pragma unroll 1
     for(int yp = -wsh; yp <= wsh; ++yp)
@@ -596,7 +653,7 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
                 // (replacing the two v_rcp_f32 by a packed third-order series in the patch's depth extent was measured, r02_e: no change —
                 // the transcendental pipe runs beside the packed FMAs, it is not what the loop waits for)
                 const v2f hz = fx * az + rowz;
-                const v2f inv = {fast_rcp(hz.x), fast_rcp(hz.y)};
+                const v2f inv = {proj_rcp(hz.x), proj_rcp(hz.y)};
                 const v2f X = (fx * axS + rowx) * inv + Ox;
                 const v2f Y = (fx * ayS + rowy) * inv + Oy;
                 const v2f fX = floor2(X), fY = floor2(Y);
@@ -640,7 +697,19 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
                 const v2f db = (v2f{rt.b, tt.b} * nnb + cb) - v2f{rb.b, tb.b} * wb;
                 const v2f sq = dL * dL + (da * da + db * db);
                 const float dcs = __builtin_amdgcn_sqrtf(sq.x) + __builtin_amdgcn_sqrtf(sq.y);
+#if AVDM_DEV_TWO_EXP
+                const float dPl = sqrtf((float)(xp * xp + yp * yp)) * A.invGammaP;
+                const float w = yk_weight(sqrtf(sq.x) * (1.0f / 65536.0f), dPl, A.invGammaC) * yk_weight(sqrtf(sq.y) * (1.0f / 65536.0f), dPl, A.invGammaC);
+#else
                 const float w = __builtin_amdgcn_exp2f(fmaf(dcs, kC, -trow[xp]));
+#endif
+#if AVDM_DEV_UNSHIFTED_SUMS
+                {
+                    // the bilinear L values themselves (x 2^16: exact horizontal products, one rounding per vertical step), then the reference's sums
+                    const v2f V = v2f{rb.L, tb.L} * wb - v2f{rt.L, tt.L} * nnb;
+                    lit.update(V.x * (1.0f / 65536.0f), V.y * (1.0f / 65536.0f), w);
+                }
+#endif
 
                 const v2f wg = dL * w;
                 wsum += w;
@@ -682,7 +751,10 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
     const float varXW = (sum2.x - sum1.x * sum1.x * iw) * iw;
     const float varYW = (sum2.y - sum1.y * sum1.y * iw) * iw;
     const float varXYW = (xysum - sum1.x * sum1.y * iw) * iw;
-    const float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
+    float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
+#if AVDM_DEV_UNSHIFTED_SUMS
+    rawSim = lit.raw_sim();
+#endif
     const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
     if(TInvert)
         return sigmoid(0.0f, 1.0f, 0.7f, -0.7f, sim);
@@ -925,6 +997,9 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
 #pragma unroll
     for(int j = 0; j < NPAIR; ++j)
         wsum[j] = s1R[j] = s1T[j] = s2R[j] = s2T[j] = sxy[j] = v2f{0.f, 0.f};
+#if AVDM_DEV_UNSHIFTED_SUMS
+    SimStatLit lit[2 * NPAIR];
+#endif
 
     struct RTaps
     {
@@ -961,7 +1036,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
         auto fetch_r = [&](int xp) __attribute__((always_inline)) -> RTaps {
             RTaps t;
             const float fx = (float)xp;
-            const float rinv = fast_rcp(fmaf(fx, rax.z, rrowz));
+            const float rinv = proj_rcp(fmaf(fx, rax.z, rrowz));
             const v2f rXY = (fx * raS + rrow) * rinv + rO;
             const v2f rF = floor2(rXY);
             const v2f rW = floor2((rXY - rF) * 256.0f + 0.5f);           // {A, B} of quant8(), in units of 1/256
@@ -993,7 +1068,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             TTaps t;
             const float fx = (float)xp;
             const v2f hz = fx * az[j] + rowz[j];
-            const v2f inv = {fast_rcp(hz.x), fast_rcp(hz.y)};
+            const v2f inv = {proj_rcp(hz.x), proj_rcp(hz.y)};
             const v2f X = (fx * axS[j] + rowx[j]) * inv + A.tcOx;
             const v2f Y = (fx * ayS[j] + rowy[j]) * inv + A.tcOy;
             const v2f fX = floor2(X), fY = floor2(Y);
@@ -1038,6 +1113,13 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             const v2f qR = dRLa * dRLa;
             const float base = fmaf(__builtin_amdgcn_sqrtf(fmaf(dRb, dRb, qR.x + qR.y)), kC, -trow[xp]);
             const float dLR = dRLa.x;
+#if AVDM_DEV_TWO_EXP
+            const float dPl = sqrtf((float)(xp * xp + yp * yp)) * A.invGammaP;
+            const float wRl = yk_weight(sqrtf(fmaf(dRb, dRb, qR.x + qR.y)) * (1.0f / 65536.0f), dPl, A.invGammaC);
+#endif
+#if AVDM_DEV_UNSHIFTED_SUMS
+            const float VR = (hr.b.L * r.rWy - hr.t.L * r.rNy) * (1.0f / 65536.0f); // the bilinear L of R itself
+#endif
 #pragma unroll
             for(int j = 0; j < NPAIR; ++j)
             {
@@ -1051,7 +1133,18 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
                 const v2f db = (v2f{h.rt.b, h.tt.b} * t[j].nnb + cb[j]) - v2f{h.rb.b, h.tb.b} * t[j].wb;
                 const v2f sq = dL * dL + (da * da + db * db);
                 const v2f e = v2f{__builtin_amdgcn_sqrtf(sq.x), __builtin_amdgcn_sqrtf(sq.y)} * kC + base;
+#if AVDM_DEV_TWO_EXP
+                const v2f w = {wRl * yk_weight(sqrtf(sq.x) * (1.0f / 65536.0f), dPl, A.invGammaC), wRl * yk_weight(sqrtf(sq.y) * (1.0f / 65536.0f), dPl, A.invGammaC)};
+#else
                 const v2f w = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+#endif
+#if AVDM_DEV_UNSHIFTED_SUMS
+                {
+                    const v2f VT = (v2f{h.rb.L, h.tb.L} * t[j].wb - v2f{h.rt.L, h.tt.L} * t[j].nnb) * (1.0f / 65536.0f);
+                    lit[2 * j].update(VR, VT.x, w.x);
+                    lit[2 * j + 1].update(VR, VT.y, w.y);
+                }
+#endif
                 const v2f wgR = w * dLR, wgT = w * dL;
                 wsum[j] += w;
                 s1R[j] += wgR;
@@ -1119,6 +1212,17 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
     sim1 = finish(wsum[0].y, s1R[0].y, s1T[0].y, s2R[0].y, s2T[0].y, sxy[0].y);
     sim2 = finish(wsum[1].x, s1R[1].x, s1T[1].x, s2R[1].x, s2T[1].x, sxy[1].x);
     sim3 = finish(wsum[1].y, s1R[1].y, s1T[1].y, s2R[1].y, s2T[1].y, sxy[1].y);
+#if AVDM_DEV_UNSHIFTED_SUMS
+    auto finish_lit = [&](const SimStatLit& st) __attribute__((always_inline)) -> float {
+        const float rawSim = st.raw_sim();
+        const float s = isfinite(rawSim) ? -rawSim : 1.0f;
+        return TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, s) : s;
+    };
+    sim0 = finish_lit(lit[0]);
+    sim1 = finish_lit(lit[1]);
+    sim2 = finish_lit(lit[2]);
+    sim3 = finish_lit(lit[3]);
+#endif
 }
 
 // recB = bytes per window record: 8 (one texel) or 16 (paired layout); rcap stays in 8-byte units
@@ -1441,7 +1545,15 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     // projection IS (x, y); using the exact pixel makes the border test deterministic on the knife-edge rows where
     // x == wsh + 2 (DESIGN.md "knife-edge rows")
     const float dd = (float)wsh + 2.0f;
-    bool rValid = inRoi && !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd));
+    bool rValid = inRoi && (AVDM_DEV_REPROJ_BORDER || !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd)));
+    // AVDM_DEV_REPROJ_BORDER: the reference's border test of R, on the patch centre projected back into R (Patch.cuh:486-496), per plane
+    auto r_border_ok = [&](f3 p) __attribute__((always_inline)) -> bool {
+        if(!AVDM_DEV_REPROJ_BORDER)
+            return true;
+        const f3 q = M3x4mulV3(rc.P, p);
+        const float rpx = q.x / q.z, rpy = q.y / q.z;
+        return !((rpx < dd) || (rpx > A.rcW1 - dd) || (rpy < dd) || (rpy > A.rcH1 - dd));
+    };
     float4 rcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
     if(rValid)
     {
@@ -1471,10 +1583,10 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         }
         const float tw = kk * RK.hrW;
         Q = make_patch_proj_on_ray(rc, tc, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, fma3(kk, RK.htB, RK.htA), ax, ay, pd);
-        const float it0 = fast_rcp(Q.ht0.z);
+        const float it0 = proj_rcp(Q.ht0.z);
         tpx = Q.ht0.x * it0;
         tpy = Q.ht0.y * it0;
-        return !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+        return r_border_ok(p) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
     };
 
     // ONE T window for the 4 planes of the chunk (see the Refine kernel; here for both record layouts of the packed path, the centre
@@ -1628,9 +1740,9 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 q.tax = M3x3mulV3(tc.P, axd);
                 raxOut = M3x3mulV3(rc.P, axd);
                 const f3 ht0 = fma3(kk, RK.htB, RK.htA);
-                const float it0 = fast_rcp(ht0.z);
+                const float it0 = proj_rcp(ht0.z);
                 const float tpx = ht0.x * it0, tpy = ht0.y * it0;
-                valid = valid && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+                valid = valid && r_border_ok(p) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
                 laneLds = true;
                 if(valid)
                 {
@@ -1853,7 +1965,15 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     const f3 dir = normalize(pMid - C);
 
     const float dd = (float)wsh + 2.0f;
-    bool rValid = pixActive && !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd));
+    bool rValid = pixActive && (AVDM_DEV_REPROJ_BORDER || !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd)));
+    // AVDM_DEV_REPROJ_BORDER: the reference's border test of R, on the patch centre projected back into R (Patch.cuh:486-496), per plane
+    auto r_border_ok = [&](f3 p) __attribute__((always_inline)) -> bool {
+        if(!AVDM_DEV_REPROJ_BORDER)
+            return true;
+        const f3 q = M3x4mulV3(rc.P, p);
+        const float rpx = q.x / q.z, rpy = q.y / q.z;
+        return !((rpx < dd) || (rpx > A.rcW1 - dd) || (rpy < dd) || (rpy > A.rcH1 - dd));
+    };
     float4 rcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
     if(rValid)
     {
@@ -1889,10 +2009,10 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         }
         const float tw = t * RK.hrW;
         Q = make_patch_proj_on_ray(rc, tc, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, fma3(t, RK.htB, RK.htA), ax, ay, pd);
-        const float it0 = fast_rcp(Q.ht0.z);
+        const float it0 = proj_rcp(Q.ht0.z);
         tpx = Q.ht0.x * it0;
         tpy = Q.ht0.y * it0;
-        return !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+        return r_border_ok(p) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
     };
 
     // ---- ONE T window for all planes of the chunk (paired records) -----------------------------------------------------------------
@@ -2053,9 +2173,9 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 q.tax = M3x3mulV3(tc.P, axd);
                 raxOut = M3x3mulV3(rc.P, axd);
                 const f3 ht0 = fma3(t, RK.htB, RK.htA);
-                const float it0 = fast_rcp(ht0.z);
+                const float it0 = proj_rcp(ht0.z);
                 const float tpx = ht0.x * it0, tpy = ht0.y * it0;
-                valid = valid && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+                valid = valid && r_border_ok(p) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
                 laneLds = true;
                 if(valid)
                 {
@@ -2860,8 +2980,9 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
             else
                 AVDM_SGM_COMBINED_LAUNCH(false)
 #undef AVDM_SGM_COMBINED_LAUNCH
-            AVDM_LAUNCH_CHECK("avdm_volume_compute_similarity");
+            return ::avdm::set_error(hipGetLastError(), "avdm_volume_compute_similarity"); // the one launch of the default path: done
         }
+        // AVDM_SIM_SPLIT=1 only: fast kernel + fix-up kernel
         const size_t nWg = (size_t)grid.x * grid.y * grid.z;
         const StreamScratch lease((hipStream_t)stream, nWg * sizeof(unsigned));
         unsigned* flags = (unsigned*)lease.ptr();
@@ -2983,8 +3104,9 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
             hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, 4>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
                                (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi,
                                (unsigned*)nullptr);
-            AVDM_LAUNCH_CHECK("avdm_volume_refine_similarity");
+            return ::avdm::set_error(hipGetLastError(), "avdm_volume_refine_similarity"); // the one launch of the default path: done
         }
+        // AVDM_SIM_SPLIT=1 only: fast kernel + fix-up kernel
         const size_t nWg = (size_t)grid.x * grid.y * grid.z;
         const StreamScratch lease((hipStream_t)stream, nWg * sizeof(unsigned));
         unsigned* flags = (unsigned*)lease.ptr();

@@ -582,8 +582,21 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
             if(error)
                 std::rethrow_exception(error);
 
-            // (A) similarity volumes, one stream per tile
+            // (A0) the adaptive-P2 maps of the group's aggregation: they depend on nothing but the R pyramids, so they are evaluated on the
+            // aggregation stream BEFORE the sweeps (avdm_volume_optimize_prepare) and step (B) is the path launches alone
             std::vector<avdm_sgm_tile_t> aggTiles;
+            const avdm_sgm_params_t sp = _sgmParams.toAvdm();
+            hipStream_t aggStream = deviceStreamManager.getStream(0);
+            if(_sgmParams.doSgmOptimizeVolume)
+            {
+                for(int k = 0; k < n; ++k)
+                    if(active[k])
+                        aggTiles.push_back(sgmPerStream.at(k)->layoutAndDescribe(tiles.at(g0 + k), *depthLists[k]));
+                if(!aggTiles.empty())
+                    avdmCheck(avdm_volume_optimize_prepare((int)aggTiles.size(), aggTiles.data(), groupScratch.ptr(), &sp, aggStream), "avdm_volume_optimize_prepare");
+            }
+
+            // (A) similarity volumes, one stream per tile
             for(int k = 0; k < n; ++k)
             {
                 if(!active[k])
@@ -594,10 +607,7 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
                 Sgm& sgm = *sgmPerStream.at(k);
                 sgm.computeVolumes(tile, *depthLists[k]);
                 if(_sgmParams.doSgmOptimizeVolume)
-                {
-                    aggTiles.push_back(sgm.sgmTileDescriptor(tile, *depthLists[k]));
                     AVDM_HIP_CHECK(hipEventRecord(volumeDone[k], sgm.getStream()));
-                }
                 else
                     sgm.optimizeDisabledCopy();
             }
@@ -605,13 +615,12 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
             // (B) one batched aggregation for the group, on stream 0 after every tile's volumes
             if(!aggTiles.empty())
             {
-                hipStream_t aggStream = deviceStreamManager.getStream(0);
                 for(int k = 0; k < n; ++k)
                     if(active[k])
                         AVDM_HIP_CHECK(hipStreamWaitEvent(aggStream, volumeDone[k], 0));
                 AVDM_LOG_INFO("SGM Optimizing volume of " << aggTiles.size() << " tile(s) in one batch (filtering axes: " << _sgmParams.filteringAxes << ").");
-                const avdm_sgm_params_t sp = _sgmParams.toAvdm();
-                avdmCheck(avdm_volume_optimize_tiles((int)aggTiles.size(), aggTiles.data(), groupScratch.ptr(), &sp, aggStream), "avdm_volume_optimize_tiles");
+                avdmCheck(avdm_volume_optimize_tiles_prepared((int)aggTiles.size(), aggTiles.data(), groupScratch.ptr(), &sp, aggStream),
+                          "avdm_volume_optimize_tiles_prepared");
                 AVDM_HIP_CHECK(hipEventRecord(aggregationDone, aggStream));
             }
 

@@ -88,7 +88,8 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
                 // one file per view named <viewId>.<ext> (MultiViewParams.cpp:83-103: exactly one file with a supported extension); this build
                 // decodes OpenEXR (PrepareDenseScene's output format), PNG, JPEG and TIFF
                 std::string candidate;
-                for(const char* ext : {".exr", ".png", ".jpg", ".jpeg", ".JPG", ".tif", ".tiff"})
+                // (each extension in lower and upper case, the spellings isPngPath / isJpegPath / isTiffPath and prepareDenseScene accept)
+                for(const char* ext : {".exr", ".EXR", ".png", ".PNG", ".jpg", ".JPG", ".jpeg", ".JPEG", ".tif", ".TIF", ".tiff", ".TIFF"})
                 {
                     const std::string c = _imagesFolder + std::to_string(view.viewId) + ext;
                     if(!fileExists(c))

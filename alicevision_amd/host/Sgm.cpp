@@ -91,16 +91,27 @@ void Sgm::layoutFor(const Tile& tile, int nbDepths)
                               << "x" << _sgmParams.maxDepths << ").");
 }
 
+avdm_sgm_tile_t Sgm::layoutAndDescribe(const Tile& tile, const SgmDepthList& tileDepthList)
+{
+    layoutFor(tile, (int)tileDepthList.getDepths().size());
+    return sgmTileDescriptor(tile, tileDepthList);
+}
+
 void Sgm::sgmRc(const Tile& tile, const SgmDepthList& tileDepthList)
 {
+    const avdm_sgm_params_t sp = _sgmParams.toAvdm();
+    avdm_sgm_tile_t t;
+    if(_sgmParams.doSgmOptimizeVolume)
+    {
+        // the adaptive-P2 maps depend only on the R pyramid: ahead of the sweep, so that the aggregation is the path launches alone
+        t = layoutAndDescribe(tile, tileDepthList);
+        avdmCheck(avdm_volume_optimize_prepare(1, &t, _optimizeScratch.ptr(), &sp, _stream), "avdm_volume_optimize_prepare");
+    }
     computeVolumes(tile, tileDepthList);
     if(_sgmParams.doSgmOptimizeVolume)
     {
         AVDM_LOG_INFO(tile << "SGM Optimizing volume (filtering axes: " << _sgmParams.filteringAxes << ").");
-        const avdm_sgm_tile_t t = sgmTileDescriptor(tile, tileDepthList);
-        const avdm_sgm_params_t sp = _sgmParams.toAvdm();
-        avdmCheck(avdm_volume_optimize(t.out_vol, t.in_vol, t.pitch_y, t.pitch_x, _optimizeScratch.ptr(), t.rc_pyr, &sp, t.last_depth_index, t.roi, _stream),
-                  "avdm_volume_optimize");
+        avdmCheck(avdm_volume_optimize_tiles_prepared(1, &t, _optimizeScratch.ptr(), &sp, _stream), "avdm_volume_optimize_tiles_prepared");
         AVDM_LOG_INFO(tile << "SGM Optimizing volume done.");
     }
     else

@@ -39,6 +39,7 @@ class Sgm
     // the three steps of sgmRc
     void computeVolumes(const Tile& tile, const SgmDepthList& tileDepthList);   // depth upload + Sgm.cpp:203-279
     avdm_sgm_tile_t sgmTileDescriptor(const Tile& tile, const SgmDepthList& tileDepthList) const; // arguments of Sgm.cpp:281-304 for a batched launch
+    avdm_sgm_tile_t layoutAndDescribe(const Tile& tile, const SgmDepthList& tileDepthList);       // the same BEFORE computeVolumes() (lays the volumes out for the tile): for avdm_volume_optimize_prepare
     size_t optimizeScratchBytes(const Tile& tile, const SgmDepthList& tileDepthList) const;
     // Sgm.cpp:327-396 (the 9-point CSV part; the Alembic exports are not built)
     void exportVolumeInformation(const Tile& tile, const SgmDepthList& tileDepthList, const DeviceBuffer& volume, const std::string& name) const;

@@ -322,6 +322,12 @@ private:
         }
         _mcusX = (_img.width + 8 * _img.hmax - 1) / (8 * _img.hmax);
         _mcusY = (_img.height + 8 * _img.vmax - 1) / (8 * _img.vmax);
+        // the header is untrusted: the coefficient planes (128 B per block) are bounded before they are allocated
+        size_t totalBlocks = 0;
+        for(const JpegComponent& c : _img.components)
+            totalBlocks += (size_t)_mcusX * c.h * (size_t)_mcusY * c.v;
+        if(totalBlocks > ((size_t)1 << 25))
+            fail("image larger than 4 GiB of coefficients (" + std::to_string(_img.width) + " x " + std::to_string(_img.height) + ")");
         for(JpegComponent& c : _img.components)
         {
             c.width = (_img.width * c.h + _img.hmax - 1) / _img.hmax;

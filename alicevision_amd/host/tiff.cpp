@@ -265,7 +265,14 @@ void readTiff(const std::string& filename, TiffImage& out, bool headerOnly)
     }
     if(offsets.empty() || offsets.size() != counts.size())
         fail("strip / tile offsets and byte counts do not match");
-    const size_t across = (width + tileW - 1) / tileW, down = (height + tileH - 1) / tileH;
+    // geometry from untrusted tags: size_t arithmetic, bounded before anything is allocated
+    if(width == 0 || height == 0 || width > (1u << 20) || height > (1u << 20))
+        fail("unreasonable image dimensions");
+    if(tileW > 4u * width + 4096u || tileH > 4u * height + 4096u)
+        fail("unreasonable tile / strip dimensions");
+    if((size_t)width * height * spp * bytesPerSample > ((size_t)1 << 33))
+        fail("image larger than 8 GiB of samples");
+    const size_t across = ((size_t)width + tileW - 1) / tileW, down = ((size_t)height + tileH - 1) / tileH;
     const size_t planes = planar == 2 ? spp : 1, samplesPerChunkPixel = planar == 2 ? 1 : spp;
     if(offsets.size() < across * down * planes)
         fail("fewer strips / tiles than the image needs");

@@ -6,6 +6,7 @@ The production host (tiling, depth lists, I/O, CLI) is the C++ code under alicev
 There is NO fallback: every stage calls libavdm.so and raises AvdmError on a non-zero status.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -53,12 +54,14 @@ def optimize_tiles_batched(tiles, rc, timers=None):
         AX, _ = t.sgm_extent()
         Z = t._sgm_pending[1]
         arr[i] = abi.SgmTile(t.best.data_ptr(), t.second.data_ptr(), AX * t.Zp, t.Zp, Z, t.sgm_extent_roi(), C.pointer(t.pyr[rc].desc))
-    rng = timers.range("sgm_optimize") if timers is not None else None
-    if rng is not None:
-        rng.__enter__()
-    abi.check(lib.avdm_volume_optimize_tiles(n, arr, _ptr(tiles[0]._batch_scratch), C.byref(sp), _stream()), "volume_optimize_tiles")
-    if rng is not None:
-        rng.__exit__(None, None, None)
+    # the adaptive-P2 maps of all tiles first (their own stage: they depend only on the R pyramid), then the path launches alone
+    for name, fn in (("sgm_p2_map", lib.avdm_volume_optimize_prepare), ("sgm_optimize", lib.avdm_volume_optimize_tiles_prepared)):
+        rng = timers.range(name) if timers is not None else None
+        if rng is not None:
+            rng.__enter__()
+        abi.check(fn(n, arr, _ptr(tiles[0]._batch_scratch), C.byref(sp), _stream()), name)
+        if rng is not None:
+            rng.__exit__(None, None, None)
     for t in tiles:
         t.finish_sgm(rc, t._sgm_pending[1])
 
@@ -103,25 +106,36 @@ class StageTimers:
 class DevicePyramid:
     """fp16 Lab mip pyramid in HBM (replaces DeviceMipmapImage)."""
 
-    def __init__(self, rgba, min_downscale, max_downscale, filter_mode, device="cuda"):
-        lib = abi.load()
+    def __init__(self, rgba, min_downscale, max_downscale, filter_mode, device="cuda", storage=None):
         h, w = rgba.shape[:2]
-        self.desc = abi.Pyramid()
-        abi.check(lib.avdm_pyramid_layout(C.byref(self.desc), w, h, min_downscale, max_downscale, filter_mode), "avdm_pyramid_layout")
-        self.buf = torch.zeros(self.desc.bytes, dtype=torch.uint8, device=device)
-        self.desc.base = self.buf.data_ptr()
+        self._layout(w, h, min_downscale, max_downscale, filter_mode, device, storage)
         if rgba is not None:
             self.fill(rgba)
 
-    @classmethod
-    def allocate(cls, width, height, min_downscale, max_downscale, filter_mode, device="cuda"):
-        """pyramid storage without content (to be filled later or received from another rank)"""
-        self = cls.__new__(cls)
+    def _layout(self, width, height, min_downscale, max_downscale, filter_mode, device, storage):
+        """storage: a byte tensor of pyramid_bytes() the pyramid lives in instead of an allocation of its own (a slot of the multi-GPU exchange
+        arena, sharding.ViewExchange.buffer)"""
         lib = abi.load()
         self.desc = abi.Pyramid()
         abi.check(lib.avdm_pyramid_layout(C.byref(self.desc), width, height, min_downscale, max_downscale, filter_mode), "avdm_pyramid_layout")
-        self.buf = torch.zeros(self.desc.bytes, dtype=torch.uint8, device=device)
+        if storage is None:
+            storage = torch.zeros(self.desc.bytes, dtype=torch.uint8, device=device)
+        if storage.dtype != torch.uint8 or storage.numel() != self.desc.bytes or not storage.is_contiguous():
+            raise ValueError("pyramid storage must be a contiguous byte tensor of %d bytes" % self.desc.bytes)
+        self.buf = storage
         self.desc.base = self.buf.data_ptr()
+
+    @staticmethod
+    def pyramid_bytes(width, height, min_downscale, max_downscale, filter_mode):
+        d = abi.Pyramid()
+        abi.check(abi.load().avdm_pyramid_layout(C.byref(d), width, height, min_downscale, max_downscale, filter_mode), "avdm_pyramid_layout")
+        return int(d.bytes)
+
+    @classmethod
+    def allocate(cls, width, height, min_downscale, max_downscale, filter_mode, device="cuda", storage=None):
+        """pyramid storage without content (to be filled later or received from another rank)"""
+        self = cls.__new__(cls)
+        self._layout(width, height, min_downscale, max_downscale, filter_mode, device, storage)
         return self
 
     def fill(self, rgba):
@@ -171,6 +185,7 @@ class DepthMapTile:
         self.roi = roi if roi is not None else (0, W, 0, H)
         self.tile_buffer = tile_buffer
         self._alloc_for = None
+        self._side = None  # side stream of the adaptive-P2 maps (run_sgm)
         self.timers = StageTimers()
 
     def enable_timers(self, on=True):
@@ -246,6 +261,23 @@ class DepthMapTile:
         st = _stream()
         self.depths_d.copy_(torch.as_tensor(depths, dtype=torch.float32), non_blocking=False)
         T = self.timers
+        # The adaptive-P2 maps of the path aggregation depend on nothing but the R pyramid: they are evaluated on a side stream beside the
+        # similarity sweep (avdm_volume_optimize_prepare), and the aggregation further down is the path launches alone.
+        # (AVDM_SGM_PREPARE=0: the one-call form avdm_volume_optimize, the A/B reference; the bytes are the same.)
+        prepared = None
+        if optimize is True and os.environ.get("AVDM_SGM_PREPARE") != "0":
+            tile1 = (abi.SgmTile * 1)(abi.SgmTile(self.best.data_ptr(), self.second.data_ptr(), py, pxx, Z, self.sgm_extent_roi(), C.pointer(self.pyr[rc].desc)))
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.best.device)
+            ready = torch.cuda.Event()
+            ready.record()  # the R pyramid is complete in the caller's stream order
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                with T.range("sgm_p2_map"):
+                    abi.check(lib.avdm_volume_optimize_prepare(1, tile1, _ptr(self.sgm_scratch), C.byref(sp), _stream()), "volume_optimize_prepare")
+                done = torch.cuda.Event()
+                done.record()
+            prepared = (tile1, done)
         with T.range("sgm_volume_init"):
             abi.check(lib.avdm_volume_initialize_u8(_ptr(self.best), py, pxx, AX, AY, Zp, 255, st), "volume_initialize")
             abi.check(lib.avdm_volume_initialize_u8(_ptr(self.second), py, pxx, AX, AY, Zp, 255, st), "volume_initialize")
@@ -264,7 +296,11 @@ class DepthMapTile:
         if optimize == "defer":  # the caller aggregates the volumes of several tiles in one batched call (optimize_tiles_batched)
             self._sgm_pending = (rc, Z)
             return None
-        if optimize:
+        if optimize and prepared is not None:
+            torch.cuda.current_stream().wait_event(prepared[1])
+            with T.range("sgm_optimize"):
+                abi.check(lib.avdm_volume_optimize_tiles_prepared(1, prepared[0], _ptr(self.sgm_scratch), C.byref(sp), st), "volume_optimize_tiles_prepared")
+        elif optimize:
             with T.range("sgm_optimize"):
                 abi.check(lib.avdm_volume_optimize(_ptr(self.best), _ptr(self.second), py, pxx, _ptr(self.sgm_scratch), C.byref(self.pyr[rc].desc),
                                                    C.byref(sp), Z, self.sgm_extent_roi(), st), "volume_optimize")

@@ -28,44 +28,101 @@ def owner_of_view(view_index, world):
 
 
 class ViewExchange:
-    """Pyramid storage of one rank: `bufs[v]` is the byte tensor of view v's pyramid on this rank.  A view is BUILT only by its owner
-    (`owner_of_view`); everyone else RECEIVES it:
+    """Pyramid storage of one rank and the exchange between ranks.  All views' pyramids (same size each) live in ONE allocation, the arena,
+    laid out [row][rank][bytes] with view v at row v // world, column v % world = its owner: the views of one ROW are one contiguous block
+    whose q-th part is built by rank q.  A view is BUILT only by its owner (`owner_of_view`); everyone else RECEIVES it:
 
-      setup()            every view's pyramid is broadcast once from its owner (neighbour views broadcast once, BASELINE north_star);
-      publish_round(vs)  steady state of a streaming job: every rank q has just (re)built the pyramid of view vs[q] (its own); one
-                         all-gather moves each of them into `bufs[vs[q]]` of every other rank, so that later depth maps on any rank
-                         use the RECEIVED bytes as their neighbour pyramids.
-    `dist` is torch.distributed (nccl = RCCL on the GPUs, gloo in the CPU tests) or None for a single rank."""
+      buffer(v)          the byte tensor of view v's pyramid on this rank (a view of the arena: DevicePyramid(..., storage=buffer(v)));
+      setup()            ONE in-place all-gather per row (ceil(V / world) collectives, each moving world pyramids) hands every pyramid to every
+                         rank — "neighbour views broadcast once" (BASELINE north_star) without a collective per view;
+      publish_async(vs)  steady state of a streaming job: every rank q has just (re)built the pyramid of view vs[q] (its own).  One
+                         all-gather moves them into a STAGING row on a side stream (GPU) while the caller's stream goes on computing with
+                         the pyramids it has;
+      commit()           at the caller's next step boundary: wait for that gather and copy the received pyramids from the staging row into
+                         their arena slots, in the caller's stream order — no kernel ever reads a pyramid while the network writes it;
+      publish_round(vs)  publish_async + commit.
+    `dist` is torch.distributed (nccl = RCCL on the GPUs, gloo in the CPU tests) or None for a single rank without a process group; a
+    process group of ONE rank runs the same collectives (bench.py --force-dist: the RCCL path exercised on one GPU)."""
 
-    def __init__(self, bufs, rank, world, dist):
-        self.bufs, self.rank, self.world, self.dist = bufs, rank, world, dist
+    def __init__(self, n_views, nbytes, rank, world, dist, device="cpu"):
+        import torch
+        self.n_views, self.nbytes, self.rank, self.world, self.dist = n_views, int(nbytes), rank, world, dist
+        self.slot = (self.nbytes + 4095) // 4096 * 4096  # every pyramid starts on a 4 KiB boundary of the arena
+        self.rows = (n_views + world - 1) // world
+        self.device = torch.device(device)
+        self.arena = torch.zeros((self.rows, world, self.slot), dtype=torch.uint8, device=self.device)
         self.bytes_received = 0
+        self.collectives = 0
+        self._staging = None
+        self._pending = None  # (views, work / None, done event / None)
+        self._side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.events = []      # GPU: (start, end) event pairs of the gathers on the side stream
 
     def owns(self, v):
         return owner_of_view(v, self.world) == self.rank
 
+    def buffer(self, v):
+        return self.arena[v // self.world][v % self.world][: self.nbytes]
+
     def setup(self):
-        if self.dist is None or self.world == 1:
+        if self.dist is None:
             return
-        for v, b in enumerate(self.bufs):
-            self.dist.broadcast(b, src=owner_of_view(v, self.world))
-            if not self.owns(v):
-                self.bytes_received += b.numel() * b.element_size()
+        for r in range(self.rows):
+            self.dist.all_gather_into_tensor(self.arena[r].view(-1), self.arena[r][self.rank])  # in place: my part is already where it belongs
+            self.collectives += 1
+        self.bytes_received += self.nbytes * sum(1 for v in range(self.n_views) if not self.owns(v))
+
+    def publish_async(self, views):
+        """views[q] = the view rank q rebuilt in this round: every rank contributes one (an all-gather has no empty slots; a rank without new
+        work republishes any view it owns)."""
+        if self.dist is None:
+            return
+        import torch
+        assert self._pending is None, "commit() the previous round first"
+        assert len(views) == self.world and all(v is not None for v in views) and self.owns(views[self.rank])
+        if self._staging is None:
+            self._staging = torch.empty((self.world, self.slot), dtype=torch.uint8, device=self.device)
+        v0 = views[self.rank]
+        mine = self.arena[v0 // self.world][v0 % self.world]
+        if self._side is not None:
+            built = torch.cuda.Event()
+            built.record()  # the caller's stream has just rebuilt `mine`
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(built)
+                start.record()
+                work = self.dist.all_gather_into_tensor(self._staging.view(-1), mine, async_op=True)
+                work.wait()  # the side stream waits for the collective (the host does not)
+                end.record()
+            self.events.append((start, end))
+            self._pending = (list(views), None, end)
+        else:
+            work = self.dist.all_gather_into_tensor(self._staging.view(-1), mine, async_op=True)
+            self._pending = (list(views), work, None)
+        self.collectives += 1
+
+    def commit(self):
+        if self._pending is None:
+            return
+        import torch
+        views, work, end = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()
+        if end is not None:
+            torch.cuda.current_stream(self.device).wait_event(end)
+        for q, v in enumerate(views):
+            if q != self.rank:
+                self.buffer(v).copy_(self._staging[q][: self.nbytes], non_blocking=True)
+        self.bytes_received += (self.world - 1) * self.nbytes
 
     def publish_round(self, views):
-        """views[q] = the view rank q rebuilt in this round: every rank contributes one (an all-gather has no empty slots; a rank without new
-        work republishes any view it owns).  All pyramids have the same size."""
-        if self.dist is None or self.world == 1:
-            return
-        assert len(views) == self.world and all(v is not None for v in views) and self.owns(views[self.rank])
-        mine = self.bufs[views[self.rank]]
-        # gather straight into the destination pyramids; my own slot is a scratch (its source is the input tensor)
-        if not hasattr(self, "_scratch") or self._scratch.shape != mine.shape:
-            import torch
-            self._scratch = torch.empty_like(mine)
-        out = [self._scratch if q == self.rank else self.bufs[views[q]] for q in range(self.world)]
-        self.dist.all_gather(out, mine)
-        self.bytes_received += (self.world - 1) * mine.numel() * mine.element_size()
+        self.publish_async(views)
+        self.commit()
+
+    def exchange_ms(self):
+        """GPU: total ms of the gathers so far (side-stream events; call after a device synchronize)"""
+        return sum(a.elapsed_time(b) for a, b in self.events)
 
 
 def exchange_pyramid(buf, src, dist, all_ranks=False):

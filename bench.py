@@ -12,9 +12,10 @@ Workloads (BASELINE.json configs; config.workload names the one that ran):
 One step = one depth map of one reference camera: R-image pyramid build -> similarity volume x10 -> 4-path SGM aggregation -> WTA ->
 thickness smoothing -> upscale -> Refine volume x10 -> sub-sample arg-min -> 100 optimisation iterations.  Every rank computes K depth
 maps of reference cameras it owns (weak scaling); value = N*K / max-over-ranks time.  Images are resident in HBM before the timed
-region.  Multi-GPU: a view's pyramid is built ONLY by the rank that owns the view; set-up broadcasts every pyramid once from its owner,
-and in the timed region each step's freshly rebuilt R pyramids travel by one all-gather INTO the other ranks' pyramid stores — the
-neighbour pyramids a rank sweeps against are the bytes it received (alicevision_amd/sharding.py: ViewExchange).
+region.  Multi-GPU: a view's pyramid is built ONLY by the rank that owns the view; all pyramids of a rank live in one arena whose rows of
+`world` views travel in ONE in-place all-gather each at set-up, and in the timed region each step's freshly rebuilt R pyramids travel by one
+all-gather on a side stream, beside the sweep, into a staging row that the next step commits to the pyramid stores — the neighbour pyramids a
+rank sweeps against are the bytes it received (alicevision_amd/sharding.py: ViewExchange).  `--force-dist` runs all of it with one rank.
 All compute goes through the C ABI of alicevision_amd/csrc/libavdm.so (hand-written HIP); the oracle is only used for the
 `cpu_baseline` leg on rank 0 at N = 1.
 """
@@ -190,9 +191,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cli-e2e", type=int, default=0, metavar="N",
+    ap.add_argument("--cli-e2e", type=int, default=-1, metavar="N",
                     help="after the timed region (1 GPU): run the C++ program aliceVision_depthMapEstimation on N reference cameras of the same scene "
-                         "(EXR files, default 1024 tiling, I/O included) and add its end-to-end rate to the line as `cli_end_to_end`")
+                         "(EXR files, default 1024 tiling, I/O included) and add its end-to-end rate to the line as `cli_end_to_end`; "
+                         "default: all cameras of cfg3 (about 10 s), 0 = off")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the process group (nccl = RCCL) and run the pyramid exchange's collectives even with ONE rank: the multi-GPU code "
+                         "path exercised on a single GPU (tests/test_gpu_parity.py::test_bench_rccl_path_on_one_gpu)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only (gloo, no GPU work): what tests/test_sharding.py runs on the CPU")
     args = ap.parse_args()
@@ -210,9 +215,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # only without a launcher (--force-dist at one rank)
+            os.environ["MASTER_PORT"] = str(free_port())
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.workload is None:
@@ -224,19 +231,20 @@ def main():
     sc = make_scene(V, W, H, seed=3, device=dev, render=[v for v in range(V) if owner_of_view(v, world) == rank])
     images = sc.images  # {view: (H, W, 4) fp32 in HBM} for the owned views
     min_ds, max_ds = min(sgm.scale, ref.scale), max(sgm.scale, ref.scale) * 64
+    # all pyramids of a rank live in the exchange arena ([row][owner rank][bytes]): a row of views travels in ONE in-place all-gather
+    exchange = ViewExchange(V, DevicePyramid.pyramid_bytes(W, H, min_ds, max_ds, abi.FILTER_CUDA_FIXED8), rank, world, dist, device=dev)
     pyr = []
     for v in range(V):
         if v in images:
-            pyr.append(DevicePyramid(images[v], min_ds, max_ds, abi.FILTER_CUDA_FIXED8, device=dev))
-        else:
-            pyr.append(DevicePyramid.allocate(W, H, min_ds, max_ds, abi.FILTER_CUDA_FIXED8, device=dev))  # received, never built here
+            pyr.append(DevicePyramid(images[v], min_ds, max_ds, abi.FILTER_CUDA_FIXED8, device=dev, storage=exchange.buffer(v)))
+        else:  # received, never built here
+            pyr.append(DevicePyramid.allocate(W, H, min_ds, max_ds, abi.FILTER_CUDA_FIXED8, device=dev, storage=exchange.buffer(v)))
     torch.cuda.synchronize()
-    exchange = ViewExchange([p.buf for p in pyr], rank, world, dist)
     t_ex = 0.0
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         t0 = time.time()
-        exchange.setup()  # every view's pyramid broadcast once from its owner over xGMI
+        exchange.setup()  # every view's pyramid handed to every rank once over xGMI: one collective per row of `world` views
         torch.cuda.synchronize()
         t_ex = time.time() - t0
     depths = plane_depths(sc, Z)
@@ -257,11 +265,15 @@ def main():
     def step(i):
         rc = my_cams[i % len(my_cams)]
         tcs = [(rc + 1 + k) % V for k in range(T)]  # the T following views of the ring: owned by other ranks when N > 1
+        if dist is not None:
+            with tile.timers.range("pyramid_commit"):
+                exchange.commit()                 # the pyramids received during the previous step -> their slots, in stream order
         with tile.timers.range("image_pyramid"):
             pyr[rc].fill(images[rc])              # image -> Lab pyramid (DeviceCache::addMipmapImage): only ever for a view I own
-        if world > 1:
-            with tile.timers.range("pyramid_exchange"):
-                exchange.publish_round([cams_of[r][i % len(cams_of[r])] for r in range(world)])
+        if dist is not None:
+            # every rank's freshly built R pyramid to every other rank: ONE all-gather into a staging row on a side stream, overlapped with
+            # this step's sweep (nothing reads the staging row before the next step's commit)
+            exchange.publish_async([cams_of[r][i % len(cams_of[r])] for r in range(world)])
         out = None
         if len(tiles) == 1:
             tiles[0].run_sgm(rc, tcs, depths)
@@ -280,7 +292,10 @@ def main():
     torch.cuda.synchronize()
     tile.reset_timers()
     lib.avdm_debug_sgm_kernel_timing(1)  # HIP events on the launch stream around every path-aggregation kernel launch
-    if world > 1:
+    exchange.commit()
+    torch.cuda.synchronize()
+    exchange.events = []
+    if dist is not None:
         dist.barrier()
     t0 = time.time()
     step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -294,16 +309,22 @@ def main():
             st = (ctypes.c_uint * 4)()
             lib.avdm_debug_similarity_stats(st)
             stats_each.append([int(v) for v in st])
+    if dist is not None:
+        with tile.timers.range("pyramid_commit"):
+            exchange.commit()  # the last round's pyramids are part of the job
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     elapsed = time.time() - t0
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     stages = tile.timers.mean_ms(per=args.steps)  # ms per step and stage (HIP events on the launch stream; summed over the tiles of a step)
+    if dist is not None:
+        # the all-gather of a step's R pyramids runs on a side stream beside the sweep: its own events, not part of the critical path
+        stages["pyramid_exchange"] = exchange.exchange_ms() / args.steps
     k_ms, k_n = ctypes.c_double(0.0), ctypes.c_long(0)
     abi.check(lib.avdm_debug_sgm_kernel_timing_read(ctypes.byref(k_ms), ctypes.byref(k_n), 1), "avdm_debug_sgm_kernel_timing_read")
     path_ms, path_n = (ctypes.c_double * 4)(), (ctypes.c_long * 4)()
@@ -402,7 +423,9 @@ def main():
             "config": {"workload": args.workload, "views": V, "width": W, "height": H, "depth_planes": Z, "t_cams": T, "tiles_per_depth_map": len(rois),
                        "sgm": "scale 2 stepXY 2 wsh 4, 4 paths", "refine": "scale 1 stepXY 1 wsh 3, 31 planes, 100 opt iters",
                        "sharding": f"round-robin reference cameras over {world} rank(s); a view's pyramid is built by its owner only",
-                       "pyramid_setup_broadcast_s": t_ex, "pyramid_bytes_received_per_rank": exchange.bytes_received},
+                       "process_group": None if dist is None else f"nccl (RCCL), {world} rank(s)" + (" [--force-dist]" if world == 1 else ""),
+                       "pyramid_setup_broadcast_s": t_ex, "pyramid_bytes_received_per_rank": exchange.bytes_received,
+                       "pyramid_exchange_collectives": exchange.collectives},
             "roofline": roof,
             "similarity": {"sgm_voxelT_per_s": vt_sgm, "refine_voxelT_per_s": vt_ref, "sgm_samples_per_s": s_sgm, "refine_samples_per_s": s_ref,
                            "sgm_lds_GBps": s_sgm * (48.0 if os.environ.get("AVDM_SIM_PLANE_PAIRS") == "0" else 36.0) / 1e9, "refine_lds_GBps": s_ref * 64.0 / 1e9, "lds_peak_GBps": 150000.0,
@@ -417,13 +440,14 @@ def main():
         if os.environ.get("AVDM_SIM_STATS") == "1":
             # [LDS path, generic: R tile unusable / nothing valid, generic: T taps leave the image, generic: T window exceeds the LDS budget] per step
             line["similarity_plane_workgroups_each"] = stats_each
-        if world == 1 and args.cli_e2e > 0:
-            line["cli_end_to_end"] = cli_end_to_end(sc, V, W, H, Z, T, args.cli_e2e)
+        n_cli = args.cli_e2e if args.cli_e2e >= 0 else (V if args.workload == "cfg3" else 0)
+        if world == 1 and n_cli > 0:
+            line["cli_end_to_end"] = cli_end_to_end(sc, V, W, H, Z, T, min(n_cli, V))
         if world == 1 and not args.no_cpu_baseline:
             small = make_scene(3, 512, 384, seed=3, device="cpu")
             line["cpu_baseline"] = cpu_baseline(small, sgm, ref, Z, W * H, T)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -271,6 +271,14 @@ typedef struct avdm_sgm_tile
     const avdm_pyramid_t* rc_pyr;
 } avdm_sgm_tile_t;
 int avdm_volume_optimize_tiles(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* params, void* stream);
+/* cuda_volumeOptimize :120-129 in two halves.  The adaptive P2 (deviceSimilarityVolumeKernels.cuh:696-720: the colour step of the R image
+ * between neighbouring stage pixels) depends on nothing but the R pyramid, the ROI and the parameters: _prepare evaluates those maps into
+ * `scratch` as soon as the R pyramid exists (the tiles' volumes are not touched and may be NULL), e.g. on a side stream beside the
+ * similarity sweep.  The caller orders the two halves (same stream, or an event). */
+int avdm_volume_optimize_prepare(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* params, void* stream);
+/* ... and the path launches alone (deviceSimilarityVolume.cu:376-425) on the SAME tiles / scratch / params after avdm_volume_optimize_prepare:
+ * prepare + prepared == avdm_volume_optimize_tiles, byte for byte. */
+int avdm_volume_optimize_tiles_prepared(int n_tiles, const avdm_sgm_tile_t* tiles, void* scratch, const avdm_sgm_params_t* params, void* stream);
 /* cuda_volumeRetrieveBestDepth :143-151 (out_depth_sim may be NULL); vol_dimZ = allocated depth of the volume (kernels.cuh:459) */
 int avdm_volume_retrieve_best_depth(float* out_depth_thickness, int dt_pitch, float* out_depth_sim, int ds_pitch,
                                     const float* depths, const uint8_t* vol, long long pitch_y, int pitch_x, int vol_dimZ,

@@ -59,11 +59,19 @@ _SIG = {
 }
 
 _lib = None
+_variants = {}
+# second, equally faithful evaluations of the same sources (oracle/ref/Makefile): "fm" = the fast intrinsics with the error model the CUDA
+# programming guide documents, "fma" = contraction of a * b + c into FMAs like nvcc's default, "cuda" = both
+VARIANTS = ("fm", "fma", "cuda")
 
 
-def available():
+def variant_path(variant):
+    return LIB_PATH if not variant else os.path.join(HERE, "_ref", "libavdm_ref_%s.so" % variant)
+
+
+def available(variant=""):
     """the library exists (prebuilt) or can be built here (reference tree present)"""
-    return os.path.exists(LIB_PATH) or os.path.exists(REFERENCE_TREE)
+    return os.path.exists(variant_path(variant)) or os.path.exists(REFERENCE_TREE)
 
 
 def build():
@@ -71,20 +79,23 @@ def build():
     return LIB_PATH
 
 
-def load():
+def load(variant=""):
     global _lib
-    if _lib is None:
+    if variant not in _variants:
         if os.path.exists(REFERENCE_TREE):
             build()  # no-op when up to date
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError("oracle/_ref is not built and /root/reference is absent")
-        lib = C.CDLL(LIB_PATH)
+        path = variant_path(variant)
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/_ref (%s) is not built and /root/reference is absent" % os.path.basename(path))
+        lib = C.CDLL(path)  # RTLD_LOCAL; the variants are linked -Bsymbolic: each one keeps its own constant memory / shim state
         for name, (res, args) in _SIG.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = lib
-    return _lib
+        _variants[variant] = lib
+        if not variant:
+            _lib = lib
+    return _variants[variant]
 
 
 def ptr(a):
@@ -98,17 +109,18 @@ def ceil_div(a, b):
 class RefImage:
     """DeviceMipmapImage (the reference's) filled from a float RGBA image."""
 
-    def __init__(self, rgba, min_downscale, max_downscale):
+    def __init__(self, rgba, min_downscale, max_downscale, variant=""):
         rgba = np.ascontiguousarray(rgba, dtype=np.float32)
         h, w = rgba.shape[:2]
         self.width0, self.height0 = w, h
         self.min_downscale = min_downscale
-        self.h = load().avr_image_create(ptr(rgba), w * 16, w, h, min_downscale, max_downscale)
+        self.lib = load(variant)
+        self.h = self.lib.avr_image_create(ptr(rgba), w * 16, w, h, min_downscale, max_downscale)
         self.levels = int(np.log2(max_downscale // min_downscale)) + 1
 
     def __del__(self):
-        if getattr(self, "h", None) and _lib is not None:
-            _lib.avr_image_destroy(self.h)
+        if getattr(self, "h", None) and getattr(self, "lib", None) is not None:
+            self.lib.avr_image_destroy(self.h)
             self.h = None
 
     def level(self, l):
@@ -117,21 +129,21 @@ class RefImage:
         for _ in range(l):
             w, h = w // 2, h // 2
         out = np.empty((h, w, 4), np.float32)
-        load().avr_image_read_level(self.h, l, w, h, ptr(out))
+        self.lib.avr_image_read_level(self.h, l, w, h, ptr(out))
         return out
 
     def tex2dlod(self, uvl):
         uvl = np.ascontiguousarray(uvl, np.float32)
         out = np.empty((len(uvl), 4), np.float32)
-        load().avr_image_tex2dlod(self.h, ptr(uvl), len(uvl), ptr(out))
+        self.lib.avr_image_tex2dlod(self.h, ptr(uvl), len(uvl), ptr(out))
         return out
 
 
 class RefDepthMap:
     """One tile of one R camera through the reference's SGM + Refine wrappers on the CPU (same interface as OracleDepthMap)."""
 
-    def __init__(self, images, K, Rs, Cs, sgm, refine, filter_mode=abi.FILTER_CUDA_FIXED8, roi=None):
-        self.lib = load()
+    def __init__(self, images, K, Rs, Cs, sgm, refine, filter_mode=abi.FILTER_CUDA_FIXED8, roi=None, variant=""):
+        self.lib = load(variant)
         self.lib.avr_set_filter_mode(filter_mode)
         self.filter_mode = filter_mode
         self.sgm, self.refine = sgm, refine
@@ -139,7 +151,7 @@ class RefDepthMap:
         self.W, self.H = W, H
         min_ds = min(sgm.scale, refine.scale)
         max_ds = max(sgm.scale, refine.scale) * 64  # DepthMapEstimator.cpp:324-325
-        self.img = [RefImage(images[i], min_ds, max_ds) for i in range(n)]
+        self.img = [RefImage(images[i], min_ds, max_ds, variant) for i in range(n)]
         self.K, self.Rs, self.Cs = K, Rs, Cs
         self.roi = roi if roi is not None else (0, W, 0, H)
         self._slots = {}

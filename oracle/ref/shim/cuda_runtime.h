@@ -71,13 +71,39 @@ extern bool g_fixed8; /* texture linear-filter weights quantised to 1.8 fixed po
 #define gridDim (::shim::t_gridDim)
 
 /* ---- math the kernels call (CUDA's global-namespace overloads) ---- */
-/* glibc's math.h already declares __expf / __powf (its internal aliases of expf / powf): same functions, map by macro */
-#define __expf(x) expf(x)
-#define __powf(x, y) powf((x), (y))
 using std::isfinite;
 using std::isinf;
 using std::isnan;
+#ifdef AVDM_SHIM_CUDA_FASTMATH
+/* Second evaluation mode of the stand-in (oracle/_ref/libavdm_ref_fm.so, libavdm_ref_cuda.so): the fast intrinsics with the ERROR MODEL the
+ * CUDA C Programming Guide documents for them ("Intrinsic Functions": __expf(x) = ex2.approx(x * log2(e)), __fdividef(x, y) = x * rcp.approx(y),
+ * __powf(x, y) = ex2.approx(y * lg2.approx(x))), each approximate instruction evaluated as the correctly rounded fp32 operation on its fp32
+ * operand (the hardware's own 1-2 ulp are not reproducible here) with denormal results flushed like the .ftz forms.  Not "the" CUDA result:
+ * a second FAITHFUL evaluation of the reference's source, next to the exact-operation mode above; the distance between the two is the
+ * platform spread of the reference itself (tests/test_platform_spread.py). */
+static inline float shim_ftz(float v) { return std::fabs(v) < 1.17549435e-38f ? (v < 0.f ? -0.f : 0.f) : v; }
+static inline float shim_ex2_approx(float t) { return shim_ftz(exp2f(t)); }
+static inline float shim_lg2_approx(float v) { return log2f(v); }
+static inline float shim_rcp_approx(float v) { return shim_ftz(1.0f / v); }
+static inline float shim_fast_expf(float x)
+{
+    volatile float t = x * 1.44269504088896340736f; /* the product is rounded to fp32 before ex2 (volatile: never fused into what follows) */
+    return shim_ex2_approx(t);
+}
+static inline float shim_fast_powf(float x, float y)
+{
+    volatile float t = y * shim_lg2_approx(x);
+    return shim_ex2_approx(t);
+}
+#define __expf(x) shim_fast_expf(x)
+#define __powf(x, y) shim_fast_powf((x), (y))
+static inline float __fdividef(float a, float b) { return a * shim_rcp_approx(b); }
+#else
+/* glibc's math.h already declares __expf / __powf (its internal aliases of expf / powf): same functions, map by macro */
+#define __expf(x) expf(x)
+#define __powf(x, y) powf((x), (y))
 static inline float __fdividef(float a, float b) { return a / b; }
+#endif
 static inline float __fsqrt_rn(float x) { return sqrtf(x); }
 static inline float __saturatef(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -1400,3 +1400,31 @@ def test_harness_batched_aggregation_equals_per_tile():
     torch.cuda.synchronize()
     for t, want in zip(tiles, seq):
         assert np.array_equal(t.sgm_depth_sim.cpu().numpy(), want)
+
+
+def test_bench_rccl_path_on_one_gpu():
+    """The multi-GPU code path of bench.py — process group over RCCL (backend "nccl"), ViewExchange.setup()'s in-place all-gathers, the
+    per-step all-gather of the freshly built R pyramids on a side stream and its commit — executed with ONE rank on the one GPU of the test
+    box (`--force-dist`), so that the first 8-GPU run cannot die on API misuse.  The line must carry the exchange's stages and the same
+    depth maps as the run without a process group."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    outs = []
+    for extra in (["--force-dist"], []):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "cfg1", "--steps", "3", "--warmup", "1",
+                            "--no-cpu-baseline", "--cli-e2e", "0"] + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        outs.append(json.loads(lines[0]))
+    forced, plain = outs
+    assert forced["config"]["process_group"].startswith("nccl") and plain["config"]["process_group"] is None
+    # cfg1 has 3 views: set-up = one all-gather per row of `world` = 1 views (3), then one per step (1 warm-up + 3 timed)
+    assert forced["config"]["pyramid_exchange_collectives"] == 3 + 4 and plain["config"]["pyramid_exchange_collectives"] == 0
+    assert forced["stages_ms"]["pyramid_exchange"] > 0.0 and "pyramid_commit" in forced["stages_ms"]
+    assert "pyramid_exchange" not in plain["stages_ms"]
+    assert forced["valid_fraction"] == plain["valid_fraction"] > 0.5
+    assert forced["n_gpus"] == plain["n_gpus"] == 1 and forced["scaling"] == "weak"

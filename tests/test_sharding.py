@@ -48,12 +48,15 @@ def _worker(rank, world, port, q):
         def build(img):
             return oracle.HostPyramid(img, 1, 128, mode)
 
-        # every rank builds ONLY the views it owns; the others start as zeros of the right size
+        # every rank builds ONLY the views it owns, into its slots of the exchange arena; the others start as zeros
         nbytes = build(imgs[0]).desc.bytes
-        bufs = [torch.from_numpy(build(imgs[v]).buf.copy()) if owner_of_view(v, world) == rank else torch.zeros(nbytes, dtype=torch.uint8)
-                for v in range(V)]
-        ex = ViewExchange(bufs, rank, world, dist)
+        ex = ViewExchange(V, nbytes, rank, world, dist)
+        bufs = [ex.buffer(v) for v in range(V)]
+        for v in range(V):
+            if owner_of_view(v, world) == rank:
+                bufs[v].copy_(torch.from_numpy(build(imgs[v]).buf.copy()))
         ex.setup()
+        ok &= ex.collectives == (V + world - 1) // world  # one collective per ROW of views, not one per view
         ok &= ex.bytes_received == nbytes * sum(1 for v in range(V) if owner_of_view(v, world) != rank)
 
         def depth_map(buffers, rc):
@@ -68,11 +71,16 @@ def _worker(rank, world, port, q):
         want = depth_map([torch.from_numpy(build(imgs[v]).buf.copy()) for v in range(V)], rc)
         ok &= bool(np.array_equal(got, want)) and bool((want[..., 0] > 0).mean() > 0.3)
 
-        # steady state: every rank rebuilds the pyramid of a view it owns (a changed image); one all-gather hands it to the others
+        # steady state: every rank rebuilds the pyramid of a view it owns (a changed image); one all-gather brings the others' new pyramids
+        # into the STAGING row — the arena keeps the old bytes until commit()
         mine = cameras_of_rank(list(range(V)), rank, world)[0]
         bufs[mine].copy_(torch.from_numpy(build(imgs[mine] * np.float32(0.8)).buf))
         views = [cameras_of_rank(list(range(V)), r, world)[0] for r in range(world)]
-        ex.publish_round(views)
+        ex.publish_async(views)
+        for r, v in enumerate(views):
+            if r != rank:
+                ok &= bool(torch.equal(bufs[v], torch.from_numpy(build(imgs[v]).buf)))  # still the set-up bytes
+        ex.commit()
         for r, v in enumerate(views):
             ok &= bool(torch.equal(bufs[v], torch.from_numpy(build(imgs[v] * np.float32(0.8)).buf)))
         # the one-shot helpers
