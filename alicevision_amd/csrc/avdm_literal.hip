@@ -61,8 +61,10 @@ enum
     DEV_SHIFTED_SUMS = 1,  // NCC statistics of L(centre) - L(sample) instead of L(sample) (shift invariant; the sums no longer cancel), FMA sums, rcp / rsq finish
     DEV_MERGED_EXP = 2,    // one hardware exp2 of the summed exponents instead of two expf multiplied; hardware sqrt of the colour distances
     DEV_HOMOGENEOUS = 4,   // sample positions as h0 + a (M x d) + b (M y d) with v_rcp_f32 instead of a 3-D point through the 3 x 4 matrix and a division
-    DEV_EXACT_PIXEL = 8,   // border test and centre colour of R on the lane's own pixel instead of the re-projected patch centre
+    DEV_EXACT_PIXEL = 8,   // centre colour of R fetched at the lane's own pixel instead of the re-projected patch centre
     DEV_SHARED_R = 16,     // R side of a sample (position, taps) from the patch of plane 1 of the aligned group of four planes
+    DEV_EXACT_BORDER = 32, // rounds 1-3 only (NOT a deviation of the default kernels any more: they evaluate the reference's own test on the
+                           // knife-edge rows, avdm_similarity.hip lit::): the R-side border test on the lane's own pixel
 };
 
 struct LitArgs
@@ -90,10 +92,11 @@ __device__ float ncc_literal(const avdm_camera_t& rc, const avdm_camera_t& tc, c
     const f3 pp = T.p;
     float2 rp = project_lit(rc.P, pp);
     const float2 tp = project_lit(tc.P, pp);
+    const float2 rpB = (dev & DEV_EXACT_BORDER) ? make_float2(x, y) : rp; // the border test
     if(dev & DEV_EXACT_PIXEL)
-        rp = make_float2(x, y);
+        rp = make_float2(x, y);                                           // the centre fetch
     const float dd = (float)L.wsh + 2.0f;
-    if((rp.x < dd) || (rp.x > (L.rcW - 1.0f) - dd) || (tp.x < dd) || (tp.x > (L.tcW - 1.0f) - dd) || (rp.y < dd) || (rp.y > (L.rcH - 1.0f) - dd) ||
+    if((rpB.x < dd) || (rpB.x > (L.rcW - 1.0f) - dd) || (tp.x < dd) || (tp.x > (L.tcW - 1.0f) - dd) || (rpB.y < dd) || (rpB.y > (L.rcH - 1.0f) - dd) ||
        (tp.y < dd) || (tp.y > (L.tcH - 1.0f) - dd))
         return INFINITY;
     const float rcIW = 1.f / L.rcW, rcIH = 1.f / L.rcH, tcIW = 1.f / L.tcW, tcIH = 1.f / L.tcH;

@@ -533,9 +533,42 @@ __device__ __forceinline__ float tex_point(const float* buf, int pitch, int W, i
     return *((const float*)((const char*)buf + (long long)y * pitch) + x);
 }
 
+// AVDM_OPT_FAST=1 (compile time; A/B'd as a variant build): the colour optimisation's IEEE divisions and square roots —
+// 24 + 14 per pixel and iteration, ~10 instructions each, more than half of the kernel's ~700 — as the hardware's v_rcp_f32 / v_rsq_f32 /
+// v_sqrt_f32 (1 ulp) and its four sigmoids through v_exp_f32.  Both forms of the stage (point map / depth map) use the same helpers, so they
+// stay bit-identical to each other; against the oracle the stage is in the tolerance class either way (acosf / expf of another library).
+#ifndef AVDM_OPT_FAST
+#define AVDM_OPT_FAST 0
+#endif
+__device__ __forceinline__ float opt_rcp(float x) { return AVDM_OPT_FAST ? __builtin_amdgcn_rcpf(x) : 1.0f / x; }
+__device__ __forceinline__ float opt_div(float a, float b) { return AVDM_OPT_FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+__device__ __forceinline__ float opt_size(f3 a) { return AVDM_OPT_FAST ? __builtin_amdgcn_sqrtf(dot(a, a)) : size(a); }
+// sigmoid / sigmoid2 of avdm_device.h (matrix.cuh:334-346) with a constant width: 1 / (1 + exp(10 (x - mid) / width))
+__device__ __forceinline__ float opt_sigmoid(float zeroVal, float endVal, float sigwidth, float sigMid, float xval)
+{
+#if AVDM_OPT_FAST
+    const float k = 10.0f * 1.44269504088896340736f / sigwidth; // folded at compile time: the widths are literals
+    return zeroVal + (endVal - zeroVal) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k * (xval - sigMid)));
+#else
+    return sigmoid(zeroVal, endVal, sigwidth, sigMid, xval);
+#endif
+}
+__device__ __forceinline__ float opt_sigmoid2(float zeroVal, float endVal, float sigwidth, float sigMid, float xval)
+{
+#if AVDM_OPT_FAST
+    const float k = 10.0f * 1.44269504088896340736f / sigwidth;
+    return zeroVal + (endVal - zeroVal) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k * (sigMid - xval)));
+#else
+    return sigmoid2(zeroVal, endVal, sigwidth, sigMid, xval);
+#endif
+}
 __device__ __forceinline__ f3 normalize_exact(f3 a)
 {
+#if AVDM_OPT_FAST
+    const float dInv = __builtin_amdgcn_rsqf(dot(a, a));
+#else
     const float dInv = 1.0f / sqrtf(dot(a, a));
+#endif
     return f3{a.x * dInv, a.y * dInv, a.z * dInv};
 }
 __device__ __forceinline__ f3 point_at_depth(const avdm_camera_t& cam, float px, float py, float depth)
@@ -608,10 +641,13 @@ __global__ void __launch_bounds__(256)
             if(dB > 0.0f) { cg = cg + pB; n++; }
             if(n > 1.0f)
             {
-                cg = f3{cg.x / n, cg.y / n, cg.z / n};
+                {
+                    const float invN = opt_rcp(n); // (exact form: three divisions by n; x / n == x * (1 / n) only up to rounding, hence the switch)
+                    cg = AVDM_OPT_FAST ? f3{cg.x * invN, cg.y * invN, cg.z * invN} : f3{cg.x / n, cg.y / n, cg.z / n};
+                }
                 const f3 vcn = normalize_exact(ld3(rc.C) - p0);
                 const f3 pS = closestPointToLine3D(cg, p0, vcn);
-                smoothStep = size(ld3(rc.C) - pS) - d0;
+                smoothStep = opt_size(ld3(rc.C) - pS) - d0;
             }
             float e = 0.0f;
             n = 0.0f;
@@ -629,22 +665,22 @@ __global__ void __launch_bounds__(256)
                 energy = e;
         }
         float stepToSmoothDepth = smoothStep;
-        stepToSmoothDepth = copysignf(fminf(fabsf(stepToSmoothDepth), sgmPixSize / 10.0f), stepToSmoothDepth);
+        stepToSmoothDepth = copysignf(fminf(fabsf(stepToSmoothDepth), (AVDM_OPT_FAST ? sgmPixSize * 0.1f : sgmPixSize / 10.0f)), stepToSmoothDepth);
         const float depthEnergy = energy;
         float stepToFineDM = refineDepth - depthOpt;
-        stepToFineDM = copysignf(fminf(fabsf(stepToFineDM), sgmPixSize / 10.0f), stepToFineDM);
+        stepToFineDM = copysignf(fminf(fabsf(stepToFineDM), (AVDM_OPT_FAST ? sgmPixSize * 0.1f : sgmPixSize / 10.0f)), stepToFineDM);
         const float stepToRoughDM = sgmDepth - depthOpt;
         const float imgColorVariance = *((const float*)((const char*)imgVariance + (long long)roiY * var_pitch) + roiX);
-        const float weightedColorVariance = sigmoid2(5.0f, 30.0f, 40.0f, 20.0f, imgColorVariance);
-        const float fineSimWeight = sigmoid(0.0f, 1.0f, 0.7f, -0.7f, refineSim);
-        const float energyLowerThanVarianceWeight = sigmoid(0.0f, 1.0f, 30.0f, weightedColorVariance, depthEnergy);
-        const float closeToRoughWeight = 1.0f - sigmoid(0.0f, 1.0f, 10.0f, 17.0f, fabsf(stepToRoughDM / sgmPixSize));
+        const float weightedColorVariance = opt_sigmoid2(5.0f, 30.0f, 40.0f, 20.0f, imgColorVariance);
+        const float fineSimWeight = opt_sigmoid(0.0f, 1.0f, 0.7f, -0.7f, refineSim);
+        const float energyLowerThanVarianceWeight = opt_sigmoid(0.0f, 1.0f, 30.0f, weightedColorVariance, depthEnergy);
+        const float closeToRoughWeight = 1.0f - opt_sigmoid(0.0f, 1.0f, 10.0f, 17.0f, fabsf(opt_div(stepToRoughDM, sgmPixSize)));
         const float depthOptStep = closeToRoughWeight * stepToRoughDM +
                                    (1.0f - closeToRoughWeight) * (energyLowerThanVarianceWeight * fineSimWeight * stepToFineDM +
                                                                   (1.0f - energyLowerThanVarianceWeight) * stepToSmoothDepth);
         outDS.x = depthOpt + depthOptStep;
         outDS.y = (1.0f - closeToRoughWeight) *
-                  (energyLowerThanVarianceWeight * fineSimWeight * refineSim + (1.0f - energyLowerThanVarianceWeight) * (depthEnergy / 20.0f));
+                  (energyLowerThanVarianceWeight * fineSimWeight * refineSim + (1.0f - energyLowerThanVarianceWeight) * (AVDM_OPT_FAST ? depthEnergy * 0.05f : depthEnergy / 20.0f));
     }
     *op = outDS;
 }
@@ -734,10 +770,13 @@ __global__ void __launch_bounds__(256)
             if(dB > 0.0f) { cg = cg + pB; n++; }
             if(n > 1.0f)
             {
-                cg = f3{cg.x / n, cg.y / n, cg.z / n};
+                {
+                    const float invN = opt_rcp(n); // (exact form: three divisions by n; x / n == x * (1 / n) only up to rounding, hence the switch)
+                    cg = AVDM_OPT_FAST ? f3{cg.x * invN, cg.y * invN, cg.z * invN} : f3{cg.x / n, cg.y / n, cg.z / n};
+                }
                 const f3 vcn = normalize_exact(ld3(rc.C) - p0);
                 const f3 pS = closestPointToLine3D(cg, p0, vcn);
-                smoothStep = size(ld3(rc.C) - pS) - d0;
+                smoothStep = opt_size(ld3(rc.C) - pS) - d0;
             }
             float e = 0.0f;
             n = 0.0f;
@@ -755,22 +794,22 @@ __global__ void __launch_bounds__(256)
                 energy = e;
         }
         float stepToSmoothDepth = smoothStep;
-        stepToSmoothDepth = copysignf(fminf(fabsf(stepToSmoothDepth), sgmPixSize / 10.0f), stepToSmoothDepth);
+        stepToSmoothDepth = copysignf(fminf(fabsf(stepToSmoothDepth), (AVDM_OPT_FAST ? sgmPixSize * 0.1f : sgmPixSize / 10.0f)), stepToSmoothDepth);
         const float depthEnergy = energy;
         float stepToFineDM = refineDepth - depthOpt;
-        stepToFineDM = copysignf(fminf(fabsf(stepToFineDM), sgmPixSize / 10.0f), stepToFineDM);
+        stepToFineDM = copysignf(fminf(fabsf(stepToFineDM), (AVDM_OPT_FAST ? sgmPixSize * 0.1f : sgmPixSize / 10.0f)), stepToFineDM);
         const float stepToRoughDM = sgmDepth - depthOpt;
         const float imgColorVariance = *((const float*)((const char*)imgVariance + (long long)roiY * var_pitch) + roiX);
-        const float weightedColorVariance = sigmoid2(5.0f, 30.0f, 40.0f, 20.0f, imgColorVariance);
-        const float fineSimWeight = sigmoid(0.0f, 1.0f, 0.7f, -0.7f, refineSim);
-        const float energyLowerThanVarianceWeight = sigmoid(0.0f, 1.0f, 30.0f, weightedColorVariance, depthEnergy);
-        const float closeToRoughWeight = 1.0f - sigmoid(0.0f, 1.0f, 10.0f, 17.0f, fabsf(stepToRoughDM / sgmPixSize));
+        const float weightedColorVariance = opt_sigmoid2(5.0f, 30.0f, 40.0f, 20.0f, imgColorVariance);
+        const float fineSimWeight = opt_sigmoid(0.0f, 1.0f, 0.7f, -0.7f, refineSim);
+        const float energyLowerThanVarianceWeight = opt_sigmoid(0.0f, 1.0f, 30.0f, weightedColorVariance, depthEnergy);
+        const float closeToRoughWeight = 1.0f - opt_sigmoid(0.0f, 1.0f, 10.0f, 17.0f, fabsf(opt_div(stepToRoughDM, sgmPixSize)));
         const float depthOptStep = closeToRoughWeight * stepToRoughDM +
                                    (1.0f - closeToRoughWeight) * (energyLowerThanVarianceWeight * fineSimWeight * stepToFineDM +
                                                                   (1.0f - energyLowerThanVarianceWeight) * stepToSmoothDepth);
         outDS.x = depthOpt + depthOptStep;
         outDS.y = (1.0f - closeToRoughWeight) *
-                  (energyLowerThanVarianceWeight * fineSimWeight * refineSim + (1.0f - energyLowerThanVarianceWeight) * (depthEnergy / 20.0f));
+                  (energyLowerThanVarianceWeight * fineSimWeight * refineSim + (1.0f - energyLowerThanVarianceWeight) * (AVDM_OPT_FAST ? depthEnergy * 0.05f : depthEnergy / 20.0f));
         if(!LAST)
             outPt = opt_point(rc, fx + offx, fy + offy, outDS.x);
     }

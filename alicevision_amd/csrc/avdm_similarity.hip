@@ -75,11 +75,13 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #define AVDM_NCC_PAIR_W3_MODE 1 // 7-tap rows of the plane-pair form: 0 = 3 + 3 + 1 with fences, 1 = 4 + 3, 2 = the whole row unrolled
 #endif
 
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 // ---- per-deviation switches (compile time; every default is the product path) ---------------------------------------------------
-// The default kernels deviate from the reference's arithmetic as written in five places; each can be REVERTED on the fast LDS path in a
-// variant build (scripts/build_variant.sh <name> -DAVDM_DEV_...=1, selected with AVDM_LIB) so that the distance default <-> reference is
-// attributed deviation by deviation (scripts/deviation_report.py).  The fifth — the R side shared by the planes of a
-// pass — is the run-time switch AVDM_SIM_PLANE_PAIRS=0; the literal kernel (avdm_literal.hip) has the same five in the other direction.
+// The default kernels deviate from the reference's arithmetic as written in four places (five until round 4: the R-side border test is the
+// reference's own since then, see lit:: below); three can be REVERTED on the fast LDS path in a variant build (scripts/build_variant.sh <name>
+// -DAVDM_DEV_...=1, selected with AVDM_LIB) so that the distance default <-> reference is attributed deviation by deviation
+// (scripts/deviation_report.py).  The fourth — the R side shared by the planes of a pass — is the run-time switch
+// AVDM_SIM_PLANE_PAIRS=0; the literal kernel (avdm_literal.hip) has the same switches in the other direction.
 #ifndef AVDM_DEV_UNSHIFTED_SUMS
 #define AVDM_DEV_UNSHIFTED_SUMS 0 // 1: the six NCC sums on the UNSHIFTED L values in the reference's order and form (SimStat.cuh:72-155), no FMA contraction
 #endif
@@ -89,9 +91,30 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #ifndef AVDM_DEV_IEEE_DIV
 #define AVDM_DEV_IEEE_DIV 0 // 1: IEEE divisions where the projections use v_rcp_f32 (matrix.cuh:117-126 evaluated like the CPU pin evaluates it)
 #endif
-#ifndef AVDM_DEV_REPROJ_BORDER
-#define AVDM_DEV_REPROJ_BORDER 0 // 1: the border test of R on the RE-PROJECTED patch centre (Patch.cuh:486-496) instead of the lane's own pixel
+// ---- instruction-count experiments of the four-plane pass (compile time, A/B'd as variant builds before they become the default) ----------
+#ifndef AVDM_KNIFE_LITERAL
+#define AVDM_KNIFE_LITERAL 1 // 0: the R-side border test on the exact pixel on the knife-edge rows too (rounds 1-3; A/B of the lit:: evaluation's cost)
 #endif
+#ifndef AVDM_QUANT_MAGIC
+#define AVDM_QUANT_MAGIC 0 // 1: the 1/256 weight quantisation floor(f * 256 + 0.5) as (f * 256 + 1.5 * 2^23) - 1.5 * 2^23: two PACKED operations for
+                           // two weights instead of a packed FMA and two v_floor_f32.  Round-to-nearest-even instead of round-half-up: differs
+                           // only where f * 256 is exactly k + 0.5 (weights (k, 256 - k) vs (k + 1, 255 - k), i.e. 1/512 of a texel step).
+#endif
+#ifndef AVDM_SUMS_NO_WGR
+#define AVDM_SUMS_NO_WGR 0 // 1: the R-side sums as fma(w, dLR, .) and fma(w, dLR^2, .) with dLR^2 formed once per sample for all planes
+#endif
+__device__ __forceinline__ v2f_t quant256(v2f_t f)
+{
+#if AVDM_QUANT_MAGIC
+    const float M = 12582912.0f;
+    v2f_t t = f * 256.0f + M;
+    asm volatile("" : "+v"(t)); // keep the two roundings apart (no re-association of (x + M) - M)
+    return t - M;
+#else
+    const v2f_t v = f * 256.0f + 0.5f;
+    return v2f_t{floorf(v.x), floorf(v.y)};
+#endif
+}
 __device__ __forceinline__ float proj_rcp(float x) { return AVDM_DEV_IEEE_DIV ? 1.0f / x : fast_rcp(x); }
 // the reference's weight of one image: exp(-(dC / gammaC + dP / gammaP)) (CostYKfromLab)
 __device__ __forceinline__ float yk_weight(float dC, float dP, float invGammaC) { return expf(-(dC * invGammaC + dP)); }
@@ -118,6 +141,63 @@ struct SimStatLit
         return varXYW / sqrtf(varXW * varYW);
     }
 };
+
+// ---- knife-edge rows: the reference's R-side border test AS WRITTEN --------------------------------------------------------------------
+// The reference tests the patch centre, projected back into R, against the wsh + 2 margin (Patch.cuh:486-496).  The centre lies on the ray
+// of the lane's own pixel, so the re-projection is the pixel itself up to fp32 rounding, and the kernels test the exact pixel — EXCEPT where
+// the pixel lies exactly on the margin (x == wsh + 2 or x == W - 1 - (wsh + 2), same in y: a handful of rows / columns per image): there the
+// reference's outcome is decided by the last bit of its re-projection, per voxel, SGM then spreads it along the row, and on small images
+// those rows carried most of the untrimmed distance between the default kernels and the reference's arithmetic (profiles/r04_deviation_table.json:
+// 0.98 of it on cfg1).  On those lanes — and only there — the test is evaluated with the reference's own operations in its own order
+// (volume_computePatch / get3DPointForPixelAndFrontoParellePlaneRC / move3DPointByRcPixSize / project3DPoint: kernels.cuh:17-35, Patch.cuh:157-170,
+// matrix.cuh:66-126), IEEE division and square root, no FMA contraction: the same bits as avdm_literal.hip and as the reference's code compiled
+// for the CPU (oracle/_ref), so the validity of every voxel of a knife-edge row equals the pinned reference's.
+#pragma clang fp contract(off)
+namespace lit {
+__device__ __forceinline__ f3 nrm(f3 a)
+{
+    const float dInv = 1.0f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    return f3{a.x * dInv, a.y * dInv, a.z * dInv};
+}
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 iPmul(const float* M, float vx, float vy)
+{
+    return f3{M[0] * vx + M[3] * vy + M[6], M[1] * vx + M[4] * vy + M[7], M[2] * vx + M[5] * vy + M[8]};
+}
+__device__ __forceinline__ bool inside(const float* P, f3 V, float dd, float W1, float H1)
+{
+    const float qx = P[0] * V.x + P[3] * V.y + P[6] * V.z + P[9], qy = P[1] * V.x + P[4] * V.y + P[7] * V.z + P[10],
+                qz = P[2] * V.x + P[5] * V.y + P[8] * V.z + P[11];
+    const float inv = 1.0f / qz;
+    const float rx = qx * inv, ry = qy * inv;
+    return !((rx < dd) || (rx > W1 - dd) || (ry < dd) || (ry > H1 - dd));
+}
+// SGM: the ray of pixel (x, y) cut with the fronto-parallel plane at `depth`
+__device__ __forceinline__ bool sgm_r_inside(const avdm_camera_t& rc, float x, float y, float depth, float dd, float W1, float H1)
+{
+    const f3 C = f3{rc.C[0], rc.C[1], rc.C[2]}, Z = f3{rc.ZVect[0], rc.ZVect[1], rc.ZVect[2]};
+    const f3 planep = f3{C.x + Z.x * depth, C.y + Z.y * depth, C.z + Z.z * depth};
+    const f3 v = nrm(iPmul(rc.iP, x, y));
+    const float k = (dot3(planep, Z) - dot3(Z, C)) / dot3(Z, v); // linePlaneIntersect
+    const f3 p = f3{C.x + v.x * k, C.y + v.y * k, C.z + v.z * k};
+    return inside(rc.P, p, dd, W1, H1);
+}
+// Refine: the point at the SGM depth on the ray, moved by rel pixel sizes along it
+__device__ __forceinline__ bool refine_r_inside(const avdm_camera_t& rc, float x, float y, float depth, float pixSize, int rel, float dd, float W1, float H1)
+{
+    const f3 C = f3{rc.C[0], rc.C[1], rc.C[2]};
+    const f3 v = nrm(iPmul(rc.iP, x, y));
+    f3 p = f3{C.x + v.x * depth, C.y + v.y * depth, C.z + v.z * depth};
+    if(rel != 0)
+    {
+        const f3 d = nrm(f3{p.x - C.x, p.y - C.y, p.z - C.z});
+        const float m = (float)rel * pixSize;
+        p = f3{p.x + d.x * m, p.y + d.y * m, p.z + d.z * m};
+    }
+    return inside(rc.P, p, dd, W1, H1);
+}
+} // namespace lit
+#pragma clang fp contract(fast)
 
 struct PatchTable
 {
@@ -1039,7 +1119,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             const float rinv = proj_rcp(fmaf(fx, rax.z, rrowz));
             const v2f rXY = (fx * raS + rrow) * rinv + rO;
             const v2f rF = floor2(rXY);
-            const v2f rW = floor2((rXY - rF) * 256.0f + 0.5f);           // {A, B} of quant8(), in units of 1/256
+            const v2f rW = quant256(rXY - rF);                           // {A, B} of quant8(), in units of 1/256
             const v2f rN = rW * v2f{-1.0f, 1.0f} + v2f{256.0f, -256.0f}; // {256 - A, -(256 - B)}
             const unsigned oR = (unsigned)(int)fmaf(rF.y, Wn.rPitchBF, fmaf(rF.x, recB, Wn.rOffB));
             __builtin_assume(oR < 65536u);
@@ -1072,8 +1152,8 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             const v2f X = (fx * axS[j] + rowx[j]) * inv + A.tcOx;
             const v2f Y = (fx * ayS[j] + rowy[j]) * inv + A.tcOy;
             const v2f fX = floor2(X), fY = floor2(Y);
-            const v2f wa = floor2((X - fX) * 256.0f + 0.5f);
-            t.wb = floor2((Y - fY) * 256.0f + 0.5f);
+            const v2f wa = quant256(X - fX);
+            t.wb = quant256(Y - fY);
             const v2f na = 256.0f - wa;
             t.nnb = t.wb - 256.0f;
             const v2f oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
@@ -1113,6 +1193,9 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             const v2f qR = dRLa * dRLa;
             const float base = fmaf(__builtin_amdgcn_sqrtf(fmaf(dRb, dRb, qR.x + qR.y)), kC, -trow[xp]);
             const float dLR = dRLa.x;
+#if AVDM_SUMS_NO_WGR
+            const float dLR2 = dLR * dLR;
+#endif
 #if AVDM_DEV_TWO_EXP
             const float dPl = sqrtf((float)(xp * xp + yp * yp)) * A.invGammaP;
             const float wRl = yk_weight(sqrtf(fmaf(dRb, dRb, qR.x + qR.y)) * (1.0f / 65536.0f), dPl, A.invGammaC);
@@ -1145,6 +1228,15 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
                     lit[2 * j + 1].update(VR, VT.y, w.y);
                 }
 #endif
+#if AVDM_SUMS_NO_WGR
+                const v2f wgT = w * dL;
+                wsum[j] += w;
+                s1R[j] = w * dLR + s1R[j];
+                s1T[j] += wgT;
+                s2R[j] = w * dLR2 + s2R[j];
+                s2T[j] = wgT * dL + s2T[j];
+                sxy[j] = wgT * dLR + sxy[j];
+#else
                 const v2f wgR = w * dLR, wgT = w * dL;
                 wsum[j] += w;
                 s1R[j] += wgR;
@@ -1152,6 +1244,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
                 s2R[j] = wgR * dLR + s2R[j];
                 s2T[j] = wgT * dL + s2T[j];
                 sxy[j] = wgR * dL + sxy[j];
+#endif
             }
         };
         if(WSH == 3 && AVDM_NCC_QUAD_W3_MODE == 1)
@@ -1545,14 +1638,30 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     // projection IS (x, y); using the exact pixel makes the border test deterministic on the knife-edge rows where
     // x == wsh + 2 (DESIGN.md "knife-edge rows")
     const float dd = (float)wsh + 2.0f;
-    bool rValid = inRoi && (AVDM_DEV_REPROJ_BORDER || !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd)));
-    // AVDM_DEV_REPROJ_BORDER: the reference's border test of R, on the patch centre projected back into R (Patch.cuh:486-496), per plane
-    auto r_border_ok = [&](f3 p) __attribute__((always_inline)) -> bool {
-        if(!AVDM_DEV_REPROJ_BORDER)
-            return true;
-        const f3 q = M3x4mulV3(rc.P, p);
-        const float rpx = q.x / q.z, rpy = q.y / q.z;
-        return !((rpx < dd) || (rpx > A.rcW1 - dd) || (rpy < dd) || (rpy > A.rcH1 - dd));
+    bool rValid = inRoi && !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd));
+    // knife-edge rows / columns (my pixel lies EXACTLY wsh + 2 from an image border): the reference's own border test, per plane (lit::)
+    // — evaluated once for the planes of this workgroup, into one bit per plane, ahead of the plane loops (a wave without such a lane skips it)
+    unsigned knifeMask = 0xffffffffu;
+    {
+        const bool knife = rValid && (x == dd || x == A.rcW1 - dd || y == dd || y == A.rcH1 - dd);
+        if(AVDM_KNIFE_LITERAL && __any(knife)) // wave-uniform
+        {
+            if(knife)
+            {
+                knifeMask = 0u;
+#pragma unroll 1
+                for(unsigned k = 0; k < 4u * kSgmChunksPerWg; ++k)
+                {
+                    const unsigned vz = z0 + k;
+                    if(vz >= zBegin && vz < zEnd && lit::sgm_r_inside(rc, x, y, depths[vz], dd, A.rcW1, A.rcH1))
+                        knifeMask |= 1u << k;
+                }
+            }
+        }
+    }
+    auto r_border_ok = [&](unsigned vz) __attribute__((always_inline)) -> bool {
+        const unsigned k = vz - z0;
+        return k >= 32u || ((knifeMask >> k) & 1u) != 0u;
     };
     float4 rcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
     if(rValid)
@@ -1586,7 +1695,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         const float it0 = proj_rcp(Q.ht0.z);
         tpx = Q.ht0.x * it0;
         tpy = Q.ht0.y * it0;
-        return r_border_ok(p) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+        return r_border_ok(vz) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
     };
 
     // ONE T window for the 4 planes of the chunk (see the Refine kernel; here for both record layouts of the packed path, the centre
@@ -1742,7 +1851,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 const f3 ht0 = fma3(kk, RK.htB, RK.htA);
                 const float it0 = proj_rcp(ht0.z);
                 const float tpx = ht0.x * it0, tpy = ht0.y * it0;
-                valid = valid && r_border_ok(p) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+                valid = valid && r_border_ok(vz) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
                 laneLds = true;
                 if(valid)
                 {
@@ -1965,14 +2074,30 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     const f3 dir = normalize(pMid - C);
 
     const float dd = (float)wsh + 2.0f;
-    bool rValid = pixActive && (AVDM_DEV_REPROJ_BORDER || !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd)));
-    // AVDM_DEV_REPROJ_BORDER: the reference's border test of R, on the patch centre projected back into R (Patch.cuh:486-496), per plane
-    auto r_border_ok = [&](f3 p) __attribute__((always_inline)) -> bool {
-        if(!AVDM_DEV_REPROJ_BORDER)
-            return true;
-        const f3 q = M3x4mulV3(rc.P, p);
-        const float rpx = q.x / q.z, rpy = q.y / q.z;
-        return !((rpx < dd) || (rpx > A.rcW1 - dd) || (rpy < dd) || (rpy > A.rcH1 - dd));
+    bool rValid = pixActive && !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd));
+    // knife-edge rows / columns (my pixel lies EXACTLY wsh + 2 from an image border): the reference's own border test, per plane (lit::)
+    // — evaluated once for the planes of this workgroup, into one bit per plane, ahead of the plane loops (a wave without such a lane skips it)
+    unsigned knifeMask = 0xffffffffu;
+    {
+        const bool knife = rValid && (x == dd || x == A.rcW1 - dd || y == dd || y == A.rcH1 - dd);
+        if(AVDM_KNIFE_LITERAL && __any(knife)) // wave-uniform
+        {
+            if(knife)
+            {
+                knifeMask = 0u;
+#pragma unroll 1
+                for(unsigned k = 0; k < 8u * kRefineChunksPerWg; ++k)
+                {
+                    const unsigned vz = z0 + k;
+                    if(vz >= zBegin && vz < zEnd && lit::refine_r_inside(rc, x, y, dps.x, dps.y, (int)vz - ((volDimZ - 1) / 2), dd, A.rcW1, A.rcH1))
+                        knifeMask |= 1u << k;
+                }
+            }
+        }
+    }
+    auto r_border_ok = [&](unsigned vz) __attribute__((always_inline)) -> bool {
+        const unsigned k = vz - z0;
+        return k >= 32u || ((knifeMask >> k) & 1u) != 0u;
     };
     float4 rcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
     if(rValid)
@@ -2012,7 +2137,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         const float it0 = proj_rcp(Q.ht0.z);
         tpx = Q.ht0.x * it0;
         tpy = Q.ht0.y * it0;
-        return r_border_ok(p) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+        return r_border_ok(vz) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
     };
 
     // ---- ONE T window for all planes of the chunk (paired records) -----------------------------------------------------------------
@@ -2175,7 +2300,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 const f3 ht0 = fma3(t, RK.htB, RK.htA);
                 const float it0 = proj_rcp(ht0.z);
                 const float tpx = ht0.x * it0, tpy = ht0.y * it0;
-                valid = valid && r_border_ok(p) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
+                valid = valid && r_border_ok(vz) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
                 laneLds = true;
                 if(valid)
                 {
@@ -2511,6 +2636,8 @@ __global__ void __launch_bounds__(256)
     const f3 v = normalize(M3x3mulV2(rc.iP, x, y));
     const float dd = (float)wsh + 2.0f;
     const bool rInside = S.useCustomPatchPattern || !((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd));
+    // knife-edge rows: the reference's own border test per plane (lit::, see above); the custom pattern has its own 2-pixel margin on the exact pixel
+    const bool knife = AVDM_KNIFE_LITERAL && !S.useCustomPatchPattern && rInside && (x == dd || x == A.rcW1 - dd || y == dd || y == A.rcH1 - dd);
 
     float2 dps = make_float2(-1.f, 0.f);
     f3 pMid = C, dir = v;
@@ -2579,7 +2706,9 @@ __global__ void __launch_bounds__(256)
             const float tpx = Q.ht0.x * it0, tpy = Q.ht0.y * it0;
             if(S.useCustomPatchPattern)
                 s = ncc_custom_pattern<REFINE>(Q, A, S, rc, tc, x, y, tpx, tpy, p);
-            else if(!((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd)))
+            else if(!((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd)) &&
+                    (!knife || (REFINE ? lit::refine_r_inside(rc, x, y, dps.x, dps.y, (int)vz - ((volDimZ - 1) / 2), dd, A.rcW1, A.rcH1)
+                                       : lit::sgm_r_inside(rc, x, y, depths[REFINE ? 0 : vz], dd, A.rcW1, A.rcH1))))
             {
                 float rcLevel = S.mipmapLevel, tcLevel = S.mipmapLevel;
                 if(S.useConsistentScale)

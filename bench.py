@@ -172,7 +172,7 @@ def cli_end_to_end(sc, V, W, H, Z, T, n_cams):
     t_write = time.time() - t0
     cmd = [cli, "-i", os.path.join(d, "scene.sfm"), "--imagesFolder", os.path.join(d, "images"), "-o", os.path.join(d, "out"), "--downscale", "1", "--rangeStart", "0",
            "--rangeSize", str(n_cams), "--sgmMaxDepths", str(Z), "--maxTCams", str(T), "--sgmMaxTCamsPerTile", str(T), "--refineMaxTCamsPerTile", str(T), "-v",
-           "warning"]
+           "info"]
     t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True)
     wall = time.time() - t0
@@ -180,7 +180,18 @@ def cli_end_to_end(sc, V, W, H, Z, T, n_cams):
     shutil.rmtree(d, ignore_errors=True)
     if r.returncode != 0:
         return {"error": (r.stdout + r.stderr)[-400:]}
-    return {"value": n_cams / wall, "unit": "depth-maps/s", "cameras": n_cams, "wall_s": wall, "scene_write_s": t_write,
+    # the program's own clock (host/DepthMapEstimator.cpp: per batch — images decoded / uploaded / converted, tiles computed, maps merged and written)
+    import re
+    log = r.stdout + r.stderr
+    dec = [float(x) for x in re.findall(r"images decoded, uploaded and converted to pyramids in ([0-9.eE+-]+) s", log)]
+    comp = [float(x) for x in re.findall(r"tile\(s\) computed, ([0-9.eE+-]+) s since the batch started", log)]
+    wr = [float(x) for x in re.findall(r"maps merged and written,\s*([0-9.eE+-]+) s since the batch started", log)]
+    task = [float(x) for x in re.findall(r"Task done in \(s\): ([0-9.eE+-]+)", log)]
+    split = None
+    if dec and comp and wr:
+        split = {"decode_upload_pyramids_s": sum(dec), "tiles_s": comp[-1] - dec[-1] if len(dec) == 1 else None, "merge_write_s": wr[-1] - comp[-1] if len(dec) == 1 else None,
+                 "task_s": task[-1] if task else None, "process_start_and_scene_s": (wall - task[-1]) if task else None}
+    return {"value": n_cams / wall, "unit": "depth-maps/s", "cameras": n_cams, "wall_s": wall, "scene_write_s": t_write, "split": split,
             "includes": "process start, EXR decode of the views, upload, pyramids, default 1024 tiling (tiles batched per SGM launch), tile merge, EXR output"}
 
 
@@ -359,11 +370,15 @@ def main():
         sgm_ms_per_launch = k_ms.value / k_n.value
         achieved = alg_bytes_per_launch / (sgm_ms_per_launch * 1e-3) / 1e9
         whole_call_ms = stages["sgm_optimize"] / n_calls
-        roof = {"bound": "hbm", "kernel": "sgm_pair_kernel" if n_launches == 2 else "sgm_path_kernel", "achieved": achieved, "peak": 8000.0,
-                "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "alg_bytes_per_launch": alg_bytes_per_launch,
+        # Headline = the WHOLE avdm_volume_optimize_tiles_prepared call (HIP events around it on the launch stream: the path launches of a volume and
+        # the gaps between them; the adaptive-P2 maps are evaluated beside the similarity sweep, stage sgm_p2_map).  The kernels alone (events
+        # bound to each launch, what rocprofv3's kernel trace averages) are reported next to it as achieved_kernels_only / frac_kernels_only.
+        achieved_call = alg_bytes_per_volume / (whole_call_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "sgm_pair_kernel" if n_launches == 2 else "sgm_path_kernel", "achieved": achieved_call, "peak": 8000.0,
+                "unit": "GB/s", "frac": achieved_call / 8000.0, "achieved_kernels_only": achieved, "traffic": None, "alg_bytes_per_launch": alg_bytes_per_launch,
                 "ms_per_launch": sgm_ms_per_launch, "launches_per_volume": n_launches, "volumes_per_launch": len(vols) if batched else 1,
                 # the same bytes over the whole avdm_volume_optimize call (path launches + sgm_p2_map_kernel, whose 64 B/pixel are in the numerator)
-                "ms_whole_call_per_volume": whole_call_ms, "frac_whole_call": alg_bytes_per_volume / (whole_call_ms * 1e-3) / 1e9 / 8000.0,
+                "ms_whole_call_per_volume": whole_call_ms, "frac_whole_call": achieved_call / 8000.0,
                 "frac_kernels_only": achieved / 8000.0,
                 # per launch of a volume: [first filtering axis (paths 0 + 1), second axis (paths 2 + 3)]
                 "ms_per_launch_by_axis": [path_ms[k] / path_n[k] if path_n[k] else None for k in (0, 2)]}
@@ -416,6 +431,35 @@ def main():
         t_sgm, t_ref = stages["sgm_similarity"] * 1e-3, stages["refine_similarity"] * 1e-3
         vt_sgm, vt_ref = px_sgm * Z * T / t_sgm, px_ref * nz_ref * T / t_ref
         s_sgm, s_ref = vt_sgm * (2 * sgm.wsh + 1) ** 2, vt_ref * (2 * ref.wsh + 1) ** 2
+        # The unit that bounds the similarity kernels is VALU ISSUE: wave-instructions x 4 cycles over the SIMD-cycles of
+        # the launch.  Instruction counts and the busy / LDS-conflict fractions come from the committed PMC session of THIS kernel source
+        # (profiles/r*_sim_pmc.json, sha256-stamped like roofline.traffic); the launch durations are this run's.
+        sim_pmc = {"valu_issue_frac": None, "source": None}
+        sha_sim = hashlib.sha256(open(os.path.join(ROOT, "alicevision_amd", "csrc", "avdm_similarity.hip"), "rb").read()).hexdigest()
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sim_pmc.json")), reverse=True):
+            if not (n_side == 1 and (W, H, Z, T) == (4000, 3000, 256, 10)):
+                break
+            try:
+                rec = json.load(open(path))
+            except Exception:
+                continue
+            name = os.path.basename(path)
+            if rec.get("kernel_source_sha256") != sha_sim:
+                sim_pmc["source"] = f"profiles/{name} was measured with another csrc/avdm_similarity.hip (sha256 differs): stale, not quoted — re-run scripts/pmc_similarity.sh + scripts/collect_sim_pmc.py"
+                break
+            simd_hz = 1024 * 2.4e9  # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md); one wave64 VALU instruction = 4 cycles of a SIMD
+            out_pmc = {}
+            for key, t_stage in (("sgm", t_sgm), ("refine", t_ref)):
+                k = rec["per_kernel"][key]
+                t_launch = t_stage / T
+                out_pmc[key] = {"valu_insts_per_launch": k["SQ_INSTS_VALU"], "ms_per_launch": 1e3 * t_launch,
+                                "valu_issue_frac": k["SQ_INSTS_VALU"] * 4.0 / (simd_hz * t_launch),
+                                "valu_busy_frac_pmc": k["valu_active_per_wave"] * rec.get("waves_per_simd", 2), "lds_conflict_frac": k["lds_conflict_frac"]}
+            sim_pmc = {"valu_issue_frac": {k: v["valu_issue_frac"] for k, v in out_pmc.items()}, "per_kernel": out_pmc,
+                       "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
+                       "source": f"profiles/{name}: rocprofv3 --pmc passes (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE) of "
+                                 "one T-camera launch of each kernel, taken with this very csrc/avdm_similarity.hip (sha256 matches); durations: this run"}
+            break
         line = {
             "metric": "depth-maps/sec (12 MP, 256 depth hyp, 10 neighbours)", "value": value, "unit": "depth-maps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -430,7 +474,8 @@ def main():
             "similarity": {"sgm_voxelT_per_s": vt_sgm, "refine_voxelT_per_s": vt_ref, "sgm_samples_per_s": s_sgm, "refine_samples_per_s": s_ref,
                            "sgm_lds_GBps": s_sgm * (48.0 if os.environ.get("AVDM_SIM_PLANE_PAIRS") == "0" else 36.0) / 1e9, "refine_lds_GBps": s_ref * 64.0 / 1e9, "lds_peak_GBps": 150000.0,
                            "sgm_fp32_TFLOPs": vt_sgm * 8.1e3 / 1e12, "refine_fp32_TFLOPs": vt_ref * 4.9e3 / 1e12,
-                           "sgm_fp32_frac": vt_sgm * 8.1e3 / 157.3e12, "refine_fp32_frac": vt_ref * 4.9e3 / 157.3e12, "fp32_vector_peak_TFLOPs": 157.3},
+                           "sgm_fp32_frac": vt_sgm * 8.1e3 / 157.3e12, "refine_fp32_frac": vt_ref * 4.9e3 / 157.3e12, "fp32_vector_peak_TFLOPs": 157.3,
+                           "valu_issue_frac": sim_pmc["valu_issue_frac"], "valu_issue": sim_pmc},
             "stages_ms": stages, "valid_fraction": valid,
             # GPU time of every timed step (HIP events between the steps): shows the clock settling under sustained load
             "ms_per_step_each": [round(step_events[i].elapsed_time(step_events[i + 1]), 2) for i in range(args.steps)],

@@ -1150,7 +1150,10 @@ void avo_set_ncc_precision(int f64) { g_ncc_f64 = f64; }
  * of pixel (x, y): in exact arithmetic rp == (x, y).  Where x == wsh + 2 (or W - 1 - (wsh + 2)) the reference's outcome is a
  * coin flip of fp32 rounding, per voxel, and SGM then spreads it along whole rows (DESIGN.md "knife-edge rows").
  * avo_set_exact_rc_pixel(1) evaluates the test (and the centre fetch) on the exact pixel instead: the value the reference's
- * arithmetic approximates.  Default 0 = literal restatement. */
+ * arithmetic approximates.  avo_set_exact_rc_pixel(2) (round 4: what the GPU kernels do, and what oracle.well_posed() selects) keeps the
+ * reference's BORDER TEST on the re-projected centre — coin flips included: the kernels evaluate it with the reference's operations on the
+ * knife-edge rows, elsewhere the two tests cannot differ — and fetches the centre colour at the exact pixel (the custom patch pattern,
+ * whose margin is 2 pixels, keeps the exact pixel for both).  Default 0 = literal restatement. */
 static int g_exact_rc_pixel = 0;
 void avo_set_exact_rc_pixel(int on) { g_exact_rc_pixel = on; }
 
@@ -1160,11 +1163,13 @@ static float compNCCby3DptsYK(int invertAndFilter, const avdm_camera_t* rc, cons
                               unsigned tcLevelHeight, float mipmapLevel, int wsh, float invGammaC, float invGammaP, int useConsistentScale,
                               const Patch* patch, f2 rcPixel)
 {
-    const f2 rp = g_exact_rc_pixel ? rcPixel : project3DPoint(rc->P, patch->p);
+    const f2 rpLit = project3DPoint(rc->P, patch->p);
+    const f2 rpB = g_exact_rc_pixel == 1 ? rcPixel : rpLit; /* the border test: mode 2 keeps the reference's re-projection (its coin flip on the knife-edge rows) */
+    const f2 rp = g_exact_rc_pixel ? rcPixel : rpLit;       /* the centre fetch (and the consistent-scale levels) */
     const f2 tp = project3DPoint(tc->P, patch->p);
     const float dd = (float)wsh + 2.0f;
-    if((rp.x < dd) || (rp.x > (float)(rcLevelWidth - 1) - dd) || (tp.x < dd) || (tp.x > (float)(tcLevelWidth - 1) - dd) || (rp.y < dd) ||
-       (rp.y > (float)(rcLevelHeight - 1) - dd) || (tp.y < dd) || (tp.y > (float)(tcLevelHeight - 1) - dd))
+    if((rpB.x < dd) || (rpB.x > (float)(rcLevelWidth - 1) - dd) || (tp.x < dd) || (tp.x > (float)(tcLevelWidth - 1) - dd) || (rpB.y < dd) ||
+       (rpB.y > (float)(rcLevelHeight - 1) - dd) || (tp.y < dd) || (tp.y > (float)(tcLevelHeight - 1) - dd))
         return INFINITY;
 
     const float rcInvLevelWidth = 1.f / (float)rcLevelWidth;

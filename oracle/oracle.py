@@ -82,12 +82,18 @@ def load():
 
 
 class well_posed:
-    """Context manager: evaluate the two ill-posed spots of the reference arithmetic in their well-posed form
-    (double-precision NCC sums, exact R pixel in the border test) — see the comments in avdm_oracle.c and DESIGN.md."""
+    """Context manager: the reference's formulas with the ill-conditioned part evaluated in its well-posed form — double-precision NCC sums,
+    the R centre colour fetched at the exact pixel.  The R-side BORDER TEST stays the reference's (on the re-projected patch centre, its
+    per-voxel coin flips on the knife-edge rows included: since round 4 the GPU kernels evaluate that test with the reference's own
+    operations there).  exact_border=True is the mode of rounds 1-3 (border test on the exact pixel as well).
+    See the comments in avdm_oracle.c and DESIGN.md."""
+
+    def __init__(self, exact_border=False):
+        self.mode = 1 if exact_border else 2
 
     def __enter__(self):
         load().avo_set_ncc_precision(1)
-        load().avo_set_exact_rc_pixel(1)
+        load().avo_set_exact_rc_pixel(self.mode)
 
     def __exit__(self, *a):
         load().avo_set_ncc_precision(0)

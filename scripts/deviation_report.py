@@ -12,7 +12,7 @@ compared with
 Variants:
     default               the product kernels                         default_own_pyramids   the same on the GPU-built pyramids
     -shared_R             AVDM_SIM_PLANE_PAIRS=0: R side per plane    -dot2_taps             AVDM_SIM_PACKED=0: plain fp32 bilinear blend
-    -shifted_sums / -merged_exp / -v_rcp / -exact_border               variant builds of the FAST path with ONE deviation reverted
+    -shifted_sums / -merged_exp / -v_rcp                               variant builds of the FAST path with ONE deviation reverted
                                                                        (scripts/build_variant.sh dev_* -DAVDM_DEV_*=1), all_reverted = all of them
     literal               AVDM_SIM_LITERAL=1: the reference's arithmetic as written, on the GPU
     literal+<deviation>   AVDM_SIM_LITERAL_DEV=<bit>: the literal evaluation with ONE deviation of the default kernels introduced
@@ -46,16 +46,18 @@ VARIANTS = {
     "-shifted_sums": ("dev_unshifted", {}),
     "-merged_exp": ("dev_twoexp", {}),
     "-v_rcp": ("dev_ieeediv", {}),
-    "-exact_border": ("dev_reproj", {}),
-    "all_reverted": ("dev_all4", {"AVDM_SIM_PLANE_PAIRS": "0"}),
+    "all_reverted": ("dev_all3", {"AVDM_SIM_PLANE_PAIRS": "0"}),
     "literal": (None, {"AVDM_SIM_LITERAL": "1"}),
     "literal+shifted_sums": (None, {"AVDM_SIM_LITERAL": "1", "AVDM_SIM_LITERAL_DEV": "1"}),
     "literal+merged_exp": (None, {"AVDM_SIM_LITERAL": "1", "AVDM_SIM_LITERAL_DEV": "2"}),
     "literal+homogeneous_v_rcp": (None, {"AVDM_SIM_LITERAL": "1", "AVDM_SIM_LITERAL_DEV": "4"}),
-    "literal+exact_pixel": (None, {"AVDM_SIM_LITERAL": "1", "AVDM_SIM_LITERAL_DEV": "8"}),
+    "literal+exact_centre": (None, {"AVDM_SIM_LITERAL": "1", "AVDM_SIM_LITERAL_DEV": "8"}),
     "literal+shared_R": (None, {"AVDM_SIM_LITERAL": "1", "AVDM_SIM_LITERAL_DEV": "16"}),
     "literal+all_but_shifted_sums": (None, {"AVDM_SIM_LITERAL": "1", "AVDM_SIM_LITERAL_DEV": "30"}),
     "literal+all": (None, {"AVDM_SIM_LITERAL": "1", "AVDM_SIM_LITERAL_DEV": "31"}),
+    # rounds 1-3: the border test on the exact pixel too (no longer a deviation of the default kernels)
+    "literal+exact_border(r1-r3)": (None, {"AVDM_SIM_LITERAL": "1", "AVDM_SIM_LITERAL_DEV": "32"}),
+    "literal+all(r1-r3)": (None, {"AVDM_SIM_LITERAL": "1", "AVDM_SIM_LITERAL_DEV": "63"}),
 }
 FIELDS = ("second", "filtered", "sgm", "refvol", "refined", "final")
 

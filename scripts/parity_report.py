@@ -25,6 +25,16 @@ CASES = {
     # 512 x 512 crops of the cfg2 / cfg3 geometry: same cameras / image size / plane count, 4 T cameras
     "crop2": dict(n_views=5, W=1920, H=1080, Z=128, seed=2, roi=(704, 1216, 284, 796), sgm={}),
     "crop3": dict(n_views=5, W=4000, H=3000, Z=256, seed=3, roi=(1744, 2256, 1244, 1756), sgm={}),
+    # cfg3's REAL shape (round 4): the image corners (border rejection Patch.cuh:486-496, clamp addressing) and all 10 T cameras of the
+    # 11-view scene bench.py runs (the outer rings: baselines 2 x and 3 x the inner ring's)
+    "crop3_corner": dict(n_views=5, W=4000, H=3000, Z=256, seed=3, roi=(0, 512, 0, 512), sgm={}),
+    "crop3_far_corner": dict(n_views=5, W=4000, H=3000, Z=256, seed=3, roi=(3488, 4000, 2488, 3000), sgm={}),
+    "crop3_10T": dict(n_views=11, W=4000, H=3000, Z=256, seed=3, roi=(1744, 2256, 1244, 1756), sgm={}),
+    # two tiles of the DEFAULT tiling of a 12 MP image (mvsUtils::getTileRoiList: buffer 1024, padding 64 -> 5 x 4 tiles of 864 x 816), laid out
+    # and aggregated over the tile BUFFER like the reference (OracleDepthMap(tile_buffer=...), pinned to Sgm.cpp / Refine.cpp): tile (2, 1) in
+    # the interior and tile (4, 3) at the far image corner (800 x 744: clipped); 2 T cameras (the oracle's time goes with pixels x T cameras)
+    "tile12mp_interior": dict(n_views=3, W=4000, H=3000, Z=256, seed=3, roi=(1600, 2464, 752, 1568), sgm={}, tile_buffer=(1024, 1024)),
+    "tile12mp_corner": dict(n_views=3, W=4000, H=3000, Z=256, seed=3, roi=(3200, 4000, 2256, 3000), sgm={}, tile_buffer=(1024, 1024)),
 }
 
 
@@ -51,14 +61,15 @@ def depth_stats(got, want, pix=None):
     return out
 
 
-def gpu_run(pyr, sc, sgm, ref, roi, tcs, depths):
+def gpu_run(pyr, sc, sgm, ref, roi, tcs, depths, tile_buffer=None):
     """one tile through the C ABI: every intermediate the table compares"""
     import torch
     from alicevision_amd.pipeline import DepthMapTile
-    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=roi)
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=roi, tile_buffer=tile_buffer)
     h.run_sgm(0, tcs, depths, keep_raw=True)
     Z = len(depths)
-    g = {"second": h.second.cpu().numpy()[..., :Z], "filtered": h.best.cpu().numpy()[..., :Z], "sgm": h.sgm_depth_sim.cpu().numpy().copy()}
+    Y, X = h.sgm_depth_sim.shape[:2]  # the tile's ROI in the corner of the (buffer-sized) volumes
+    g = {"second": h.second.cpu().numpy()[:Y, :X, :Z], "filtered": h.best.cpu().numpy()[:Y, :X, :Z], "sgm": h.sgm_depth_sim.cpu().numpy().copy()}
     g["final"] = h.run_refine(0, tcs).cpu().numpy().copy()
     g["refvol"] = h.refine_volume.cpu().numpy()[..., : h.Zr].astype(np.float32)
     g["refined"] = h.refined.cpu().numpy().copy()
@@ -67,7 +78,12 @@ def gpu_run(pyr, sc, sgm, ref, roi, tcs, depths):
     return g
 
 
-def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False):
+# AVDM_SIM_LITERAL_DEV bits (csrc/avdm_literal.hip): the deviations of the default kernels, introduced into the literal evaluation one at a time
+# ("exact_border_r3": the border test on the exact pixel — a deviation of rounds 1-3 that the default kernels no longer have)
+DEVIATIONS = {"shifted_sums": 1, "merged_exp": 2, "homogeneous_v_rcp": 4, "exact_centre": 8, "shared_R": 16, "all": 31, "exact_border_r3": 32, "all_r3": 63}
+
+
+def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False, spread=False, deviations=()):
     import torch
     from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
     from oracle import oracle
@@ -84,20 +100,23 @@ def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False):
 
     pyr = [DevicePyramid(sc.images[i], 1, 128, filter_mode) for i in range(spec["n_views"])]
     Z = len(depths)
-    g = gpu_run(pyr, sc, sgm, ref, roi, tcs, depths)
+    tb = spec.get("tile_buffer")
+    okw = {"tile_buffer": tb} if tb is not None else {}
+    g = gpu_run(pyr, sc, sgm, ref, roi, tcs, depths, tb)
     g_second, g_filtered, g_sgm, g_final, g_refvol, g_refined, Zr = g["second"], g["filtered"], g["sgm"], g["final"], g["refvol"], g["refined"], g["Zr"]
     res["t_gpu_s"] = time.time() - t0
 
     o = oracle.OracleDepthMap(images_np, sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi)
+    wants = {}
     for mode in ("well_posed", "literal"):
         t1 = time.time()
         if mode == "well_posed":
             with oracle.well_posed():
-                o.run_sgm(0, tcs, depths)
-                want = o.run_refine(0, tcs).copy()
+                o.run_sgm(0, tcs, depths, **okw)
+                want = o.run_refine(0, tcs, **okw).copy()
         else:
-            o.run_sgm(0, tcs, depths)
-            want = o.run_refine(0, tcs).copy()
+            o.run_sgm(0, tcs, depths, **okw)
+            want = o.run_refine(0, tcs, **okw).copy()
         r = {}
         r["similarity_volume_levels"] = level_hist(o.second[..., :Z], g_second)
         r["sgm_filtered_volume_levels"] = level_hist(o.filtered[..., :Z], g_filtered)
@@ -115,6 +134,7 @@ def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False):
                                            "oracle": float(np.median(np.abs(want[..., 0] - gt)[both]))}
         r["t_oracle_s"] = time.time() - t1
         res[mode] = r
+        wants[mode] = (want, o.second[..., :Z].copy())
     # AVDM_SIM_LITERAL=1: the reference's similarity arithmetic as written, ON THE GPU (csrc/avdm_literal.hip), against the oracle's literal
     # mode on the oracle's own pyramids — what is left when the conditioning of the NCC sums is taken out of the comparison
     if gpu_literal:
@@ -122,7 +142,7 @@ def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False):
         opyr = [DevicePyramid.from_host_bytes(p.desc, p.buf) for p in o.pyr]
         os.environ["AVDM_SIM_LITERAL"] = "1"
         try:
-            gl = gpu_run(opyr, sc, sgm, ref, roi, tcs, depths)
+            gl = gpu_run(opyr, sc, sgm, ref, roi, tcs, depths, tb)
         finally:
             os.environ.pop("AVDM_SIM_LITERAL", None)
         d = np.abs(o.refine_volume[..., :Zr].astype(np.float32) - gl["refvol"])
@@ -132,9 +152,43 @@ def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False):
             "sgm_wta_depth_differs": float((o.sgm_depth_sim[..., 0] != gl["sgm"][..., 0]).mean()),
             "refine_volume_abs": {">2e-3": float((d > 2e-3).mean()), ">2e-2": float((d > 2e-2).mean()), "max": float(d.max())},
             "final_depth": depth_stats(gl["final"], want, o.sgm_upscaled[..., 1]), "t_s": time.time() - t1}
+    from oracle import ref as refmod
+    pix = o.sgm_upscaled[..., 1]
+    # the literal evaluation on the GPU with ONE deviation of the default kernels introduced at a time (AVDM_SIM_LITERAL_DEV): which of them
+    # carries the distance between the default kernels and the reference's arithmetic
+    if deviations:
+        opyr = [DevicePyramid.from_host_bytes(p.desc, p.buf) for p in o.pyr]
+        res["literal_plus_deviation"] = {}
+        for dname in deviations:
+            os.environ["AVDM_SIM_LITERAL"] = "1"
+            os.environ["AVDM_SIM_LITERAL_DEV"] = str(DEVIATIONS[dname])
+            try:
+                gd = gpu_run(opyr, sc, sgm, ref, roi, tcs, depths, tb)
+            finally:
+                os.environ.pop("AVDM_SIM_LITERAL", None)
+                os.environ.pop("AVDM_SIM_LITERAL_DEV", None)
+            res["literal_plus_deviation"][dname] = {
+                "vs_literal": {"final_depth": depth_stats(gd["final"], wants["literal"][0], pix), "similarity_volume_levels": level_hist(wants["literal"][1], gd["second"])},
+                "vs_well_posed": {"final_depth": depth_stats(gd["final"], wants["well_posed"][0], pix),
+                                  "similarity_volume_levels": level_hist(wants["well_posed"][1], gd["second"])}}
+    # THE REFERENCE'S OWN PLATFORM SPREAD: the same reference sources evaluated the way an nvcc build evaluates them as far as this container
+    # can tell (oracle/_ref/libavdm_ref_cuda.so: FMA contraction + the documented error model of the fast intrinsics) against their evaluation
+    # with every fp32 operation as written (= the literal oracle) — the yardstick for the default kernels' distance to either
+    if spread and refmod.available("cuda"):
+        t1 = time.time()
+        rc_ = refmod.RefDepthMap(images_np, sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi, variant="cuda")
+        if tb is None:
+            rc_.run_sgm(0, tcs, depths)
+            want_cuda = rc_.run_refine(0, tcs).copy()
+            res["platform_spread"] = {
+                "cuda_vs_literal": {"final_depth": depth_stats(want_cuda, wants["literal"][0], pix), "similarity_volume_levels": level_hist(wants["literal"][1], rc_.second[..., :Z])},
+                "cuda_vs_well_posed": {"final_depth": depth_stats(want_cuda, wants["well_posed"][0], pix)},
+                "well_posed_vs_literal": {"final_depth": depth_stats(wants["well_posed"][0], wants["literal"][0], pix),
+                                          "similarity_volume_levels": level_hist(wants["literal"][1], wants["well_posed"][1])},
+                "default_vs_cuda": {"final_depth": depth_stats(g_final, want_cuda, pix), "similarity_volume_levels": level_hist(rc_.second[..., :Z], g_second)},
+                "t_s": time.time() - t1}
     # the REFERENCE'S OWN kernels (oracle/_ref, prebuilt library travelling with the snapshot): the literal oracle must equal them bit for
     # bit, which makes the "literal" block above GPU-vs-reference-code numbers
-    from oracle import ref as refmod
     if with_ref and refmod.available():
         t1 = time.time()
         r = refmod.RefDepthMap(images_np, sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi)
@@ -158,12 +212,14 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--ref-cases", default="cfg1", help="cases also run through oracle/_ref (the reference's own kernels on the CPU)")
     ap.add_argument("--literal-cases", default="cfg1,crop2,crop3", help="cases also run with AVDM_SIM_LITERAL=1 on the GPU")
+    ap.add_argument("--spread-cases", default="", help="cases also run through oracle/_ref's CUDA-like evaluation (the reference's platform spread)")
     a = ap.parse_args()
     out = []
     for name in a.cases.split(","):
         for f in a.filters.split(","):
             mode = abi.FILTER_CUDA_FIXED8 if f == "fixed8" else abi.FILTER_EXACT
-            r = run_case(name, CASES[name], mode, with_ref=name in a.ref_cases.split(","), gpu_literal=name in a.literal_cases.split(","))
+            r = run_case(name, CASES[name], mode, with_ref=name in a.ref_cases.split(","), gpu_literal=name in a.literal_cases.split(","),
+                         spread=name in a.spread_cases.split(","))
             out.append(r)
             print(json.dumps(r), flush=True)
     if a.out:

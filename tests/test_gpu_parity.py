@@ -547,7 +547,12 @@ def test_offset_tile_equals_oracle_over_buffer_extent(mode, axes, W, H, NP, roi,
     assert both.mean() > 0.5 and ((want[..., 0] > 0) != (out[..., 0] > 0)).mean() < 5e-3
     err = (out[..., 0] - want[..., 0])[both]
     rmse = np.sqrt(np.mean(np.sort(err ** 2)[: int(0.995 * err.size)]))
-    assert rmse < 1e-3, (rmse, float(np.sqrt(np.mean(err ** 2))))
+    untrimmed = float(np.sqrt(np.mean(err ** 2)))
+    print("offset tile", roi, "rmse over the best 99.5 %%: %.3e, untrimmed: %.3e" % (rmse, untrimmed))
+    assert rmse < 1e-3, (rmse, untrimmed)
+    # untrimmed: these are 250-320-pixel images (a pixel is 1.3e-2 depth units, one plane step 1e-2): a handful of pixels whose winning plane
+    # flips carry the excess — at 12 MP the same assertion holds at 1e-3 (test_parity_of_default_tiles_at_12mp)
+    assert untrimmed < 3e-3, (rmse, untrimmed)
 
 
 def test_sgm_aggregation_tiles_batch_at_scale_bit_exact(big_pyramid):
@@ -1280,13 +1285,29 @@ def test_full_size_cfg2_sweep_only_properties():
     assert np.percentile(nearest / zplane[m][:200000], 99) < 2e-5
 
 
+_PARITY_CACHE = {}
+# cases that also go through the reference's CUDA-like evaluation (its platform spread) and the literal kernel's per-deviation switches
+_ATTRIBUTED = ("cfg1", "crop3")
+
+
 def _parity_case(name):
+    """scripts/parity_report.py's measurement of one case, once per session (several tests read it); AVDM_PARITY_DUMP=<dir> keeps the JSON"""
     _torch()
+    import json
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
-    import parity_report
-    return parity_report.run_case(name, parity_report.CASES[name], abi.FILTER_CUDA_FIXED8, with_ref=False, gpu_literal=True)
+    if name not in _PARITY_CACHE:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+        import parity_report
+        attributed = name in _ATTRIBUTED
+        _PARITY_CACHE[name] = parity_report.run_case(name, parity_report.CASES[name], abi.FILTER_CUDA_FIXED8, with_ref=False, gpu_literal=True, spread=attributed,
+                                                     deviations=tuple(parity_report.DEVIATIONS) if attributed else ())
+        d = os.environ.get("AVDM_PARITY_DUMP")
+        if d:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "parity_%s.json" % name), "w") as f:
+                json.dump(_PARITY_CACHE[name], f, indent=1)
+    return _PARITY_CACHE[name]
 
 
 def _assert_literal_on_gpu(gl):
@@ -1341,6 +1362,107 @@ def test_parity_table_crops_of_the_full_size_geometry(name):
     lv = wp["similarity_volume_levels"]
     assert lv["2"] + lv["3+"] < 2e-3 and lv["1"] < 0.05 and lv["validity_differs"] < 1e-3, lv
     _assert_literal_on_gpu(r["gpu_literal_vs_oracle_literal"])
+
+
+@pytest.mark.parametrize("name", ["crop3_corner", "crop3_far_corner", "crop3_10T"])
+def test_parity_at_the_real_shape_of_cfg3(name):
+    """BASELINE's configuration 3 at its REAL shape: the image corners of the 4000 x 3000 frame — border rejection
+    (Patch.cuh:486-496) and clamp addressing inside the tile — and all TEN T cameras of the 11-view scene bench.py runs, the outer rings
+    (2 x and 3 x the inner ring's baseline) included; 256 planes, everything on the GPU against everything in the oracle, NO trimming.
+    The bar (final depth RMSE < 1e-3) holds against both evaluations of the oracle.  In the corner crops two of the tile's borders are image
+    borders: the rows / columns where the patch centre lies exactly wsh + 2 pixels from the border are valid or not by the last bit of the
+    reference's re-projection (literal mode) — the default kernels test the exact pixel (DESIGN.md "knife-edge rows") — so the validity masks
+    may differ on those rows against the literal oracle (two of 128 SGM columns / rows), not against the well-posed one."""
+    r = _parity_case(name)
+    wp, lit = r["well_posed"], r["literal"]
+    corner = "corner" in name
+    for key, m in (("well_posed", wp), ("literal", lit)):
+        assert m["final_depth"]["rmse_untrimmed"] < 1e-3, (key, m["final_depth"])
+        assert m["final_depth"]["validity_differs"] < (0.03 if corner and key == "literal" else 1e-3), (key, m["final_depth"])
+        g = m["median_abs_vs_ground_truth"]
+        assert g["gpu"] <= 1.02 * g["oracle"] + 1e-6, (key, g)
+    lv = wp["similarity_volume_levels"]
+    assert lv["2"] + lv["3+"] < 3e-3 and lv["1"] < 0.06 and lv["validity_differs"] < 1e-3, lv
+    gl = r["gpu_literal_vs_oracle_literal"]
+    assert gl["final_depth"]["rmse_untrimmed"] < 1e-3, gl["final_depth"]
+
+
+@pytest.mark.parametrize("name", ["tile12mp_interior", "tile12mp_corner"])
+def test_parity_of_default_tiles_at_12mp(name):
+    """Two tiles of the DEFAULT tiling of a 12 MP image (mvsUtils::getTileRoiList: buffer 1024, padding 64 -> 5 x 4 tiles of 864 x 816; tile
+    (2, 1) in the interior, tile (4, 3) clipped at the far image corner), laid out and aggregated over the tile BUFFER like the reference
+    (OracleDepthMap(tile_buffer=...) is pinned to the reference's own Sgm.cpp / Refine.cpp, tests/test_oracle_ref.py): 256 planes, 2 T
+    cameras, everything on the GPU against everything in the oracle, NO trimming."""
+    r = _parity_case(name)
+    wp, lit = r["well_posed"], r["literal"]
+    corner = "corner" in name
+    for key, m in (("well_posed", wp), ("literal", lit)):
+        assert m["final_depth"]["rmse_untrimmed"] < 1e-3, (key, m["final_depth"])
+        assert m["final_depth"]["validity_differs"] < (0.03 if corner and key == "literal" else 1e-3), (key, m["final_depth"])
+    lv = wp["similarity_volume_levels"]
+    assert lv["2"] + lv["3+"] < 3e-3 and lv["1"] < 0.06 and lv["validity_differs"] < 1e-3, lv
+    assert wp["sgm_wta_depth_differs"] < 0.02, wp["sgm_wta_depth_differs"]
+
+
+@pytest.mark.parametrize("name", _ATTRIBUTED)
+def test_deviation_attribution(name):
+    """the distance between the default similarity kernels and the reference's arithmetic, measured against the
+    reference's OWN platform spread and attributed deviation by deviation (profiles/r04_deviation_table.json has all four scenes, the
+    fast-path variant builds included).
+
+    * The yardstick.  BASELINE's bar is depth RMSE vs "the reference CUDA path".  The reference's sources evaluated two equally faithful ways —
+      every fp32 operation as written (= the literal oracle, bit for bit the reference's kernels compiled for the CPU) and the way an nvcc
+      build evaluates them as far as this container can tell (oracle/_ref/libavdm_ref_cuda.so: FMA contraction, the documented error model of
+      the fast intrinsics; tests/test_platform_spread.py) — differ from EACH OTHER by X: 1.8e-3 on cfg1, 2.6e-4 on crop3 (1.3e-2 on the round-3
+      smoke scene), untrimmed, because the reference forms its NCC variance as a difference of fp32 sums of ~5e6 and decides the validity of
+      the rows next to the image border by the last bit of a re-projection.
+    * The default kernels are within 1.6 X of EITHER evaluation (measured 1.46 / 1.30 on cfg1, 0.96 / 1.02 on crop3), and nearer to the
+      well-posed value both approximate than either of them is.
+    * The literal arithmetic on the GPU with ONE deviation of the default kernels switched on (AVDM_SIM_LITERAL_DEV):
+        crop3 (no image border in the tile): EVERY single deviation — shifted sums, one merged exp2, homogeneous projection + v_rcp, R side
+        shared by four planes — moves the literal evaluation by ~0.9-1.0 of the full distance: the ill-conditioned sums decorrelate under
+        any perturbation, the distances do not add; the exact-pixel border test changes nothing there;
+        cfg1 (the tile is the image): the exact-pixel border test ALONE carries 0.98 of the distance (the knife-edge rows), each of the
+        others stays at 0.26-0.34 of it;
+      all five together reproduce the default kernels (within 1e-3 of the well-posed oracle, volumes identical on > 95 % of the voxels)."""
+    r = _parity_case(name)
+    if "platform_spread" not in r:
+        pytest.skip("oracle/_ref/libavdm_ref_cuda.so did not travel")
+    sp, dev = r["platform_spread"], r["literal_plus_deviation"]
+    rm = lambda m: m["final_depth"]["rmse_untrimmed"]
+    X = rm(sp["cuda_vs_literal"])
+    d_lit, d_wp, d_cuda = rm(r["literal"]), rm(r["well_posed"]), rm(sp["default_vs_cuda"])
+    floor = rm(r["gpu_literal_vs_oracle_literal"])
+    info = {"X": X, "default_vs_literal": d_lit, "default_vs_cuda": d_cuda, "default_vs_well_posed": d_wp, "literal_gpu_vs_literal": floor,
+            "literal_plus": {k: rm(v["vs_literal"]) for k, v in dev.items()}}
+    print(name, info)
+    # two faithful evaluations of the reference differ by far more than its literal arithmetic differs between the CPU and the GPU
+    assert X > 2.0 * floor and floor < 1e-3, info
+    # the default kernels: within the reference's own spread of both evaluations ...
+    assert d_lit <= 1.6 * X and d_cuda <= 1.6 * X, info
+    t_lit, t_X = r["literal"]["final_depth"]["rmse_best_99.5pct"], sp["cuda_vs_literal"]["final_depth"]["rmse_best_99.5pct"]
+    assert t_lit <= 1.25 * t_X, (t_lit, t_X)
+    # ... and nearer to the value both approximate than either of them
+    assert d_wp < 1e-3 and d_wp < 0.55 * min(rm(sp["well_posed_vs_literal"]), rm(sp["cuda_vs_well_posed"])), info
+    # volumes: the two evaluations of the reference agree on fewer voxels with each other than the default kernels do with the well-posed oracle
+    assert sp["cuda_vs_literal"]["similarity_volume_levels"]["0"] < 0.85 < r["well_posed"]["similarity_volume_levels"]["0"]
+    # attribution
+    full = rm(dev["all"]["vs_literal"])
+    assert abs(full - d_lit) < 0.15 * d_lit + 5e-5, info  # the default's four deviations switched on in the literal kernel: as far from the reference as the default kernels
+    assert rm(dev["all"]["vs_well_posed"]) < 1e-3 and dev["all"]["vs_well_posed"]["similarity_volume_levels"]["0"] > 0.95, dev["all"]["vs_well_posed"]
+    others = ("shifted_sums", "merged_exp", "homogeneous_v_rcp", "shared_R")
+    if name == "crop3":
+        # no image border in the tile: neither the exact-pixel border test of rounds 1-3 nor ... changes a bit
+        assert abs(rm(dev["exact_border_r3"]["vs_literal"]) - floor) < 1e-9, info
+        for k in others:
+            assert rm(dev[k]["vs_literal"]) > 0.7 * full, (k, info)
+    else:
+        # the tile is the image: what rounds 1-3 carried on the knife-edge rows, and what is left of it
+        assert rm(dev["exact_border_r3"]["vs_literal"]) > 2.0e-3, info
+        assert d_lit < 0.6 * rm(dev["all_r3"]["vs_literal"]), info
+    # the sums alone are what makes the VOLUMES differ: with shifted sums the literal kernel's volume is the well-posed oracle's
+    assert dev["shifted_sums"]["vs_well_posed"]["similarity_volume_levels"]["0"] > 0.98
+    assert dev["shifted_sums"]["vs_literal"]["similarity_volume_levels"]["0"] < 0.65
 
 
 def test_full_size_cfg2_sweep_against_the_oracle():
@@ -1428,3 +1550,82 @@ def test_bench_rccl_path_on_one_gpu():
     assert "pyramid_exchange" not in plain["stages_ms"]
     assert forced["valid_fraction"] == plain["valid_fraction"] > 0.5
     assert forced["n_gpus"] == plain["n_gpus"] == 1 and forced["scaling"] == "weak"
+
+
+# ---- the switch matrix: every non-default AVDM_* code-path switch still passes its parity class ------------------------
+# DESIGN.md section 4.5 leans on these switches as A/B references; a switch that rots silently would take its A/B with it.
+_SIM_SWITCHES = [("AVDM_SIM_PLANE_PAIRS", "0"), ("AVDM_SIM_CHUNK_WINDOW", "0"), ("AVDM_SIM_PACKED", "0"), ("AVDM_SIM_PAIRED", "0"), ("AVDM_SIM_REC12", "0"),
+                 ("AVDM_SIM_SPLIT", "1"), ("AVDM_SIM_LDS", "0"), ("AVDM_SIM_STATS", "1")]                       # tolerance class (similarity arithmetic)
+_EXACT_SWITCHES = [("AVDM_SGM_PAIR", "0"), ("AVDM_SGM_INT16", "0"), ("AVDM_SGM_PREPARE", "0"), ("AVDM_OPT_DEPTH_MAP_FORM", "1")]  # bit-exact class
+_STATIC_SWITCHES = [("AVDM_SGM_P2_MAP", "legacy"), ("AVDM_SGM_TIMER", "record")]                                # read once per process: own process
+
+
+def _switch_run(o, sc, sgm, ref, depths):
+    """one tile through every stage on the ORACLE's pyramids; (second-best volume, aggregated volume, final map)"""
+    torch = _torch()
+    h = make_hip_from_oracle(o, sc, sgm, ref)
+    h.run_sgm(0, [1, 2], depths, keep_raw=True)
+    Z = len(depths)
+    second, filtered = h.second.cpu().numpy()[..., :Z].copy(), h.best.cpu().numpy()[..., :Z].copy()
+    final = h.run_refine(0, [1, 2]).cpu().numpy().copy()
+    torch.cuda.synchronize()
+    return second, filtered, final
+
+
+@pytest.fixture(scope="module")
+def switch_baseline(case):
+    sc, sgm, ref, depths, o = case
+    for var, _ in _SIM_SWITCHES + _EXACT_SWITCHES + _STATIC_SWITCHES:
+        assert var not in os.environ, var + " is set in the test environment"
+    return _switch_run(o, sc, sgm, ref, depths)
+
+
+@pytest.mark.parametrize("var,val", _SIM_SWITCHES + _EXACT_SWITCHES)
+def test_switch_matrix(case, switch_baseline, var, val):
+    sc, sgm, ref, depths, o = case
+    Z = len(depths)
+    base_second, base_filtered, base_final = switch_baseline
+    os.environ[var] = val
+    try:
+        second, filtered, final = _switch_run(o, sc, sgm, ref, depths)
+    finally:
+        os.environ.pop(var, None)
+    if (var, val) in _EXACT_SWITCHES:
+        # the switch selects another FORM of a bit-exact stage: the same bytes end to end
+        assert np.array_equal(second, base_second) and np.array_equal(filtered, base_filtered), (var, level_mismatch(filtered, base_filtered))
+        assert np.array_equal(final, base_final), var
+        return
+    # a switch of the similarity kernels: the tolerance class of test_similarity_volume_parity against the well-posed oracle ...
+    want = o.second[..., :Z]
+    frac, mx = level_mismatch(want, second)
+    d = np.abs(want.astype(np.int16) - second.astype(np.int16))
+    assert frac <= 0.03 and (d > 1).mean() <= 2e-3 and ((want == 255) != (second == 255)).mean() <= 2e-3, (var, frac, mx, float((d > 1).mean()))
+    # ... the form actually changed something or is a pure instrumentation switch, and the depth map stays within the end-to-end class
+    both = (final[..., 0] > 0) & (o.optimized[..., 0] > 0)
+    assert both.mean() > 0.5 and ((final[..., 0] > 0) != (o.optimized[..., 0] > 0)).mean() < 5e-3
+    err = np.sort((final[..., 0] - o.optimized[..., 0])[both] ** 2)
+    assert np.sqrt(err[: int(0.995 * err.size)].mean()) < 1e-3, (var, float(np.sqrt(err.mean())))
+    fracb, _ = level_mismatch(base_second, second)
+    assert fracb < 0.02, (var, fracb)
+
+
+@pytest.mark.parametrize("var,val", _STATIC_SWITCHES)
+def test_switch_matrix_static(case, switch_baseline, var, val):
+    """switches the library reads once per process: the same tile in a process of its own, compared by digest"""
+    import hashlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib, ctypes; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from alicevision_amd import abi\n"
+            "from common import small_case, make_oracle\n"
+            "from test_gpu_parity import _switch_run\n"
+            "lib = abi.load(); lib.avdm_debug_sgm_kernel_timing.argtypes = [ctypes.c_int]; lib.avdm_debug_sgm_kernel_timing(1)\n"
+            "sc, sgm, ref, depths = small_case(); o = make_oracle(sc, sgm, ref)\n"
+            "print('DIGEST', ' '.join(hashlib.sha256(a.tobytes()).hexdigest() for a in _switch_run(o, sc, sgm, ref, depths)))\n") % (root, os.path.join(root, "tests"))
+    env = dict(os.environ)
+    env[var] = val
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    got = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0].split()[1:]
+    assert got == [hashlib.sha256(a.tobytes()).hexdigest() for a in switch_baseline], var

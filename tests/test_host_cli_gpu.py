@@ -241,14 +241,19 @@ def test_tiled_run_equals_harness_and_oracle_per_tile(dataset):
     both = (wd > 0) & (depth > 0)
     assert ((wd > 0) != (depth > 0)).mean() < 0.005
     err = np.sort((depth - wd)[both] ** 2)
-    rmse = float(np.sqrt(err[: int(0.995 * err.size)].mean()))
-    assert rmse < 1e-3, (rmse, float(np.sqrt(err.mean())))
+    rmse, untrimmed = float(np.sqrt(err[: int(0.995 * err.size)].mean())), float(np.sqrt(err.mean()))
+    print("merged map: rmse over the best 99.5 %%: %.3e, untrimmed: %.3e" % (rmse, untrimmed))
+    assert rmse < 1e-3, (rmse, untrimmed)
+    # untrimmed as well: an ~800-pixel image (one plane step is ~1e-2 depth units); at 12 MP the default tiles meet 1e-3 untrimmed
+    # (tests/test_gpu_parity.py::test_parity_of_default_tiles_at_12mp)
+    assert untrimmed < 3e-3, (rmse, untrimmed)
     # per tile, offset tiles on their own (no merge in between)
     for g, w, roi in zip(got_final, want_final, rois):
         m = (g[..., 0] > 0) & (w[..., 0] > 0)
         e = np.sort((g[..., 0] - w[..., 0])[m] ** 2)
-        r = float(np.sqrt(e[: int(0.995 * e.size)].mean()))
-        assert r < 1e-3, (roi, r)
+        r, ru = float(np.sqrt(e[: int(0.995 * e.size)].mean())), float(np.sqrt(e.mean()))
+        print("tile", roi, "rmse over the best 99.5 %%: %.3e, untrimmed: %.3e" % (r, ru))
+        assert r < 1e-3 and ru < 3e-3, (roi, r, ru)
 
 
 def test_cli_fails_loudly_without_inputs(dataset):
