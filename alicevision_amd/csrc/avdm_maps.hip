@@ -533,12 +533,14 @@ __device__ __forceinline__ float tex_point(const float* buf, int pitch, int W, i
     return *((const float*)((const char*)buf + (long long)y * pitch) + x);
 }
 
-// AVDM_OPT_FAST=1 (compile time; A/B'd as a variant build): the colour optimisation's IEEE divisions and square roots —
-// 24 + 14 per pixel and iteration, ~10 instructions each, more than half of the kernel's ~700 — as the hardware's v_rcp_f32 / v_rsq_f32 /
-// v_sqrt_f32 (1 ulp) and its four sigmoids through v_exp_f32.  Both forms of the stage (point map / depth map) use the same helpers, so they
-// stay bit-identical to each other; against the oracle the stage is in the tolerance class either way (acosf / expf of another library).
+// AVDM_OPT_FAST=1 (compile time, the default since round 4; 0 = the IEEE form of rounds 1-3 for an A/B): the colour
+// optimisation's IEEE divisions and square roots — 24 + 14 per pixel and iteration, ~10 instructions each, more than half of the kernel's 943
+// VALU instructions — as the hardware's v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp) and its four sigmoids through v_exp_f32: 559 instructions,
+// 20.7 -> 14 ms per 12 MP depth map (profiles/r04_e_ab.txt).  The two unit vectors of the smoothness angle keep the IEEE form (see
+// angleBetwABandAC).  Both forms of the stage (point map / depth map) use the same helpers, so they stay bit-identical to each other; against the
+// oracle the stage is in the tolerance class either way (acosf / expf of another library).
 #ifndef AVDM_OPT_FAST
-#define AVDM_OPT_FAST 0
+#define AVDM_OPT_FAST 1
 #endif
 __device__ __forceinline__ float opt_rcp(float x) { return AVDM_OPT_FAST ? __builtin_amdgcn_rcpf(x) : 1.0f / x; }
 __device__ __forceinline__ float opt_div(float a, float b) { return AVDM_OPT_FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
@@ -562,14 +564,19 @@ __device__ __forceinline__ float opt_sigmoid2(float zeroVal, float endVal, float
     return sigmoid2(zeroVal, endVal, sigwidth, sigMid, xval);
 #endif
 }
+__device__ __forceinline__ f3 normalize_ieee(f3 a)
+{
+    const float dInv = 1.0f / sqrtf(dot(a, a));
+    return f3{a.x * dInv, a.y * dInv, a.z * dInv};
+}
 __device__ __forceinline__ f3 normalize_exact(f3 a)
 {
 #if AVDM_OPT_FAST
     const float dInv = __builtin_amdgcn_rsqf(dot(a, a));
-#else
-    const float dInv = 1.0f / sqrtf(dot(a, a));
-#endif
     return f3{a.x * dInv, a.y * dInv, a.z * dInv};
+#else
+    return normalize_ieee(a);
+#endif
 }
 __device__ __forceinline__ f3 point_at_depth(const avdm_camera_t& cam, float px, float py, float depth)
 {
@@ -578,6 +585,10 @@ __device__ __forceinline__ f3 point_at_depth(const avdm_camera_t& cam, float px,
 }
 __device__ __forceinline__ float angleBetwABandAC(f3 A, f3 B, f3 C)
 {
+    // (measured, r04_f: IEEE unit vectors here cost 2.4 ms per 12 MP depth map and change nothing — |d sim| max 1.19e-2 against the oracle
+    // either way: for a neighbourhood 0.5 degrees from flat the last bit of the two vectors moves the energy by 8e-4 degrees, 4e-5 in the
+    // similarity; for a flatter one the fp32 dot product itself cannot resolve 1 - |cos| and the energy is rounding noise in ANY fp32
+    // evaluation, the reference's included)
     const f3 V1 = normalize_exact(B - A);
     const f3 V2 = normalize_exact(C - A);
     // The reference evaluates acos in double precision (matrix.cuh:306-322: the fp32 dot product converted, `acos`, then back to float).

@@ -91,23 +91,30 @@ typedef float v2f_t __attribute__((ext_vector_type(2)));
 #ifndef AVDM_DEV_IEEE_DIV
 #define AVDM_DEV_IEEE_DIV 0 // 1: IEEE divisions where the projections use v_rcp_f32 (matrix.cuh:117-126 evaluated like the CPU pin evaluates it)
 #endif
-// ---- instruction-count experiments of the four-plane pass (compile time, A/B'd as variant builds before they become the default) ----------
+// ---- forms of the four-plane pass that were A/B'd as variant builds (compile time; 0 restores the round-3 form for an A/B) ------------------
+// profiles/r04_e_ab.txt, same box, 11 steps: 563.9 ms per depth map -> 551.1 with AVDM_QUANT_MAGIC + AVDM_SUMS_NO_WGR (SGM similarity 249.7 -> 245.5,
+// Refine 287.5 -> 279.0: 541 -> 518 and 1338 -> 1284 VALU instructions per twelve / 28 plane-samples of the loop body); the knife-edge
+// evaluation costs 563.9 against 558.0 without it (AVDM_KNIFE_LITERAL=0: one more live register in the set-up blocks of the SGM kernel).
 #ifndef AVDM_KNIFE_LITERAL
 #define AVDM_KNIFE_LITERAL 1 // 0: the R-side border test on the exact pixel on the knife-edge rows too (rounds 1-3; A/B of the lit:: evaluation's cost)
 #endif
 #ifndef AVDM_QUANT_MAGIC
-#define AVDM_QUANT_MAGIC 0 // 1: the 1/256 weight quantisation floor(f * 256 + 0.5) as (f * 256 + 1.5 * 2^23) - 1.5 * 2^23: two PACKED operations for
-                           // two weights instead of a packed FMA and two v_floor_f32.  Round-to-nearest-even instead of round-half-up: differs
-                           // only where f * 256 is exactly k + 0.5 (weights (k, 256 - k) vs (k + 1, 255 - k), i.e. 1/512 of a texel step).
+#define AVDM_QUANT_MAGIC 1 // 1: the 1/256 weight quantisation floor(f * 256 + 0.5) as fma(f, 256 + 2^-14, 1.5 * 2^23) - 1.5 * 2^23: two PACKED
+                           // operations for two weights instead of a packed FMA and two v_floor_f32.  The add rounds to nearest EVEN where
+                           // floor(. + 0.5) rounds half UP, and exact halves are common — a texel coordinate near 2000 is a multiple of
+                           // 2^-13, so f * 256 is a multiple of 1/32 and one weight in 32 is a tie (r04_f: the plain magic add moved the
+                           // similarity volume of the far image corner from 94.4 % to 93.5 % identical voxels).  The 2^-14 in the
+                           // multiplier lifts every tie k + 0.5 by (k + 0.5) 2^-22 inside the ONE rounding of the FMA: round half up again;
+                           // a value is lifted across a tie wrongly only within 6e-5 below it, finer than the coordinate grid for x >= 4.
 #endif
 #ifndef AVDM_SUMS_NO_WGR
-#define AVDM_SUMS_NO_WGR 0 // 1: the R-side sums as fma(w, dLR, .) and fma(w, dLR^2, .) with dLR^2 formed once per sample for all planes
+#define AVDM_SUMS_NO_WGR 1 // 1: the R-side sums as fma(w, dLR, .) and fma(w, dLR^2, .) with dLR^2 formed once per sample for all planes
 #endif
 __device__ __forceinline__ v2f_t quant256(v2f_t f)
 {
 #if AVDM_QUANT_MAGIC
     const float M = 12582912.0f;
-    v2f_t t = f * 256.0f + M;
+    v2f_t t = f * 256.00006103515625f + M; // 256 + 2^-14 (exact in fp32)
     asm volatile("" : "+v"(t)); // keep the two roundings apart (no re-association of (x + M) - M)
     return t - M;
 #else

@@ -183,14 +183,20 @@ def cli_end_to_end(sc, V, W, H, Z, T, n_cams):
     # the program's own clock (host/DepthMapEstimator.cpp: per batch — images decoded / uploaded / converted, tiles computed, maps merged and written)
     import re
     log = r.stdout + r.stderr
-    dec = [float(x) for x in re.findall(r"images decoded, uploaded and converted to pyramids in ([0-9.eE+-]+) s", log)]
-    comp = [float(x) for x in re.findall(r"tile\(s\) computed, ([0-9.eE+-]+) s since the batch started", log)]
-    wr = [float(x) for x in re.findall(r"maps merged and written,\s*([0-9.eE+-]+) s since the batch started", log)]
-    task = [float(x) for x in re.findall(r"Task done in \(s\): ([0-9.eE+-]+)", log)]
+    num = r"([0-9.eE+-]+)"
+    dec = {int(b): float(x) for b, x in re.findall(r"Batch (\d+)/\d+: images decoded, uploaded and converted to pyramids in " + num + " s", log)}
+    comp = {}
+    for b, x in re.findall(r"Batch (\d+)/\d+: \d+ tile\(s\) computed, " + num + " s since the batch started", log):
+        comp[int(b)] = max(comp.get(int(b), 0.0), float(x))
+    wr = {int(b): float(x) for b, x in re.findall(r"Batch (\d+)/\d+: depth / similarity maps merged and written,\s*" + num + " s since the batch started", log)}
+    task = [float(x) for x in re.findall(r"Task done in \(s\): " + num, log)]
     split = None
-    if dec and comp and wr:
-        split = {"decode_upload_pyramids_s": sum(dec), "tiles_s": comp[-1] - dec[-1] if len(dec) == 1 else None, "merge_write_s": wr[-1] - comp[-1] if len(dec) == 1 else None,
-                 "task_s": task[-1] if task else None, "process_start_and_scene_s": (wall - task[-1]) if task else None}
+    if dec and set(dec) == set(comp):
+        # per batch: decode + upload + pyramids, then the tiles (every stage of every tile, results copied back), then merge + EXR output — the
+        # output of a batch runs in the background beside the next batch's tiles, so only its tail after the last tile is on the critical path
+        split = {"batches": len(dec), "decode_upload_pyramids_s": sum(dec.values()), "tiles_s": sum(comp[b] - dec[b] for b in dec),
+                 "merge_write_tail_s": sum(max(wr[b] - comp[b], 0.0) for b in wr if b in comp), "task_s": task[-1] if task else None,
+                 "process_start_and_scene_s": (wall - task[-1]) if task else None}
     return {"value": n_cams / wall, "unit": "depth-maps/s", "cameras": n_cams, "wall_s": wall, "scene_write_s": t_write, "split": split,
             "includes": "process start, EXR decode of the views, upload, pyramids, default 1024 tiling (tiles batched per SGM launch), tile merge, EXR output"}
 
