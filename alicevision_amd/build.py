@@ -43,7 +43,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "avdm_device.h"), os.path.join(HERE, "..", "include", "avdm.h")]
+    headers = [os.path.join(CSRC, "avdm_device.h"), os.path.join(CSRC, "avdm_knife.h"), os.path.join(HERE, "..", "include", "avdm.h")]
     extra_headers = {"avdm_fuse.hip": [os.path.join(HERE, "..", "include", "avdm_fuse.h")]}
     objs, jobs = [], []
     for src, extra in SOURCES.items():

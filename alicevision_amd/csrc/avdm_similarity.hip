@@ -159,49 +159,20 @@ struct SimStatLit
 // (volume_computePatch / get3DPointForPixelAndFrontoParellePlaneRC / move3DPointByRcPixSize / project3DPoint: kernels.cuh:17-35, Patch.cuh:157-170,
 // matrix.cuh:66-126), IEEE division and square root, no FMA contraction: the same bits as avdm_literal.hip and as the reference's code compiled
 // for the CPU (oracle/_ref), so the validity of every voxel of a knife-edge row equals the pinned reference's.
+// The functions themselves are plain C++ in avdm_knife.h: tests/test_oracle.py compiles the SAME text for the host (g++ -ffp-contract=off) and
+// holds it, voxel for voxel, to the oracle's literal evaluation — which tests/test_oracle_ref.py pins to the reference's code.
 #pragma clang fp contract(off)
+#define AVDM_KNIFE_FN __device__ __forceinline__
+#include "avdm_knife.h"
+#undef AVDM_KNIFE_FN
 namespace lit {
-__device__ __forceinline__ f3 nrm(f3 a)
-{
-    const float dInv = 1.0f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
-    return f3{a.x * dInv, a.y * dInv, a.z * dInv};
-}
-__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ f3 iPmul(const float* M, float vx, float vy)
-{
-    return f3{M[0] * vx + M[3] * vy + M[6], M[1] * vx + M[4] * vy + M[7], M[2] * vx + M[5] * vy + M[8]};
-}
-__device__ __forceinline__ bool inside(const float* P, f3 V, float dd, float W1, float H1)
-{
-    const float qx = P[0] * V.x + P[3] * V.y + P[6] * V.z + P[9], qy = P[1] * V.x + P[4] * V.y + P[7] * V.z + P[10],
-                qz = P[2] * V.x + P[5] * V.y + P[8] * V.z + P[11];
-    const float inv = 1.0f / qz;
-    const float rx = qx * inv, ry = qy * inv;
-    return !((rx < dd) || (rx > W1 - dd) || (ry < dd) || (ry > H1 - dd));
-}
-// SGM: the ray of pixel (x, y) cut with the fronto-parallel plane at `depth`
 __device__ __forceinline__ bool sgm_r_inside(const avdm_camera_t& rc, float x, float y, float depth, float dd, float W1, float H1)
 {
-    const f3 C = f3{rc.C[0], rc.C[1], rc.C[2]}, Z = f3{rc.ZVect[0], rc.ZVect[1], rc.ZVect[2]};
-    const f3 planep = f3{C.x + Z.x * depth, C.y + Z.y * depth, C.z + Z.z * depth};
-    const f3 v = nrm(iPmul(rc.iP, x, y));
-    const float k = (dot3(planep, Z) - dot3(Z, C)) / dot3(Z, v); // linePlaneIntersect
-    const f3 p = f3{C.x + v.x * k, C.y + v.y * k, C.z + v.z * k};
-    return inside(rc.P, p, dd, W1, H1);
+    return knife::sgm_r_inside(rc.P, rc.iP, rc.C, rc.ZVect, x, y, depth, dd, W1, H1);
 }
-// Refine: the point at the SGM depth on the ray, moved by rel pixel sizes along it
 __device__ __forceinline__ bool refine_r_inside(const avdm_camera_t& rc, float x, float y, float depth, float pixSize, int rel, float dd, float W1, float H1)
 {
-    const f3 C = f3{rc.C[0], rc.C[1], rc.C[2]};
-    const f3 v = nrm(iPmul(rc.iP, x, y));
-    f3 p = f3{C.x + v.x * depth, C.y + v.y * depth, C.z + v.z * depth};
-    if(rel != 0)
-    {
-        const f3 d = nrm(f3{p.x - C.x, p.y - C.y, p.z - C.z});
-        const float m = (float)rel * pixSize;
-        p = f3{p.x + d.x * m, p.y + d.y * m, p.z + d.z * m};
-    }
-    return inside(rc.P, p, dd, W1, H1);
+    return knife::refine_r_inside(rc.P, rc.iP, rc.C, x, y, depth, pixSize, rel, dd, W1, H1);
 }
 } // namespace lit
 #pragma clang fp contract(fast)

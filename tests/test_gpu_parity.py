@@ -1345,6 +1345,8 @@ def test_parity_table_cfg1():
     assert lit["final_depth"]["rmse_best_99.5pct"] < 1e-3, lit["final_depth"]
     assert lit["final_depth"]["rmse_untrimmed"] < 1e-3, lit["final_depth"]  # 6.7e-4 since the knife-edge rows run the reference's own border test (2.6e-3 in rounds 2-3)
     assert lit["final_depth"]["validity_differs"] < 2e-3
+    # the whole image is one tile: knife-edge rows on all four borders, and the validity mask of the similarity volume equals the reference code's
+    assert lit["similarity_volume_levels"]["validity_differs"] == 0.0, lit["similarity_volume_levels"]
     g = lit["median_abs_vs_ground_truth"]
     assert g["gpu"] <= 1.02 * g["oracle"] + 1e-6, g
     _assert_literal_on_gpu(r["gpu_literal_vs_oracle_literal"])
@@ -1389,6 +1391,10 @@ def test_parity_at_the_real_shape_of_cfg3(name):
     assert lv["2"] + lv["3+"] < 3e-3 and lv["1"] < 0.06 and lv["validity_differs"] < 1e-3, lv
     gl = r["gpu_literal_vs_oracle_literal"]
     assert gl["final_depth"]["rmse_untrimmed"] < 1e-3, gl["final_depth"]
+    # the knife-edge rows of the SGM stage (crop3_corner: stage column / row 3): the default kernels evaluate the reference's own border test
+    # there (avdm_similarity.hip lit::) — the validity of EVERY voxel of the similarity volume equals the reference code's (1.2 % of the
+    # voxels differed in rounds 1-3, when the kernels tested the exact pixel)
+    assert lit["similarity_volume_levels"]["validity_differs"] == 0.0, lit["similarity_volume_levels"]
 
 
 @pytest.mark.parametrize("name", ["tile12mp_interior", "tile12mp_corner"])
@@ -1401,10 +1407,9 @@ def test_parity_of_default_tiles_at_12mp(name):
     wp, lit = r["well_posed"], r["literal"]
     corner = "corner" in name
     for key, m in (("well_posed", wp), ("literal", lit)):
-        # the corner tile against the LITERAL oracle: its Refine stage has knife-edge rows (x = 3994, y = 2994: exactly wsh + 2 from the border),
-        # whose validity the reference decides per voxel from the last bit of a re-projection of the SGM depth — the kernels evaluate the same
-        # test with the same operations, but where the SGM depths of the two runs differ (different evaluations of the ill-conditioned sums
-        # upstream) the coin falls differently: 0.8 % of the tile's pixels move by more than 1e-3 (1.24e-3 untrimmed, 1.3e-4 over the best 99.5 %)
+        # the corner tile against the LITERAL oracle: 1.24e-3 untrimmed, 1.3e-4 over the best 99.5 %, identical validity masks, the literal
+        # arithmetic on the GPU at 6.6e-5.  Located oracle against oracle on the CPU: TWO SGM pixels of 43 000 whose winner-take-all plane flips
+        # between near-equal minima 30 planes apart — 36 full-size pixels carry the excess, 2.0e-4 without them
         bar = 2e-3 if corner and key == "literal" else 1e-3
         assert m["final_depth"]["rmse_untrimmed"] < bar, (key, m["final_depth"])
         assert m["final_depth"]["rmse_best_99.5pct"] < 3e-4, (key, m["final_depth"])
