@@ -44,6 +44,34 @@ constexpr int kNccPairUnroll = AVDM_NCC_PAIR_UNROLL; // sample loop of the plane
 #define AVDM_NCC_MULTI_UNROLL 3
 #endif
 constexpr int kNccMultiUnroll = AVDM_NCC_MULTI_UNROLL; // sample loop of the four-plane form (wsh != 3)
+// The eight-plane pass (ncc_accumulate_lds_fixed8_multi<4>, AVDM_SIM_PLANES8=1) — how its sample loop is scheduled, measured on the bench's SGM
+// sweep against the four-plane default at 247.1 ms (sessions r04_j, l, m; profiles/r04_planes8_ab.txt):
+//   AVDM_NCC_MULTI_PIPE 0 = the T taps of AVDM_NCC_MULTI_GROUP pairs of planes requested together, a scheduling fence between the groups
+//                           (groups of 2: 246.0 / 244.0 ms at unroll 1 / 3; all 4 pairs in flight: 260.3 ms, the taps spill),
+//                       1 = rotating: the taps of pair j + 1 are requested before pair j is consumed (236.9 ms at unroll 1, 239.7 at 3),
+//                       2 = rotating across the samples of a row too (242.4 ms).
+// The loop issues 34 VALU instructions per plane and sample instead of 43 (-20 %); the time follows by -4 % only: each wave now waits on the
+// LDS four times per sample with two waves per SIMD to cover it.  AVDM_NCC_PIPE_MIN_PAIRS = 2 with AVDM_QUAD_VIA_MULTI = 1 puts the four-plane
+// pass through the same code (A/B builds only): every rotating form of it is slower than the compiler's own schedule (251.5 ... 255.3 ms).
+#ifndef AVDM_NCC_OCTO_UNROLL
+#define AVDM_NCC_OCTO_UNROLL 1
+#endif
+constexpr int kNccOctoUnroll = AVDM_NCC_OCTO_UNROLL; // sample loop of the eight-plane form
+#ifndef AVDM_NCC_MULTI_PIPE
+#define AVDM_NCC_MULTI_PIPE 1
+#endif
+#ifndef AVDM_NCC_PIPE_MIN_PAIRS
+#define AVDM_NCC_PIPE_MIN_PAIRS 3
+#endif
+#ifndef AVDM_QUAD_VIA_MULTI
+#define AVDM_QUAD_VIA_MULTI 0
+#endif
+#ifndef AVDM_NCC_MULTI_GROUP
+#define AVDM_NCC_MULTI_GROUP 2
+#endif
+constexpr int kMultiGroup = AVDM_NCC_MULTI_GROUP;
+constexpr int kPipeMinPairs = AVDM_NCC_PIPE_MIN_PAIRS;
+constexpr int kMultiPipe = AVDM_NCC_MULTI_PIPE;
 #ifndef AVDM_SGM_PLANES_PER_PASS
 #define AVDM_SGM_PLANES_PER_PASS 4 // planes per pass over the patch in the default SGM similarity instantiation: 2 (pairs) or 4
 #endif
@@ -243,6 +271,16 @@ struct LdsTap
 
 // LDS row pitch (texels) for a window of w texels: smallest value = 8 (mod 16) that is >= w
 __host__ __device__ __forceinline__ int lds_pitch_for(int w) { return (((w + 7) >> 4) << 4) + 8; }
+// De-interleaved T windows (AVDM_SIM_DEINT=1, experimental; 12-byte records only).  The SGM sweep samples every stepXY-th pixel of the level it
+// reads: with stepXY = 2 the lanes of a wave (8 x 8 pixels, pixel_of_lane) address records two columns and two rows apart — 6 dwords per lane,
+// an even number of dwords per row — so the 32 lanes of an LDS access share the 16 even banks: a two-way conflict on every tap
+// (profiles/r04_sim_pmc.json: 58 % of the LDS cycles of the kernel are conflict cycles).  Storing column c of the window at record
+// (c >> 1) + (c & 1) * pitch / 2 puts the lanes of a row on consecutive records (3 dwords apart: 8 distinct banks) and a pitch of 4 (mod 8)
+// records puts the four rows of the access 8 or 24 banks apart: 32 lanes, 32 banks.  The reader pays two v_fract and two packed FMAs per
+// pair of planes for the column's parity.  MEASURED (session r04_k): volumes bit-identical to the default's, the SGM sweep 2.3 % SLOWER
+// (252.8 against 247.1 ms) — the +4.6 % VALU instructions cost more than the conflict cycles they remove: the LDS is ~55 % busy in this kernel,
+// it is not what the waves wait for.  Kept as a switch for the record; not a candidate.
+__host__ __device__ __forceinline__ int lds_pitch_deint(int w) { return (((w + 4) >> 3) << 3) + 4; }
 
 // cooperative copy of the window [x0, x0+w) x [y0, y0+h) of level L into LDS (row pitch `pitch` texels); the window is inside the image
 __device__ __forceinline__ void stage_window(uint2* dst, int pitch, const TexLevel& L, int x0, int y0, int w, int h)
@@ -324,6 +362,32 @@ __device__ __forceinline__ void stage_window_rec12(Rec12* dst, int pitch, const 
             rec.b = __builtin_amdgcn_perm(t1.y, t0.y, AVDM_PERM_LO);
             if(lane < 63 && c < w)
                 d[c] = rec;
+        }
+    }
+}
+
+// the same records, column c at (c >> 1) + (c & 1) * pitch / 2 (lds_pitch_deint)
+__device__ __forceinline__ void stage_window_rec12_deint(Rec12* dst, int pitch, const TexLevel& L, int x0, int y0, int w, int h)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = pitch >> 1;
+    for(int r = wave; r < h; r += 4)
+    {
+        const uint2* src = L.base + (long long)(y0 + r) * L.pitch8 + x0;
+        Rec12* d = dst + r * pitch;
+        for(int c0 = 0; c0 < w; c0 += 63)
+        {
+            const int c = c0 + lane;
+            const uint2 t0 = src[min(c, w - 1)];
+            uint2 t1;
+            t1.x = (unsigned)__builtin_amdgcn_update_dpp((int)t0.x, (int)t0.x, 0x130, 0xf, 0xf, false);
+            t1.y = (unsigned)__builtin_amdgcn_update_dpp((int)t0.y, (int)t0.y, 0x130, 0xf, 0xf, false);
+            Rec12 rec;
+            rec.L = __builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_LO);
+            rec.a = __builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_HI);
+            rec.b = __builtin_amdgcn_perm(t1.y, t0.y, AVDM_PERM_LO);
+            if(lane < 63 && c < w)
+                d[(c >> 1) + (c & 1) * half] = rec;
         }
     }
 }
@@ -549,6 +613,14 @@ struct LdsWindows
     float rPitchBF, tPitchBF;
     float rOffB, tOffB;        // LDS byte address of texel (0, 0) of each window: base + 8 * (-(y0 * pitch + x0) [+ rcap]); |.| < 2^24
 };
+// De-interleaved T window (lds_pitch_deint; its first column is even and make_windows() received x0 / 2): byte address of the record of column
+// fX — 6 fX on the even columns, tPitchB / 2 - 6 further on the odd ones (fract(fX / 2) = 0.5) — for a pair of planes, less the row term
+__device__ __forceinline__ v2f deint_col(const LdsWindows& Wn, v2f fX)
+{
+    const v2f hx = fX * 0.5f;
+    const v2f fr = {__builtin_amdgcn_fractf(hx.x), __builtin_amdgcn_fractf(hx.y)};
+    return fX * 6.0f + (fr * (Wn.tPitchBF - 12.0f) + Wn.tOffB);
+}
 typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const v4u32* lds_record_ptr; // one ds_read_b128
 __device__ __forceinline__ uint4 lds_record(unsigned byteAddr)
@@ -677,7 +749,7 @@ __device__ __forceinline__ Lab3x2 hlerp3x2_halfpaired(uint2 r0, unsigned r0n, ui
     return o;
 }
 
-template <int WSH, bool TInvert, bool PAIRED, int RP = 0, bool REC12 = false>
+template <int WSH, bool TInvert, bool PAIRED, int RP = 0, bool REC12 = false, bool DEINT = false>
 __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const LdsWindows& Wn,
                                                            float4 rcCenter, float4 tcCenter)
 {
@@ -719,7 +791,9 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
                 const v2f wa = floor2((X - fX) * 256.0f + 0.5f), wb = floor2((Y - fY) * 256.0f + 0.5f);
                 const v2f na = 256.0f - wa, nnb = wb - 256.0f; // nnb = -(256 - B)
                 // LDS byte address of the top-left tap, formed in fp32 (exact integers), then one conversion per image
-                const v2f oidx = fY * pitch2 + (fX * (PAIRED ? 16.0f : (REC12 ? 12.0f : 8.0f)) + off2);
+                v2f oidx = fY * pitch2 + (fX * (PAIRED ? 16.0f : (REC12 ? 12.0f : 8.0f)) + off2);
+                if constexpr(DEINT) // (the T half again, with the column's parity: see lds_pitch_deint)
+                    oidx.y = fmaf(fY.y, Wn.tPitchBF, fmaf(fX.y, 6.0f, fmaf(__builtin_amdgcn_fractf(fX.y * 0.5f), Wn.tPitchBF - 12.0f, Wn.tOffB)));
                 const unsigned oR = (unsigned)(int)oidx.x, oT = (unsigned)(int)oidx.y;
                 const v2h wr = pk_half_weights(na.x, wa.x), wt = pk_half_weights(na.y, wa.y);
                 Lab3x4 h;
@@ -1021,7 +1095,7 @@ struct QuadPlane
     f3 tax;   // M_T * (patch.x * pixSize)
     float4 c; // T centre colour
 };
-template <int WSH, bool TInvert, bool PAIRED, int RP, bool REC12 = false>
+template <int WSH, bool TInvert, bool PAIRED, int RP, bool REC12 = false, bool DEINT = false>
 __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f3 hr0, const QuadPlane& q0, const QuadPlane& q1, const QuadPlane& q2,
                                                                const QuadPlane& q3, f3 Bt, f3 htB, f3 htA, const NccArgs& A, const PatchTable& tab,
                                                                const LdsWindows& Wn, float4 rcCenter, float& sim0, float& sim1, float& sim2, float& sim3)
@@ -1134,7 +1208,11 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             t.wb = quant256(Y - fY);
             const v2f na = 256.0f - wa;
             t.nnb = t.wb - 256.0f;
-            const v2f oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
+            v2f oidx;
+            if constexpr(DEINT)
+                oidx = fY * Wn.tPitchBF + deint_col(Wn, fX);
+            else
+                oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
             const unsigned oA = (unsigned)(int)oidx.x, oB = (unsigned)(int)oidx.y;
             t.wtA = pk_half_weights(na.x, wa.x);
             t.wtB = pk_half_weights(na.y, wa.y);
@@ -1293,6 +1371,326 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
     sim1 = finish_lit(lit[1]);
     sim2 = finish_lit(lit[2]);
     sim3 = finish_lit(lit[3]);
+#endif
+}
+
+// ncc_accumulate_lds_fixed8_quad generalised to NPAIR pairs of adjacent planes per pass (a copy: the four-plane pass above is the measured default
+// and stays byte for byte what it is).  NPAIR = 4 = EIGHT planes per pass: the R side of a sample — 37 of the 518 VALU instructions of twelve
+// plane-samples are per SAMPLE — amortised over twice the planes.  Behind AVDM_SIM_PLANES8=1: -4 % on the SGM sweep (see AVDM_NCC_MULTI_PIPE
+// above), volumes equal to the default's to the storage quantum (tests/test_gpu_parity.py::test_sgm_similarity_experiments_equal_the_default);
+// not the default until the parity tables have been re-measured with it (the R side now comes from a plane up to four depth steps away).
+template <int WSH, bool TInvert, bool PAIRED, int RP, bool REC12, int NPAIR, bool DEINT = false>
+__device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, f3 hr0, const QuadPlane (&q)[2 * NPAIR], f3 Bt, f3 htB, f3 htA, const NccArgs& A,
+                                                                const PatchTable& tab, const LdsWindows& Wn, float4 rcCenter, float (&sim)[2 * NPAIR])
+{
+    const int wsh = WSH > 0 ? WSH : A.wsh;
+    const int n = 2 * wsh + 1;
+    const float S16 = 65536.0f;
+    v2f tt[NPAIR], axS[NPAIR], ayS[NPAIR], az[NPAIR], cL[NPAIR], ca[NPAIR], cb[NPAIR];
+    auto set_pair = [&](int j, const QuadPlane& a, const QuadPlane& b) __attribute__((always_inline)) {
+        tt[j] = v2f{a.t, b.t};
+        axS[j] = v2f{a.tax.x, b.tax.x} * A.tcSx;
+        ayS[j] = v2f{a.tax.y, b.tax.y} * A.tcSy;
+        az[j] = v2f{a.tax.z, b.tax.z};
+        cL[j] = v2f{a.c.x, b.c.x} * S16;
+        ca[j] = v2f{a.c.y, b.c.y} * S16;
+        cb[j] = v2f{a.c.z, b.c.z} * S16;
+    };
+#pragma unroll
+    for(int j = 0; j < NPAIR; ++j)
+        set_pair(j, q[2 * j], q[2 * j + 1]);
+    // R side, {x, y} of the one image
+    const v2f raS = {rax.x * A.rcSx, rax.y * A.rcSy};
+    const v2f rS = {A.rcSx, A.rcSy}, rO = {A.rcOx, A.rcOy};
+    const v2f rcLa = v2f{rcCenter.x, rcCenter.y} * S16;
+    const float rcb = rcCenter.z * S16;
+    const float kC = A.negInvGammaC_log2e * (1.0f / 65536.0f);
+    constexpr float recB = PAIRED ? 16.0f : (REC12 ? 12.0f : 8.0f);
+    constexpr bool WIDE = PAIRED || REC12; // a tap's record IS its three dot2 operands
+
+    v2f wsum[NPAIR], s1R[NPAIR], s1T[NPAIR], s2R[NPAIR], s2T[NPAIR], sxy[NPAIR];
+#pragma unroll
+    for(int j = 0; j < NPAIR; ++j)
+        wsum[j] = s1R[j] = s1T[j] = s2R[j] = s2T[j] = sxy[j] = v2f{0.f, 0.f};
+#if AVDM_DEV_UNSHIFTED_SUMS
+    SimStatLit lit[2 * NPAIR];
+#endif
+
+    struct RTaps
+    {
+        typename std::conditional<PAIRED || REC12, uint4, uint2>::type r0, r1;
+        unsigned r0n, r1n;
+        float rNy, rWy;
+        v2h wr;
+    };
+    struct TTaps
+    {
+        typename std::conditional<PAIRED || REC12, uint4, uint2>::type a0, a1, b0, b1;
+        unsigned a0n, a1n, b0n, b1n;
+        v2f nnb, wb;
+        v2h wtA, wtB;
+    };
+
+#pragma unroll 1
+    for(int yp = -wsh; yp <= wsh; ++yp)
+    {
+        const float fy = (float)yp;
+        // row of plane k: htA + t_k * (htB + fy * Bt), the texel-space scale folded into x and y
+        const f3 sB = f3{fmaf(fy, Bt.x, htB.x), fmaf(fy, Bt.y, htB.y), fmaf(fy, Bt.z, htB.z)};
+        v2f rowx[NPAIR], rowy[NPAIR], rowz[NPAIR];
+#pragma unroll
+        for(int j = 0; j < NPAIR; ++j)
+        {
+            rowx[j] = (tt[j] * sB.x + htA.x) * A.tcSx;
+            rowy[j] = (tt[j] * sB.y + htA.y) * A.tcSy;
+            rowz[j] = tt[j] * sB.z + htA.z;
+        }
+        const v2f rrow = (fy * v2f{ray.x, ray.y} + v2f{hr0.x, hr0.y}) * rS;
+        const float rrowz = fmaf(fy, ray.z, hr0.z);
+        const float* trow = tab.c + (yp + wsh) * n + wsh;
+        auto fetch_r = [&](int xp) __attribute__((always_inline)) -> RTaps {
+            RTaps t;
+            const float fx = (float)xp;
+            const float rinv = proj_rcp(fmaf(fx, rax.z, rrowz));
+            const v2f rXY = (fx * raS + rrow) * rinv + rO;
+            const v2f rF = floor2(rXY);
+            const v2f rW = quant256(rXY - rF);                           // {A, B} of quant8(), in units of 1/256
+            const v2f rN = rW * v2f{-1.0f, 1.0f} + v2f{256.0f, -256.0f}; // {256 - A, -(256 - B)}
+            const unsigned oR = (unsigned)(int)fmaf(rF.y, Wn.rPitchBF, fmaf(rF.x, recB, Wn.rOffB));
+            __builtin_assume(oR < 65536u);
+            t.wr = pk_half_weights(rN.x, rW.x);
+            t.rNy = rN.y;
+            t.rWy = rW.y;
+            const unsigned oRb = RP > 0 ? oR + (unsigned)(RP * (PAIRED ? 16 : (REC12 ? 12 : 8))) : oR + Wn.rPitchB;
+            if constexpr(PAIRED)
+            {
+                t.r0 = lds_record(oR), t.r1 = lds_record(oRb);
+                t.r0n = t.r1n = 0u;
+            }
+            else if constexpr(REC12)
+            {
+                t.r0 = lds_record12(oR), t.r1 = lds_record12(oRb);
+                t.r0n = t.r1n = 0u;
+            }
+            else
+            {
+                t.r0 = lds_texel(oR), t.r1 = lds_texel(oRb);
+                t.r0n = lds_u32(oR + 12u), t.r1n = lds_u32(oRb + 12u);
+            }
+            return t;
+        };
+        auto fetch_t = [&](int xp, int j) __attribute__((always_inline)) -> TTaps {
+            TTaps t;
+            const float fx = (float)xp;
+            const v2f hz = fx * az[j] + rowz[j];
+            const v2f inv = {proj_rcp(hz.x), proj_rcp(hz.y)};
+            const v2f X = (fx * axS[j] + rowx[j]) * inv + A.tcOx;
+            const v2f Y = (fx * ayS[j] + rowy[j]) * inv + A.tcOy;
+            const v2f fX = floor2(X), fY = floor2(Y);
+            const v2f wa = quant256(X - fX);
+            t.wb = quant256(Y - fY);
+            const v2f na = 256.0f - wa;
+            t.nnb = t.wb - 256.0f;
+            v2f oidx;
+            if constexpr(DEINT)
+                oidx = fY * Wn.tPitchBF + deint_col(Wn, fX);
+            else
+                oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
+            const unsigned oA = (unsigned)(int)oidx.x, oB = (unsigned)(int)oidx.y;
+            t.wtA = pk_half_weights(na.x, wa.x);
+            t.wtB = pk_half_weights(na.y, wa.y);
+            if constexpr(PAIRED)
+            {
+                t.a0 = lds_record(oA), t.a1 = lds_record(oA + Wn.tPitchB), t.b0 = lds_record(oB), t.b1 = lds_record(oB + Wn.tPitchB);
+                t.a0n = t.a1n = t.b0n = t.b1n = 0u;
+            }
+            else if constexpr(REC12)
+            {
+                t.a0 = lds_record12(oA), t.a1 = lds_record12(oA + Wn.tPitchB), t.b0 = lds_record12(oB), t.b1 = lds_record12(oB + Wn.tPitchB);
+                t.a0n = t.a1n = t.b0n = t.b1n = 0u;
+            }
+            else
+            {
+                t.a0 = lds_texel(oA), t.a1 = lds_texel(oA + Wn.tPitchB), t.b0 = lds_texel(oB), t.b1 = lds_texel(oB + Wn.tPitchB);
+                t.a0n = lds_u32(oA + 12u), t.a1n = lds_u32(oA + Wn.tPitchB + 12u), t.b0n = lds_u32(oB + 12u), t.b1n = lds_u32(oB + Wn.tPitchB + 12u);
+            }
+            return t;
+        };
+        // kMultiPipe == 2: the R taps and the first pair's T taps of sample xp were requested during the last pair of sample xp - 1 (rNext, tNext)
+        [[maybe_unused]] RTaps rNext;
+        [[maybe_unused]] TTaps tNext;
+        if constexpr(kMultiPipe == 2 && NPAIR >= kPipeMinPairs)
+        {
+            rNext = fetch_r(-wsh);
+            tNext = fetch_t(-wsh, 0);
+        }
+        auto sample = [&](int xp) __attribute__((always_inline)) {
+            RTaps r;
+            if constexpr(kMultiPipe == 2 && NPAIR >= kPipeMinPairs)
+                r = rNext;
+            else
+                r = fetch_r(xp);
+            Lab3x2 hr;
+            if constexpr(WIDE)
+                hr = hlerp3x2_paired(r.r0, r.r1, r.wr);
+            else
+                hr = hlerp3x2_halfpaired(r.r0, r.r0n, r.r1, r.r1n, r.wr);
+            const v2f dRLa = (v2f{hr.t.L, hr.t.a} * r.rNy + rcLa) - v2f{hr.b.L, hr.b.a} * r.rWy;
+            const float dRb = fmaf(hr.t.b, r.rNy, rcb) - hr.b.b * r.rWy;
+            const v2f qR = dRLa * dRLa;
+            const float base = fmaf(__builtin_amdgcn_sqrtf(fmaf(dRb, dRb, qR.x + qR.y)), kC, -trow[xp]);
+            const float dLR = dRLa.x;
+#if AVDM_SUMS_NO_WGR
+            const float dLR2 = dLR * dLR;
+#endif
+#if AVDM_DEV_TWO_EXP
+            const float dPl = sqrtf((float)(xp * xp + yp * yp)) * A.invGammaP;
+            const float wRl = yk_weight(sqrtf(fmaf(dRb, dRb, qR.x + qR.y)) * (1.0f / 65536.0f), dPl, A.invGammaC);
+#endif
+#if AVDM_DEV_UNSHIFTED_SUMS
+            const float VR = (hr.b.L * r.rWy - hr.t.L * r.rNy) * (1.0f / 65536.0f); // the bilinear L of R itself
+#endif
+            // the T taps of AVDM_NCC_MULTI_GROUP pairs in flight at a time (all of them for the four-plane pass; the eight-plane pass would hold
+            // 4 x 18 registers of taps per sample otherwise)
+            TTaps t[NPAIR];
+#pragma unroll
+            for(int j = 0; j < NPAIR; ++j)
+            {
+                if constexpr(kMultiPipe != 0 && NPAIR >= kPipeMinPairs)
+                {
+                    // rotating: the taps of pair j + 1 are requested before pair j is consumed; kMultiPipe == 2: and those of the next sample's R side
+                    // and first pair before the last pair is (one sample past the row's end at its last sample: an LDS read nobody uses)
+                    if(j == 0)
+                        t[0] = kMultiPipe == 2 ? tNext : fetch_t(xp, 0);
+                    if(j + 1 < NPAIR)
+                        t[j + 1] = fetch_t(xp, j + 1);
+                    else if(kMultiPipe == 2)
+                    {
+                        rNext = fetch_r(xp + 1);
+                        tNext = fetch_t(xp + 1, 0);
+                    }
+                }
+                else if(j % kMultiGroup == 0)
+                {
+                    if(j > 0)
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for(int g = j; g < j + kMultiGroup && g < NPAIR; ++g)
+                        t[g] = fetch_t(xp, g);
+                }
+                Lab3x4 h; // rt / rb = plane 2j top / bottom row, tt / tb = plane 2j + 1
+                if constexpr(WIDE)
+                    h = hlerp3x4_paired(t[j].a0, t[j].a1, t[j].b0, t[j].b1, t[j].wtA, t[j].wtB);
+                else
+                    h = hlerp3x4_halfpaired(t[j].a0, t[j].a0n, t[j].a1, t[j].a1n, t[j].b0, t[j].b0n, t[j].b1, t[j].b1n, t[j].wtA, t[j].wtB);
+                const v2f dL = (v2f{h.rt.L, h.tt.L} * t[j].nnb + cL[j]) - v2f{h.rb.L, h.tb.L} * t[j].wb;
+                const v2f da = (v2f{h.rt.a, h.tt.a} * t[j].nnb + ca[j]) - v2f{h.rb.a, h.tb.a} * t[j].wb;
+                const v2f db = (v2f{h.rt.b, h.tt.b} * t[j].nnb + cb[j]) - v2f{h.rb.b, h.tb.b} * t[j].wb;
+                const v2f sq = dL * dL + (da * da + db * db);
+                const v2f e = v2f{__builtin_amdgcn_sqrtf(sq.x), __builtin_amdgcn_sqrtf(sq.y)} * kC + base;
+#if AVDM_DEV_TWO_EXP
+                const v2f w = {wRl * yk_weight(sqrtf(sq.x) * (1.0f / 65536.0f), dPl, A.invGammaC), wRl * yk_weight(sqrtf(sq.y) * (1.0f / 65536.0f), dPl, A.invGammaC)};
+#else
+                const v2f w = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+#endif
+#if AVDM_DEV_UNSHIFTED_SUMS
+                {
+                    const v2f VT = (v2f{h.rb.L, h.tb.L} * t[j].wb - v2f{h.rt.L, h.tt.L} * t[j].nnb) * (1.0f / 65536.0f);
+                    lit[2 * j].update(VR, VT.x, w.x);
+                    lit[2 * j + 1].update(VR, VT.y, w.y);
+                }
+#endif
+#if AVDM_SUMS_NO_WGR
+                const v2f wgT = w * dL;
+                wsum[j] += w;
+                s1R[j] = w * dLR + s1R[j];
+                s1T[j] += wgT;
+                s2R[j] = w * dLR2 + s2R[j];
+                s2T[j] = wgT * dL + s2T[j];
+                sxy[j] = wgT * dLR + sxy[j];
+#else
+                const v2f wgR = w * dLR, wgT = w * dL;
+                wsum[j] += w;
+                s1R[j] += wgR;
+                s1T[j] += wgT;
+                s2R[j] = wgR * dLR + s2R[j];
+                s2T[j] = wgT * dL + s2T[j];
+                sxy[j] = wgR * dL + sxy[j];
+#endif
+                if constexpr(kMultiPipe != 0 && NPAIR >= kPipeMinPairs)
+                    if(j + 1 < NPAIR || kMultiPipe == 2)
+                        __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if(WSH == 3 && AVDM_NCC_QUAD_W3_MODE == 1)
+        {
+            // one sample at a time
+#pragma unroll
+            for(int xp = -3; xp <= 3; ++xp)
+            {
+                sample(xp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        else if(WSH == 3 && AVDM_NCC_QUAD_W3_MODE == 2)
+        {
+            // 7 taps per row as 3 + 3 + 1
+#pragma unroll
+            for(int xp = -3; xp < 0; ++xp)
+                sample(xp);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for(int xp = 0; xp < 3; ++xp)
+                sample(xp);
+            __builtin_amdgcn_sched_barrier(0);
+            sample(3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        else if(WSH == 3)
+        {
+            // 7 taps per row as 2 + 2 + 2 + 1 (see ncc_accumulate_lds_fixed8: an unroll factor with a remainder unrolls the whole row)
+#pragma unroll
+            for(int g = 0; g < 3; ++g)
+            {
+                sample(-3 + 2 * g);
+                sample(-2 + 2 * g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sample(3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        else
+        {
+#pragma unroll(NPAIR == 2 ? kNccMultiUnroll : kNccOctoUnroll)
+            for(int xp = -wsh; xp <= wsh; ++xp)
+                sample(xp);
+        }
+    }
+
+    auto finish = [&](float ws, float x1, float y1, float xx, float yy, float xy) __attribute__((always_inline)) -> float {
+        const float iw = fast_rcp(ws);
+        const float varXW = (xx - x1 * x1 * iw) * iw;
+        const float varYW = (yy - y1 * y1 * iw) * iw;
+        const float varXYW = (xy - x1 * y1 * iw) * iw;
+        const float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
+        const float s = isfinite(rawSim) ? -rawSim : 1.0f;
+        return TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, s) : s;
+    };
+#pragma unroll
+    for(int j = 0; j < NPAIR; ++j)
+    {
+        sim[2 * j] = finish(wsum[j].x, s1R[j].x, s1T[j].x, s2R[j].x, s2T[j].x, sxy[j].x);
+        sim[2 * j + 1] = finish(wsum[j].y, s1R[j].y, s1T[j].y, s2R[j].y, s2T[j].y, sxy[j].y);
+    }
+#if AVDM_DEV_UNSHIFTED_SUMS
+    auto finish_lit = [&](const SimStatLit& st) __attribute__((always_inline)) -> float {
+        const float rawSim = st.raw_sim();
+        const float s = isfinite(rawSim) ? -rawSim : 1.0f;
+        return TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, s) : s;
+    };
+#pragma unroll
+    for(int j = 0; j < 2 * NPAIR; ++j)
+        sim[j] = finish_lit(lit[j]);
 #endif
 }
 
@@ -1496,7 +1894,7 @@ struct TWindow
 
 // second half (after the barrier): decide — uniformly for the workgroup — whether plane k runs from LDS, and stage the T window
 __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk, bool paired, bool halfPaired,
-                                                  bool lean = false, bool rec12 = false)
+                                                  bool lean = false, bool rec12 = false, bool deint = false)
 {
     TWindow Wd;
     const int mnx = sh.box[k][0], mny = sh.box[k][1], mxx = sh.box[k][2], mxy = sh.box[k][3];
@@ -1510,11 +1908,13 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
         // (see corner_boxes), clipped at the image edge
         const bool inImage = mnx >= 0 && mny >= 0 && mxx + 1 <= A.tcL.W - 1 && mxy + 1 <= A.tcL.H - 1;
         Wd.x0 = max(mnx - 1, 0);
+        if(deint)
+            Wd.x0 &= ~1; // the parity of a column of the window is the parity of its image column
         Wd.y0 = max(mny - 1, 0);
         const int x1 = min(mxx + 2, A.tcL.W - 1), y1 = min(mxy + 2, A.tcL.H - 1);
         Wd.w = x1 - Wd.x0 + 1;
         Wd.h = y1 - Wd.y0 + 1;
-        Wd.pitch = lds_pitch_for(Wd.w);
+        Wd.pitch = deint ? lds_pitch_deint(Wd.w) : lds_pitch_for(Wd.w);
         const bool fits = Wd.w <= 4096 && Wd.h <= 4096 && lds_units(Wd.pitch * Wd.h, paired, rec12) <= A.tcap;
         Wd.ok = inImage && fits;
         reason = Wd.ok ? 0 : (inImage ? 3 : 2);
@@ -1524,6 +1924,8 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
     {
         if(paired)
             stage_window_paired((uint4*)sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
+        else if(rec12 && deint)
+            stage_window_rec12_deint((Rec12*)sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
         else if(rec12)
             stage_window_rec12((Rec12*)sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
         else if(halfPaired)
@@ -1558,7 +1960,7 @@ __device__ __forceinline__ void init_shared(BlockShared& sh)
 //       plane per pass with per-plane windows / global-memory taps, exactly like MODE 0 does for them; their other waves only keep the
 //       barriers company.  Same NccArgs, hence the same window decisions as the fast kernel.
 // The split keeps the rarely taken paths (~5 % of the plane-workgroups) out of the hot kernel's register allocation.
-template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, bool REC12 = false, int MODE = 0>
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, bool REC12 = false, int MODE = 0, bool DEINT = false>
 __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
                     avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi,
@@ -1566,6 +1968,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
 {
     constexpr bool FAST = MODE == 1, FIXUP = MODE == 2;
     static_assert(!FAST || PLANES == 4, "the fast kernel is the four-plane pass");
+    static_assert(!DEINT || (REC12 && FIXED8 && RP > 0 && PLANES >= 4), "de-interleaved T windows: the 12-byte records of the default instantiation");
     const unsigned wgIndex = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const unsigned waveInWg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned myFlags = 0u;
@@ -1717,7 +2120,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             }
             publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
             __syncthreads();
-            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12);
+            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12, DEINT);
             __syncthreads();
             if(Wc.tooLarge) // uniform
             {
@@ -1729,7 +2132,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 part = wave_inlier(part, 0.5f * (bx0 + bx1), 0.5f * (by0 + by1), 16.0f * (float)stepXY + 16.0f);
                 publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
                 __syncthreads();
-                Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12);
+                Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12, DEINT);
                 __syncthreads();
             }
             chunkWin = Wc.ok;
@@ -1803,7 +2206,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     };
     bool quadDone = false;
     const bool mine = !FIXUP || ((myFlags >> (4u * c + waveInWg)) & 1u) != 0u; // fix-up: is this (chunk, wave) unit mine?  (wave-uniform)
-    if constexpr(PLANES == 4 && FIXED8 && !FIXUP)
+    if constexpr(PLANES >= 4 && FIXED8 && !FIXUP)
     {
         // the four planes of the chunk in one pass over the patch (ncc_accumulate_lds_fixed8_multi): uniform conditions
         if(chunkWin && usePlanePairs && !noPacked)
@@ -1841,6 +2244,94 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 }
                 laneLds = __ballot(valid && !laneLds) == 0ull; // wave-uniform choice of the tap source
             };
+            // EIGHT planes per pass (AVDM_SIM_PLANES8=1, experimental): this chunk and the next one together when both lie in the T camera's
+            // range; the R side comes from plane 3 of the eight (or its stand-in): at most four depth steps from every plane of the pass.
+            // Falls through to the four-plane pass below whenever it cannot take the two chunks (uniform conditions).
+            if constexpr(PLANES == 8)
+            {
+                if((c & 1u) == 0u && c + 1u < kSgmChunksPerWg && zc >= zBegin && zc + 8u <= zEnd) // uniform: eight planes, all in range
+                {
+                    QuadPlane q[8];
+                    f3 ra[8];
+                    bool vv[8], ll[8];
+#pragma unroll
+                    for(int k = 0; k < 8; ++k)
+                        plane_q(zc + (unsigned)k, q[k], ra[k], vv[k], ll[k]);
+                    bool allLds = true, anyValid = false;
+#pragma unroll
+                    for(int k = 0; k < 8; ++k)
+                    {
+                        allLds = allLds && ll[k];
+                        anyValid = anyValid || vv[k];
+                    }
+                    if(allLds) // wave-uniform
+                    {
+                        uint8_t* const pbB = pb + 4;
+                        uint8_t* const psB = ps + 4;
+                        unsigned wbB = 0, wsB = 0;
+                        if(inRoi)
+                        {
+                            wbB = *reinterpret_cast<const unsigned*>(pbB);
+                            wsB = *reinterpret_cast<const unsigned*>(psB);
+                        }
+                        float sim[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        if(anyValid)
+                        {
+                            auto selP8 = [](bool cnd, const QuadPlane& a, const QuadPlane& b) __attribute__((always_inline)) -> QuadPlane {
+                                QuadPlane r;
+                                r.t = cnd ? a.t : b.t;
+                                r.tax = sel3(cnd, a.tax, b.tax);
+                                r.c = sel4(cnd, a.c, b.c);
+                                return r;
+                            };
+                            // the reference plane of the R side: the first valid one in the order 3, 4, 2, 5, 1, 6, 0, 7
+                            QuadPlane qf = q[7];
+                            f3 raf = ra[7];
+                            constexpr int order[7] = {0, 6, 1, 5, 2, 4, 3};
+#pragma unroll
+                            for(int i = 0; i < 7; ++i)
+                            {
+                                qf = selP8(vv[order[i]], q[order[i]], qf);
+                                raf = sel3(vv[order[i]], ra[order[i]], raf);
+                            }
+                            QuadPlane qq[8];
+#pragma unroll
+                            for(int k = 0; k < 8; ++k)
+                                qq[k] = selP8(vv[k], q[k], qf);
+                            const float tw = qf.t * RK.hrW;
+                            ncc_accumulate_lds_fixed8_multi<WSH, false, PAIRED, RP, REC12, 4, DEINT>(
+                              raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, qq, Bt, RK.htB, RK.htA, A, tab,
+                              make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, DEINT ? Wc.x0 >> 1 : Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter, sim);
+                        }
+                        auto commit2 = [&](unsigned& wbx, unsigned& wsx, int k, float fsim) __attribute__((always_inline)) {
+                            const unsigned sh8 = 8u * k;
+                            const unsigned b1 = (wbx >> sh8) & 0xffu, b2 = (wsx >> sh8) & 0xffu;
+                            if(fsim < (float)b1)
+                            {
+                                wsx = (wsx & ~(0xffu << sh8)) | (b1 << sh8);
+                                wbx = (wbx & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
+                            }
+                            else if(fsim < (float)b2)
+                                wsx = (wsx & ~(0xffu << sh8)) | ((unsigned)fsim << sh8);
+                        };
+#pragma unroll
+                        for(int k = 0; k < 4; ++k)
+                        {
+                            commit2(wb, ws, k, vv[k] ? to_fsim(sim[k]) : 255.0f);
+                            commit2(wbB, wsB, k, vv[k + 4] ? to_fsim(sim[k + 4]) : 255.0f);
+                        }
+                        if(inRoi)
+                        {
+                            *reinterpret_cast<unsigned*>(pb) = wb;
+                            *reinterpret_cast<unsigned*>(ps) = ws;
+                            *reinterpret_cast<unsigned*>(pbB) = wbB;
+                            *reinterpret_cast<unsigned*>(psB) = wsB;
+                        }
+                        ++c; // the next chunk is done too
+                        continue;
+                    }
+                }
+            }
             QuadPlane q0, q1, q2, q3;
             f3 ra0, ra1, ra2, ra3;
             bool v0, v1b, v2b, v3, l0, l1, l2, l3;
@@ -1865,10 +2356,19 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                     const QuadPlane qf = selP(v1b, q1, selP(v2b, q2, selP(v0, q0, q3)));
                     const f3 raf = sel3(v1b, ra1, sel3(v2b, ra2, sel3(v0, ra0, ra3)));
                     const float tw = qf.t * RK.hrW;
-                    ncc_accumulate_lds_fixed8_quad<WSH, false, PAIRED, RP, REC12>(raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
+#if AVDM_QUAD_VIA_MULTI
+                    const QuadPlane qa[4] = {selP(v0, q0, qf), selP(v1b, q1, qf), selP(v2b, q2, qf), selP(v3, q3, qf)};
+                    float sm[4] = {0.f, 0.f, 0.f, 0.f};
+                    ncc_accumulate_lds_fixed8_multi<WSH, false, PAIRED, RP, REC12, 2, DEINT>(
+                      raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, qa, Bt, RK.htB, RK.htA, A, tab,
+                      make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, DEINT ? Wc.x0 >> 1 : Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter, sm);
+                    s0 = sm[0], s1 = sm[1], s2 = sm[2], s3 = sm[3];
+#else
+                    ncc_accumulate_lds_fixed8_quad<WSH, false, PAIRED, RP, REC12, DEINT>(raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
                                                                     selP(v0, q0, qf), selP(v1b, q1, qf), selP(v2b, q2, qf), selP(v3, q3, qf), Bt, RK.htB, RK.htA, A, tab,
-                                                                    make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
+                                                                    make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, DEINT ? Wc.x0 >> 1 : Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
                                                                     s0, s1, s2, s3);
+#endif
                 }
                 // (a plane outside the range is not committed at all: its bytes belong to other T cameras)
                 if(zc >= zBegin && zc < zEnd)
@@ -1911,7 +2411,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                         // a lane with one valid plane runs it in both halves
                         const PatchProj PA = selQ(validA, QA, QB), PB = selQ(validB, QB, QA);
                         ncc_accumulate_lds_fixed8_pair<WSH, false, PAIRED, RP>(PA.rax, PA.ray, PA.hr0, PA, PB, A, tab,
-                                                                               make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)),
+                                                                               make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, DEINT ? Wc.x0 >> 1 : Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)),
                                                                                rcCenter, sel4(validA, cA, cB), sel4(validB, cB, cA), sA, sB);
                     }
                     commit(k0, validA ? to_fsim(sA) : 255.0f);
@@ -1961,7 +2461,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 corner_boxes(Q, A, wsh, R, bx0, by0, bx1, by1, rInside);
             publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
             __syncthreads();
-            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired, LEAN, rec12);
+            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired, LEAN, rec12, DEINT);
             __syncthreads();
         }
 
@@ -1970,7 +2470,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         {
             float s;
             if(Wd.ok && laneLds && FIXED8 && !noPacked)
-                s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED, RP, REC12>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
+                s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED, RP, REC12, DEINT>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, DEINT ? Wd.x0 >> 1 : Wd.x0, Wd.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
                                                           tcCenter);
             else if(Wd.ok && laneLds)
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
@@ -3082,7 +3582,29 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
         hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, 4, R12>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x,     \
                            depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi, (unsigned*)nullptr);                                             \
     }
-            if(rec12)
+            // experiments, read at each call (12-byte records only): AVDM_SIM_PLANES8=1 — eight planes per pass where two chunks of a workgroup lie in
+            // the T camera's range; AVDM_SIM_DEINT=1 — de-interleaved T windows (lds_pitch_deint)
+            const char* p8 = getenv("AVDM_SIM_PLANES8");
+            const char* pd = getenv("AVDM_SIM_DEINT");
+            const bool planes8 = p8 != nullptr && p8[0] == '1', deint = pd != nullptr && pd[0] == '1';
+#define AVDM_SGM_EXPERIMENT_LAUNCH(P, D)                                                                                                                  \
+    {                                                                                                                                                     \
+        static std::once_flag onceX[64];                                                                                                                  \
+        std::call_once(onceX[dev & 63], [&] {                                                                                                             \
+            (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, P, true, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                      kLdsHalf);                                                                                                          \
+        });                                                                                                                                               \
+        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, P, true, 0, D>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y,       \
+                           pitch_x, depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi, (unsigned*)nullptr);                                    \
+    }
+            if(rec12 && planes8 && deint)
+                AVDM_SGM_EXPERIMENT_LAUNCH(8, true)
+            else if(rec12 && planes8)
+                AVDM_SGM_EXPERIMENT_LAUNCH(8, false)
+            else if(rec12 && deint)
+                AVDM_SGM_EXPERIMENT_LAUNCH(4, true)
+#undef AVDM_SGM_EXPERIMENT_LAUNCH
+            else if(rec12)
                 AVDM_SGM_COMBINED_LAUNCH(true)
             else
                 AVDM_SGM_COMBINED_LAUNCH(false)

@@ -450,9 +450,13 @@ def main():
             except Exception:
                 continue
             name = os.path.basename(path)
-            if rec.get("kernel_source_sha256") != sha_sim:
+            # the source the counters were taken with, or one whose kernels compile to the same instructions (scripts/isa_identity.py --certify)
+            same_isa = [e for e in rec.get("isa_identical_sources", []) if e.get("sha256") == sha_sim]
+            if rec.get("kernel_source_sha256") != sha_sim and not same_isa:
                 sim_pmc["source"] = f"profiles/{name} was measured with another csrc/avdm_similarity.hip (sha256 differs): stale, not quoted — re-run scripts/pmc_similarity.sh + scripts/collect_sim_pmc.py"
                 break
+            stamp = ("taken with this very csrc/avdm_similarity.hip (sha256 matches)" if not same_isa else
+                     "taken with a csrc/avdm_similarity.hip whose kernels compile to the same gfx950 instructions as this one's (" + str(same_isa[0].get("evidence")) + ")")
             simd_hz = 1024 * 2.4e9  # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock (MI355X_MICROARCH.md); one wave64 VALU instruction = 4 cycles of a SIMD
             out_pmc = {}
             for key, t_stage in (("sgm", t_sgm), ("refine", t_ref)):
@@ -464,7 +468,7 @@ def main():
             sim_pmc = {"valu_issue_frac": {k: v["valu_issue_frac"] for k, v in out_pmc.items()}, "per_kernel": out_pmc,
                        "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
                        "source": f"profiles/{name}: rocprofv3 --pmc passes (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE) of "
-                                 "one T-camera launch of each kernel, taken with this very csrc/avdm_similarity.hip (sha256 matches); durations: this run"}
+                                 "one T-camera launch of each kernel, " + stamp + "; durations: this run"}
             break
         line = {
             "metric": "depth-maps/sec (12 MP, 256 depth hyp, 10 neighbours)", "value": value, "unit": "depth-maps/s", "n_gpus": world,

@@ -145,3 +145,22 @@ def test_custom_patch_pattern_builder_matches_oracle(oracle_lib):
         assert lib.avdm_build_custom_patch_pattern(len(spec), arr, int(group), None) != 0, spec
         assert b"custom patch pattern" in lib.avdm_last_error()
         assert oracle_lib.avo_build_custom_patch_pattern(len(spec), arr, int(group), None) != 0, spec
+
+
+def test_counter_summaries_describe_the_kernels_that_ship():
+    """bench.py quotes hardware-counter figures (roofline.traffic, similarity.valu_issue_frac) from the committed summaries under profiles/ only when
+    they were taken with the kernel source that is being built — or, for the similarity kernels, with one whose kernels compile to the same
+    instructions (scripts/isa_identity.py --certify).  A source change without a new counter session (or certificate) would silently drop those
+    figures from the bench line: caught here, on the CPU."""
+    import glob
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for pattern, src in (("r*_sim_pmc.json", "avdm_similarity.hip"), ("r*_sgm_pmc.json", "avdm_sgm.hip")):
+        newest = sorted(glob.glob(os.path.join(root, "profiles", pattern)))[-1]
+        rec = json.load(open(newest))
+        sha = hashlib.sha256(open(os.path.join(root, "alicevision_amd", "csrc", src), "rb").read()).hexdigest()
+        ok = [rec.get("kernel_source_sha256")] + [e.get("sha256") for e in rec.get("isa_identical_sources", [])]
+        assert sha in ok, "%s does not describe csrc/%s as it is now: re-measure, or scripts/isa_identity.py <measured rev> --certify" % (os.path.basename(newest), src)
+        for e in rec.get("isa_identical_sources", []):
+            assert os.path.exists(os.path.join(root, e["evidence"])), e

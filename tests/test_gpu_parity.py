@@ -772,6 +772,50 @@ def test_split_launches_equal_the_combined_kernels():
         assert dr.max() <= 4e-3 and (dr > 0).mean() <= 1e-4, (float(dr.max()), float((dr > 0).mean()))
 
 
+@pytest.mark.parametrize("switches", [("AVDM_SIM_DEINT",), ("AVDM_SIM_PLANES8",), ("AVDM_SIM_DEINT", "AVDM_SIM_PLANES8")], ids=lambda s: "+".join(x[9:] for x in s))
+def test_sgm_similarity_experiments_equal_the_default(switches, capsys):
+    """The two experimental forms of the SGM similarity kernel (default off) against the default one, on full and partial
+    plane ranges and on a tile with an offset.
+    AVDM_SIM_DEINT=1 stores the T windows de-interleaved (lds_pitch_deint: the bank conflicts of the stepXY = 2 sweep) — the same taps through
+    the same arithmetic from another LDS address: only a window that fits one layout and not the other changes a path, and a level.
+    AVDM_SIM_PLANES8=1 runs eight planes per pass where two chunks of a workgroup lie in the T camera's range: the R side of a sample comes from
+    ONE of the eight planes (as from one of four by default): storage-quantum differences, as between four planes per pass and one
+    (test_plane_pairs_equal_single_planes)."""
+    import os
+    torch = _torch()
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    sc, sgm, ref, depths = small_case(width=330, height=250, n_planes=70, seed=3)
+    Z = len(depths)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(3)]
+    out = {}
+    for flag in ("0", "1"):
+        for sw in switches:
+            os.environ[sw] = flag
+        try:
+            res = []
+            for roi, tcr in ((None, [(0, Z), (5, 61)]), ((64, 330, 48, 250), None)):
+                h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref, roi=roi)
+                h.run_sgm(0, [1, 2], depths, tc_ranges=tcr, keep_raw=True)
+                torch.cuda.synchronize()
+                res.append((h.best_raw.cpu().numpy()[..., :Z].copy(), h.second.cpu().numpy()[..., :Z].copy()))
+            out[flag] = res
+        finally:
+            for sw in switches:
+                os.environ.pop(sw, None)
+    eight = "AVDM_SIM_PLANES8" in switches
+    for (b0, s0), (b1, s1) in zip(out["0"], out["1"]):
+        assert (b0 != 255).mean() > 0.3
+        assert ((b0 == 255) != (b1 == 255)).mean() == 0.0  # validity is decided before the samples
+        for a, b in ((b0, b1), (s0, s1)):
+            d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+            with capsys.disabled():
+                print("\n%s vs default: %.6f of the voxels differ, %.6f by more than one level, max %d" % ("+".join(switches), (d > 0).mean(), (d > 1).mean(), d.max()))
+            if eight:
+                assert (d > 0).mean() <= 0.02 and (d > 1).mean() <= 2e-4 and d.max() <= 16, ((d > 0).mean(), (d > 1).mean(), d.max())
+            else:
+                assert (d > 0).mean() <= 1e-4 and d.max() <= 1, ((d > 0).mean(), d.max())
+
+
 def test_refine_best_depth_bit_exact(case):
     torch = _torch()
     sc, sgm, ref, depths, o = case
@@ -1573,7 +1617,8 @@ def test_bench_rccl_path_on_one_gpu():
 # ---- the switch matrix: every non-default AVDM_* code-path switch still passes its parity class ------------------------
 # DESIGN.md section 4.5 leans on these switches as A/B references; a switch that rots silently would take its A/B with it.
 _SIM_SWITCHES = [("AVDM_SIM_PLANE_PAIRS", "0"), ("AVDM_SIM_CHUNK_WINDOW", "0"), ("AVDM_SIM_PACKED", "0"), ("AVDM_SIM_PAIRED", "0"), ("AVDM_SIM_REC12", "0"),
-                 ("AVDM_SIM_SPLIT", "1"), ("AVDM_SIM_LDS", "0"), ("AVDM_SIM_STATS", "1")]                       # tolerance class (similarity arithmetic)
+                 ("AVDM_SIM_SPLIT", "1"), ("AVDM_SIM_LDS", "0"), ("AVDM_SIM_STATS", "1"),
+                 ("AVDM_SIM_PLANES8", "1"), ("AVDM_SIM_DEINT", "1")]                                             # tolerance class (similarity arithmetic)
 _EXACT_SWITCHES = [("AVDM_SGM_PAIR", "0"), ("AVDM_SGM_INT16", "0"), ("AVDM_SGM_PREPARE", "0"), ("AVDM_OPT_DEPTH_MAP_FORM", "1")]  # bit-exact class
 _STATIC_SWITCHES = [("AVDM_SGM_P2_MAP", "legacy"), ("AVDM_SGM_TIMER", "record")]                                # read once per process: own process
 
