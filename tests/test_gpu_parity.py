@@ -816,6 +816,37 @@ def test_sgm_similarity_experiments_equal_the_default(switches, capsys):
                 assert (d > 0).mean() <= 1e-4 and d.max() <= 1, ((d > 0).mean(), d.max())
 
 
+def test_refine_similarity_experiment_equals_the_default(capsys):
+    """AVDM_REFINE_PLANES8=1 (default off) runs the eight planes of a Refine chunk in one pass where the chunk lies in the T camera's range: the R
+    side of a sample comes from one of eight planes instead of one of four — fp16-quantum differences in the accumulated volume, as between four
+    planes per pass and one (test_plane_pairs_equal_single_planes)."""
+    import os
+    torch = _torch()
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    sc, sgm, ref, depths = small_case(width=320, height=240, n_planes=128, seed=11)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(3)]
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+    h.run_sgm(0, [1, 2], depths)
+    sgm_map = h.sgm_depth_thickness.clone()
+    out = {}
+    for flag in ("0", "1"):
+        os.environ["AVDM_REFINE_PLANES8"] = flag
+        try:
+            h.sgm_depth_thickness.copy_(sgm_map)
+            h.run_refine(0, [1, 2], optimize_enabled=False)
+            torch.cuda.synchronize()
+            out[flag] = h.refine_volume.cpu().numpy().astype(np.float32)
+        finally:
+            os.environ.pop("AVDM_REFINE_PLANES8", None)
+    d = np.abs(out["1"] - out["0"])
+    with capsys.disabled():
+        print("\nAVDM_REFINE_PLANES8 vs default: %.4f of the entries differ, %.5f by more than one fp16 quantum (2e-3), max %.2e" % ((d > 0).mean(), (d > 2e-3).mean(), d.max()))
+    assert (out["0"] != 0).mean() > 0.3
+    assert ((out["0"] == 0) != (out["1"] == 0)).mean() <= 1e-4
+    assert (d > 0).mean() > 0.0, "the switch did not take effect"
+    assert (d > 2e-3).mean() <= 1e-3 and (d > 2e-2).mean() <= 1e-5 and d.max() <= 0.15, ((d > 2e-3).mean(), (d > 2e-2).mean(), d.max())
+
+
 def test_refine_best_depth_bit_exact(case):
     torch = _torch()
     sc, sgm, ref, depths, o = case
@@ -1618,7 +1649,7 @@ def test_bench_rccl_path_on_one_gpu():
 # DESIGN.md section 4.5 leans on these switches as A/B references; a switch that rots silently would take its A/B with it.
 _SIM_SWITCHES = [("AVDM_SIM_PLANE_PAIRS", "0"), ("AVDM_SIM_CHUNK_WINDOW", "0"), ("AVDM_SIM_PACKED", "0"), ("AVDM_SIM_PAIRED", "0"), ("AVDM_SIM_REC12", "0"),
                  ("AVDM_SIM_SPLIT", "1"), ("AVDM_SIM_LDS", "0"), ("AVDM_SIM_STATS", "1"),
-                 ("AVDM_SIM_PLANES8", "1"), ("AVDM_SIM_DEINT", "1")]                                             # tolerance class (similarity arithmetic)
+                 ("AVDM_SIM_PLANES8", "1"), ("AVDM_SIM_DEINT", "1"), ("AVDM_REFINE_PLANES8", "1")]                                           # tolerance class (similarity arithmetic)
 _EXACT_SWITCHES = [("AVDM_SGM_PAIR", "0"), ("AVDM_SGM_INT16", "0"), ("AVDM_SGM_PREPARE", "0"), ("AVDM_OPT_DEPTH_MAP_FORM", "1")]  # bit-exact class
 _STATIC_SWITCHES = [("AVDM_SGM_P2_MAP", "legacy"), ("AVDM_SGM_TIMER", "record")]                                # read once per process: own process
 
