@@ -49,7 +49,8 @@ constexpr int kNccMultiUnroll = AVDM_NCC_MULTI_UNROLL; // sample loop of the fou
 //   AVDM_NCC_MULTI_PIPE 0 = the T taps of AVDM_NCC_MULTI_GROUP pairs of planes requested together, a scheduling fence between the groups
 //                           (groups of 2: 246.0 / 244.0 ms at unroll 1 / 3; all 4 pairs in flight: 260.3 ms, the taps spill),
 //                       1 = rotating: the taps of pair j + 1 are requested before pair j is consumed (236.9 ms at unroll 1, 239.7 at 3),
-//                       2 = rotating across the samples of a row too (242.4 ms).
+//                       2 = rotating across the samples of a row too (242.4 ms),
+//                       3 = as 1, and the R taps of the next sample requested during the last pair (not measured).
 // The loop issues 34 VALU instructions per plane and sample instead of 43 (-20 %); the time follows by -4 % only: each wave now waits on the
 // LDS four times per sample with two waves per SIMD to cover it.  AVDM_NCC_PIPE_MIN_PAIRS = 2 with AVDM_QUAD_VIA_MULTI = 1 puts the four-plane
 // pass through the same code (A/B builds only): every rotating form of it is slower than the compiler's own schedule (251.5 ... 255.3 ms).
@@ -98,6 +99,9 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #endif
 #ifndef AVDM_NCC_QUAD_W3_MODE
 #define AVDM_NCC_QUAD_W3_MODE 0 // 7-tap rows of the four-plane form: 0 = 2 + 2 + 2 + 1 with fences, 1 = one sample at a time, 2 = 3 + 3 + 1
+#endif
+#ifndef AVDM_REFINE_OCTO_PARTIAL
+#define AVDM_REFINE_OCTO_PARTIAL 0
 #endif
 #ifndef AVDM_NCC_OCTO_W3_MODE
 #define AVDM_NCC_OCTO_W3_MODE 3 // 7-tap rows of the eight-plane form: as AVDM_NCC_QUAD_W3_MODE, 3 = a rolled loop (unroll AVDM_NCC_OCTO_UNROLL)
@@ -1522,14 +1526,15 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
         // kMultiPipe == 2: the R taps and the first pair's T taps of sample xp were requested during the last pair of sample xp - 1 (rNext, tNext)
         [[maybe_unused]] RTaps rNext;
         [[maybe_unused]] TTaps tNext;
-        if constexpr(kMultiPipe == 2 && NPAIR >= kPipeMinPairs)
+        if constexpr(kMultiPipe >= 2 && NPAIR >= kPipeMinPairs)
         {
             rNext = fetch_r(-wsh);
-            tNext = fetch_t(-wsh, 0);
+            if constexpr(kMultiPipe == 2)
+                tNext = fetch_t(-wsh, 0);
         }
         auto sample = [&](int xp) __attribute__((always_inline)) {
             RTaps r;
-            if constexpr(kMultiPipe == 2 && NPAIR >= kPipeMinPairs)
+            if constexpr(kMultiPipe >= 2 && NPAIR >= kPipeMinPairs)
                 r = rNext;
             else
                 r = fetch_r(xp);
@@ -1567,10 +1572,11 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
                         t[0] = kMultiPipe == 2 ? tNext : fetch_t(xp, 0);
                     if(j + 1 < NPAIR)
                         t[j + 1] = fetch_t(xp, j + 1);
-                    else if(kMultiPipe == 2)
+                    else if(kMultiPipe >= 2)
                     {
                         rNext = fetch_r(xp + 1);
-                        tNext = fetch_t(xp + 1, 0);
+                        if(kMultiPipe == 2)
+                            tNext = fetch_t(xp + 1, 0);
                     }
                 }
                 else if(j % kMultiGroup == 0)
@@ -1621,7 +1627,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
                 sxy[j] = wgR * dL + sxy[j];
 #endif
                 if constexpr(kMultiPipe != 0 && NPAIR >= kPipeMinPairs)
-                    if(j + 1 < NPAIR || kMultiPipe == 2)
+                    if(j + 1 < NPAIR || kMultiPipe >= 2)
                         __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -2810,7 +2816,9 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             // sweep 267.2 against 276.4 ms, volumes within the fp16 quantum of the default's on all but 2e-5 of the entries.
             if constexpr(PLANES == 8)
             {
-                if(zc >= zBegin && zc + 8u <= zEnd) // uniform
+                // (AVDM_REFINE_OCTO_PARTIAL, A/B builds, not measured: a chunk that only overlaps the range too — its planes outside are invalid planes
+                // of the pass, like those of a four-plane pass; the 31 planes of the default sweep are then four passes of eight)
+                if(AVDM_REFINE_OCTO_PARTIAL ? (zc + 8u > zBegin) : (zc >= zBegin && zc + 8u <= zEnd)) // uniform
                 {
                     QuadPlane q[8];
                     f3 ra[8];
