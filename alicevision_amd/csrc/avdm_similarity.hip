@@ -50,7 +50,8 @@ constexpr int kNccMultiUnroll = AVDM_NCC_MULTI_UNROLL; // sample loop of the fou
 //                           (groups of 2: 246.0 / 244.0 ms at unroll 1 / 3; all 4 pairs in flight: 260.3 ms, the taps spill),
 //                       1 = rotating: the taps of pair j + 1 are requested before pair j is consumed (236.9 ms at unroll 1, 239.7 at 3),
 //                       2 = rotating across the samples of a row too (242.4 ms),
-//                       3 = as 1, and the R taps of the next sample requested during the last pair (not measured).
+//                       3 = as 1, and the R taps of the next sample requested during the last pair (not measured),
+//                       4 = as 1, and the first pair's taps requested before the R side's arithmetic instead of after it (not measured).
 // The loop issues 34 VALU instructions per plane and sample instead of 43 (-20 %); the time follows by -4 % only: each wave now waits on the
 // LDS four times per sample with two waves per SIMD to cover it.  AVDM_NCC_PIPE_MIN_PAIRS = 2 with AVDM_QUAD_VIA_MULTI = 1 puts the four-plane
 // pass through the same code (A/B builds only): every rotating form of it is slower than the compiler's own schedule (251.5 ... 255.3 ms).
@@ -73,6 +74,7 @@ constexpr int kNccOctoUnroll = AVDM_NCC_OCTO_UNROLL; // sample loop of the eight
 constexpr int kMultiGroup = AVDM_NCC_MULTI_GROUP;
 constexpr int kPipeMinPairs = AVDM_NCC_PIPE_MIN_PAIRS;
 constexpr int kMultiPipe = AVDM_NCC_MULTI_PIPE;
+constexpr bool kPipeRNext = kMultiPipe == 2 || kMultiPipe == 3; // the R taps of the next sample are requested during the last pair
 #ifndef AVDM_SGM_PLANES_PER_PASS
 #define AVDM_SGM_PLANES_PER_PASS 4 // planes per pass over the patch in the default SGM similarity instantiation: 2 (pairs) or 4
 #endif
@@ -1526,7 +1528,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
         // kMultiPipe == 2: the R taps and the first pair's T taps of sample xp were requested during the last pair of sample xp - 1 (rNext, tNext)
         [[maybe_unused]] RTaps rNext;
         [[maybe_unused]] TTaps tNext;
-        if constexpr(kMultiPipe >= 2 && NPAIR >= kPipeMinPairs)
+        if constexpr(kPipeRNext && NPAIR >= kPipeMinPairs)
         {
             rNext = fetch_r(-wsh);
             if constexpr(kMultiPipe == 2)
@@ -1534,10 +1536,18 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
         }
         auto sample = [&](int xp) __attribute__((always_inline)) {
             RTaps r;
-            if constexpr(kMultiPipe >= 2 && NPAIR >= kPipeMinPairs)
+            if constexpr(kPipeRNext && NPAIR >= kPipeMinPairs)
                 r = rNext;
             else
                 r = fetch_r(xp);
+            // kMultiPipe == 4: the first pair's T taps are requested BEFORE the R side's arithmetic (which then covers their round trip, as the
+            // first pair's address arithmetic covers the R taps'), not after it
+            [[maybe_unused]] TTaps tFirst;
+            if constexpr(kMultiPipe == 4 && NPAIR >= kPipeMinPairs)
+            {
+                tFirst = fetch_t(xp, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             Lab3x2 hr;
             if constexpr(WIDE)
                 hr = hlerp3x2_paired(r.r0, r.r1, r.wr);
@@ -1569,10 +1579,10 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
                     // rotating: the taps of pair j + 1 are requested before pair j is consumed; kMultiPipe == 2: and those of the next sample's R side
                     // and first pair before the last pair is (one sample past the row's end at its last sample: an LDS read nobody uses)
                     if(j == 0)
-                        t[0] = kMultiPipe == 2 ? tNext : fetch_t(xp, 0);
+                        t[0] = kMultiPipe == 2 ? tNext : (kMultiPipe == 4 ? tFirst : fetch_t(xp, 0));
                     if(j + 1 < NPAIR)
                         t[j + 1] = fetch_t(xp, j + 1);
-                    else if(kMultiPipe >= 2)
+                    else if(kPipeRNext)
                     {
                         rNext = fetch_r(xp + 1);
                         if(kMultiPipe == 2)
@@ -1627,7 +1637,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
                 sxy[j] = wgR * dL + sxy[j];
 #endif
                 if constexpr(kMultiPipe != 0 && NPAIR >= kPipeMinPairs)
-                    if(j + 1 < NPAIR || kMultiPipe >= 2)
+                    if(j + 1 < NPAIR || kPipeRNext)
                         __builtin_amdgcn_sched_barrier(0);
             }
         };
