@@ -425,6 +425,9 @@ static int aliceVision_main(int argc, char* argv[])
             const Point3d t = (pose.rotation * pose.center) * -1.0;
             const Matrix3x4 P = composeP(K, R, t);
             ExrAttributes metadata = exr.attributes; // the source image's own metadata travel with it (main_prepareDenseScene.cpp:146-147)
+            // the exposure values are written whether or not --saveMetadata is set (main_prepareDenseScene.cpp:241-246)
+            metadata.setFloat("AliceVision:EV", float(ev));
+            metadata.setFloat("AliceVision:EVComp", exposureCompensation);
             if(saveMetadata)
             {
                 double vP[16] = {P(0, 0), P(0, 1), P(0, 2), P(0, 3), P(1, 0), P(1, 1), P(1, 2), P(1, 3), P(2, 0), P(2, 1), P(2, 2), P(2, 3), 0, 0, 0, 1};
@@ -435,8 +438,6 @@ static int aliceVision_main(int argc, char* argv[])
                         vK[3 * r + c] = K(r, c);
                         vR[3 * r + c] = R(r, c);
                     }
-                metadata.setFloat("AliceVision:EV", float(ev));
-                metadata.setFloat("AliceVision:EVComp", exposureCompensation);
                 metadata.setInt("AliceVision:downscale", 1);
                 metadata.setM44d("AliceVision:P", vP);
                 metadata.setM33d("AliceVision:K", vK);

@@ -919,3 +919,10 @@ def test_prepare_dense_scene_exposure_metadata_and_correction(tmp_path):
             if correct:
                 want[..., :3] = src[..., :3] * comp
             assert np.array_equal(got, want), (correct, i)
+    # the exposure values do not depend on --saveMetadata (main_prepareDenseScene.cpp:241-246 push them before the switch is looked at)
+    out = os.path.join(d, "prepared_nometa")
+    r = subprocess.run([exe, "-i", sfm, "-o", out, "--saveMetadata", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ch, info = exr_io.read_exr(os.path.join(out, "%d.exr" % scene_io.view_id(0)))
+    assert exr_io.attr_value(info, "AliceVision:EVComp") == np.float32(median / exposures[0])
+    assert "AliceVision:EV" in info["attributes"] and "AliceVision:P" not in info["attributes"]
