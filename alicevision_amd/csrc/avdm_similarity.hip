@@ -3667,7 +3667,7 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
             // the T camera's range; AVDM_SIM_DEINT=1 — de-interleaved T windows (lds_pitch_deint)
             const char* p8 = getenv("AVDM_SIM_PLANES8");
             const char* pd = getenv("AVDM_SIM_DEINT");
-            const bool planes8 = p8 != nullptr && p8[0] == '1', deint = pd != nullptr && pd[0] == '1';
+            const bool planes8 = !(p8 != nullptr && p8[0] == '0'), deint = pd != nullptr && pd[0] == '1'; // eight planes per pass: the default since round 5
 #define AVDM_SGM_EXPERIMENT_LAUNCH(P, D)                                                                                                                  \
     {                                                                                                                                                     \
         static std::once_flag onceX[64];                                                                                                                  \
@@ -3813,7 +3813,7 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
             });
             // AVDM_REFINE_PLANES8=1 (experimental, read at each call): eight planes per pass on the chunks that lie in the T camera's range
             const char* p8 = getenv("AVDM_REFINE_PLANES8");
-            if(p8 != nullptr && p8[0] == '1')
+            if(!(p8 != nullptr && p8[0] == '0')) // the default since round 5 (parity tables: profiles/r05_a_parity_*.json)
             {
                 static std::once_flag once8[64];
                 std::call_once(once8[dev0 & 63], [&] {

@@ -62,8 +62,20 @@ _SIG = {
 _lib = None
 
 
+def locked_make(directory, *args):
+    """`make` under an exclusive file lock: the test suite runs in several processes (pytest-xdist) that all want the checker built"""
+    import fcntl
+    import tempfile
+    with open(os.path.join(tempfile.gettempdir(), "avdm_make_%s.lock" % abs(hash(os.path.abspath(directory)))), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.run(["make", "-C", directory, "-s"] + list(args), check=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def build():
-    subprocess.run(["make", "-C", HERE, "-s"], check=True)
+    locked_make(HERE)
     return LIB_PATH
 
 

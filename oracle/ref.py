@@ -75,7 +75,8 @@ def available(variant=""):
 
 
 def build():
-    subprocess.run(["make", "-C", os.path.join(HERE, "ref"), "-s"], check=True)
+    from oracle.oracle import locked_make
+    locked_make(os.path.join(HERE, "ref"))
     return LIB_PATH
 
 

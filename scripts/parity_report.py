@@ -35,6 +35,12 @@ CASES = {
     # the interior and tile (4, 3) at the far image corner (800 x 744: clipped); 2 T cameras (the oracle's time goes with pixels x T cameras)
     "tile12mp_interior": dict(n_views=3, W=4000, H=3000, Z=256, seed=3, roi=(1600, 2464, 752, 1568), sgm={}, tile_buffer=(1024, 1024)),
     "tile12mp_corner": dict(n_views=3, W=4000, H=3000, Z=256, seed=3, roi=(3200, 4000, 2256, 3000), sgm={}, tile_buffer=(1024, 1024)),
+    # BASELINE configuration 5 at its OWN shape (round 5): 24 MP frame (6000 x 4000), `--tileBufferWidth 1664 --tileBufferHeight 1152 --tilePadding 64`
+    # -> 4 x 4 tiles of 1564 x 1064 (TileParams.cpp:15-61; tests/test_host_ref.py pins the grid to the reference's own getTileRoiList): tile (1, 1) in
+    # the interior and tile (3, 3) at the far image corner (1500 x 1000: clipped), volumes laid out and aggregated over the NON-SQUARE tile buffer
+    # (416 x 288 SGM columns / rows, deviceSimilarityVolume.cu:278-283), 256 planes, 2 T cameras
+    "tile24mp_interior": dict(n_views=3, W=6000, H=4000, Z=256, seed=5, roi=(1500, 3064, 1000, 2064), sgm={}, tile_buffer=(1664, 1152)),
+    "tile24mp_corner": dict(n_views=3, W=6000, H=4000, Z=256, seed=5, roi=(4500, 6000, 3000, 4000), sgm={}, tile_buffer=(1664, 1152)),
 }
 
 
@@ -55,9 +61,13 @@ def depth_stats(got, want, pix=None):
            "rmse_best_99pct": float(np.sqrt(s[: int(0.99 * s.size)].mean())),
            "median_abs": float(np.median(np.abs(err))), "p99_abs": float(np.percentile(np.abs(err), 99)), "max_abs": float(np.abs(err).max()),
            "frac_abs_gt_1e-3": float((np.abs(err) > 1e-3).mean())}
+    # scale-free forms: relative to the depth itself, and in units of the pixel size
+    out["median_depth"] = float(np.median(want[..., 0][both]))
+    out["rmse_untrimmed_relative"] = float(np.sqrt(((err / want[..., 0][both]) ** 2).mean()))
     if pix is not None:  # in units of the pixel size (depth step of one Refine plane): SURVEY 8c's "1e-3 * pixSize"
         e = err / pix[both]
         out["rmse_untrimmed_in_pixsize"] = float(np.sqrt((e ** 2).mean()))
+        out["median_pixsize"] = float(np.median(pix[both]))
     return out
 
 
@@ -176,7 +186,28 @@ def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False, spread=
     # with every fp32 operation as written (= the literal oracle) — the yardstick for the default kernels' distance to either
     if spread and refmod.available("cuda"):
         t1 = time.time()
-        rc_ = refmod.RefDepthMap(images_np, sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi, variant="cuda")
+        if tb is not None:
+            # a tile of the tile workflow: the reference's own host classes (Sgm.cpp / Refine.cpp compiled whole) over the CUDA-like kernels — maps
+            # only (the classes keep their volumes); the yardstick of the tile cases (tile12mp_corner)
+            # Both evaluations go through RefTile: where the tile is smaller than its buffer the reference's colour optimisation reads texels
+            # beyond the tile that no kernel wrote (a frame of iterations + 1 pixels) — the same "whatever" in both of them.  Against the
+            # product and the oracle (which clamp at the tile) the comparison is on the INTERIOR, without that frame.
+            def tile_run(variant):
+                rt = refmod.RefTile(images_np, sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi, variant=variant)
+                return rt.run_tile(0, tcs, depths, [(0, Z)] * len(tcs), tile_buffer=tb, max_depths=Z).copy()
+            want_base, want_cuda = tile_run(""), tile_run("cuda")
+            fb = ref.optimizationNbIterations + 1
+            inner = lambda a: a[fb:-fb, fb:-fb]
+            res["platform_spread"] = {
+                "cuda_vs_literal": {"final_depth": depth_stats(want_cuda, want_base, pix)},
+                "interior_frame": fb,
+                "cuda_vs_literal_interior": {"final_depth": depth_stats(inner(want_cuda), inner(want_base), inner(pix))},
+                "literal_oracle_vs_reference_tile_interior": {"final_depth": depth_stats(inner(wants["literal"][0]), inner(want_base), inner(pix))},
+                "well_posed_vs_literal_interior": {"final_depth": depth_stats(inner(wants["well_posed"][0]), inner(wants["literal"][0]), inner(pix))},
+                "default_vs_literal_interior": {"final_depth": depth_stats(inner(g_final), inner(wants["literal"][0]), inner(pix))},
+                "default_vs_cuda_interior": {"final_depth": depth_stats(inner(g_final), inner(want_cuda), inner(pix))},
+                "t_s": time.time() - t1}
+        rc_ = None if tb is not None else refmod.RefDepthMap(images_np, sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi, variant="cuda")
         if tb is None:
             rc_.run_sgm(0, tcs, depths)
             want_cuda = rc_.run_refine(0, tcs).copy()

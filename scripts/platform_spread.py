@@ -29,9 +29,16 @@ ALL_CASES = dict(CASES)
 ALL_CASES["smoke"] = dict(n_views=3, W=320, H=240, Z=48, seed=11, roi=None, sgm={})
 
 
-def run_variant(variant, images, sc, sgm, ref, roi, tcs, depths, filter_mode):
+def run_variant(variant, images, sc, sgm, ref, roi, tcs, depths, filter_mode, tile_buffer=None):
     from oracle import ref as refmod
     t0 = time.time()
+    if tile_buffer is not None:
+        # a tile of the tile workflow: the reference's OWN host classes (Sgm.cpp / Refine.cpp compiled whole, oracle/ref/tile_driver.cpp) over the
+        # variant's kernels — volumes and maps allocated for the tile buffer, aggregation over the buffer extent.  Maps only (the classes keep their volumes).
+        r = refmod.RefTile(images, sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi, variant=variant)
+        Z = len(depths)
+        final = r.run_tile(0, tcs, depths, [(0, Z)] * len(tcs), tile_buffer=tile_buffer, max_depths=Z).copy()
+        return {"sgm": r.sgm_depth_sim.copy(), "final": final, "t_s": time.time() - t0}
     r = refmod.RefDepthMap(images, sc.K, sc.R, sc.C, sgm, ref, filter_mode=filter_mode, roi=roi, variant=variant)
     r.run_sgm(0, tcs, depths)
     final = r.run_refine(0, tcs).copy()
@@ -40,7 +47,9 @@ def run_variant(variant, images, sc, sgm, ref, roi, tcs, depths, filter_mode):
             "refined": r.refined.copy(), "final": final, "pix": r.sgm_upscaled[..., 1].copy(), "t_s": time.time() - t0}
 
 
-def compare(a, b):
+def compare(a, b, pix=None):
+    if "refvol" not in a:  # tile cases: maps only
+        return {"sgm_wta_depth_differs": float((a["sgm"][..., 0] != b["sgm"][..., 0]).mean()), "final_depth": depth_stats(b["final"], a["final"], pix)}
     d = np.abs(a["refvol"] - b["refvol"])
     return {"similarity_volume_levels": level_hist(a["second"], b["second"]), "sgm_filtered_volume_levels": level_hist(a["filtered"], b["filtered"]),
             "sgm_wta_depth_differs": float((a["sgm"][..., 0] != b["sgm"][..., 0]).mean()),
@@ -57,10 +66,11 @@ def run_case(name, variants, filter_mode=abi.FILTER_CUDA_FIXED8):
     depths = plane_depths(sc, spec["Z"])
     tcs = list(range(1, spec["n_views"]))
     res = {"case": name, "image": [spec["W"], spec["H"]], "planes": spec["Z"], "t_cams": len(tcs), "roi": spec["roi"]}
-    base = run_variant("", images, sc, sgm, ref, spec["roi"], tcs, depths, filter_mode)
+    tb = spec.get("tile_buffer")
+    base = run_variant("", images, sc, sgm, ref, spec["roi"], tcs, depths, filter_mode, tb)
     res["t_base_s"] = base["t_s"]
     for v in variants:
-        got = run_variant(v, images, sc, sgm, ref, spec["roi"], tcs, depths, filter_mode)
+        got = run_variant(v, images, sc, sgm, ref, spec["roi"], tcs, depths, filter_mode, tb)
         res["base_vs_" + v] = compare(base, got)
     return res
 

@@ -29,3 +29,10 @@ def level_mismatch(a, b):
     """fraction of differing entries and max abs difference of two uint8 arrays"""
     d = np.abs(a.astype(np.int16) - b.astype(np.int16))
     return float((d != 0).mean()), int(d.max())
+
+
+def build_host():
+    """the C++ host programs (alicevision_amd/host), built under the checker's make lock: the suite runs in several processes (pytest-xdist)"""
+    import os
+    from oracle.oracle import locked_make
+    locked_make(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alicevision_amd", "host"), "-j8")

@@ -24,7 +24,7 @@ TOOL = os.path.join(ROOT, "alicevision_amd", "bin", "avdm_host_tool")
 
 @pytest.fixture(scope="session", autouse=True)
 def built():
-    subprocess.run(["make", "-C", os.path.join(ROOT, "alicevision_amd", "host"), "-s", "-j8"], check=True)
+    __import__("common").build_host()
     assert os.path.exists(CLI) and os.path.exists(TOOL)
 
 

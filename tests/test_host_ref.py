@@ -219,7 +219,7 @@ def test_exposure_setting_equals_reference():
     lib.avr_exposure.argtypes = [C.c_double] * 3
     lib.avr_exposure_partially_defined.argtypes = [C.c_double] * 3
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alicevision_amd", "bin", "avdm_host_tool")
-    subprocess.run(["make", "-C", os.path.join(os.path.dirname(tool), "..", "host"), "-s", "-j8"], check=True)
+    __import__("common").build_host()
     triples = [(s, f, i) for s in (-1.0, 0.0, 1.0 / 4000, 1.0 / 200, 0.005, 1.0 / 3, 2.5, float("nan"))
                for f in (-1.0, 0.0, 1.4, 2.8, 5.6, 22.0, float("inf")) for i in (-1.0, 0.0, 1e-7, 50.0, 100.0, 800.0, 25600.0)]
     args = [repr(v) for t in triples for v in t]

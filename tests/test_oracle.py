@@ -502,7 +502,7 @@ def test_jpeg_entropy_decoder_and_oracle_equal_libjpeg_turbo_on_the_golden_files
     """host/jpeg.cpp (markers, Huffman, sequential and progressive scans, restart markers) + the oracle's restatement of libjpeg's inverse
     DCT, fancy up-sampling and colour conversion == the pixels libjpeg-turbo decoded from the same files (tests/golden/jpeg: 4:4:4 /
     4:2:2 / 4:2:0, baseline / progressive, restarts, optimised tables, grey, RGB-stored, sizes down to 1 x 1, quality 1 .. 100)."""
-    subprocess.run(["make", "-C", os.path.join(os.path.dirname(JPEG_GOLDEN), "..", "..", "alicevision_amd", "host"), "-s", "-j8"], check=True)
+    __import__("common").build_host()
     exp = np.load(os.path.join(JPEG_GOLDEN, "expected.npz"))
     assert len(exp.files) >= 17
     seen_progressive = seen_rgb = 0
@@ -517,7 +517,7 @@ def test_jpeg_entropy_decoder_and_oracle_equal_libjpeg_turbo_on_the_golden_files
 def test_jpeg_decoder_against_pillow_when_available(tmp_path):
     """the same comparison on files made now (when this host has Pillow): a larger image per sampling mode, and malformed input"""
     Image = pytest.importorskip("PIL.Image")
-    subprocess.run(["make", "-C", os.path.join(os.path.dirname(JPEG_GOLDEN), "..", "..", "alicevision_amd", "host"), "-s", "-j8"], check=True)
+    __import__("common").build_host()
     rng = np.random.default_rng(5)
     y, x = np.mgrid[0:301, 0:413]
     a = np.clip(np.stack([128 + 100 * np.sin(x / 17.0) * np.cos(y / 11.0), 128 + 90 * np.cos(x / 13.0 + y / 9.0), 60 + x * 0.4 + 20 * np.sin(y / 2.0)], -1) +
