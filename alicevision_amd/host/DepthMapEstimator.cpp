@@ -537,6 +537,10 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         AVDM_HIP_CHECK(hipDeviceSynchronize());
         AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": images decoded, uploaded and converted to pyramids in " << secondsSince(tBatch0) << " s.");
 
+        // what the batch actually sweeps, in the kernels' work unit (voxel x T camera): the depth lists are capped per tile and every T camera has
+        // its own plane range, so this is NOT tiles x maxDepths x maxTCams — logged so that the program's rate can be compared with a sweep of known size
+        long long workSgmVoxelT = 0, workRefineVoxelT = 0, workPlanes = 0, workSgmT = 0, workRefineT = 0;
+        int workTiles = 0;
         // groups of nbStreams tiles
         for(int g0 = firstTileIndex; g0 < lastTileIndex; g0 += nbStreams)
         {
@@ -581,6 +585,25 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
             }
             if(error)
                 std::rethrow_exception(error);
+
+            for(int k = 0; k < n; ++k)
+            {
+                if(!active[k])
+                    continue;
+                const Tile& tile = tiles.at(g0 + k);
+                const ROI rs = downscaleROI(tile.roi, (float)(_sgmParams.scale * _sgmParams.stepXY));
+                const ROI rr = downscaleROI(tile.roi, (float)(_refineParams.scale * _refineParams.stepXY));
+                long long planesT = 0;
+                for(const Pixel& lim : depthLists[k]->getDepthsTcLimits())
+                    planesT += lim.y;
+                workSgmVoxelT += (long long)rs.width() * rs.height() * planesT;
+                if(_depthMapParams.useRefine)
+                    workRefineVoxelT += (long long)rr.width() * rr.height() * (2 * _refineParams.halfNbDepths + 1) * (long long)tile.refineTCams.size();
+                workPlanes += (long long)depthLists[k]->getDepths().size();
+                workSgmT += (long long)tile.sgmTCams.size();
+                workRefineT += (long long)tile.refineTCams.size();
+                ++workTiles;
+            }
 
             // (A0) the adaptive-P2 maps of the group's aggregation: they depend on nothing but the R pyramids, so they are evaluated on the
             // aggregation stream BEFORE the sweeps (avdm_volume_optimize_prepare) and step (B) is the path launches alone
@@ -660,6 +683,10 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
             AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": " << n << " tile(s) computed, " << secondsSince(tBatch0) << " s since the batch started.");
         }
 
+        if(workTiles > 0)
+            AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": swept " << workTiles << " tile(s): " << workSgmVoxelT << " SGM voxel-T, " << workRefineVoxelT
+                                   << " Refine voxel-T; per tile on average " << (double)workPlanes / workTiles << " planes, " << (double)workSgmT / workTiles
+                                   << " SGM T cameras, " << (double)workRefineT / workTiles << " Refine T cameras.");
         // write the finished cameras of the batch, in the background: the previous batch's task must be done first (it owns the other set)
         if(pendingWrite.valid())
             pendingWrite.get();

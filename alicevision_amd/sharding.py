@@ -125,6 +125,76 @@ class ViewExchange:
         return sum(a.elapsed_time(b) for a, b in self.events)
 
 
+class StepProtocol:
+    """What ONE step of a rank is, in the order the streams see it — the rank-side protocol of bench.py, separated from the kernels so that
+    tests/test_sharding.py can run the WHOLE of it with two gloo ranks on the CPU (stub `build` / `sweep`):
+
+        commit()                       pyramids received during the previous step -> their arena slots (only when views are streamed)
+        build(rc)                      image -> Lab pyramid of the reference camera of this step: a view this rank OWNS, in its arena slot
+        publish_async(views)           [stream_views only] every rank's freshly built pyramid to every other rank, beside the sweep
+        sweep(rc, tcs)                 the depth map of rc against its T cameras: pyramids this rank RECEIVED (set-up, or a committed round)
+
+    stream_views = False (default): the pyramids were handed to every rank ONCE by ViewExchange.setup() — "neighbour views broadcast once"
+    (BASELINE north_star) — and no collective runs inside the timed region.  stream_views = True is the streaming job (new images every
+    round): one all-gather per step on a side stream.  `cams_of[r]` = the reference cameras of rank r; every rank steps through its own list."""
+
+    def __init__(self, exchange, cams_of, n_views, n_tcams, build, sweep, stream_views=False, on_stage=None):
+        self.ex, self.cams_of, self.V, self.T = exchange, cams_of, n_views, n_tcams
+        self.build, self.sweep, self.stream_views = build, sweep, stream_views
+        self.stage = on_stage if on_stage is not None else _no_stage
+        self.rank = exchange.rank
+
+    def camera_of_step(self, rank, i):
+        cams = self.cams_of[rank]
+        return cams[i % len(cams)]
+
+    def tcams_of(self, rc):
+        return [(rc + 1 + k) % self.V for k in range(self.T)]  # the T following views of the ring: owned by other ranks when N > 1
+
+    def step(self, i):
+        rc = self.camera_of_step(self.rank, i)
+        streaming = self.stream_views and self.ex.dist is not None
+        if streaming:
+            with self.stage("pyramid_commit"):
+                self.ex.commit()
+        with self.stage("image_pyramid"):
+            self.build(rc)
+        if streaming:
+            self.ex.publish_async([self.camera_of_step(r, i) for r in range(self.ex.world)])
+        return self.sweep(rc, self.tcams_of(rc))
+
+    def finish(self):
+        """the last round's pyramids are part of a streaming job"""
+        if self.stream_views and self.ex.dist is not None:
+            with self.stage("pyramid_commit"):
+                self.ex.commit()
+
+
+class _no_stage:
+    def __init__(self, name):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def fixed_job(n_cameras, world, step_s_of_rank):
+    """The FIXED job BASELINE.json quotes its multi-GPU target on ("20 x 12 MP views ... >= 6 x at 8 GPUs"): all n_cameras reference cameras
+    dealt round-robin to `world` ranks, finished when the slowest rank is — next to the weak-scaling `value` of the bench (K steps on every
+    rank), which cannot show the imbalance of 20 cameras on 8 ranks (3, 3, 3, 3, 2, 2, 2, 2: the ceiling of the speed-up is 20 / 3 = 6.67).
+    step_s_of_rank[r] = seconds per depth map measured on rank r.  (computeOnMultiGPUs.cpp:15-69: the reference's job is this one.)"""
+    per_rank = [len(cameras_of_rank(range(n_cameras), r, world)) for r in range(world)]
+    busy = [n * float(t) for n, t in zip(per_rank, step_s_of_rank)]
+    makespan = max(busy)
+    return {"cameras": n_cameras, "cameras_per_rank": per_rank, "step_s_per_rank": [float(t) for t in step_s_of_rank], "makespan_s": makespan,
+            "depth_maps_per_s": n_cameras / makespan if makespan > 0 else None,
+            "speedup_ceiling": n_cameras / max(per_rank),  # against one rank at the same seconds per depth map
+            "how": "per-rank seconds per depth map measured in this run x the cameras round-robin deals to the rank; makespan = the slowest rank"}
+
+
 def exchange_pyramid(buf, src, dist, all_ranks=False):
     """One-shot helpers kept for callers that hold a single buffer: broadcast of `buf` from `src`, or (all_ranks) an all-gather returning
     the list of every rank's buffer."""

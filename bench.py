@@ -11,11 +11,14 @@ Workloads (BASELINE.json configs; config.workload names the one that ran):
   cfg2 / cfg1              the smaller parity configurations.
 One step = one depth map of one reference camera: R-image pyramid build -> similarity volume x10 -> 4-path SGM aggregation -> WTA ->
 thickness smoothing -> upscale -> Refine volume x10 -> sub-sample arg-min -> 100 optimisation iterations.  Every rank computes K depth
-maps of reference cameras it owns (weak scaling); value = N*K / max-over-ranks time.  Images are resident in HBM before the timed
-region.  Multi-GPU: a view's pyramid is built ONLY by the rank that owns the view; all pyramids of a rank live in one arena whose rows of
-`world` views travel in ONE in-place all-gather each at set-up, and in the timed region each step's freshly rebuilt R pyramids travel by one
-all-gather on a side stream, beside the sweep, into a staging row that the next step commits to the pyramid stores — the neighbour pyramids a
-rank sweeps against are the bytes it received (alicevision_amd/sharding.py: ViewExchange).  `--force-dist` runs all of it with one rank.
+maps of reference cameras it owns (weak scaling); value = N*K / max-over-ranks time; `fixed_job` next to it prices the FIXED job BASELINE
+quotes (all 20 cameras of cfg4 dealt to the N ranks, finished when the slowest rank is) from the per-rank seconds per depth map of this run.
+Images are resident in HBM before the timed region.  Multi-GPU: a view's pyramid is built ONLY by the rank that owns the view; all pyramids
+of a rank live in one arena whose rows of `world` views travel in ONE in-place all-gather each at set-up ("neighbour views broadcast once"),
+and NO collective runs inside the timed region — the neighbour pyramids a rank sweeps against are the bytes it received
+(alicevision_amd/sharding.py: ViewExchange, StepProtocol).  `--stream-views` is the streaming job instead: each step's freshly rebuilt R
+pyramids travel by one all-gather on a side stream, beside the sweep, into a staging row that the next step commits.  `--force-dist` runs
+all of it with one rank.
 All compute goes through the C ABI of alicevision_amd/csrc/libavdm.so (hand-written HIP); the oracle is only used for the
 `cpu_baseline` leg on rank 0 at N = 1.
 """
@@ -35,7 +38,7 @@ import torch
 
 from alicevision_amd import abi
 from alicevision_amd.pipeline import DepthMapTile, DevicePyramid, optimize_tiles_batched
-from alicevision_amd.sharding import ViewExchange, cameras_of_rank, owner_of_view
+from alicevision_amd.sharding import StepProtocol, ViewExchange, cameras_of_rank, fixed_job, owner_of_view
 from alicevision_amd.synthetic import make_scene, plane_depths
 
 WORKLOADS = {
@@ -123,27 +126,57 @@ def dry_run(args, rank, world):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    V = WORKLOADS[args.workload or ("cfg3" if world == 1 else "cfg4")][0]
-    my_cams = cameras_of_rank(list(range(V)), rank, world)
+    V, _, _, _, T, _ = WORKLOADS[args.workload or ("cfg3" if world == 1 else "cfg4")]
+    cams_of = [cameras_of_rank(list(range(V)), r, world) for r in range(world)]
+    my_cams = cams_of[rank]
     owned = [v for v in range(V) if owner_of_view(v, world) == rank]
+    # the rank-side protocol of a step with stand-ins for the kernels: "pyramids" of 64 bytes whose content names (view, version)
+    ex = ViewExchange(V, 64, rank, world, dist if world > 1 else None)
+    version = {v: 0 for v in range(V)}
+    for v in owned:
+        ex.buffer(v).fill_(1 + (v % 16))
+    ex.setup()
+    done, checked = [], [0]
+
+    def build(rc):
+        assert owner_of_view(rc, world) == rank, "a rank only ever builds a view it owns"
+        if args.stream_views:
+            version[rc] += 1
+        ex.buffer(rc).fill_(1 + (rc % 16) + 16 * (version[rc] % 15))
+
+    def sweep(rc, tcs):
+        for v in tcs:  # whatever this rank sweeps against is a WHOLE pyramid of the right view: built here or received
+            b = ex.buffer(v)
+            assert int(b[0]) == int(b[-1]) and (int(b[0]) - 1) % 16 == v % 16, (v, int(b[0]), int(b[-1]))
+            checked[0] += 1
+        done.append(rc)
+
+    proto = StepProtocol(ex, cams_of, V, min(T, V - 1), build, sweep, stream_views=args.stream_views)
     for i in range(args.warmup):
-        pass
+        proto.step(i)
+    done.clear()
     if world > 1:
         dist.barrier()
     t0 = time.time()
-    done = [my_cams[(args.warmup + i) % len(my_cams)] for i in range(args.steps)]
+    for i in range(args.steps):
+        proto.step(args.warmup + i)
+    proto.finish()
     if world > 1:
         dist.barrier()
     elapsed = time.time() - t0
-    counts = torch.tensor([len(owned), len(my_cams)], dtype=torch.int64)
+    counts = torch.tensor([len(owned), len(my_cams), checked[0]], dtype=torch.int64)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         dist.all_reduce(counts)
     if rank == 0:
+        # the fixed-job accounting with one second per depth map on every rank: cameras per rank, makespan, the ceiling of the speed-up
+        n_job = WORKLOADS["cfg4"][0] if (args.workload or "cfg3") in ("cfg3", "cfg4") else V
         print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "views": V, "views_owned_total": int(counts[0]),
-                          "reference_cameras_total": int(counts[1]), "rank0_cameras": done, "elapsed_s": elapsed, "scaling": "weak"}), flush=True)
+                          "reference_cameras_total": int(counts[1]), "rank0_cameras": done, "elapsed_s": elapsed, "scaling": "weak",
+                          "stream_views": bool(args.stream_views), "exchange_collectives": ex.collectives, "tcam_pyramids_checked": int(counts[2]),
+                          "fixed_job": fixed_job(n_job, world, [1.0] * world)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -190,6 +223,16 @@ def cli_end_to_end(sc, V, W, H, Z, T, n_cams):
         comp[int(b)] = max(comp.get(int(b), 0.0), float(x))
     wr = {int(b): float(x) for b, x in re.findall(r"Batch (\d+)/\d+: depth / similarity maps merged and written,\s*" + num + " s since the batch started", log)}
     task = [float(x) for x in re.findall(r"Task done in \(s\): " + num, log)]
+    # what the program actually swept (host/DepthMapEstimator.cpp: per batch, in voxel x T camera; the depth lists are capped per tile and every
+    # T camera has its own plane range)
+    work = re.findall(r"Batch \d+/\d+: swept (\d+) tile\(s\): (\d+) SGM voxel-T, (\d+) Refine voxel-T; per tile on average " + num + " planes, " + num +
+                      " SGM T cameras, " + num + " Refine T cameras", log)
+    swept = None
+    if work:
+        nt = sum(int(w[0]) for w in work)
+        swept = {"tiles": nt, "sgm_voxelT": sum(int(w[1]) for w in work), "refine_voxelT": sum(int(w[2]) for w in work),
+                 "planes_per_tile": sum(int(w[0]) * float(w[3]) for w in work) / nt, "sgm_tcams_per_tile": sum(int(w[0]) * float(w[4]) for w in work) / nt,
+                 "refine_tcams_per_tile": sum(int(w[0]) * float(w[5]) for w in work) / nt}
     split = None
     if dec and set(dec) == set(comp):
         # per batch: decode + upload + pyramids, then the tiles (every stage of every tile, results copied back), then merge + EXR output — the
@@ -197,7 +240,7 @@ def cli_end_to_end(sc, V, W, H, Z, T, n_cams):
         split = {"batches": len(dec), "decode_upload_pyramids_s": sum(dec.values()), "tiles_s": sum(comp[b] - dec[b] for b in dec),
                  "merge_write_tail_s": sum(max(wr[b] - comp[b], 0.0) for b in wr if b in comp), "task_s": task[-1] if task else None,
                  "process_start_and_scene_s": (wall - task[-1]) if task else None}
-    return {"value": n_cams / wall, "unit": "depth-maps/s", "cameras": n_cams, "wall_s": wall, "scene_write_s": t_write, "split": split,
+    return {"value": n_cams / wall, "unit": "depth-maps/s", "cameras": n_cams, "wall_s": wall, "scene_write_s": t_write, "split": split, "swept": swept,
             "includes": "process start, EXR decode of the views, upload, pyramids, default 1024 tiling (tiles batched per SGM launch), tile merge, EXR output"}
 
 
@@ -215,6 +258,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="create the process group (nccl = RCCL) and run the pyramid exchange's collectives even with ONE rank: the multi-GPU code "
                          "path exercised on a single GPU (tests/test_gpu_parity.py::test_bench_rccl_path_on_one_gpu)")
+    ap.add_argument("--stream-views", action="store_true",
+                    help="the streaming job: every step's freshly rebuilt R pyramids travel to every other rank by one all-gather on a side stream "
+                         "(stages pyramid_exchange / pyramid_commit).  Default: the pyramids are handed over once, before the timed region")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only (gloo, no GPU work): what tests/test_sharding.py runs on the CPU")
     args = ap.parse_args()
@@ -279,18 +325,10 @@ def main():
     cams_of = [cameras_of_rank(list(range(V)), r, world) for r in range(world)]  # reference cameras per rank (round-robin = the views it owns)
     my_cams = cams_of[rank]
 
-    def step(i):
-        rc = my_cams[i % len(my_cams)]
-        tcs = [(rc + 1 + k) % V for k in range(T)]  # the T following views of the ring: owned by other ranks when N > 1
-        if dist is not None:
-            with tile.timers.range("pyramid_commit"):
-                exchange.commit()                 # the pyramids received during the previous step -> their slots, in stream order
-        with tile.timers.range("image_pyramid"):
-            pyr[rc].fill(images[rc])              # image -> Lab pyramid (DeviceCache::addMipmapImage): only ever for a view I own
-        if dist is not None:
-            # every rank's freshly built R pyramid to every other rank: ONE all-gather into a staging row on a side stream, overlapped with
-            # this step's sweep (nothing reads the staging row before the next step's commit)
-            exchange.publish_async([cams_of[r][i % len(cams_of[r])] for r in range(world)])
+    def build(rc):
+        pyr[rc].fill(images[rc])                  # image -> Lab pyramid (DeviceCache::addMipmapImage): only ever for a view I own
+
+    def sweep(rc, tcs):
         out = None
         if len(tiles) == 1:
             tiles[0].run_sgm(rc, tcs, depths)
@@ -303,6 +341,11 @@ def main():
         for t in tiles:
             out = t.run_refine(rc, tcs)
         return out
+
+    # the rank-side order of a step (commit / build / publish / sweep: sharding.StepProtocol — the same object tests/test_sharding.py runs with
+    # two gloo ranks and stand-in kernels)
+    proto = StepProtocol(exchange, cams_of, V, T, build, sweep, stream_views=args.stream_views, on_stage=tile.timers.range)
+    step = proto.step
 
     for i in range(args.warmup):
         step(i)
@@ -326,20 +369,24 @@ def main():
             st = (ctypes.c_uint * 4)()
             lib.avdm_debug_similarity_stats(st)
             stats_each.append([int(v) for v in st])
-    if dist is not None:
-        with tile.timers.range("pyramid_commit"):
-            exchange.commit()  # the last round's pyramids are part of the job
+    proto.finish()  # (streaming job: the last round's pyramids are part of it)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.time() - t0
+    # seconds per depth map on every rank (GPU time between the step events): what the fixed-job figure is priced with
+    my_step_s = 1e-3 * step_events[0].elapsed_time(step_events[-1]) / args.steps
+    step_s_of_rank = [my_step_s]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        allt = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, torch.tensor([my_step_s], dtype=torch.float64, device=dev))
+        step_s_of_rank = [float(x) for x in allt.cpu()]
 
     stages = tile.timers.mean_ms(per=args.steps)  # ms per step and stage (HIP events on the launch stream; summed over the tiles of a step)
-    if dist is not None:
+    if dist is not None and args.stream_views:
         # the all-gather of a step's R pyramids runs on a side stream beside the sweep: its own events, not part of the critical path
         stages["pyramid_exchange"] = exchange.exchange_ms() / args.steps
     k_ms, k_n = ctypes.c_double(0.0), ctypes.c_long(0)
@@ -367,7 +414,13 @@ def main():
         # several tiles per depth map are aggregated by ONE call (all their volumes per launch): the "volume" of the accounting is then the batch
         batched = len(vols) > 1
         n_calls = 1 if batched else len(vols)
-        alg_bytes_per_volume = sum(11.0 * x * y * Z + 64.0 * x * y for x, y in vols) / n_calls
+        # SURVEY 8(d)'s figure for the whole aggregation, adaptive-P2 maps included: 11 B/voxel + 64 B/pixel of R texels
+        survey_bytes_per_volume = sum(11.0 * x * y * Z + 64.0 * x * y for x, y in vols) / n_calls
+        # ... of which the TIMED call (avdm_volume_optimize_tiles_prepared: the path launches alone) moves the 11 B/voxel and READS the P2 maps — one
+        # float per (path, pixel) = 16 B/pixel; the 64 B/pixel of R texels belong to the map kernel, which runs beside the similarity sweep
+        # (stage sgm_p2_map) since round 4.  One-call form (AVDM_SGM_PREPARE=0): the map kernel is inside the call, SURVEY's figure is the numerator.
+        prepared = os.environ.get("AVDM_SGM_PREPARE") != "0"
+        alg_bytes_per_volume = (sum(11.0 * x * y * Z + 16.0 * x * y for x, y in vols) / n_calls) if prepared else survey_bytes_per_volume
         alg_bytes_per_launch = alg_bytes_per_volume / n_launches
         # average duration of one path-aggregation kernel launch (HIP events around the launches alone, on their stream);
         # stages["sgm_optimize"] is the whole avdm_volume_optimize call, i.e. these launches + the adaptive-P2 map kernel
@@ -383,9 +436,13 @@ def main():
         roof = {"bound": "hbm", "kernel": "sgm_pair_kernel" if n_launches == 2 else "sgm_path_kernel", "achieved": achieved_call, "peak": 8000.0,
                 "unit": "GB/s", "frac": achieved_call / 8000.0, "achieved_kernels_only": achieved, "traffic": None, "alg_bytes_per_launch": alg_bytes_per_launch,
                 "ms_per_launch": sgm_ms_per_launch, "launches_per_volume": n_launches, "volumes_per_launch": len(vols) if batched else 1,
-                # the same bytes over the whole avdm_volume_optimize call (path launches + sgm_p2_map_kernel, whose 64 B/pixel are in the numerator)
+                "alg_bytes_per_volume": alg_bytes_per_volume,
+                "alg_bytes": "11 B/voxel + 16 B/pixel (the P2 maps the path launches read)" if prepared else "SURVEY 8(d): 11 B/voxel + 64 B/pixel",
                 "ms_whole_call_per_volume": whole_call_ms, "frac_whole_call": achieved_call / 8000.0,
                 "frac_kernels_only": achieved / 8000.0,
+                # SURVEY 8(d)'s bytes (with the 64 B/pixel of R texels) over the timed call PLUS the adaptive-P2 map kernel that reads them (stage
+                # sgm_p2_map, beside the similarity sweep): the other self-consistent form of the same figure
+                "frac_with_p2_map": survey_bytes_per_volume / ((whole_call_ms + stages.get("sgm_p2_map", 0.0) / n_calls) * 1e-3) / 1e9 / 8000.0,
                 # per launch of a volume: [first filtering axis (paths 0 + 1), second axis (paths 2 + 3)]
                 "ms_per_launch_by_axis": [path_ms[k] / path_n[k] if path_n[k] else None for k in (0, 2)]}
         # what this box's HBM delivers to a plain device-to-device copy (1 GiB read + 1 GiB written, measured here, after the timed region):
@@ -473,18 +530,21 @@ def main():
         line = {
             "metric": "depth-maps/sec (12 MP, 256 depth hyp, 10 neighbours)", "value": value, "unit": "depth-maps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            # the FIXED job BASELINE quotes at N GPUs (cfg4: 20 reference cameras dealt to the ranks — the same 20 at N = 1, where cfg3 runs the same
+            # work per depth map), priced with this run's per-rank seconds per depth map — `value` above is the weak-scaling rate (K steps per rank)
+            "fixed_job": fixed_job(WORKLOADS["cfg4"][0] if args.workload in ("cfg3", "cfg4") else V, world, step_s_of_rank),
             "vs_baseline": None, "dtype": "f32 (fp16 texels, u8 cost volume)", "data": "synthetic",
             "config": {"workload": args.workload, "views": V, "width": W, "height": H, "depth_planes": Z, "t_cams": T, "tiles_per_depth_map": len(rois),
                        "sgm": "scale 2 stepXY 2 wsh 4, 4 paths", "refine": "scale 1 stepXY 1 wsh 3, 31 planes, 100 opt iters",
                        "sharding": f"round-robin reference cameras over {world} rank(s); a view's pyramid is built by its owner only",
+                       "stream_views": bool(args.stream_views),
                        "process_group": None if dist is None else f"nccl (RCCL), {world} rank(s)" + (" [--force-dist]" if world == 1 else ""),
                        "pyramid_setup_broadcast_s": t_ex, "pyramid_bytes_received_per_rank": exchange.bytes_received,
                        "pyramid_exchange_collectives": exchange.collectives},
             "roofline": roof,
             "similarity": {"sgm_voxelT_per_s": vt_sgm, "refine_voxelT_per_s": vt_ref, "sgm_samples_per_s": s_sgm, "refine_samples_per_s": s_ref,
                            "sgm_lds_GBps": s_sgm * (48.0 if os.environ.get("AVDM_SIM_PLANE_PAIRS") == "0" else 36.0) / 1e9, "refine_lds_GBps": s_ref * 64.0 / 1e9, "lds_peak_GBps": 150000.0,
-                           "sgm_fp32_TFLOPs": vt_sgm * 8.1e3 / 1e12, "refine_fp32_TFLOPs": vt_ref * 4.9e3 / 1e12,
-                           "sgm_fp32_frac": vt_sgm * 8.1e3 / 157.3e12, "refine_fp32_frac": vt_ref * 4.9e3 / 157.3e12, "fp32_vector_peak_TFLOPs": 157.3,
+                           # (the estimated-flop fractions of rounds 1-4 are gone: the kernels are bound by VALU ISSUE of mostly non-FMA instructions)
                            "valu_issue_frac": sim_pmc["valu_issue_frac"], "valu_issue": sim_pmc},
             "stages_ms": stages, "valid_fraction": valid,
             # GPU time of every timed step (HIP events between the steps): shows the clock settling under sustained load
@@ -497,7 +557,20 @@ def main():
             line["similarity_plane_workgroups_each"] = stats_each
         n_cli = args.cli_e2e if args.cli_e2e >= 0 else (V if args.workload == "cfg3" else 0)
         if world == 1 and n_cli > 0:
-            line["cli_end_to_end"] = cli_end_to_end(sc, V, W, H, Z, T, min(n_cli, V))
+            e2e = cli_end_to_end(sc, V, W, H, Z, T, min(n_cli, V))
+            sw = e2e.get("swept")
+            if sw and e2e.get("split"):
+                # the same work at THIS run's kernel rates (seconds per voxel-T of the two similarity stages; every other stage per camera):
+                # what the program's tiles would take if it ran exactly at the bench's rate — the program sweeps other amounts than the
+                # bench's 256 planes x 10 T cameras (padded tiles: more pixels; per-tile depth lists and per-T plane ranges: fewer voxel-T)
+                other_ms = ms_per_step - stages["sgm_similarity"] - stages["refine_similarity"]
+                pred = (sw["sgm_voxelT"] / vt_sgm) + (sw["refine_voxelT"] / vt_ref) + e2e["cameras"] * other_ms * 1e-3
+                e2e["kernel_only_s_for_the_same_work"] = pred
+                e2e["kernel_only_rate_for_the_same_work"] = e2e["cameras"] / pred
+                e2e["value_over_kernel_only_rate"] = e2e["value"] / (e2e["cameras"] / pred)
+                e2e["tiles_s_over_kernel_only_s"] = e2e["split"]["tiles_s"] / pred
+                e2e["bench_voxelT_per_depth_map"] = {"sgm": px_sgm * Z * T, "refine": px_ref * nz_ref * T}
+            line["cli_end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             small = make_scene(3, 512, 384, seed=3, device="cpu")
             line["cpu_baseline"] = cpu_baseline(small, sgm, ref, Z, W * H, T)

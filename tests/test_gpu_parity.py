@@ -1662,31 +1662,36 @@ def test_harness_batched_aggregation_equals_per_tile():
 
 
 def test_bench_rccl_path_on_one_gpu():
-    """The multi-GPU code path of bench.py — process group over RCCL (backend "nccl"), ViewExchange.setup()'s in-place all-gathers, the
-    per-step all-gather of the freshly built R pyramids on a side stream and its commit — executed with ONE rank on the one GPU of the test
-    box (`--force-dist`), so that the first 8-GPU run cannot die on API misuse.  The line must carry the exchange's stages and the same
-    depth maps as the run without a process group."""
+    """The multi-GPU code path of bench.py — process group over RCCL (backend "nccl"), ViewExchange.setup()'s in-place all-gathers and, for the
+    streaming job (--stream-views), the per-step all-gather of the freshly built R pyramids on a side stream and its commit — executed with ONE
+    rank on the one GPU of the test box (`--force-dist`), so that the first 8-GPU run cannot die on API misuse.  By default the timed region
+    runs NO collective (the pyramids are handed over once, at set-up); the lines must carry the same depth maps as the run without a process
+    group, and the fixed-job figure next to the weak-scaling value."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     outs = []
-    for extra in (["--force-dist"], []):
+    for extra in (["--force-dist", "--stream-views"], ["--force-dist"], []):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "cfg1", "--steps", "3", "--warmup", "1",
                             "--no-cpu-baseline", "--cli-e2e", "0"] + extra, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, r.stdout
         outs.append(json.loads(lines[0]))
-    forced, plain = outs
-    assert forced["config"]["process_group"].startswith("nccl") and plain["config"]["process_group"] is None
-    # cfg1 has 3 views: set-up = one all-gather per row of `world` = 1 views (3), then one per step (1 warm-up + 3 timed)
-    assert forced["config"]["pyramid_exchange_collectives"] == 3 + 4 and plain["config"]["pyramid_exchange_collectives"] == 0
-    assert forced["stages_ms"]["pyramid_exchange"] > 0.0 and "pyramid_commit" in forced["stages_ms"]
-    assert "pyramid_exchange" not in plain["stages_ms"]
-    assert forced["valid_fraction"] == plain["valid_fraction"] > 0.5
-    assert forced["n_gpus"] == plain["n_gpus"] == 1 and forced["scaling"] == "weak"
+    streamed, forced, plain = outs
+    assert streamed["config"]["process_group"].startswith("nccl") and forced["config"]["process_group"].startswith("nccl") and plain["config"]["process_group"] is None
+    # cfg1 has 3 views: set-up = one all-gather per row of `world` = 1 views (3); the streaming job adds one per step (1 warm-up + 3 timed)
+    assert streamed["config"]["pyramid_exchange_collectives"] == 3 + 4 and forced["config"]["pyramid_exchange_collectives"] == 3
+    assert plain["config"]["pyramid_exchange_collectives"] == 0
+    assert streamed["stages_ms"]["pyramid_exchange"] > 0.0 and "pyramid_commit" in streamed["stages_ms"]
+    assert "pyramid_exchange" not in forced["stages_ms"] and "pyramid_exchange" not in plain["stages_ms"]
+    assert streamed["valid_fraction"] == forced["valid_fraction"] == plain["valid_fraction"] > 0.5
+    for o in outs:
+        assert o["n_gpus"] == 1 and o["scaling"] == "weak"
+        fj = o["fixed_job"]
+        assert fj["cameras"] == 3 and fj["cameras_per_rank"] == [3] and abs(fj["makespan_s"] - 3 * fj["step_s_per_rank"][0]) < 1e-9
 
 
 # ---- the switch matrix (VERDICT r3, item 8): every non-default AVDM_* code-path switch still passes its parity class ------------------------

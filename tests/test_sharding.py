@@ -138,3 +138,123 @@ def test_bench_launches_its_own_ranks():
     cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "2"], port=29511)
     assert cmd[1:9] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "29511"]
     assert cmd[9].endswith("bench.py") and cmd[10:] == ["--gpus", "4", "--steps", "2"]
+
+
+def _bench_dry_run(n, extra=()):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run", "--steps", "3", "--warmup", "1"] + list(extra),
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n,per_rank,ceiling", [(1, [20], 1.0), (2, [10, 10], 2.0), (4, [5] * 4, 4.0), (8, [3, 3, 3, 3, 2, 2, 2, 2], 20.0 / 3.0)])
+def test_fixed_job_accounting(n, per_rank, ceiling):
+    """`bench.py --gpus N` prices, next to its weak-scaling value, the FIXED job BASELINE.json quotes its multi-GPU target on — the 20 reference
+    cameras of cfg4 dealt round-robin to N ranks, finished when the slowest rank is (computeOnMultiGPUs.cpp:15-69 is that job).  The accounting
+    (cameras per rank, makespan, ceiling of the speed-up: 6.67 at 8 ranks, not 8) through the real launch with --dry-run: N processes, gloo, one
+    second per depth map on every rank.  The default timed region runs NO collective: the pyramids were handed over once at set-up."""
+    out = _bench_dry_run(n)
+    fj = out["fixed_job"]
+    assert out["n_gpus"] == n and fj["cameras"] == 20 and fj["cameras_per_rank"] == per_rank
+    assert fj["makespan_s"] == max(per_rank) * 1.0 and abs(fj["depth_maps_per_s"] - 20.0 / max(per_rank)) < 1e-12
+    assert abs(fj["speedup_ceiling"] - ceiling) < 1e-12
+    V = out["views"]
+    assert out["views_owned_total"] == V and out["reference_cameras_total"] == V
+    # set-up: one collective per row of N views; nothing after it (3 + 1 steps ran)
+    assert not out["stream_views"] and out["exchange_collectives"] == (0 if n == 1 else (V + n - 1) // n)
+    assert out["tcam_pyramids_checked"] == n * 4 * 10  # every T-camera pyramid a rank swept against was whole and of the right view
+
+
+def test_streaming_job_runs_one_collective_per_step():
+    """--stream-views: every step's rebuilt R pyramids travel by ONE all-gather (beside the sweep) and are committed at the next step boundary"""
+    out = _bench_dry_run(2, ["--stream-views"])
+    assert out["stream_views"] and out["exchange_collectives"] == 10 + 4  # 10 rows of 2 views at set-up + (1 warm-up + 3 timed) steps
+    assert out["tcam_pyramids_checked"] == 2 * 4 * 10
+
+
+def _protocol_worker(rank, world, port, q, stream_views):
+    """the WHOLE rank-side step — commit / build / publish / sweep (sharding.StepProtocol, the object bench.py steps) — with two gloo ranks and
+    stand-in kernels: `build` writes a pyramid whose bytes name (view, version), `sweep` records what the rank would have swept against"""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from alicevision_amd.sharding import StepProtocol, ViewExchange, cameras_of_rank, owner_of_view
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, T, nbytes = 5, 3, 4096 + 17
+        ex = ViewExchange(V, nbytes, rank, world, dist)
+        cams_of = [cameras_of_rank(list(range(V)), r, world) for r in range(world)]
+        version = {v: 0 for v in range(V)}
+        content = lambda v, k: (7 * v + 3 * k + 1) % 251
+        for v in range(V):
+            if owner_of_view(v, world) == rank:
+                ex.buffer(v).fill_(content(v, 0))
+        ex.setup()
+        seen, built, stages = [], [], []
+
+        def build(rc):
+            built.append(rc)
+            if stream_views:
+                version[rc] += 1
+            ex.buffer(rc).fill_(content(rc, version[rc]))
+
+        def sweep(rc, tcs):
+            seen.append((rc, [(v, int(ex.buffer(v)[0]), int(ex.buffer(v)[-1])) for v in tcs]))
+
+        class stage:
+            def __init__(self, name):
+                stages.append(name)
+
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return False
+
+        proto = StepProtocol(ex, cams_of, V, T, build, sweep, stream_views=stream_views, on_stage=stage)
+        n_steps = 5
+        for i in range(n_steps):
+            proto.step(i)
+        proto.finish()
+        ok = all(owner_of_view(rc, world) == rank for rc in built) and built == [cams_of[rank][i % len(cams_of[rank])] for i in range(n_steps)]
+        # what step i sweeps against: view v at the version its owner had built BEFORE step i's round was committed, i.e. after i rounds for a
+        # streamed job (a round is committed at the next step boundary: the pyramids of round i are visible from step i + 1), version 0 otherwise
+        for i, (rc, taps) in enumerate(seen):
+            ok &= [v for v, _, _ in taps] == [(rc + 1 + k) % V for k in range(T)]
+            for v, first, last in taps:
+                o = owner_of_view(v, world)
+                rounds = i if o != rank else i + 1  # my own views: rebuilt in place by build() up to and including this step
+                want_k = sum(1 for j in range(rounds) if cams_of[o][j % len(cams_of[o])] == v) if stream_views else 0
+                ok &= first == last == content(v, want_k)
+        ok &= ex.collectives == (V + world - 1) // world + (n_steps if stream_views else 0)
+        ok &= (stages.count("pyramid_commit") == (n_steps + 1 if stream_views else 0)) and stages.count("image_pyramid") == n_steps
+        ok &= ex._pending is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stream_views", [False, True])
+def test_whole_step_protocol_gloo_world2(stream_views):
+    """not only ViewExchange — the whole step() of a rank (commit / fill / publish / sweep stub) with world_size 2 on gloo, in
+    both modes: the default (pyramids handed over once, no collective per step) and the streaming job (one all-gather per step, visible to the
+    sweeps from the NEXT step on, never half-written)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + (1 if stream_views else 0)
+    procs = [ctx.Process(target=_protocol_worker, args=(r, 2, port, q, stream_views)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
