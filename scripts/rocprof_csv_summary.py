@@ -38,18 +38,22 @@ def counters(d, out):
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     agg = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(set)
+    dur = defaultdict(dict)  # kernel -> dispatch -> ns (the duration of the launch UNDER the counter pass: what GRBM_GUI_ACTIVE is divided by)
     for f in files:
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                dur[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     names = sorted({c for v in agg.values() for c in v})
     with open(out, "w", newline="") as fh:
         w = csv.writer(fh)
-        w.writerow(["kernel", "launches"] + [n + "_per_launch" for n in names])
+        w.writerow(["kernel", "launches", "us_per_launch"] + [n + "_per_launch" for n in names])
         for k in sorted(agg):
             n = max(len(disp[k]), 1)
-            w.writerow([k, n] + [f"{agg[k].get(c, 0.0) / n:.1f}" for c in names])
+            us = (sum(dur[k].values()) / len(dur[k]) / 1e3) if dur[k] else 0.0
+            w.writerow([k, n, f"{us:.2f}"] + [f"{agg[k].get(c, 0.0) / n:.1f}" for c in names])
 
 
 if __name__ == "__main__":

@@ -1,30 +1,64 @@
 #!/bin/bash
-# session r05_a (prepared at the end of round 4, not run yet): do AVDM_SIM_PLANES8=1 and AVDM_REFINE_PLANES8=1 keep the parity tables of DESIGN.md
-# section 2?
-#   1. parity tables of the cases the switch touches (12-byte records: the crops and tiles of the 4000 x 3000 geometry; cfg1's windows fit the
-#      16-byte records and never reach the eight-plane pass), with the literal kernel and the reference's platform spread beside them;
-#   2. the whole GPU suite under the switch: which thresholds move (expected: test_split_launches_equal_the_combined_kernels — the split
-#      launches keep the four-plane pass, the combined kernel takes eight — and nothing else);
-#   3. A/B bench on this box.
-# If 1 holds the < 1e-3 lines and 2 shows only that one test: flip the defaults in avdm_volume_compute_similarity / avdm_volume_refine_similarity
-# (planes8 = !(p8 && p8[0] == '0')),
-# re-run scripts/pmc_similarity.sh + scripts/collect_sim_pmc.py (the default kernel changes: the certificate of r04 no longer applies).
+# session r05_a: eight planes per pass as the DEFAULT of both similarity kernels (flipped before this session) —
+#   1. the whole GPU suite in pytest-xdist workers (new: one worker per parity case; cfg5-shape tiles; tile-case platform spread), every parity
+#      measurement dumped (-> profiles/r05_a_parity_*.json);
+#   2. counter passes over the similarity kernels, eight planes (default) and four planes (AVDM_*_PLANES8=0) in the same session: instruction
+#      counts, real clock (GRBM_GUI_ACTIVE / duration), VALU-busy, LDS waits, parked waves, vector-memory activity;
+#   3. A/B bench: four / eight planes, the prepared variants of the eight-plane passes.
 cd "$(dirname "$0")/../.."
+ROOT=$(pwd)
 TAG=${1:-r05_a}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-export AVDM_SIM_PLANES8=1 AVDM_REFINE_PLANES8=1
-timeout 900 python scripts/parity_report.py --cases crop2,crop3,crop3_corner,tile12mp_corner --literal-cases crop2,crop3,crop3_corner,tile12mp_corner --spread-cases crop3 \
-    --out $OUT/parity_planes8.json 2>&1 | grep -v amdgpu.ids | tail -40
-AVDM_PARITY_DUMP=$OUT timeout 2400 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider -rP > $OUT/pytest_planes8.log 2>&1; echo "pytest exit $?"
-grep -E "passed|failed|^FAILED|^E   " $OUT/pytest_planes8.log | cut -c1-400 | tail -30
-unset AVDM_SIM_PLANES8 AVDM_REFINE_PLANES8
-for V in 0 1 0 1; do
-  AVDM_SIM_PLANES8=$V AVDM_REFINE_PLANES8=$V timeout 200 python bench.py --steps 11 --warmup 2 --no-cpu-baseline --cli-e2e 0 2>/dev/null > $OUT/bench_p8_$V.json
-  python - $OUT/bench_p8_$V.json $V <<'PY'
+echo "== the whole GPU suite (xdist)"
+T0=$(date +%s)
+AVDM_PARITY_DUMP=$ROOT/$OUT timeout 1500 python -m pytest tests -m gpu -q --no-header -rP > $OUT/pytest.log 2>&1; echo "pytest exit $? in $(( $(date +%s) - T0 )) s"
+grep -E "passed|failed|^FAILED|^ERROR|^E   " $OUT/pytest.log | cut -c1-600 | tail -40
+python - $OUT <<'PY'
+import json, glob, sys, os
+for f in sorted(glob.glob(os.path.join(sys.argv[1], "parity_*.json"))):
+    r = json.load(open(f))
+    fd = lambda m: (m["final_depth"]["rmse_untrimmed"], m["final_depth"].get("rmse_untrimmed_relative"), m["final_depth"].get("rmse_untrimmed_in_pixsize"))
+    line = "%-18s wp %.2e rel %.1e pix %.2f | lit %.2e rel %.1e pix %.2f | gpu-lit %.2e | vol0 wp %.3f lit %.3f" % ((r["case"],) + fd(r["well_posed"]) + fd(r["literal"]) + (r["gpu_literal_vs_oracle_literal"]["final_depth"]["rmse_untrimmed"], r["well_posed"]["similarity_volume_levels"]["0"], r["literal"]["similarity_volume_levels"]["0"]))
+    sp = r.get("platform_spread")
+    if sp:
+        line += " | X %.2e" % sp["cuda_vs_literal"]["final_depth"]["rmse_untrimmed"]
+        for k in ("cuda_vs_literal_interior", "default_vs_literal_interior", "default_vs_cuda_interior", "well_posed_vs_literal_interior", "literal_oracle_vs_reference_tile_interior"):
+            if k in sp:
+                line += " %s %.2e" % (k.replace("_interior", "_in").replace("_vs_", "/"), sp[k]["final_depth"]["rmse_untrimmed"])
+    print(line)
+PY
+echo "== PMC: similarity kernels, eight planes (default)"
+bash scripts/pmc_similarity.sh ${TAG}_p8 2>&1 | grep -v amdgpu.ids | tail -14
+echo "== PMC: similarity kernels, four planes"
+AVDM_SIM_PLANES8=0 AVDM_REFINE_PLANES8=0 bash scripts/pmc_similarity.sh ${TAG}_p4 2>&1 | grep -v amdgpu.ids | tail -14
+echo "== A/B bench"
+run() { # name, env...
+  N=$1; shift
+  env "$@" timeout 200 python bench.py --steps 11 --warmup 2 --no-cpu-baseline --cli-e2e 0 2>/dev/null > $OUT/bench_$N.json
+  python - $OUT/bench_$N.json $N <<'PY'
+import json,sys
+try:
+    r=json.load(open(sys.argv[1])); s=r['stages_ms']
+    print('%-18s %.4f maps/s  %.1f ms  sgm_sim %.1f  refine_sim %.1f  opt %.2f  frac %.3f' % (sys.argv[2], r['value'], r['ms_per_step'], s['sgm_similarity'], s['refine_similarity'], s['color_optimize'], r['roofline']['frac']))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e)
+PY
+}
+run p4_a AVDM_SIM_PLANES8=0 AVDM_REFINE_PLANES8=0
+run p8_a X=1
+for V in p8_pipe3 p8_pipe4 r8_partial; do
+  [ -f $ROOT/scripts/ab/$V/libavdm.so ] && run $V AVDM_LIB=$ROOT/scripts/ab/$V/libavdm.so
+done
+run p4_b AVDM_SIM_PLANES8=0 AVDM_REFINE_PLANES8=0
+run p8_b X=1
+echo "== bench (the driver's command)"
+timeout 600 python bench.py --steps 20 --warmup 5 2> $OUT/bench_final.err > $OUT/bench_final.json; python - $OUT/bench_final.json <<'PY'
 import json,sys
 r=json.load(open(sys.argv[1])); s=r['stages_ms']
-print('PLANES8=%s %.4f maps/s  %.1f ms  sgm_sim %.1f  refine_sim %.1f' % (sys.argv[2], r['value'], r['ms_per_step'], s['sgm_similarity'], s['refine_similarity']))
+print('%.4f maps/s  %.1f ms' % (r['value'], r['ms_per_step'])); print({k: round(v, 3) for k, v in s.items()})
+print({k: v for k, v in r['roofline'].items() if k in ('frac','frac_kernels_only','frac_with_p2_map','ms_per_launch_by_axis','box_copy_GBps','traffic')})
+print(r.get('cli_end_to_end')); print(r.get('cpu_baseline')); print(r.get('fixed_job'))
 PY
-done
+find $OUT -name "*.db" -delete; find $OUT -name "*.csv" -size +2M -delete
 echo "== done"
