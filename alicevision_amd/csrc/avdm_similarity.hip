@@ -25,6 +25,7 @@
 #include <cmath>
 #include <iterator>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdlib.h>
 #include <type_traits>
@@ -89,6 +90,7 @@ constexpr unsigned kSgmChunksPerWg = AVDM_SGM_CHUNKS_PER_WG; // SGM similarity: 
 #ifndef AVDM_REFINE_CHUNKS_PER_WG
 #define AVDM_REFINE_CHUNKS_PER_WG 4
 #endif
+constexpr unsigned kOutlierGrid = 2048; // workgroups of refine_outlier_kernel: its lanes stride over the units of the list
 constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: chunks of 8 planes per workgroup (they share one R tile, T window and pixel set-up)
 #ifndef AVDM_SIM_WAVES_PER_SIMD
 #define AVDM_SIM_WAVES_PER_SIMD 2 // occupancy the two kernels are compiled for: 3 -> 168 VGPRs, 2 -> 256 VGPRs
@@ -2518,10 +2520,18 @@ template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, int MOD
 __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   refine_similarity_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize,
                            int map_pitch, const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A,
-                           PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi, unsigned* __restrict__ wgFlags)
+                           PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi, unsigned* __restrict__ wgFlags, unsigned listCap)
 {
     constexpr bool FAST = MODE == 1, FIXUP = MODE == 2;
     static_assert(!FAST || PLANES == 4, "the fast kernel is the four-plane pass");
+    // The OUTLIER LIST (MODE 0, listCap > 0; round 5).  A pixel whose SGM depth is wrong projects its patch tens of texels away from its
+    // neighbours' in a wide-baseline T camera: it cannot take its taps from the workgroup's T window, and until round 4 its whole WAVE then ran
+    // the chunk one plane per pass with every tap from global memory (~4 x the instructions per plane-sample, for 64 lanes, because of one) —
+    // 30 % more sweep time on the outer cameras of the bench.  Now such a LANE is taken out of the pass (all of its planes invalid: the lane is
+    // masked off inside the pass, it reads nothing) and appended to a list of (pixel, first plane, number of planes) units in wgFlags —
+    // {count, pad, entries ...} — that refine_outlier_kernel works off after this kernel with one lane per unit; the other 63 lanes keep the
+    // eight-plane pass.  A full list (count >= listCap) leaves the wave on the old path.
+    const bool listing = MODE == 0 && PLANES >= 4 && listCap != 0u;
     const unsigned wgIndex = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const unsigned waveInWg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned myFlags = 0u;
@@ -2775,7 +2785,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             const f3 v1 = f3{-dir.x, -dir.y, -dir.z};
             const f3 ay = normalize(cross(v1, ld3(tc.C) - C));
             const f3 Bt = M3x3mulV3(tc.P, ay) * RK.pixK, Br = M3x3mulV3(rc.P, ay) * RK.pixK;
-            auto plane_q = [&](unsigned vz, QuadPlane& q, f3& raxOut, bool& valid, bool& laneLds) __attribute__((always_inline)) {
+            auto plane_q = [&](unsigned vz, QuadPlane& q, f3& raxOut, bool& valid, bool& laneLds, bool& misfit) __attribute__((always_inline)) {
                 const bool inRange = vz >= zBegin && vz < zEnd; // uniform; a plane outside the range is an invalid plane of the pass
                 valid = rValid && inRange;
                 q.c = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2800,6 +2810,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 const float tpx = ht0.x * it0, tpy = ht0.y * it0;
                 valid = valid && r_border_ok(vz) && !((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd));
                 laneLds = true;
+                misfit = false;
                 if(valid)
                 {
                     const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
@@ -2807,11 +2818,33 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                               (cyT - extY - 1.0f >= (float)Wc.y0) && (cyT + extY + 2.0f <= (float)(Wc.y0 + Wc.h - 1));
                     if(laneLds)
                         q.c = lds_center_paired(sT, Wc.pitch, Wc.x0, Wc.y0, cxT, cyT);
-                    else
+                    else if(!listing)
                         q.c = tex_bilinear_px<FIXED8>(A.tcL, cxT, cyT);
-                    valid = !(q.c.w < (255.f * 0.4f));
+                    // (listing: a plane of mine outside the window sends me to the outlier list, where every plane is evaluated from scratch —
+                    // its centre colour is not needed here)
+                    if(laneLds || !listing)
+                        valid = !(q.c.w < (255.f * 0.4f));
+                    misfit = !laneLds;
                 }
                 laneLds = __ballot(valid && !laneLds) == 0ull; // wave-uniform choice of the tap source
+            };
+            // append the lanes of `outl` as units (my pixel, planes zFirst ... zFirst + nPlanes - 1) to the outlier list; wave-uniform result:
+            // false = the list is full (the wave stays on the old path; slots it was granted below the capacity are written as empty units)
+            auto list_outliers = [&](bool outl, unsigned zFirst, unsigned nPlanes) __attribute__((always_inline)) -> bool {
+                const unsigned long long m = __ballot(outl);
+                const unsigned n = (unsigned)__popcll(m);
+                unsigned base = 0u;
+                if((threadIdx.x & 63u) == 0u)
+                    base = atomicAdd(wgFlags, n);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                const bool granted = base + n <= listCap; // uniform
+                if(outl)
+                {
+                    const unsigned idx = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if(idx < listCap)
+                        reinterpret_cast<uint2*>(wgFlags)[1u + idx] = make_uint2(vx | (vy << 16), granted ? (zFirst | (nPlanes << 16)) : 0u);
+                }
+                return granted;
             };
             auto selP = [](bool c, const QuadPlane& a, const QuadPlane& b) __attribute__((always_inline)) -> QuadPlane {
                 QuadPlane r;
@@ -2832,17 +2865,28 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 {
                     QuadPlane q[8];
                     f3 ra[8];
-                    bool vv[8], ll[8];
+                    bool vv[8], ll[8], mf[8];
 #pragma unroll
                     for(int k = 0; k < 8; ++k)
-                        plane_q(zc + (unsigned)k, q[k], ra[k], vv[k], ll[k]);
-                    bool allLds = true, anyValid = false;
+                        plane_q(zc + (unsigned)k, q[k], ra[k], vv[k], ll[k], mf[k]);
+                    bool allLds = true, anyValid = false, outl = false;
 #pragma unroll
                     for(int k = 0; k < 8; ++k)
                     {
                         allLds = allLds && ll[k];
-                        anyValid = anyValid || vv[k];
+                        outl = outl || (vv[k] && mf[k]);
                     }
+                    if(listing && !allLds && list_outliers(outl, zc, 8u)) // wave-uniform
+                    {
+                        // my chunk is on the list: I take no part in the pass; the rest of the wave runs it from the window
+#pragma unroll
+                        for(int k = 0; k < 8; ++k)
+                            vv[k] = vv[k] && !outl;
+                        allLds = true;
+                    }
+#pragma unroll
+                    for(int k = 0; k < 8; ++k)
+                        anyValid = anyValid || vv[k];
                     if(allLds) // wave-uniform
                     {
                         if(anyValid)
@@ -2892,12 +2936,22 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 }
                 QuadPlane q0, q1, q2, q3;
                 f3 ra0, ra1, ra2, ra3;
-                bool v0, v1b, v2b, v3, l0, l1, l2, l3;
-                plane_q(zq, q0, ra0, v0, l0);
-                plane_q(zq + 1u, q1, ra1, v1b, l1);
-                plane_q(zq + 2u, q2, ra2, v2b, l2);
-                plane_q(zq + 3u, q3, ra3, v3, l3);
-                if(!(l0 && l1 && l2 && l3)) // wave-uniform: this wave runs the quad one plane per pass (fast kernel: leaves it to the fix-up kernel)
+                bool v0, v1b, v2b, v3, l0, l1, l2, l3, m0, m1, m2, m3;
+                plane_q(zq, q0, ra0, v0, l0, m0);
+                plane_q(zq + 1u, q1, ra1, v1b, l1, m1);
+                plane_q(zq + 2u, q2, ra2, v2b, l2, m2);
+                plane_q(zq + 3u, q3, ra3, v3, l3, m3);
+                bool quadLds = l0 && l1 && l2 && l3;
+                if(listing && !quadLds)
+                {
+                    const bool outl = (v0 && m0) || (v1b && m1) || (v2b && m2) || (v3 && m3);
+                    if(list_outliers(outl, zq, 4u)) // wave-uniform: the lanes outside the window are on the list, the others run the pass
+                    {
+                        v0 = v0 && !outl, v1b = v1b && !outl, v2b = v2b && !outl, v3 = v3 && !outl;
+                        quadLds = true;
+                    }
+                }
+                if(!quadLds) // wave-uniform: this wave runs the quad one plane per pass (fast kernel: leaves it to the fix-up kernel)
                 {
                     if(FAST && (threadIdx.x & 63) == 0)
                         atomicOr(&wgFlags[wgIndex], 1u << (4u * (2u * c + qd) + waveInWg));
@@ -3040,6 +3094,93 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     }
     if(pixActive)
         *reinterpret_cast<uint4*>(pv) = packed;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The outlier list of refine_similarity_kernel, worked off: one LANE per unit (pixel, first plane, number of planes), every plane of the unit
+// evaluated from scratch exactly as the per-plane fall-back of refine_similarity_kernel evaluates it for a lane whose taps leave the
+// workgroup's T window — the pixel's ray, the plane's patch, the border tests (the reference's own on a knife-edge row), both centre colours
+// and every tap through the software texture unit from global memory (clamp addressing), one plane per pass — and added to the fp16 volume.
+// The units of a launch are scattered pixels (wrong SGM depths): no window would serve 64 of them.  Launched after the sweep kernel on the same
+// stream with a fixed grid; the lanes stride over min(count, capacity) units.
+// ---------------------------------------------------------------------------------------------
+template <bool FIXED8, int WSH>
+__global__ void __launch_bounds__(256)
+  refine_outlier_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize, int map_pitch,
+                        const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY,
+                        unsigned zBegin, unsigned zEnd, avdm_roi_t roi, const unsigned* __restrict__ list, unsigned listCap, unsigned* __restrict__ totals)
+{
+    const int wsh = WSH > 0 ? WSH : A.wsh;
+    const unsigned count = min(list[0], listCap);
+    if(totals != nullptr && blockIdx.x == 0u && threadIdx.x == 0u) // AVDM_REFINE_OUTLIER_STATS=1: {units worked off, units that found the list full}
+    {
+        atomicAdd(&totals[0], count);
+        atomicAdd(&totals[1], list[0] - count);
+    }
+    const uint2* const units = reinterpret_cast<const uint2*>(list) + 1;
+#pragma unroll 1
+    for(unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u)
+    {
+        const uint2 u = units[i];
+        const unsigned vx = u.x & 0xffffu, vy = u.x >> 16, zFirst = u.y & 0xffffu, nPlanes = u.y >> 16;
+        if(nPlanes == 0u) // a slot of a wave that found the list full
+            continue;
+        const float2 dps = *((const float2*)((const char*)sgmDepthPixSize + (long long)vy * map_pitch) + vx);
+        if(!(dps.x > 0.0f))
+            continue;
+        const float x = (float)(roi.x.begin + vx) * (float)stepXY;
+        const float y = (float)(roi.y.begin + vy) * (float)stepXY;
+        const f3 C = ld3(rc.C);
+        const f3 rpv = normalize(M3x3mulV2(rc.iP, x, y));
+        const f3 pMid = C + rpv * dps.x;
+        const f3 dir = normalize(pMid - C); // kernels.cuh:17-24
+        const float dd = (float)wsh + 2.0f;
+        if((x < dd) || (x > A.rcW1 - dd) || (y < dd) || (y > A.rcH1 - dd))
+            continue;
+        const bool knife = AVDM_KNIFE_LITERAL && (x == dd || x == A.rcW1 - dd || y == dd || y == A.rcH1 - dd);
+        const float4 rcCenter = tex_bilinear_px<FIXED8>(A.rcL, fmaf(x, A.rcSx, A.rcOx), fmaf(y, A.rcSy, A.rcOy));
+        if(rcCenter.w < (255.f * 0.9f))
+            continue;
+        const RayConsts RK = make_ray_consts(rc, tc, C, dir, x, y);
+        __half* const pv = vol + ((long long)vy * pitch_y + (long long)vx * pitch_x) / 2;
+#pragma unroll 1
+        for(unsigned vz = max(zFirst, zBegin); vz < min(zFirst + nPlanes, zEnd); ++vz)
+        {
+            const int rel = (int)vz - ((volDimZ - 1) / 2);
+            if(knife && !lit::refine_r_inside(rc, x, y, dps.x, dps.y, rel, dd, A.rcW1, A.rcH1))
+                continue;
+            // the plane's geometry: refine_similarity_kernel's plane_geometry
+            const float t = fmaf((float)rel, dps.y, dps.x);
+            const f3 p = C + dir * t;
+            const float pd = RK.pixK * t;
+            f3 ax, ay;
+            {
+                const f3 v1 = f3{-dir.x, -dir.y, -dir.z};
+                const f3 v2 = normalize(ld3(tc.C) - p);
+                ay = normalize(cross(v1, v2));
+                f3 n;
+                if(sgmNormal != nullptr)
+                {
+                    const float* nn = (const float*)((const char*)sgmNormal + (long long)vy * normal_pitch) + 3 * vx;
+                    n = f3{nn[0], nn[1], nn[2]};
+                }
+                else
+                    n = normalize((v1 + v2) * 0.5f);
+                ax = normalize(cross(ay, n));
+            }
+            const float tw = t * RK.hrW;
+            const PatchProj Q = make_patch_proj_on_ray(rc, tc, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, fma3(t, RK.htB, RK.htA), ax, ay, pd);
+            const float it0 = proj_rcp(Q.ht0.z);
+            const float tpx = Q.ht0.x * it0, tpy = Q.ht0.y * it0;
+            if((tpx < dd) || (tpx > A.tcW1 - dd) || (tpy < dd) || (tpy > A.tcH1 - dd))
+                continue;
+            const float4 tcCenter = tex_bilinear_px<FIXED8>(A.tcL, fmaf(tpx, A.tcSx, A.tcOx), fmaf(tpy, A.tcSy, A.tcOy));
+            if(tcCenter.w < (255.f * 0.4f))
+                continue;
+            const float sim = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
+            pv[vz] = __float2half(__half2float(pv[vz]) + sim);
+        }
     }
 }
 
@@ -3336,6 +3477,23 @@ static avdm_patch_pattern_t g_patchPattern = {}; // the reference's constantPatc
 static bool g_patchPatternSet = false;
 static std::mutex g_patchPatternMutex;           // one host thread per device may build / read it (computeOnMultiGPUs)
 static unsigned* g_stats = nullptr; // device counters, allocated on first use when AVDM_SIM_STATS=1
+static unsigned* g_outlierTotals = nullptr; // {units worked off, units refused by a full list} of refine_outlier_kernel when AVDM_REFINE_OUTLIER_STATS=1
+static unsigned* outlier_totals()
+{
+    const char* e = getenv("AVDM_REFINE_OUTLIER_STATS");
+    if(!(e != nullptr && e[0] == '1'))
+        return nullptr;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if(g_outlierTotals == nullptr)
+    {
+        if(hipMalloc((void**)&g_outlierTotals, 2 * sizeof(unsigned)) != hipSuccess)
+            g_outlierTotals = nullptr;
+        else
+            (void)hipMemset(g_outlierTotals, 0, 2 * sizeof(unsigned));
+    }
+    return g_outlierTotals;
+}
 
 // paired: in = the caller would like the 16-byte paired records (FIXED8 pyramids only); out = whether the LDS budget allows them
 // fractional: out = the stage's level of detail is not an integral level of the pyramids (scales that are not a power-of-two multiple of the
@@ -3588,6 +3746,18 @@ int avdm_debug_similarity_stats(unsigned out[4])
     return 0;
 }
 
+/* debugging aid (not part of avdm.h; AVDM_REFINE_OUTLIER_STATS=1): units of the Refine outlier list since the last call {worked off, refused by a full list} */
+int avdm_debug_refine_outlier_units(unsigned out[2])
+{
+    out[0] = out[1] = 0;
+    if(g_outlierTotals == nullptr)
+        return 0;
+    if(hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, g_outlierTotals, 2 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess)
+        return 1;
+    (void)hipMemset(g_outlierTotals, 0, 2 * sizeof(unsigned));
+    return 0;
+}
+
 int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, const float* depths, const avdm_camera_t* rc,
                                    const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
                                    const avdm_sgm_params_t* sp, avdm_range_t dr, avdm_roi_t roi, void* stream)
@@ -3798,7 +3968,7 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
 #define LAUNCH(F8, W, PR)                                                                                                                          \
     hipLaunchKernelGGL((refine_similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,   \
                        (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi, \
-                       (unsigned*)nullptr)
+                       (unsigned*)nullptr, 0u)
     if(runDefault)
     {
         // the default: scale 1, stepXY 1, wsh 3 — four planes per pass, 16-byte records, up to half of the compute unit's LDS
@@ -3813,6 +3983,25 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
             });
             // AVDM_REFINE_PLANES8=1 (experimental, read at each call): eight planes per pass on the chunks that lie in the T camera's range
             const char* p8 = getenv("AVDM_REFINE_PLANES8");
+            // The outlier list (AVDM_REFINE_OUTLIER_LIST, default on; refine_similarity_kernel): lanes whose taps leave their workgroup's T window are
+            // appended to a list in the stream's scratch block and worked off by refine_outlier_kernel right after the sweep — {count, pad,
+            // (pixel, planes) units}; capacity = a quarter of the launch's (pixel, chunk) pairs, a full list leaves the remaining waves on the old path
+            const char* ol = getenv("AVDM_REFINE_OUTLIER_LIST");
+            const bool useList = !(ol != nullptr && ol[0] == '0');
+            const size_t nPix = (size_t)(roi.x.end - roi.x.begin) * (roi.y.end - roi.y.begin);
+            const unsigned listCap = useList ? (unsigned)std::min<size_t>(std::max<size_t>(nPix * nchunks / 4, 4096), 0x7fffff00u) : 0u;
+            std::unique_ptr<StreamScratch> lease;
+            if(useList)
+                lease.reset(new StreamScratch((hipStream_t)stream, 8 + (size_t)listCap * sizeof(uint2)));
+            unsigned* list = useList ? (unsigned*)lease->ptr() : nullptr;
+            if(useList && list == nullptr)
+                return set_error_msg(2, "avdm_volume_refine_similarity: scratch allocation failed");
+            if(useList)
+            {
+                const hipError_t me = hipMemsetAsync(list, 0, 8, (hipStream_t)stream);
+                if(me != hipSuccess)
+                    return set_error(me, "avdm_volume_refine_similarity");
+            }
             if(!(p8 != nullptr && p8[0] == '0')) // the default since round 5 (parity tables: profiles/r05_a_parity_*.json)
             {
                 static std::once_flag once8[64];
@@ -3821,13 +4010,17 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
                 });
                 hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, 8>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x,
                                    dimZ, (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end,
-                                   roi, (unsigned*)nullptr);
+                                   roi, list, listCap);
             }
             else
                 hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, 4>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x,
                                    dimZ, (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end,
-                                   roi, (unsigned*)nullptr);
-            return ::avdm::set_error(hipGetLastError(), "avdm_volume_refine_similarity"); // the one launch of the default path: done
+                                   roi, list, listCap);
+            if(useList)
+                hipLaunchKernelGGL((refine_outlier_kernel<true, 3>), dim3(kOutlierGrid), dim3(256), 0, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
+                                   (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi,
+                                   (const unsigned*)list, listCap, outlier_totals());
+            return ::avdm::set_error(hipGetLastError(), "avdm_volume_refine_similarity"); // the launches of the default path: done
         }
         // AVDM_SIM_SPLIT=1 only: fast kernel + fix-up kernel
         const size_t nWg = (size_t)grid.x * grid.y * grid.z;
@@ -3846,9 +4039,9 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
             (void)hipFuncSetAttribute((const void*)refine_similarity_kernel<true, 3, true, 40, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);
         });
         hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, 4, 1>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
-                           (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi, flags);
+                           (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi, flags, 0u);
         hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, 1, 2>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
-                           (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi, flags);
+                           (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi, flags, 0u);
     }
     else if(fixed8 && paired)
     {

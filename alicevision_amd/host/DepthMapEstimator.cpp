@@ -120,45 +120,66 @@ DepthMapEstimator::DepthMapEstimator(const MultiViewParams& mp, const TileParams
 
 int DepthMapEstimator::getNbSimultaneousTiles() const
 {
+    // How many tiles may be in flight on this device — the question of the reference's getNbSimultaneousTiles (DepthMapEstimator.cpp:57-135),
+    // answered from what THIS implementation allocates on an MI355X rather than from the CUDA-era estimate (80 % of the free memory, 1.5 x
+    // the image for a mip pyramid, nothing for the scratch blocks):
+    //   per tile slot (= stream)   the Sgm / Refine device buffers of the slot (sizes only: deviceMemoryConsumption);
+    //                              the stream's scratch block of the library (avdm::stream_scratch): the two point maps of the colour
+    //                              optimisation (2 x 16 B per pixel of the tile buffer) or the Refine outlier list (8 B per 4 (pixel, chunk)
+    //                              pairs), whichever is larger — they follow each other on the stream;
+    //                              its share of the batched aggregation's scratch (adaptive-P2 maps of the group);
+    //   per camera of a batch      the Lab pyramids of R + maxTCams views at their EXACT size (avdm_pyramid_layout);
+    //   what is free               as the device reports it NOW — after the multi-GPU pre-pass, i.e. without the pyramids this worker
+    //                              publishes to the others (PyramidExchange, bounded by its own budget) — minus 1 GiB for code objects and
+    //                              the runtime's own pools.
+    // A batch holds whole cameras, so n tiles need the images of ceil(n / tiles per camera) cameras.  With 288 GB the answer is "as many as
+    // one aggregation launch takes" (AVDM_SGM_MAX_TILES, applied by the caller) except for very large images or a nearly full device.
     const int nbTilesPerCamera = (int)_tileRoiList.size();
-    // mipmap image cost: not more than (1.5 * max_width) * max_height texels of 8 B (fp16 RGBA)
-    const double mipmapCostMB = ((_mp.getMaxImageWidth() * 1.5) * _mp.getMaxImageHeight() * 8.0) / (1024.0 * 1024.0);
-    const double rcCamsCostMB = mipmapCostMB + _depthMapParams.maxTCams * mipmapCostMB;
+    const int minDs = std::min(_refineParams.scale, _sgmParams.scale), maxDs = std::max(_refineParams.scale, _sgmParams.scale) * 64;
+    avdm_pyramid_t layout;
+    avdmCheck(avdm_pyramid_layout(&layout, _mp.getMaxImageWidth(), _mp.getMaxImageHeight(), minDs, maxDs, filterModeFromEnv()), "avdm_pyramid_layout");
+    const double MB = 1024.0 * 1024.0;
+    const double mipmapCostMB = (double)layout.bytes / MB;
+    const double rcCamsCostMB = (1 + _depthMapParams.maxTCams) * mipmapCostMB;
 
-    // sizes only, no allocation (the reference constructs throw-away Sgm / Refine objects, :81-99)
     const double sgmTileCostMB = Sgm::deviceMemoryConsumption(_tileParams, _sgmParams, !_depthMapParams.useRefine, _refineParams.useSgmNormalMap);
     const double refineTileCostMB = _depthMapParams.useRefine ? Refine::deviceMemoryConsumption(_tileParams, _refineParams) : 0.0;
-    const double tileCostMB = sgmTileCostMB + refineTileCostMB;
-    const double rcMinCostMB = rcCamsCostMB + tileCostMB;
-    const double rcMaxCostMB = rcCamsCostMB + nbTilesPerCamera * tileCostMB;
+    double scratchCostMB = 0.0;
+    if(_depthMapParams.useRefine)
+    {
+        const int ds = _refineParams.scale * _refineParams.stepXY;
+        const double px = (double)divideRoundUp(_tileParams.bufferWidth, ds) * divideRoundUp(_tileParams.bufferHeight, ds);
+        const double pointMaps = _refineParams.useColorOptimization ? 2.0 * 16.0 * px : 0.0;
+        const double outlierList = 8.0 + 8.0 * px * divideRoundUp(_refineParams.halfNbDepths * 2 + 1, 8) / 4.0;
+        scratchCostMB = std::max(pointMaps, outlierList) / MB;
+    }
+    const double tileCostMB = sgmTileCostMB + refineTileCostMB + scratchCostMB; // (the aggregation's scratch is inside the Sgm figure)
 
-    double deviceMemoryMB;
+    double availableMB, usedMB, totalMB;
+    getDeviceMemoryInfo(availableMB, usedMB, totalMB);
+    const double deviceMemoryMB = availableMB - 1024.0;
+    const double rcMinCostMB = rcCamsCostMB + tileCostMB;
+    const int cap = maxStreamsFromEnv() * 64; // far beyond what the caller will take: the search below is bounded
+    int out_nbSimultaneousTiles = 0;
+    for(int n = 1; n <= cap; ++n)
     {
-        double availableMB, usedMB, totalMB;
-        getDeviceMemoryInfo(availableMB, usedMB, totalMB);
-        deviceMemoryMB = availableMB * 0.8;
+        if(n * tileCostMB + divideRoundUp(n, nbTilesPerCamera) * rcCamsCostMB > deviceMemoryMB)
+            break;
+        out_nbSimultaneousTiles = n;
     }
-    const int nbSimultaneousFullRc = static_cast<int>(deviceMemoryMB / rcMaxCostMB);
-    int nbRemainingTiles = 0;
-    {
-        const double remainingMemoryMB = deviceMemoryMB - (nbSimultaneousFullRc * rcMaxCostMB);
-        nbRemainingTiles = static_cast<int>(std::max(0.0, remainingMemoryMB - rcCamsCostMB) / tileCostMB);
-    }
-    const int out_nbSimultaneousTiles = nbSimultaneousFullRc * nbTilesPerCamera + nbRemainingTiles;
 
     AVDM_LOG_INFO("Device memory:" << std::endl
-                                   << "\t- available: " << deviceMemoryMB << " MB" << std::endl
+                                   << "\t- available: " << deviceMemoryMB << " MB (free now, minus 1024 MB kept for the runtime)" << std::endl
                                    << "\t- requirement for the first tile: " << rcMinCostMB << " MB" << std::endl
                                    << "\t- # computation buffers per tile: " << tileCostMB << " MB"
                                    << " (Sgm: " << sgmTileCostMB << " MB"
-                                   << ", Refine: " << refineTileCostMB << " MB)" << std::endl
+                                   << ", Refine: " << refineTileCostMB << " MB, stream scratch: " << scratchCostMB << " MB)" << std::endl
                                    << "\t- # input images (R + " << _depthMapParams.maxTCams << " Ts): " << rcCamsCostMB
                                    << " MB (single mipmap image size: " << mipmapCostMB << " MB)");
     AVDM_LOG_INFO("Parallelization:" << std::endl
                                      << "\t- # tiles per image: " << nbTilesPerCamera << std::endl
-                                     << "\t- # simultaneous depth maps computation: "
-                                     << ((nbRemainingTiles < 1) ? nbSimultaneousFullRc : (nbSimultaneousFullRc + 1)) << std::endl
-                                     << "\t- # simultaneous tiles computation: " << out_nbSimultaneousTiles);
+                                     << "\t- # simultaneous depth maps computation: " << divideRoundUp(out_nbSimultaneousTiles, nbTilesPerCamera) << std::endl
+                                     << "\t- # simultaneous tiles computation: " << out_nbSimultaneousTiles << (out_nbSimultaneousTiles == cap ? " (or more)" : ""));
     if(out_nbSimultaneousTiles < 1)
         AVDM_THROW_ERROR("Not enough GPU memory to compute a single tile.");
     return out_nbSimultaneousTiles;
@@ -260,6 +281,7 @@ void DepthMapEstimator::computeShared(int worker, int deviceId, const std::vecto
 void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, int worker, const std::vector<int>* allViews, PyramidExchange* exchange)
 {
     AVDM_HIP_CHECK(hipSetDevice(deviceId));
+    const auto tCompute0 = std::chrono::steady_clock::now();
 
     ImagesCache ic(_mp);
 
@@ -463,8 +485,11 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         }
     } writerGuard{pendingWrite};
     logDeviceMemoryInfo();
+    AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): set-up (streams, per-stream device buffers, page-locked result tiles) in "
+                            << std::chrono::duration<double>(std::chrono::steady_clock::now() - tCompute0).count() << " s.");
 
     const int nbBatches = divideRoundUp(static_cast<int>(tiles.size()), nbTilesPerBatch);
+    double tilesSeconds = 0.0; // from "the batch's images are on the device" to "its tiles are computed", summed over the batches
     const int finalScaleStep = _depthMapParams.useRefine ? _refineParams.scale * _refineParams.stepXY : _sgmParams.scale * _sgmParams.stepXY;
 
     // camera index inside a batch: the reference uses rc % nbRcPerBatch (:390), which only separates the cameras of a batch
@@ -536,6 +561,7 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         }
         AVDM_HIP_CHECK(hipDeviceSynchronize());
         AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": images decoded, uploaded and converted to pyramids in " << secondsSince(tBatch0) << " s.");
+        const auto tTiles0 = std::chrono::steady_clock::now();
 
         // what the batch actually sweeps, in the kernels' work unit (voxel x T camera): the depth lists are capped per tile and every T camera has
         // its own plane range, so this is NOT tiles x maxDepths x maxTCams — logged so that the program's rate can be compared with a sweep of known size
@@ -683,13 +709,20 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
             AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": " << n << " tile(s) computed, " << secondsSince(tBatch0) << " s since the batch started.");
         }
 
+        tilesSeconds += secondsSince(tTiles0);
         if(workTiles > 0)
             AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": swept " << workTiles << " tile(s): " << workSgmVoxelT << " SGM voxel-T, " << workRefineVoxelT
                                    << " Refine voxel-T; per tile on average " << (double)workPlanes / workTiles << " planes, " << (double)workSgmT / workTiles
                                    << " SGM T cameras, " << (double)workRefineT / workTiles << " Refine T cameras.");
         // write the finished cameras of the batch, in the background: the previous batch's task must be done first (it owns the other set)
         if(pendingWrite.valid())
+        {
+            const auto tw0 = std::chrono::steady_clock::now();
             pendingWrite.get();
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+            if(waited > 0.01)
+                AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": waited " << waited << " s for the previous batch's maps to be written.");
+        }
         std::vector<int> batchCams;
         for(int ci = 0; ci * nbTilesPerCamera + firstTileIndex < lastTileIndex; ++ci)
             batchCams.push_back(tiles.at(firstTileIndex + ci * nbTilesPerCamera).rc);
@@ -708,8 +741,19 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
                                    << std::chrono::duration<double>(std::chrono::steady_clock::now() - tBatch0).count() << " s since the batch started.");
         });
     }
-    if(pendingWrite.valid())
-        pendingWrite.get();
+    {
+        const auto tTail0 = std::chrono::steady_clock::now();
+        if(pendingWrite.valid())
+            pendingWrite.get();
+        AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): waited " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tTail0).count()
+                                << " s for the last batch's maps to be merged and written; " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tCompute0).count()
+                                << " s for " << cams.size() << " camera(s) in all.");
+        const DeviceCache::ImageTimes& it = deviceCache.imageTimes();
+        AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): images of the tiles' batches — " << it.received << " pyramid(s) received from their owners ("
+                                << (it.bytesReceived >> 20) << " MB; " << it.awaitOwner << " s waiting for the owner, " << it.peerCopy << " s copying), " << it.built
+                                << " built here (" << it.localBuild << " s: decode unless cached, upload, pyramid); tiles: " << tilesSeconds << " s in " << nbBatches
+                                << " batch(es).");
+    }
 
     // merge intermediate result tiles (:470-505)
     if(tiles.size() > cams.size())

@@ -1,6 +1,8 @@
 // device.cpp — see device.hpp.
 #include "device.hpp"
 
+#include <chrono>
+
 #include "jpeg.hpp"
 #include "log.hpp"
 
@@ -207,23 +209,36 @@ void DeviceCache::addMipmapImage(int camId, int minDownscale, int maxDownscale, 
             }
             // declined (the exchange's residency budget is spent): an ordinary LRU entry of this device, below
         }
-        else if(const std::shared_ptr<const DeviceMipmapImage> src = _exchange->await(camId))
+        else
         {
-            // another worker's: its pyramid copied over the fabric
-            auto copy = std::make_shared<DeviceMipmapImage>();
-            copy->copyFromPeer(*src, _exchange->deviceOf(owner), _exchange->deviceOf(_worker), stream);
-            AVDM_HIP_CHECK(hipStreamSynchronize(stream)); // `src` may be released by its owner's exchange only after the copy has read it
-            ++_exchange->nbCopied;
-            _exchange->bytesCopied += (long long)src->bytes();
-            _mipmaps.at(slot) = copy;
-            return;
+            const auto tA = std::chrono::steady_clock::now();
+            const std::shared_ptr<const DeviceMipmapImage> src = _exchange->await(camId);
+            const auto tB = std::chrono::steady_clock::now();
+            _times.awaitOwner += std::chrono::duration<double>(tB - tA).count();
+            if(src)
+            {
+                // another worker's: its pyramid copied over the fabric
+                auto copy = std::make_shared<DeviceMipmapImage>();
+                copy->copyFromPeer(*src, _exchange->deviceOf(owner), _exchange->deviceOf(_worker), stream);
+                AVDM_HIP_CHECK(hipStreamSynchronize(stream)); // `src` may be released by its owner's exchange only after the copy has read it
+                _times.peerCopy += std::chrono::duration<double>(std::chrono::steady_clock::now() - tB).count();
+                ++_times.received;
+                _times.bytesReceived += (long long)src->bytes();
+                ++_exchange->nbCopied;
+                _exchange->bytesCopied += (long long)src->bytes();
+                _mipmaps.at(slot) = copy;
+                return;
+            }
         }
         // declined by its owner: decode and convert it here, like the reference does for every neighbour on every device
     }
+    const auto tL = std::chrono::steady_clock::now();
     const std::shared_ptr<const HostImage> img = imageCache.getImg_sync(camId);
     auto own = std::make_shared<DeviceMipmapImage>();
     own->fill(*img, minDownscale, maxDownscale, _filterMode, stream);
     _mipmaps.at(slot) = own;
+    _times.localBuild += std::chrono::duration<double>(std::chrono::steady_clock::now() - tL).count();
+    ++_times.built;
 }
 
 void DeviceCache::buildOwnedView(int camId, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp, hipStream_t stream)

@@ -262,7 +262,19 @@ class DeviceCache
     const DeviceMipmapImage& requestMipmapImage(int camId, const MultiViewParams& mp) const;
     const avdm_camera_t& requestCameraParams(int camId, int downscale, const MultiViewParams& mp) const;
 
+    // where this worker's image time went (seconds on its host thread): one log line per worker makes a multi-GPU run diagnosable
+    struct ImageTimes
+    {
+        double awaitOwner = 0.0;   // blocked until another worker had published the view
+        double peerCopy = 0.0;     // hipMemcpyPeerAsync + wait
+        double localBuild = 0.0;   // decode (unless cached) + upload + pyramid on this device
+        int received = 0, built = 0;
+        long long bytesReceived = 0;
+    };
+    const ImageTimes& imageTimes() const { return _times; }
+
   private:
+    ImageTimes _times;
     int _filterMode;
     LRUCache<int> _mipmapCache;
     LRUCache<std::pair<int, int>> _cameraParamCache;

@@ -237,9 +237,14 @@ def cli_end_to_end(sc, V, W, H, Z, T, n_cams):
     if dec and set(dec) == set(comp):
         # per batch: decode + upload + pyramids, then the tiles (every stage of every tile, results copied back), then merge + EXR output — the
         # output of a batch runs in the background beside the next batch's tiles, so only its tail after the last tile is on the critical path
+        setup = [float(x) for x in re.findall(r"set-up \(streams, per-stream device buffers, page-locked result tiles\) in " + num + " s", log)]
+        tail = [float(x) for x in re.findall(r"waited " + num + " s for the last batch's maps to be merged and written", log)]
+        stalls = [float(x) for x in re.findall(r"waited " + num + " s for the previous batch's maps to be written", log)]
         split = {"batches": len(dec), "decode_upload_pyramids_s": sum(dec.values()), "tiles_s": sum(comp[b] - dec[b] for b in dec),
-                 "merge_write_tail_s": sum(max(wr[b] - comp[b], 0.0) for b in wr if b in comp), "task_s": task[-1] if task else None,
-                 "process_start_and_scene_s": (wall - task[-1]) if task else None}
+                 # merge + EXR output of a batch runs beside the next batch's tiles: on the critical path are only the waits for it
+                 "merge_write_beside_the_tiles_s": sum(max(wr[b] - comp[b], 0.0) for b in wr if b in comp),
+                 "merge_write_waited_s": (sum(stalls) + sum(tail)) if tail else None, "setup_s": setup[0] if setup else None,
+                 "task_s": task[-1] if task else None, "process_start_and_scene_s": (wall - task[-1]) if task else None}
     return {"value": n_cams / wall, "unit": "depth-maps/s", "cameras": n_cams, "wall_s": wall, "scene_write_s": t_write, "split": split, "swept": swept,
             "includes": "process start, EXR decode of the views, upload, pyramids, default 1024 tiling (tiles batched per SGM launch), tile merge, EXR output"}
 

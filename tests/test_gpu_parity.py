@@ -863,6 +863,52 @@ def test_refine_similarity_experiment_equals_the_default(capsys):
     assert (d > 2e-3).mean() <= 1e-3 and (d > 2e-2).mean() <= 1e-5 and d.max() <= 0.15, ((d > 2e-3).mean(), (d > 2e-2).mean(), d.max())
 
 
+def test_refine_outlier_list_equals_the_wave_fallback(capsys):
+    """The outlier list of the default Refine kernel (round 5; AVDM_REFINE_OUTLIER_LIST=0 is the round-4 form): a pixel whose SGM depth is wrong
+    projects its patch far from its neighbours' in T; its LANE leaves the eight-plane pass and is appended to a list that refine_outlier_kernel
+    works off — every plane from scratch, taps from global memory, the arithmetic of the per-plane fall-back — instead of dragging its whole WAVE
+    onto that fall-back.  On a map with wrong depths on 2 % of the SGM pixels (4 x 4 blocks of Refine pixels): the list is used and never full,
+    the listed pixels get what the fall-back gave them, the other lanes of their waves the eight-plane pass instead of the one-plane global
+    path — fp16-quantum differences, the class of test_plane_pairs_equal_single_planes."""
+    import ctypes
+    torch = _torch()
+    from alicevision_amd.pipeline import DepthMapTile, DevicePyramid
+    sc, sgm, ref, depths = small_case(width=320, height=240, n_planes=128, seed=11)
+    pyr = [DevicePyramid(sc.images[i].cuda(), 1, 128, abi.FILTER_CUDA_FIXED8) for i in range(3)]
+    h = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm, ref)
+    h.run_sgm(0, [1, 2], depths)
+    bad = h.sgm_depth_thickness.clone()
+    g = torch.Generator().manual_seed(5)
+    wrong = (torch.rand(bad.shape[:2], generator=g) < 0.02).to(bad.device) & (bad[..., 0] > 0)
+    bad[..., 0] = torch.where(wrong, bad[..., 0] * 0.35, bad[..., 0])  # much too near: the patch lands tens of texels away in T
+    lib = abi.load()
+    lib.avdm_debug_refine_outlier_units.argtypes = [ctypes.POINTER(ctypes.c_uint)]
+    out, units = {}, {}
+    os.environ["AVDM_REFINE_OUTLIER_STATS"] = "1"
+    try:
+        for flag in ("0", "1"):
+            os.environ["AVDM_REFINE_OUTLIER_LIST"] = flag
+            h.sgm_depth_thickness.copy_(bad)
+            u = (ctypes.c_uint * 2)()
+            lib.avdm_debug_refine_outlier_units(u)  # reset
+            h.run_refine(0, [1, 2], optimize_enabled=False)
+            torch.cuda.synchronize()
+            assert lib.avdm_debug_refine_outlier_units(u) == 0
+            units[flag] = (int(u[0]), int(u[1]))
+            out[flag] = h.refine_volume.cpu().numpy().astype(np.float32)
+    finally:
+        os.environ.pop("AVDM_REFINE_OUTLIER_LIST", None)
+        os.environ.pop("AVDM_REFINE_OUTLIER_STATS", None)
+    d = np.abs(out["1"] - out["0"])
+    with capsys.disabled():
+        print("\noutlier list: %d units worked off, %d refused; vs the wave fall-back: %.4f of the entries differ, %.5f by more than one fp16 quantum (2e-3), max %.2e"
+              % (units["1"] + ((d > 0).mean(), (d > 2e-3).mean(), d.max())))
+    assert units["0"] == (0, 0) and units["1"][0] > 50 and units["1"][1] == 0, units
+    assert (out["0"] != 0).mean() > 0.3
+    assert ((out["0"] == 0) != (out["1"] == 0)).mean() <= 1e-4
+    assert (d > 2e-3).mean() <= 1e-3 and (d > 2e-2).mean() <= 1e-5 and d.max() <= 0.15, ((d > 2e-3).mean(), (d > 2e-2).mean(), d.max())
+
+
 def test_refine_best_depth_bit_exact(case):
     torch = _torch()
     sc, sgm, ref, depths, o = case
@@ -1698,7 +1744,7 @@ def test_bench_rccl_path_on_one_gpu():
 # DESIGN.md section 4.5 leans on these switches as A/B references; a switch that rots silently would take its A/B with it.
 _SIM_SWITCHES = [("AVDM_SIM_PLANE_PAIRS", "0"), ("AVDM_SIM_CHUNK_WINDOW", "0"), ("AVDM_SIM_PACKED", "0"), ("AVDM_SIM_PAIRED", "0"), ("AVDM_SIM_REC12", "0"),
                  ("AVDM_SIM_SPLIT", "1"), ("AVDM_SIM_LDS", "0"), ("AVDM_SIM_STATS", "1"),
-                 ("AVDM_SIM_PLANES8", "0"), ("AVDM_SIM_DEINT", "1"), ("AVDM_REFINE_PLANES8", "0")]                                           # tolerance class (similarity arithmetic)
+                 ("AVDM_SIM_PLANES8", "0"), ("AVDM_SIM_DEINT", "1"), ("AVDM_REFINE_PLANES8", "0"), ("AVDM_REFINE_OUTLIER_LIST", "0")]                                           # tolerance class (similarity arithmetic)
 _EXACT_SWITCHES = [("AVDM_SGM_PAIR", "0"), ("AVDM_SGM_INT16", "0"), ("AVDM_SGM_PREPARE", "0"), ("AVDM_OPT_DEPTH_MAP_FORM", "1")]  # bit-exact class
 _STATIC_SWITCHES = [("AVDM_SGM_P2_MAP", "legacy"), ("AVDM_SGM_TIMER", "record")]                                # read once per process: own process
 
