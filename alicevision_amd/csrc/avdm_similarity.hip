@@ -105,8 +105,8 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #define AVDM_NCC_QUAD_W3_MODE 0 // 7-tap rows of the four-plane form: 0 = 2 + 2 + 2 + 1 with fences, 1 = one sample at a time, 2 = 3 + 3 + 1
 #endif
 #ifndef AVDM_REFINE_OCTO_PARTIAL
-#define AVDM_REFINE_OCTO_PARTIAL 0
-#endif
+#define AVDM_REFINE_OCTO_PARTIAL 1 // Refine: a chunk that only overlaps the plane range (the last 7 of the default 31 planes) through the eight-plane pass too,
+#endif                             // its planes outside as invalid planes of the pass: 267.1 against 271.6 ms per depth map (session r05_a); 0 = two four-plane passes
 #ifndef AVDM_NCC_OCTO_W3_MODE
 #define AVDM_NCC_OCTO_W3_MODE 3 // 7-tap rows of the eight-plane form: as AVDM_NCC_QUAD_W3_MODE, 3 = a rolled loop (unroll AVDM_NCC_OCTO_UNROLL)
 #endif
@@ -2859,7 +2859,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             // sweep 267.2 against 276.4 ms, volumes within the fp16 quantum of the default's on all but 2e-5 of the entries.
             if constexpr(PLANES == 8)
             {
-                // (AVDM_REFINE_OCTO_PARTIAL, A/B builds, not measured: a chunk that only overlaps the range too — its planes outside are invalid planes
+                // (AVDM_REFINE_OCTO_PARTIAL, the default since round 5: a chunk that only overlaps the range too — its planes outside are invalid planes
                 // of the pass, like those of a four-plane pass; the 31 planes of the default sweep are then four passes of eight)
                 if(AVDM_REFINE_OCTO_PARTIAL ? (zc + 8u > zBegin) : (zc >= zBegin && zc + 8u <= zEnd)) // uniform
                 {

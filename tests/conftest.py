@@ -10,9 +10,13 @@ if ROOT not in sys.path:
 # The suite runs in several worker processes (pytest-xdist, `addopts` of pytest.ini: the parity cases spend their time in the CPU oracle, one
 # case per worker instead of one after the other).  A worker's OpenMP teams (oracle, oracle/_ref) get their share of the host cores, not all
 # of them: eight teams of 256 threads on 256 cores spend their time in barriers.
+# (Measured the hard way, session r05_a: eight workers x 64 threads on 256 cores — twice the cores — ran the oracle FIFTEEN times slower, its
+# teams spinning in each other's barriers; the sum over the workers must stay within the cores, and waiting threads must sleep.)
 _workers = int(os.environ.get("PYTEST_XDIST_WORKER_COUNT", "0") or 0)
 if _workers > 1 and "OMP_NUM_THREADS" not in os.environ:
-    os.environ["OMP_NUM_THREADS"] = str(max(4, 2 * (os.cpu_count() or 8) // _workers))
+    os.environ["OMP_NUM_THREADS"] = str(max(2, (os.cpu_count() or 8) // _workers))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("GOMP_SPINCOUNT", "1000")
 
 
 def pytest_xdist_auto_num_workers(config):
