@@ -37,10 +37,6 @@ namespace avdm {
 #define AVDM_NCC_UNROLL 3
 #endif
 constexpr int kNccUnroll = AVDM_NCC_UNROLL;
-#ifndef AVDM_NCC_PAIR_UNROLL
-#define AVDM_NCC_PAIR_UNROLL 3
-#endif
-constexpr int kNccPairUnroll = AVDM_NCC_PAIR_UNROLL; // sample loop of the plane-pair form (wsh != 3)
 #ifndef AVDM_NCC_MULTI_UNROLL
 #define AVDM_NCC_MULTI_UNROLL 3
 #endif
@@ -51,11 +47,11 @@ constexpr int kNccMultiUnroll = AVDM_NCC_MULTI_UNROLL; // sample loop of the fou
 //                           (groups of 2: 246.0 / 244.0 ms at unroll 1 / 3; all 4 pairs in flight: 260.3 ms, the taps spill),
 //                       1 = rotating: the taps of pair j + 1 are requested before pair j is consumed (236.9 ms at unroll 1, 239.7 at 3),
 //                       2 = rotating across the samples of a row too (242.4 ms),
-//                       3 = as 1, and the R taps of the next sample requested during the last pair (not measured),
-//                       4 = as 1, and the first pair's taps requested before the R side's arithmetic instead of after it (not measured).
+//                       3 = as 1, and the R taps of the next sample requested during the last pair,
+//                       4 = as 1, and the first pair's taps requested before the R side's arithmetic instead of after it.
 // The loop issues 34 VALU instructions per plane and sample instead of 43 (-20 %); the time follows by -4 % only: each wave now waits on the
-// LDS four times per sample with two waves per SIMD to cover it.  AVDM_NCC_PIPE_MIN_PAIRS = 2 with AVDM_QUAD_VIA_MULTI = 1 puts the four-plane
-// pass through the same code (A/B builds only): every rotating form of it is slower than the compiler's own schedule (251.5 ... 255.3 ms).
+// LDS four times per sample with two waves per SIMD to cover it.  (Rotating forms of the FOUR-plane pass were A/B builds of round 4: every one
+// of them slower than the compiler's own schedule, 251.5 ... 255.3 ms.)  Session r05_a measured 3 and 4: 238.4 / 236.2 against 237.1 ... 237.7 ms.
 #ifndef AVDM_NCC_OCTO_UNROLL
 #define AVDM_NCC_OCTO_UNROLL 1
 #endif
@@ -66,9 +62,6 @@ constexpr int kNccOctoUnroll = AVDM_NCC_OCTO_UNROLL; // sample loop of the eight
 #ifndef AVDM_NCC_PIPE_MIN_PAIRS
 #define AVDM_NCC_PIPE_MIN_PAIRS 3
 #endif
-#ifndef AVDM_QUAD_VIA_MULTI
-#define AVDM_QUAD_VIA_MULTI 0
-#endif
 #ifndef AVDM_NCC_MULTI_GROUP
 #define AVDM_NCC_MULTI_GROUP 2
 #endif
@@ -76,9 +69,6 @@ constexpr int kMultiGroup = AVDM_NCC_MULTI_GROUP;
 constexpr int kPipeMinPairs = AVDM_NCC_PIPE_MIN_PAIRS;
 constexpr int kMultiPipe = AVDM_NCC_MULTI_PIPE;
 constexpr bool kPipeRNext = kMultiPipe == 2 || kMultiPipe == 3; // the R taps of the next sample are requested during the last pair
-#ifndef AVDM_SGM_PLANES_PER_PASS
-#define AVDM_SGM_PLANES_PER_PASS 4 // planes per pass over the patch in the default SGM similarity instantiation: 2 (pairs) or 4
-#endif
 #ifndef AVDM_NCC_W3_MODE
 #define AVDM_NCC_W3_MODE 2 // 7-tap rows (wsh 3, the Refine default): 0 = plain `unroll 3` (spills), 1 = no unroll, 2 = 3 + 3 + 1 with fences
 #endif
@@ -95,12 +85,6 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #ifndef AVDM_SIM_WAVES_PER_SIMD
 #define AVDM_SIM_WAVES_PER_SIMD 2 // occupancy the two kernels are compiled for: 3 -> 168 VGPRs, 2 -> 256 VGPRs
 #endif
-#ifndef AVDM_REFINE_PLANES_PER_PASS
-#define AVDM_REFINE_PLANES_PER_PASS 4 // planes per pass over the patch in the default Refine instantiation: 1, 2 (pairs) or 4
-#endif
-#ifndef AVDM_EXPERIMENT_FAST_ONLY
-#define AVDM_EXPERIMENT_FAST_ONLY 0 // compile-time experiment (register accounting only): the default instantiations without their fall-back loops
-#endif
 #ifndef AVDM_NCC_QUAD_W3_MODE
 #define AVDM_NCC_QUAD_W3_MODE 0 // 7-tap rows of the four-plane form: 0 = 2 + 2 + 2 + 1 with fences, 1 = one sample at a time, 2 = 3 + 3 + 1
 #endif
@@ -109,9 +93,6 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #endif                             // its planes outside as invalid planes of the pass: 267.1 against 271.6 ms per depth map (session r05_a); 0 = two four-plane passes
 #ifndef AVDM_NCC_OCTO_W3_MODE
 #define AVDM_NCC_OCTO_W3_MODE 3 // 7-tap rows of the eight-plane form: as AVDM_NCC_QUAD_W3_MODE, 3 = a rolled loop (unroll AVDM_NCC_OCTO_UNROLL)
-#endif
-#ifndef AVDM_NCC_PAIR_W3_MODE
-#define AVDM_NCC_PAIR_W3_MODE 1 // 7-tap rows of the plane-pair form: 0 = 3 + 3 + 1 with fences, 1 = 4 + 3, 2 = the whole row unrolled
 #endif
 
 typedef float v2f_t __attribute__((ext_vector_type(2)));
@@ -282,16 +263,9 @@ struct LdsTap
 
 // LDS row pitch (texels) for a window of w texels: smallest value = 8 (mod 16) that is >= w
 __host__ __device__ __forceinline__ int lds_pitch_for(int w) { return (((w + 7) >> 4) << 4) + 8; }
-// De-interleaved T windows (AVDM_SIM_DEINT=1, experimental; 12-byte records only).  The SGM sweep samples every stepXY-th pixel of the level it
-// reads: with stepXY = 2 the lanes of a wave (8 x 8 pixels, pixel_of_lane) address records two columns and two rows apart — 6 dwords per lane,
-// an even number of dwords per row — so the 32 lanes of an LDS access share the 16 even banks: a two-way conflict on every tap
-// (profiles/r04_sim_pmc.json: 58 % of the LDS cycles of the kernel are conflict cycles).  Storing column c of the window at record
-// (c >> 1) + (c & 1) * pitch / 2 puts the lanes of a row on consecutive records (3 dwords apart: 8 distinct banks) and a pitch of 4 (mod 8)
-// records puts the four rows of the access 8 or 24 banks apart: 32 lanes, 32 banks.  The reader pays two v_fract and two packed FMAs per
-// pair of planes for the column's parity.  MEASURED (session r04_k): volumes bit-identical to the default's, the SGM sweep 2.3 % SLOWER
-// (252.8 against 247.1 ms) — the +4.6 % VALU instructions cost more than the conflict cycles they remove: the LDS is ~55 % busy in this kernel,
-// it is not what the waves wait for.  Kept as a switch for the record; not a candidate.
-__host__ __device__ __forceinline__ int lds_pitch_deint(int w) { return (((w + 4) >> 3) << 3) + 4; }
+// (De-interleaved T windows — column c of a 12-byte-record window at record (c >> 1) + (c & 1) * pitch / 2, which removes the two-way bank
+// conflicts of the stepXY = 2 sweep — were built and measured in round 4 (AVDM_SIM_DEINT: volumes bit-identical, the sweep 2.3 % SLOWER: the
+// + 4.6 % VALU instructions cost more than the conflict cycles they remove) and removed in round 5.)
 
 // cooperative copy of the window [x0, x0+w) x [y0, y0+h) of level L into LDS (row pitch `pitch` texels); the window is inside the image
 __device__ __forceinline__ void stage_window(uint2* dst, int pitch, const TexLevel& L, int x0, int y0, int w, int h)
@@ -373,32 +347,6 @@ __device__ __forceinline__ void stage_window_rec12(Rec12* dst, int pitch, const 
             rec.b = __builtin_amdgcn_perm(t1.y, t0.y, AVDM_PERM_LO);
             if(lane < 63 && c < w)
                 d[c] = rec;
-        }
-    }
-}
-
-// the same records, column c at (c >> 1) + (c & 1) * pitch / 2 (lds_pitch_deint)
-__device__ __forceinline__ void stage_window_rec12_deint(Rec12* dst, int pitch, const TexLevel& L, int x0, int y0, int w, int h)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = pitch >> 1;
-    for(int r = wave; r < h; r += 4)
-    {
-        const uint2* src = L.base + (long long)(y0 + r) * L.pitch8 + x0;
-        Rec12* d = dst + r * pitch;
-        for(int c0 = 0; c0 < w; c0 += 63)
-        {
-            const int c = c0 + lane;
-            const uint2 t0 = src[min(c, w - 1)];
-            uint2 t1;
-            t1.x = (unsigned)__builtin_amdgcn_update_dpp((int)t0.x, (int)t0.x, 0x130, 0xf, 0xf, false);
-            t1.y = (unsigned)__builtin_amdgcn_update_dpp((int)t0.y, (int)t0.y, 0x130, 0xf, 0xf, false);
-            Rec12 rec;
-            rec.L = __builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_LO);
-            rec.a = __builtin_amdgcn_perm(t1.x, t0.x, AVDM_PERM_HI);
-            rec.b = __builtin_amdgcn_perm(t1.y, t0.y, AVDM_PERM_LO);
-            if(lane < 63 && c < w)
-                d[(c >> 1) + (c & 1) * half] = rec;
         }
     }
 }
@@ -624,14 +572,6 @@ struct LdsWindows
     float rPitchBF, tPitchBF;
     float rOffB, tOffB;        // LDS byte address of texel (0, 0) of each window: base + 8 * (-(y0 * pitch + x0) [+ rcap]); |.| < 2^24
 };
-// De-interleaved T window (lds_pitch_deint; its first column is even and make_windows() received x0 / 2): byte address of the record of column
-// fX — 6 fX on the even columns, tPitchB / 2 - 6 further on the odd ones (fract(fX / 2) = 0.5) — for a pair of planes, less the row term
-__device__ __forceinline__ v2f deint_col(const LdsWindows& Wn, v2f fX)
-{
-    const v2f hx = fX * 0.5f;
-    const v2f fr = {__builtin_amdgcn_fractf(hx.x), __builtin_amdgcn_fractf(hx.y)};
-    return fX * 6.0f + (fr * (Wn.tPitchBF - 12.0f) + Wn.tOffB);
-}
 typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const v4u32* lds_record_ptr; // one ds_read_b128
 __device__ __forceinline__ uint4 lds_record(unsigned byteAddr)
@@ -760,7 +700,7 @@ __device__ __forceinline__ Lab3x2 hlerp3x2_halfpaired(uint2 r0, unsigned r0n, ui
     return o;
 }
 
-template <int WSH, bool TInvert, bool PAIRED, int RP = 0, bool REC12 = false, bool DEINT = false>
+template <int WSH, bool TInvert, bool PAIRED, int RP = 0, bool REC12 = false>
 __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const LdsWindows& Wn,
                                                            float4 rcCenter, float4 tcCenter)
 {
@@ -803,8 +743,6 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
                 const v2f na = 256.0f - wa, nnb = wb - 256.0f; // nnb = -(256 - B)
                 // LDS byte address of the top-left tap, formed in fp32 (exact integers), then one conversion per image
                 v2f oidx = fY * pitch2 + (fX * (PAIRED ? 16.0f : (REC12 ? 12.0f : 8.0f)) + off2);
-                if constexpr(DEINT) // (the T half again, with the column's parity: see lds_pitch_deint)
-                    oidx.y = fmaf(fY.y, Wn.tPitchBF, fmaf(fX.y, 6.0f, fmaf(__builtin_amdgcn_fractf(fX.y * 0.5f), Wn.tPitchBF - 12.0f, Wn.tOffB)));
                 const unsigned oR = (unsigned)(int)oidx.x, oT = (unsigned)(int)oidx.y;
                 const v2h wr = pk_half_weights(na.x, wa.x), wt = pk_half_weights(na.y, wa.y);
                 Lab3x4 h;
@@ -904,193 +842,6 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
     return sim;
 }
 
-// the taps of one sample of a plane pair, between the two stages of ncc_accumulate_lds_fixed8_pair's pipeline
-template <bool PAIRED>
-struct PairTaps;
-template <>
-struct PairTaps<true>
-{
-    uint4 r0, r1, a0, a1, b0, b1; // paired records: R top / bottom, plane A top / bottom, plane B top / bottom
-    v2f nnb, wb;                  // T vertical weights {plane A, plane B}
-    float rNy, rWy;               // R vertical weights
-    v2h wr, wtA, wtB;             // horizontal weight pairs
-    __device__ __forceinline__ void load(unsigned oR, unsigned oRb, unsigned oA, unsigned oAb, unsigned oB, unsigned oBb)
-    {
-        r0 = lds_record(oR), r1 = lds_record(oRb), a0 = lds_record(oA), a1 = lds_record(oAb), b0 = lds_record(oB), b1 = lds_record(oBb);
-    }
-    __device__ __forceinline__ Lab3x2 r_products() const { return hlerp3x2_paired(r0, r1, wr); }
-    __device__ __forceinline__ Lab3x4 t_products() const { return hlerp3x4_paired(a0, a1, b0, b1, wtA, wtB); }
-};
-template <>
-struct PairTaps<false>
-{
-    uint2 r0, r1, a0, a1, b0, b1; // half-paired records: column c whole, of column c + 1 the {a | b} dword
-    unsigned r0n, r1n, a0n, a1n, b0n, b1n;
-    v2f nnb, wb;
-    float rNy, rWy;
-    v2h wr, wtA, wtB;
-    __device__ __forceinline__ void load(unsigned oR, unsigned oRb, unsigned oA, unsigned oAb, unsigned oB, unsigned oBb)
-    {
-        r0 = lds_texel(oR), r1 = lds_texel(oRb), a0 = lds_texel(oA), a1 = lds_texel(oAb), b0 = lds_texel(oB), b1 = lds_texel(oBb);
-        r0n = lds_u32(oR + 12u), r1n = lds_u32(oRb + 12u), a0n = lds_u32(oA + 12u), a1n = lds_u32(oAb + 12u), b0n = lds_u32(oB + 12u),
-        b1n = lds_u32(oBb + 12u);
-    }
-    __device__ __forceinline__ Lab3x2 r_products() const { return hlerp3x2_halfpaired(r0, r0n, r1, r1n, wr); }
-    __device__ __forceinline__ Lab3x4 t_products() const { return hlerp3x4_halfpaired(a0, a0n, a1, a1n, b0, b0n, b1, b1n, wtA, wtB); }
-};
-
-// Two ADJACENT planes of a pixel in one pass over the patch (the default path of both kernels when the chunk's T window serves both):
-// the packed registers carry {T of plane A, T of plane B} instead of {R, T}, and the R side — position, taps, colour distance — is
-// evaluated ONCE per sample for both planes, from plane A's patch.  The R taps of the two planes differ only through the tilt of the
-// patch's x axis (ay and the centre's R projection do not depend on the plane): for planes one depth step apart that moves an R tap by
-// ~1e-4 texel at most, below one ulp of the fp32 pixel coordinate of a 12 MP image (2.4e-4), i.e. inside the rounding noise of the
-// reference's own per-plane evaluation.  Per pair of plane-samples: 33 (R) + 60 (T pair) + 13 instead of 2 x 68 VALU instructions
-// (half-paired records; 29 + 52 + 13 instead of 2 x 60 with paired records).
-template <int WSH, bool TInvert, bool PAIRED, int RP = 0>
-__device__ __forceinline__ void ncc_accumulate_lds_fixed8_pair(f3 rax, f3 ray, f3 hr0, const PatchProj& QA, const PatchProj& QB, const NccArgs& A,
-                                                               const PatchTable& tab, const LdsWindows& Wn, float4 rcCenter, float4 tcCenterA,
-                                                               float4 tcCenterB, float& simA, float& simB)
-{
-    const int wsh = WSH > 0 ? WSH : A.wsh;
-    const int n = 2 * wsh + 1;
-    // T side, {plane A, plane B}
-    const v2f ax = {QA.tax.x, QB.tax.x}, ay = {QA.tax.y, QB.tax.y}, az = {QA.tax.z, QB.tax.z};
-    const v2f bx = {QA.tay.x, QB.tay.x}, by = {QA.tay.y, QB.tay.y}, bz = {QA.tay.z, QB.tay.z};
-    const v2f h0x = {QA.ht0.x, QB.ht0.x}, h0y = {QA.ht0.y, QB.ht0.y}, h0z = {QA.ht0.z, QB.ht0.z};
-    const v2f axS = ax * A.tcSx, ayS = ay * A.tcSy;
-    const float S16 = 65536.0f;
-    const v2f cL = v2f{tcCenterA.x, tcCenterB.x} * S16, ca = v2f{tcCenterA.y, tcCenterB.y} * S16, cb = v2f{tcCenterA.z, tcCenterB.z} * S16;
-    // R side, {x, y} of the one image
-    const v2f raS = {rax.x * A.rcSx, rax.y * A.rcSy};
-    const v2f rS = {A.rcSx, A.rcSy}, rO = {A.rcOx, A.rcOy};
-    const v2f rcLa = v2f{rcCenter.x, rcCenter.y} * S16;
-    const float rcb = rcCenter.z * S16;
-    const float kC = A.negInvGammaC_log2e * (1.0f / 65536.0f);
-    constexpr float recB = PAIRED ? 16.0f : 8.0f;
-
-    v2f wsum = {0.f, 0.f};
-    v2f s1R = {0.f, 0.f}, s1T = {0.f, 0.f}, s2R = {0.f, 0.f}, s2T = {0.f, 0.f}, sxy = {0.f, 0.f};
-
-#pragma unroll 1
-    for(int yp = -wsh; yp <= wsh; ++yp)
-    {
-        const float fy = (float)yp;
-        const v2f rowx = (fy * bx + h0x) * A.tcSx, rowy = (fy * by + h0y) * A.tcSy, rowz = fy * bz + h0z;
-        const v2f rrow = (fy * v2f{ray.x, ray.y} + v2f{hr0.x, hr0.y}) * rS;
-        const float rrowz = fmaf(fy, ray.z, hr0.z);
-        const float* trow = tab.c + (yp + wsh) * n + wsh;
-        // One sample in two stages: fetch() — positions, weights and the LDS reads of the R image and of both planes' T taps, issued
-        // together — then consume().  (A hand-pipelined row, fetch(xp + 1) fenced in front of consume(xp), measured 12 % / 34 % SLOWER
-        // than this form for the SGM / Refine kernel: DESIGN.md §4.4.)
-        auto fetch = [&](int xp) __attribute__((always_inline)) -> PairTaps<PAIRED> {
-            PairTaps<PAIRED> t;
-            const float fx = (float)xp;
-            // ---- R: one image, {X, Y} packed
-            const float rinv = fast_rcp(fmaf(fx, rax.z, rrowz));
-            const v2f rXY = (fx * raS + rrow) * rinv + rO;
-            const v2f rF = floor2(rXY);
-            const v2f rW = floor2((rXY - rF) * 256.0f + 0.5f);           // {A, B} of quant8(), in units of 1/256
-            const v2f rN = rW * v2f{-1.0f, 1.0f} + v2f{256.0f, -256.0f}; // {256 - A, -(256 - B)}
-            const unsigned oR = (unsigned)(int)fmaf(rF.y, Wn.rPitchBF, fmaf(rF.x, recB, Wn.rOffB));
-            __builtin_assume(oR < 65536u);
-            t.wr = pk_half_weights(rN.x, rW.x);
-            t.rNy = rN.y;
-            t.rWy = rW.y;
-            // ---- T: {plane A, plane B}
-            const v2f hz = fx * az + rowz;
-            const v2f inv = {fast_rcp(hz.x), fast_rcp(hz.y)};
-            const v2f X = (fx * axS + rowx) * inv + A.tcOx;
-            const v2f Y = (fx * ayS + rowy) * inv + A.tcOy;
-            const v2f fX = floor2(X), fY = floor2(Y);
-            const v2f wa = floor2((X - fX) * 256.0f + 0.5f);
-            t.wb = floor2((Y - fY) * 256.0f + 0.5f);
-            const v2f na = 256.0f - wa;
-            t.nnb = t.wb - 256.0f;
-            const v2f oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
-            const unsigned oA = (unsigned)(int)oidx.x, oB = (unsigned)(int)oidx.y;
-            t.wtA = pk_half_weights(na.x, wa.x);
-            t.wtB = pk_half_weights(na.y, wa.y);
-            const unsigned oRb = RP > 0 ? oR + (unsigned)(RP * (PAIRED ? 16 : 8)) : oR + Wn.rPitchB;
-            t.load(oR, oRb, oA, oA + Wn.tPitchB, oB, oB + Wn.tPitchB);
-            return t;
-        };
-        auto consume = [&](int xp, const PairTaps<PAIRED>& t) __attribute__((always_inline)) {
-            const Lab3x2 hr = t.r_products();
-            const v2f dRLa = (v2f{hr.t.L, hr.t.a} * t.rNy + rcLa) - v2f{hr.b.L, hr.b.a} * t.rWy;
-            const float dRb = fmaf(hr.t.b, t.rNy, rcb) - hr.b.b * t.rWy;
-            const v2f qR = dRLa * dRLa;
-            const float base = fmaf(__builtin_amdgcn_sqrtf(fmaf(dRb, dRb, qR.x + qR.y)), kC, -trow[xp]);
-            const float dLR = dRLa.x;
-
-            const Lab3x4 h = t.t_products(); // rt / rb = plane A top / bottom row, tt / tb = plane B
-            const v2f dL = (v2f{h.rt.L, h.tt.L} * t.nnb + cL) - v2f{h.rb.L, h.tb.L} * t.wb;
-            const v2f da = (v2f{h.rt.a, h.tt.a} * t.nnb + ca) - v2f{h.rb.a, h.tb.a} * t.wb;
-            const v2f db = (v2f{h.rt.b, h.tt.b} * t.nnb + cb) - v2f{h.rb.b, h.tb.b} * t.wb;
-            const v2f sq = dL * dL + (da * da + db * db);
-            const v2f e = v2f{__builtin_amdgcn_sqrtf(sq.x), __builtin_amdgcn_sqrtf(sq.y)} * kC + base;
-            const v2f w = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-
-            const v2f wgR = w * dLR, wgT = w * dL;
-            wsum += w;
-            s1R += wgR;
-            s1T += wgT;
-            s2R = wgR * dLR + s2R;
-            s2T = wgT * dL + s2T;
-            sxy = wgR * dL + sxy;
-        };
-        if(WSH == 3 && AVDM_NCC_PAIR_W3_MODE == 1)
-        {
-            // 7 taps per row as 4 + 3: one more pair-sample of taps in flight (256 VGPRs at two waves per SIMD leave room for it)
-#pragma unroll
-            for(int xp = -3; xp < 1; ++xp)
-                consume(xp, fetch(xp));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for(int xp = 1; xp <= 3; ++xp)
-                consume(xp, fetch(xp));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        else if(WSH == 3 && AVDM_NCC_PAIR_W3_MODE == 2)
-        {
-#pragma unroll
-            for(int xp = -3; xp <= 3; ++xp)
-                consume(xp, fetch(xp));
-        }
-        else if(WSH == 3)
-        {
-            // 7 taps per row as 3 + 3 + 1 (see ncc_accumulate_lds_fixed8)
-#pragma unroll
-            for(int xp = -3; xp < 0; ++xp)
-                consume(xp, fetch(xp));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for(int xp = 0; xp < 3; ++xp)
-                consume(xp, fetch(xp));
-            __builtin_amdgcn_sched_barrier(0);
-            consume(3, fetch(3));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        else
-        {
-#pragma unroll kNccPairUnroll
-            for(int xp = -wsh; xp <= wsh; ++xp)
-                consume(xp, fetch(xp));
-        }
-    }
-
-    auto finish = [&](float ws, float x1, float y1, float xx, float yy, float xy) __attribute__((always_inline)) -> float {
-        const float iw = fast_rcp(ws);
-        const float varXW = (xx - x1 * x1 * iw) * iw;
-        const float varYW = (yy - y1 * y1 * iw) * iw;
-        const float varXYW = (xy - x1 * y1 * iw) * iw;
-        const float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
-        const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
-        return TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, sim) : sim;
-    };
-    simA = finish(wsum.x, s1R.x, s1T.x, s2R.x, s2T.x, sxy.x);
-    simB = finish(wsum.y, s1R.y, s1T.y, s2R.y, s2T.y, sxy.y);
-}
-
 // FOUR adjacent planes of a pixel (one chunk of the SGM kernel) in one pass over the patch: ncc_accumulate_lds_fixed8_pair taken one step
 // further.  The R side of a sample — position, weights, taps, colour distance — is evaluated ONCE, from the patch of a reference plane, for
 // two packed T pairs {plane 0, plane 1}, {plane 2, plane 3}: per plane-sample (37 + 2 x 81) / 4 = 50 VALU instructions instead of 59.
@@ -1106,7 +857,7 @@ struct QuadPlane
     f3 tax;   // M_T * (patch.x * pixSize)
     float4 c; // T centre colour
 };
-template <int WSH, bool TInvert, bool PAIRED, int RP, bool REC12 = false, bool DEINT = false>
+template <int WSH, bool TInvert, bool PAIRED, int RP, bool REC12 = false>
 __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f3 hr0, const QuadPlane& q0, const QuadPlane& q1, const QuadPlane& q2,
                                                                const QuadPlane& q3, f3 Bt, f3 htB, f3 htA, const NccArgs& A, const PatchTable& tab,
                                                                const LdsWindows& Wn, float4 rcCenter, float& sim0, float& sim1, float& sim2, float& sim3)
@@ -1219,11 +970,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             t.wb = quant256(Y - fY);
             const v2f na = 256.0f - wa;
             t.nnb = t.wb - 256.0f;
-            v2f oidx;
-            if constexpr(DEINT)
-                oidx = fY * Wn.tPitchBF + deint_col(Wn, fX);
-            else
-                oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
+            const v2f oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
             const unsigned oA = (unsigned)(int)oidx.x, oB = (unsigned)(int)oidx.y;
             t.wtA = pk_half_weights(na.x, wa.x);
             t.wtB = pk_half_weights(na.y, wa.y);
@@ -1390,7 +1137,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
 // plane-samples are per SAMPLE — amortised over twice the planes.  Behind AVDM_SIM_PLANES8=1: -4 % on the SGM sweep (see AVDM_NCC_MULTI_PIPE
 // above), volumes equal to the default's to the storage quantum (tests/test_gpu_parity.py::test_sgm_similarity_experiments_equal_the_default);
 // not the default until the parity tables have been re-measured with it (the R side now comes from a plane up to four depth steps away).
-template <int WSH, bool TInvert, bool PAIRED, int RP, bool REC12, int NPAIR, bool DEINT = false>
+template <int WSH, bool TInvert, bool PAIRED, int RP, bool REC12, int NPAIR>
 __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, f3 hr0, const QuadPlane (&q)[2 * NPAIR], f3 Bt, f3 htB, f3 htA, const NccArgs& A,
                                                                 const PatchTable& tab, const LdsWindows& Wn, float4 rcCenter, float (&sim)[2 * NPAIR])
 {
@@ -1502,11 +1249,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
             t.wb = quant256(Y - fY);
             const v2f na = 256.0f - wa;
             t.nnb = t.wb - 256.0f;
-            v2f oidx;
-            if constexpr(DEINT)
-                oidx = fY * Wn.tPitchBF + deint_col(Wn, fX);
-            else
-                oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
+            const v2f oidx = fY * Wn.tPitchBF + (fX * recB + Wn.tOffB);
             const unsigned oA = (unsigned)(int)oidx.x, oB = (unsigned)(int)oidx.y;
             t.wtA = pk_half_weights(na.x, wa.x);
             t.wtB = pk_half_weights(na.y, wa.y);
@@ -1916,7 +1659,7 @@ struct TWindow
 
 // second half (after the barrier): decide — uniformly for the workgroup — whether plane k runs from LDS, and stage the T window
 __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk, bool paired, bool halfPaired,
-                                                  bool lean = false, bool rec12 = false, bool deint = false)
+                                                  bool lean = false, bool rec12 = false)
 {
     TWindow Wd;
     const int mnx = sh.box[k][0], mny = sh.box[k][1], mxx = sh.box[k][2], mxy = sh.box[k][3];
@@ -1930,13 +1673,11 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
         // (see corner_boxes), clipped at the image edge
         const bool inImage = mnx >= 0 && mny >= 0 && mxx + 1 <= A.tcL.W - 1 && mxy + 1 <= A.tcL.H - 1;
         Wd.x0 = max(mnx - 1, 0);
-        if(deint)
-            Wd.x0 &= ~1; // the parity of a column of the window is the parity of its image column
         Wd.y0 = max(mny - 1, 0);
         const int x1 = min(mxx + 2, A.tcL.W - 1), y1 = min(mxy + 2, A.tcL.H - 1);
         Wd.w = x1 - Wd.x0 + 1;
         Wd.h = y1 - Wd.y0 + 1;
-        Wd.pitch = deint ? lds_pitch_deint(Wd.w) : lds_pitch_for(Wd.w);
+        Wd.pitch = lds_pitch_for(Wd.w);
         const bool fits = Wd.w <= 4096 && Wd.h <= 4096 && lds_units(Wd.pitch * Wd.h, paired, rec12) <= A.tcap;
         Wd.ok = inImage && fits;
         reason = Wd.ok ? 0 : (inImage ? 3 : 2);
@@ -1946,8 +1687,6 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
     {
         if(paired)
             stage_window_paired((uint4*)sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
-        else if(rec12 && deint)
-            stage_window_rec12_deint((Rec12*)sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
         else if(rec12)
             stage_window_rec12((Rec12*)sT, Wd.pitch, A.tcL, Wd.x0, Wd.y0, Wd.w, Wd.h);
         else if(halfPaired)
@@ -1974,32 +1713,13 @@ __device__ __forceinline__ void init_shared(BlockShared& sh)
 // PLANES = planes per pass over the patch on the packed chunk-window path: 1, 2 (ncc_accumulate_lds_fixed8_pair) or 4 (..._multi<2>: the
 // whole chunk in one pass; chunks it cannot take — a plane range that ends inside the chunk, a wave with a lane outside the window — run
 // one plane per pass)
-// MODE (the default instantiations run as TWO launches; everything else as one, MODE 0):
-//   1 = the FAST kernel: the R tile, the chunk window and the four-plane pass — nothing else.  What it cannot take — a workgroup without a
-//       chunk window (image border, hull beyond the LDS budget), a wave with a lane outside the window — it FLAGS in wgFlags (one word per
-//       workgroup: bit 4 c + w = chunk c, wave w) and leaves untouched;
-//   2 = the FIX-UP kernel on the same grid: a workgroup without flags returns at once, the others run the flagged (chunk, wave) units one
-//       plane per pass with per-plane windows / global-memory taps, exactly like MODE 0 does for them; their other waves only keep the
-//       barriers company.  Same NccArgs, hence the same window decisions as the fast kernel.
-// The split keeps the rarely taken paths (~5 % of the plane-workgroups) out of the hot kernel's register allocation.
-template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, bool REC12 = false, int MODE = 0, bool DEINT = false>
+// (Rounds 3-4 also carried a two-launch form of the default instantiations — a fast kernel and a fix-up kernel over the same grid,
+// AVDM_SIM_SPLIT — measured 3 % slower than the combined kernel (profiles/r03_o_split_ab.txt) and removed in round 5.)
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, bool REC12 = false>
 __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   similarity_kernel(uint8_t* __restrict__ best, uint8_t* __restrict__ second, long long pitch_y, int pitch_x, const float* __restrict__ depths,
-                    avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi,
-                    unsigned* __restrict__ wgFlags)
+                    avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi)
 {
-    constexpr bool FAST = MODE == 1, FIXUP = MODE == 2;
-    static_assert(!FAST || PLANES == 4, "the fast kernel is the four-plane pass");
-    static_assert(!DEINT || (REC12 && FIXED8 && RP > 0 && PLANES >= 4), "de-interleaved T windows: the 12-byte records of the default instantiation");
-    const unsigned wgIndex = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const unsigned waveInWg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    unsigned myFlags = 0u;
-    if(FIXUP)
-    {
-        myFlags = (unsigned)__builtin_amdgcn_readfirstlane((int)wgFlags[wgIndex]);
-        if(myFlags == 0u) // uniform for the workgroup: nothing was left for it
-            return;
-    }
     extern __shared__ __attribute__((aligned(16))) uint2 smem[];
     uint2* sR = smem;
     uint2* sT = smem + A.rcap;
@@ -2021,7 +1741,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     const bool useChunkWindow = LEAN ? true : (A.chunkWindow != 0);
     const bool usePlanePairs = LEAN ? true : (A.planePairs != 0);
     // paired LDS records only feed the packed FIXED8 path (uniform)
-    static_assert(!(REC12 && (PAIRED || PLANES == 2)), "12-byte records: one or four planes per pass");
+    static_assert(!(REC12 && PAIRED), "12-byte records or 16-byte records");
     const bool paired = PAIRED && FIXED8 && !noPacked;
     const bool rec12 = REC12 && FIXED8 && !noPacked;                  // 12-byte records (see stage_window_rec12)
     const bool halfPaired = !PAIRED && !REC12 && FIXED8 && !noPacked; // the packed path without room for wider records
@@ -2142,7 +1862,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             }
             publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
             __syncthreads();
-            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12, DEINT);
+            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12);
             __syncthreads();
             if(Wc.tooLarge) // uniform
             {
@@ -2154,18 +1874,12 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 part = wave_inlier(part, 0.5f * (bx0 + bx1), 0.5f * (by0 + by1), 16.0f * (float)stepXY + 16.0f);
                 publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
                 __syncthreads();
-                Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12, DEINT);
+                Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12);
                 __syncthreads();
             }
             chunkWin = Wc.ok;
             lanePart = part;
         }
-    }
-    if(FAST && !chunkWin) // uniform: the whole workgroup goes to the fix-up kernel
-    {
-        if(threadIdx.x == 0)
-            wgFlags[wgIndex] = 0xffffu;
-        return;
     }
 
 #pragma unroll 1
@@ -2174,8 +1888,6 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     const unsigned zc = z0 + 4u * c;
     if(zc >= zEnd) // uniform
         break;
-    if(FIXUP && ((myFlags >> (4u * c)) & 0xfu) == 0u) // uniform: the fast kernel finished this chunk for all four waves
-        continue;
     uint8_t* const pb = pb0 + 4u * c;
     uint8_t* const ps = ps0 + 4u * c;
     unsigned wb = 0, ws = 0;
@@ -2207,28 +1919,8 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         s = fminf(1.0f, fmaxf(0.0f, s));
         return s * 254.0f;
     };
-    // geometry, centre colour and tap source of plane vz when the chunk window is in use
-    auto prep = [&](unsigned vz, PatchProj& Q, float4& tcCenter, bool& valid, bool& laneLds) __attribute__((always_inline)) {
-        valid = rValid;
-        tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
-        float tpx = 0.f, tpy = 0.f;
-        if(valid)
-            valid = plane_geometry(vz, Q, tpx, tpy);
-        laneLds = true;
-        if(valid)
-        {
-            const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
-            tcCenter = tex_bilinear_px<FIXED8>(A.tcL, cxT, cyT);
-            valid = !(tcCenter.w < (255.f * 0.4f));
-            // (a lane that was valid on neither extreme plane has no extent on record: it never reads the window)
-            laneLds = lanePart && (cxT - extX - 1.0f >= (float)Wc.x0) && (cxT + extX + 2.0f <= (float)(Wc.x0 + Wc.w - 1)) &&
-                      (cyT - extY - 1.0f >= (float)Wc.y0) && (cyT + extY + 2.0f <= (float)(Wc.y0 + Wc.h - 1));
-        }
-        laneLds = __ballot(valid && !laneLds) == 0ull; // wave-uniform choice of the tap source (see the Refine kernel)
-    };
     bool quadDone = false;
-    const bool mine = !FIXUP || ((myFlags >> (4u * c + waveInWg)) & 1u) != 0u; // fix-up: is this (chunk, wave) unit mine?  (wave-uniform)
-    if constexpr(PLANES >= 4 && FIXED8 && !FIXUP)
+    if constexpr(PLANES >= 4 && FIXED8)
     {
         // the four planes of the chunk in one pass over the patch (ncc_accumulate_lds_fixed8_multi): uniform conditions
         if(chunkWin && usePlanePairs && !noPacked)
@@ -2321,9 +2013,9 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                             for(int k = 0; k < 8; ++k)
                                 qq[k] = selP8(vv[k], q[k], qf);
                             const float tw = qf.t * RK.hrW;
-                            ncc_accumulate_lds_fixed8_multi<WSH, false, PAIRED, RP, REC12, 4, DEINT>(
+                            ncc_accumulate_lds_fixed8_multi<WSH, false, PAIRED, RP, REC12, 4>(
                               raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, qq, Bt, RK.htB, RK.htA, A, tab,
-                              make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, DEINT ? Wc.x0 >> 1 : Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter, sim);
+                              make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter, sim);
                         }
                         auto commit2 = [&](unsigned& wbx, unsigned& wsx, int k, float fsim) __attribute__((always_inline)) {
                             const unsigned sh8 = 8u * k;
@@ -2378,19 +2070,10 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                     const QuadPlane qf = selP(v1b, q1, selP(v2b, q2, selP(v0, q0, q3)));
                     const f3 raf = sel3(v1b, ra1, sel3(v2b, ra2, sel3(v0, ra0, ra3)));
                     const float tw = qf.t * RK.hrW;
-#if AVDM_QUAD_VIA_MULTI
-                    const QuadPlane qa[4] = {selP(v0, q0, qf), selP(v1b, q1, qf), selP(v2b, q2, qf), selP(v3, q3, qf)};
-                    float sm[4] = {0.f, 0.f, 0.f, 0.f};
-                    ncc_accumulate_lds_fixed8_multi<WSH, false, PAIRED, RP, REC12, 2, DEINT>(
-                      raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, qa, Bt, RK.htB, RK.htA, A, tab,
-                      make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, DEINT ? Wc.x0 >> 1 : Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter, sm);
-                    s0 = sm[0], s1 = sm[1], s2 = sm[2], s3 = sm[3];
-#else
-                    ncc_accumulate_lds_fixed8_quad<WSH, false, PAIRED, RP, REC12, DEINT>(raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
+                    ncc_accumulate_lds_fixed8_quad<WSH, false, PAIRED, RP, REC12>(raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
                                                                     selP(v0, q0, qf), selP(v1b, q1, qf), selP(v2b, q2, qf), selP(v3, q3, qf), Bt, RK.htB, RK.htA, A, tab,
-                                                                    make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, DEINT ? Wc.x0 >> 1 : Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
+                                                                    make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
                                                                     s0, s1, s2, s3);
-#endif
                 }
                 // (a plane outside the range is not committed at all: its bytes belong to other T cameras)
                 if(zc >= zBegin && zc < zEnd)
@@ -2403,47 +2086,11 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                     commit(3, v3 ? to_fsim(s3) : 255.0f);
                 quadDone = true;
             }
-            else if(FAST)
-            {
-                // a lane of this wave lies outside the chunk window on one of the planes: the unit is left to the fix-up kernel
-                if((threadIdx.x & 63) == 0)
-                    atomicOr(&wgFlags[wgIndex], 1u << (4u * c + waveInWg));
-            }
         }
     }
 #pragma unroll 1
-    for(int k0 = 0; k0 < 4 && !quadDone && !FAST && !(AVDM_EXPERIMENT_FAST_ONLY && LEAN); k0 += 2)
+    for(int k0 = 0; k0 < 4 && !quadDone; k0 += 2)
     {
-        bool pairDone = false;
-        {
-            const unsigned vzA = zc + k0, vzB = vzA + 1u;
-            // two adjacent planes in one pass over the patch (ncc_accumulate_lds_fixed8_pair): uniform conditions
-            if(PLANES == 2 && FIXED8 && chunkWin && usePlanePairs && !noPacked && vzA >= zBegin && vzB < zEnd)
-            {
-                PatchProj QA, QB;
-                float4 cA, cB;
-                bool validA, validB, ldsA, ldsB;
-                prep(vzA, QA, cA, validA, ldsA);
-                prep(vzB, QB, cB, validB, ldsB);
-                if(ldsA && ldsB) // wave-uniform
-                {
-                    float sA = 0.f, sB = 0.f;
-                    if(validA || validB)
-                    {
-                        // a lane with one valid plane runs it in both halves
-                        const PatchProj PA = selQ(validA, QA, QB), PB = selQ(validB, QB, QA);
-                        ncc_accumulate_lds_fixed8_pair<WSH, false, PAIRED, RP>(PA.rax, PA.ray, PA.hr0, PA, PB, A, tab,
-                                                                               make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, DEINT ? Wc.x0 >> 1 : Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)),
-                                                                               rcCenter, sel4(validA, cA, cB), sel4(validB, cB, cA), sA, sB);
-                    }
-                    commit(k0, validA ? to_fsim(sA) : 255.0f);
-                    commit(k0 + 1, validB ? to_fsim(sB) : 255.0f);
-                    pairDone = true;
-                }
-            }
-        }
-        if(pairDone)
-            continue;
 #pragma unroll 1
     for(int k = k0; k < k0 + 2; ++k)
     {
@@ -2451,7 +2098,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         if(vz < zBegin || vz >= zEnd) // uniform
             continue;
 
-        bool valid = rValid && mine; // (fix-up: the waves whose unit the fast kernel finished only keep the barriers company)
+        bool valid = rValid;
         PatchProj Q;
         float4 tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
         float tpx = 0.f, tpy = 0.f;
@@ -2483,7 +2130,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 corner_boxes(Q, A, wsh, R, bx0, by0, bx1, by1, rInside);
             publish_box(sh, k, valid, bx0, by0, bx1, by1, rInside);
             __syncthreads();
-            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired, LEAN, rec12, DEINT);
+            Wd = stage_t_window(sT, sh, k, A, R.ok, paired, halfPaired, LEAN, rec12);
             __syncthreads();
         }
 
@@ -2492,7 +2139,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         {
             float s;
             if(Wd.ok && laneLds && FIXED8 && !noPacked)
-                s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED, RP, REC12, DEINT>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, DEINT ? Wd.x0 >> 1 : Wd.x0, Wd.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
+                s = ncc_accumulate_lds_fixed8<WSH, false, PAIRED, RP, REC12>(Q, A, tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wd.pitch, Wd.x0, Wd.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
                                                           tcCenter);
             else if(Wd.ok && laneLds)
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, LdsTap{sR, R.pitch, R.x0, R.y0}, LdsTap{sT, Wd.pitch, Wd.x0, Wd.y0}, rcCenter, tcCenter);
@@ -2500,8 +2147,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 s = ncc_accumulate<FIXED8, WSH, false>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
             fsim = to_fsim(s);
         }
-        if(mine)
-            commit(k, fsim);
+        commit(k, fsim);
     }
     }
     if(inRoi)
@@ -2515,32 +2161,20 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
 // ---------------------------------------------------------------------------------------------
 // Refine similarity: fp16 volume += sigmoid-filtered NCC, 8 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-// MODE: see similarity_kernel (flag bits: 4 (2 c + q) + w = chunk c, quad q of its eight planes, wave w)
-template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, int MODE = 0>
+template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1>
 __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
   refine_similarity_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize,
                            int map_pitch, const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A,
-                           PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi, unsigned* __restrict__ wgFlags, unsigned listCap)
+                           PatchTable tab, int stepXY, unsigned zBegin, unsigned zEnd, avdm_roi_t roi, unsigned* __restrict__ outliers, unsigned listCap)
 {
-    constexpr bool FAST = MODE == 1, FIXUP = MODE == 2;
-    static_assert(!FAST || PLANES == 4, "the fast kernel is the four-plane pass");
-    // The OUTLIER LIST (MODE 0, listCap > 0; round 5).  A pixel whose SGM depth is wrong projects its patch tens of texels away from its
+    // The OUTLIER LIST (listCap > 0; round 5).  A pixel whose SGM depth is wrong projects its patch tens of texels away from its
     // neighbours' in a wide-baseline T camera: it cannot take its taps from the workgroup's T window, and until round 4 its whole WAVE then ran
     // the chunk one plane per pass with every tap from global memory (~4 x the instructions per plane-sample, for 64 lanes, because of one) —
     // 30 % more sweep time on the outer cameras of the bench.  Now such a LANE is taken out of the pass (all of its planes invalid: the lane is
-    // masked off inside the pass, it reads nothing) and appended to a list of (pixel, first plane, number of planes) units in wgFlags —
+    // masked off inside the pass, it reads nothing) and appended to a list of (pixel, first plane, number of planes) units in `outliers` —
     // {count, pad, entries ...} — that refine_outlier_kernel works off after this kernel with one lane per unit; the other 63 lanes keep the
     // eight-plane pass.  A full list (count >= listCap) leaves the wave on the old path.
-    const bool listing = MODE == 0 && PLANES >= 4 && listCap != 0u;
-    const unsigned wgIndex = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const unsigned waveInWg = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    unsigned myFlags = 0u;
-    if(FIXUP)
-    {
-        myFlags = (unsigned)__builtin_amdgcn_readfirstlane((int)wgFlags[wgIndex]);
-        if(myFlags == 0u) // uniform for the workgroup: nothing was left for it
-            return;
-    }
+    const bool listing = PLANES >= 4 && listCap != 0u;
     extern __shared__ __attribute__((aligned(16))) uint2 smem[];
     uint2* sR = smem;
     uint2* sT = smem + A.rcap;
@@ -2716,12 +2350,6 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             lanePart = part;
         }
     }
-    if(FAST && !chunkWin) // uniform: the whole workgroup goes to the fix-up kernel
-    {
-        if(threadIdx.x == 0)
-            wgFlags[wgIndex] = 0xffffffffu;
-        return;
-    }
 
 #pragma unroll 1
     for(unsigned c = 0; c < kRefineChunksPerWg; ++c)
@@ -2729,8 +2357,6 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
     const unsigned zc = z0 + 8u * c;
     if(zc >= zEnd) // uniform
         break;
-    if(FIXUP && ((myFlags >> (8u * c)) & 0xffu) == 0u) // uniform: the fast kernel finished this chunk for all four waves
-        continue;
     __half* const pv = pv0 + 8u * c;
     uint4 packed = make_uint4(0u, 0u, 0u, 0u);
     if(pixActive)
@@ -2754,29 +2380,8 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         packed.z = sel == 2 ? word : packed.z;
         packed.w = sel == 3 ? word : packed.w;
     };
-    // geometry, centre colour and tap source of plane vz when the chunk window is in use
-    auto prep = [&](unsigned vz, PatchProj& Q, float4& tcCenter, bool& valid, bool& laneLds) __attribute__((always_inline)) {
-        valid = rValid;
-        tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
-        float tpx = 0.f, tpy = 0.f;
-        if(valid)
-            valid = plane_geometry(vz, Q, tpx, tpy);
-        laneLds = true;
-        if(valid)
-        {
-            const float cxT = fmaf(tpx, A.tcSx, A.tcOx), cyT = fmaf(tpy, A.tcSy, A.tcOy);
-            laneLds = lanePart && (cxT - extX - 1.0f >= (float)Wc.x0) && (cxT + extX + 2.0f <= (float)(Wc.x0 + Wc.w - 1)) &&
-                      (cyT - extY - 1.0f >= (float)Wc.y0) && (cyT + extY + 2.0f <= (float)(Wc.y0 + Wc.h - 1));
-            if(laneLds)
-                tcCenter = lds_center_paired(sT, Wc.pitch, Wc.x0, Wc.y0, cxT, cyT);
-            else
-                tcCenter = tex_bilinear_px<FIXED8>(A.tcL, cxT, cyT);
-            valid = !(tcCenter.w < (255.f * 0.4f));
-        }
-        laneLds = __ballot(valid && !laneLds) == 0ull;
-    };
     unsigned quadsDone = 0u; // bit q: planes 4 q ... 4 q + 3 of the chunk went through the four-plane pass
-    if constexpr(PLANES >= 4 && CHUNK_CAPABLE && !FIXUP)
+    if constexpr(PLANES >= 4 && CHUNK_CAPABLE)
     {
         if(chunkWin && usePlanePairs && !noPacked)
         {
@@ -2835,14 +2440,14 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 const unsigned n = (unsigned)__popcll(m);
                 unsigned base = 0u;
                 if((threadIdx.x & 63u) == 0u)
-                    base = atomicAdd(wgFlags, n);
+                    base = atomicAdd(outliers, n);
                 base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
                 const bool granted = base + n <= listCap; // uniform
                 if(outl)
                 {
                     const unsigned idx = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                     if(idx < listCap)
-                        reinterpret_cast<uint2*>(wgFlags)[1u + idx] = make_uint2(vx | (vy << 16), granted ? (zFirst | (nPlanes << 16)) : 0u);
+                        reinterpret_cast<uint2*>(outliers)[1u + idx] = make_uint2(vx | (vy << 16), granted ? (zFirst | (nPlanes << 16)) : 0u);
                 }
                 return granted;
             };
@@ -2951,12 +2556,8 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                         quadLds = true;
                     }
                 }
-                if(!quadLds) // wave-uniform: this wave runs the quad one plane per pass (fast kernel: leaves it to the fix-up kernel)
-                {
-                    if(FAST && (threadIdx.x & 63) == 0)
-                        atomicOr(&wgFlags[wgIndex], 1u << (4u * (2u * c + qd) + waveInWg));
+                if(!quadLds) // wave-uniform: this wave runs the quad one plane per pass
                     continue;
-                }
                 if(v0 || v1b || v2b || v3)
                 {
                     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -2990,42 +2591,9 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         }
     }
 #pragma unroll 1
-    for(int k0 = 0; k0 < 8 && !FAST && !(AVDM_EXPERIMENT_FAST_ONLY && LEAN); k0 += 2)
+    for(int k0 = 0; k0 < 8; k0 += 2)
     {
         if((quadsDone >> (k0 >> 2)) & 1u) // uniform per wave
-            continue;
-        const bool mine = !FIXUP || ((myFlags >> (4u * (2u * c + (unsigned)(k0 >> 2)) + waveInWg)) & 1u) != 0u; // fix-up: my (chunk, quad, wave) unit?
-        bool pairDone = false;
-        {
-            const unsigned vzA = zc + k0, vzB = vzA + 1u;
-            // two adjacent planes in one pass over the patch (ncc_accumulate_lds_fixed8_pair): uniform conditions
-            if(PLANES == 2 && CHUNK_CAPABLE && chunkWin && usePlanePairs && !noPacked && vzA >= zBegin && vzB < zEnd)
-            {
-                PatchProj QA, QB;
-                float4 cA, cB;
-                bool validA, validB, ldsA, ldsB;
-                prep(vzA, QA, cA, validA, ldsA);
-                prep(vzB, QB, cB, validB, ldsB);
-                if(ldsA && ldsB) // wave-uniform
-                {
-                    if(validA || validB)
-                    {
-                        float sA = 0.f, sB = 0.f;
-                        // a lane with one valid plane runs it in both halves
-                        const PatchProj PA = selQ(validA, QA, QB), PB = selQ(validB, QB, QA);
-                        ncc_accumulate_lds_fixed8_pair<WSH, true, PAIRED, RP>(PA.rax, PA.ray, PA.hr0, PA, PB, A, tab,
-                                                                              make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8),
-                                                                              rcCenter, sel4(validA, cA, cB), sel4(validB, cB, cA), sA, sB);
-                        if(validA)
-                            commit(k0, sA);
-                        if(validB)
-                            commit(k0 + 1, sB);
-                    }
-                    pairDone = true;
-                }
-            }
-        }
-        if(pairDone)
             continue;
 #pragma unroll 1
     for(int k = k0; k < k0 + 2; ++k)
@@ -3034,7 +2602,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         if(vz < zBegin || vz >= zEnd) // uniform
             continue;
 
-        bool valid = rValid && mine; // (fix-up: the waves whose unit the fast kernel finished only keep the barriers company)
+        bool valid = rValid;
         PatchProj Q;
         float4 tcCenter = make_float4(0.f, 0.f, 0.f, 0.f);
         float tpx = 0.f, tpy = 0.f;
@@ -3618,12 +3186,6 @@ int literal_compute_similarity(uint8_t* best, uint8_t* second, long long pitch_y
 int literal_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x, int dimZ, const float* sgm_depth_pixsize, int map_pitch, const float* sgm_normal,
                               int normal_pitch, const avdm_camera_t* rc, const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
                               const avdm_refine_params_t* rp, avdm_range_t dr, avdm_roi_t roi, void* stream);
-// AVDM_SIM_SPLIT=1 (read at each call): the default instantiations as a fast + a fix-up launch
-static bool sim_split_mode()
-{
-    const char* e = getenv("AVDM_SIM_SPLIT");
-    return e != nullptr && e[0] == '1';
-}
 static bool sim_literal_mode()
 {
     const char* e = getenv("AVDM_SIM_LITERAL");
@@ -3779,7 +3341,7 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
     // A/B switches: those fall back to the general instantiations and their layout.
     const bool wantDefault = fixed8 && sp->wsh == 4 && lds_pitch_for(15 * sp->stepXY + 2 * (sp->wsh + 2) + 5) == 56;
     fill_ncc_args(A, tab, rc_pyr, tc_pyr, sp->scale, sp->stepXY, sp->wsh, sp->gammaC, sp->gammaP, paired, fractional, wantDefault ? kLdsHalf : kLdsThird,
-                  (wantDefault && AVDM_SGM_PLANES_PER_PASS != 2) ? &rec12 : nullptr);
+                  wantDefault ? &rec12 : nullptr);
     bool runDefault = wantDefault && !paired && !A.noPacked && !A.forceGeneric && A.chunkWindow && A.planePairs && A.stats == nullptr && !fractional &&
                       !sp->useConsistentScale && !sp->useCustomPatchPattern;
     if(wantDefault && !runDefault)
@@ -3814,80 +3376,33 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
     const size_t lds = (size_t)(A.rcap + A.tcap) * sizeof(uint2);
 #define LAUNCH(F8, W, PR)                                                                                                                                 \
     hipLaunchKernelGGL((similarity_kernel<F8, W, PR>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x, depths, *rc, *tc, A, tab, \
-                       sp->stepXY, dr.begin, dr.end, roi, (unsigned*)nullptr)
+                       sp->stepXY, dr.begin, dr.end, roi)
     if(runDefault)
     {
-        // the default: scale 2, stepXY 2, wsh 4 — four planes per pass, 12-byte records, up to half of the compute unit's LDS.
-        // AVDM_SIM_SPLIT=1: as TWO launches, the fast kernel and the fix-up kernel for what it flagged (see similarity_kernel): hot kernels
-        // without a VGPR spill, but the second launch over a grid of which ~5 % has work measured 3 % slower per depth map
+        // the default: scale 2, stepXY 2, wsh 4 — eight planes per pass (AVDM_SIM_PLANES8=0: four), 12-byte records, up to half of the compute
+        // unit's LDS; one launch
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if(!sim_split_mode())
-        {
-#define AVDM_SGM_COMBINED_LAUNCH(R12)                                                                                                                     \
+#define AVDM_SGM_DEFAULT_LAUNCH(P, R12)                                                                                                                   \
     {                                                                                                                                                     \
         static std::once_flag once[64]; /* the attribute belongs to the function on ONE device */                                                        \
         std::call_once(once[dev & 63], [&] {                                                                                                              \
-            (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, 4, R12>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);  \
+            (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, P, R12>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);  \
         });                                                                                                                                               \
-        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, 4, R12>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x,     \
-                           depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi, (unsigned*)nullptr);                                             \
+        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, P, R12>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x,     \
+                           depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi);                                                                 \
     }
-            // experiments, read at each call (12-byte records only): AVDM_SIM_PLANES8=1 — eight planes per pass where two chunks of a workgroup lie in
-            // the T camera's range; AVDM_SIM_DEINT=1 — de-interleaved T windows (lds_pitch_deint)
-            const char* p8 = getenv("AVDM_SIM_PLANES8");
-            const char* pd = getenv("AVDM_SIM_DEINT");
-            const bool planes8 = !(p8 != nullptr && p8[0] == '0'), deint = pd != nullptr && pd[0] == '1'; // eight planes per pass: the default since round 5
-#define AVDM_SGM_EXPERIMENT_LAUNCH(P, D)                                                                                                                  \
-    {                                                                                                                                                     \
-        static std::once_flag onceX[64];                                                                                                                  \
-        std::call_once(onceX[dev & 63], [&] {                                                                                                             \
-            (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, P, true, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                      kLdsHalf);                                                                                                          \
-        });                                                                                                                                               \
-        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, P, true, 0, D>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y,       \
-                           pitch_x, depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi, (unsigned*)nullptr);                                    \
-    }
-            if(rec12 && planes8 && deint)
-                AVDM_SGM_EXPERIMENT_LAUNCH(8, true)
-            else if(rec12 && planes8)
-                AVDM_SGM_EXPERIMENT_LAUNCH(8, false)
-            else if(rec12 && deint)
-                AVDM_SGM_EXPERIMENT_LAUNCH(4, true)
-#undef AVDM_SGM_EXPERIMENT_LAUNCH
-            else if(rec12)
-                AVDM_SGM_COMBINED_LAUNCH(true)
-            else
-                AVDM_SGM_COMBINED_LAUNCH(false)
-#undef AVDM_SGM_COMBINED_LAUNCH
-            return ::avdm::set_error(hipGetLastError(), "avdm_volume_compute_similarity"); // the one launch of the default path: done
-        }
-        // AVDM_SIM_SPLIT=1 only: fast kernel + fix-up kernel
-        const size_t nWg = (size_t)grid.x * grid.y * grid.z;
-        const StreamScratch lease((hipStream_t)stream, nWg * sizeof(unsigned));
-        unsigned* flags = (unsigned*)lease.ptr();
-        if(flags == nullptr)
-            return set_error_msg(2, "avdm_volume_compute_similarity: scratch allocation failed");
-        const hipError_t me = hipMemsetAsync(flags, 0, nWg * sizeof(unsigned), (hipStream_t)stream);
-        if(me != hipSuccess)
-            return set_error(me, "avdm_volume_compute_similarity");
-#define AVDM_SGM_DEFAULT_LAUNCH(R12)                                                                                                                      \
-    {                                                                                                                                                     \
-        static std::once_flag once[64]; /* the attribute belongs to the function on ONE device */                                                        \
-        std::call_once(once[dev & 63], [&] {                                                                                                              \
-            (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, 4, R12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf); \
-            (void)hipFuncSetAttribute((const void*)similarity_kernel<true, 4, false, 56, 1, R12, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf); \
-        });                                                                                                                                               \
-        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, 4, R12, 1>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x,   \
-                           depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi, flags);                                                          \
-        hipLaunchKernelGGL((similarity_kernel<true, 4, false, 56, 1, R12, 2>), grid, dim3(256), lds, (hipStream_t)stream, best, second, pitch_y, pitch_x,   \
-                           depths, *rc, *tc, A, tab, sp->stepXY, dr.begin, dr.end, roi, flags);                                                          \
-    }
-        if(rec12)
-            AVDM_SGM_DEFAULT_LAUNCH(true)
+        // read at each call (12-byte records only): AVDM_SIM_PLANES8=0 — four planes per pass everywhere (the round-4 default)
+        const char* p8 = getenv("AVDM_SIM_PLANES8");
+        const bool planes8 = !(p8 != nullptr && p8[0] == '0'); // eight planes per pass: the default since round 5
+        if(rec12 && planes8)
+            AVDM_SGM_DEFAULT_LAUNCH(8, true)
+        else if(rec12)
+            AVDM_SGM_DEFAULT_LAUNCH(4, true)
         else
-            AVDM_SGM_DEFAULT_LAUNCH(false)
+            AVDM_SGM_DEFAULT_LAUNCH(4, false)
 #undef AVDM_SGM_DEFAULT_LAUNCH
+        return ::avdm::set_error(hipGetLastError(), "avdm_volume_compute_similarity"); // the one launch of the default path: done
     }
     else if(fixed8 && paired)
     {
@@ -3971,9 +3486,8 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
                        (unsigned*)nullptr, 0u)
     if(runDefault)
     {
-        // the default: scale 1, stepXY 1, wsh 3 — four planes per pass, 16-byte records, up to half of the compute unit's LDS
-        // (AVDM_SIM_SPLIT=1: as two launches, the fast kernel and the fix-up kernel for what it flagged, see similarity_kernel)
-        if(!sim_split_mode())
+        // the default: scale 1, stepXY 1, wsh 3 — eight planes per pass (AVDM_REFINE_PLANES8=0: four), 16-byte records, up to half of the compute
+        // unit's LDS; the sweep kernel + the kernel that works off its outlier list
         {
             static std::once_flag once0[64]; // the attribute belongs to the function on ONE device
             int dev0 = 0;
@@ -4022,26 +3536,6 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
                                    (const unsigned*)list, listCap, outlier_totals());
             return ::avdm::set_error(hipGetLastError(), "avdm_volume_refine_similarity"); // the launches of the default path: done
         }
-        // AVDM_SIM_SPLIT=1 only: fast kernel + fix-up kernel
-        const size_t nWg = (size_t)grid.x * grid.y * grid.z;
-        const StreamScratch lease((hipStream_t)stream, nWg * sizeof(unsigned));
-        unsigned* flags = (unsigned*)lease.ptr();
-        if(flags == nullptr)
-            return set_error_msg(2, "avdm_volume_refine_similarity: scratch allocation failed");
-        const hipError_t me = hipMemsetAsync(flags, 0, nWg * sizeof(unsigned), (hipStream_t)stream);
-        if(me != hipSuccess)
-            return set_error(me, "avdm_volume_refine_similarity");
-        static std::once_flag once[64]; // the attribute belongs to the function on ONE device
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::call_once(once[dev & 63], [&] {
-            (void)hipFuncSetAttribute((const void*)refine_similarity_kernel<true, 3, true, 40, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);
-            (void)hipFuncSetAttribute((const void*)refine_similarity_kernel<true, 3, true, 40, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalf);
-        });
-        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, 4, 1>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
-                           (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi, flags, 0u);
-        hipLaunchKernelGGL((refine_similarity_kernel<true, 3, true, 40, 1, 2>), grid, dim3(256), lds, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
-                           (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi, flags, 0u);
     }
     else if(fixed8 && paired)
     {
