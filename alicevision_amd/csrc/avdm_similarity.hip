@@ -91,6 +91,9 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #ifndef AVDM_REFINE_OCTO_PARTIAL
 #define AVDM_REFINE_OCTO_PARTIAL 1 // Refine: a chunk that only overlaps the plane range (the last 7 of the default 31 planes) through the eight-plane pass too,
 #endif                             // its planes outside as invalid planes of the pass: 267.1 against 271.6 ms per depth map (session r05_a); 0 = two four-plane passes
+#ifndef AVDM_REFINE_ANCHORED_WINDOW
+#define AVDM_REFINE_ANCHORED_WINDOW 1 // Refine with an outlier list: a workgroup whose lanes' hull is no window gets an anchored one (0: the round-4 tiers, for an A/B)
+#endif
 #ifndef AVDM_NCC_OCTO_W3_MODE
 #define AVDM_NCC_OCTO_W3_MODE 3 // 7-tap rows of the eight-plane form: as AVDM_NCC_QUAD_W3_MODE, 3 = a rolled loop (unroll AVDM_NCC_OCTO_UNROLL)
 #endif
@@ -2333,7 +2336,68 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             __syncthreads();
             Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN);
             __syncthreads();
-            if(Wc.tooLarge) // uniform
+            if(AVDM_REFINE_ANCHORED_WINDOW && listing && !Wc.ok && R.ok) // uniform
+            {
+                // The hull of ALL lanes is no window (it exceeds the LDS budget, leaves the image, or some lane's R taps leave the R tile) and there
+                // is an outlier list: an ANCHORED window instead — as large as the budget allows, centred on where most of the workgroup's patches
+                // land (the mean of the lanes' hull centres, taken once more over the lanes within 24 texels of it: a depth edge or a patch of wrong
+                // SGM depths does not drag it into the gap between two clusters), clipped to the image.  Whoever fits takes the eight-plane pass
+                // from it; whoever does not — plane by plane, plane_q — goes to the list.  The workgroup never falls back as a whole.
+                const float hcx = 0.5f * (bx0 + bx1), hcy = 0.5f * (by0 + by1);
+                float mx = 0.f, my = 0.f, nn = 0.f;
+                const unsigned wv = threadIdx.x >> 6;
+#pragma unroll 1
+                for(int pass = 0; pass < 2; ++pass)
+                {
+                    const bool in = part && (pass == 0 || (fabsf(hcx - mx) <= 24.0f && fabsf(hcy - my) <= 24.0f));
+                    const float n = wave_sum_f32(in ? 1.0f : 0.0f), sx = wave_sum_f32(in ? hcx : 0.0f), sy = wave_sum_f32(in ? hcy : 0.0f);
+                    if((threadIdx.x & 63u) == 0u) // the per-plane boxes are idle while a chunk window is being sought: four of them carry the sums
+                    {
+                        sh.box[wv][0] = __float_as_int(n);
+                        sh.box[wv][1] = __float_as_int(sx);
+                        sh.box[wv][2] = __float_as_int(sy);
+                    }
+                    __syncthreads();
+                    float N = 0.f, SX = 0.f, SY = 0.f;
+#pragma unroll
+                    for(int w = 0; w < 4; ++w)
+                    {
+                        N += __int_as_float(sh.box[w][0]);
+                        SX += __int_as_float(sh.box[w][1]);
+                        SY += __int_as_float(sh.box[w][2]);
+                    }
+                    __syncthreads();
+                    if(N > 0.0f) // uniform (pass 1 with nobody near the mean keeps the mean of pass 0)
+                    {
+                        nn = N;
+                        mx = SX / N;
+                        my = SY / N;
+                    }
+                }
+                init_shared(sh);
+                __syncthreads();
+                if(nn > 0.0f) // uniform
+                {
+                    if(threadIdx.x == 0)
+                    {
+                        // box extent E (stage_t_window adds one texel before and two behind): the largest even E whose window fits the T budget
+                        int E = 64;
+                        while(E > 8 && lds_units(lds_pitch_for(E + 4) * (E + 4), paired, false) > A.tcap)
+                            E -= 2;
+                        const int cx = (int)floorf(mx), cy = (int)floorf(my);
+                        const int x0b = min(max(cx - E / 2, 0), max(A.tcL.W - 2 - E, 0)), y0b = min(max(cy - E / 2, 0), max(A.tcL.H - 2 - E, 0));
+                        sh.box[AVDM_CHUNK_BOX][0] = x0b;
+                        sh.box[AVDM_CHUNK_BOX][1] = y0b;
+                        sh.box[AVDM_CHUNK_BOX][2] = min(x0b + E, A.tcL.W - 2);
+                        sh.box[AVDM_CHUNK_BOX][3] = min(y0b + E, A.tcL.H - 2);
+                    }
+                    __syncthreads();
+                    Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN);
+                    __syncthreads();
+                    part = part && rIn; // a lane whose R taps leave the staged R tile is an outlier too
+                }
+            }
+            else if(Wc.tooLarge) // uniform
             {
                 // the hull of ALL lanes does not fit: once more without the outliers (wave_inlier) — their waves then take the global-memory
                 // taps on the planes they are valid on, the rest of the workgroup keeps the LDS path

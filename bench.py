@@ -560,6 +560,13 @@ def main():
         if os.environ.get("AVDM_SIM_STATS") == "1":
             # [LDS path, generic: R tile unusable / nothing valid, generic: T taps leave the image, generic: T window exceeds the LDS budget] per step
             line["similarity_plane_workgroups_each"] = stats_each
+        if os.environ.get("AVDM_REFINE_OUTLIER_STATS") == "1":
+            # diagnosis: (pixel, chunk) units of the Refine outlier list over the timed steps {worked off, refused by a full list}, and per T-camera launch
+            u = (ctypes.c_uint * 2)()
+            lib.avdm_debug_refine_outlier_units.argtypes = [ctypes.POINTER(ctypes.c_uint)]
+            lib.avdm_debug_refine_outlier_units(u)
+            line["refine_outlier_units"] = {"worked_off": int(u[0]), "refused": int(u[1]), "per_launch": int(u[0]) / max(args.steps * T * len(tiles), 1),
+                                            "pixel_chunks_per_launch": px_ref * ((nz_ref + 7) // 8) / max(len(tiles), 1), "includes_warmup": True}
         n_cli = args.cli_e2e if args.cli_e2e >= 0 else (V if args.workload == "cfg3" else 0)
         if world == 1 and n_cli > 0:
             e2e = cli_end_to_end(sc, V, W, H, Z, T, min(n_cli, V))

@@ -862,7 +862,9 @@ def test_refine_outlier_list_equals_the_wave_fallback(capsys):
     assert units["0"] == (0, 0) and units["1"][0] > 50 and units["1"][1] == 0, units
     assert (out["0"] != 0).mean() > 0.3
     assert ((out["0"] == 0) != (out["1"] == 0)).mean() <= 1e-4
-    assert (d > 2e-3).mean() <= 1e-3 and (d > 2e-2).mean() <= 1e-5 and d.max() <= 0.15, ((d > 2e-3).mean(), (d > 2e-2).mean(), d.max())
+    # (the inlier lanes of a wave with an outlier used to run one plane per pass with fp32 taps from global memory, now the packed eight-plane
+    # pass from the window: the Refine volume's tolerance class)
+    assert (d > 2e-3).mean() <= 2e-3 and (d > 2e-2).mean() <= 1e-4 and d.max() <= 0.15, ((d > 2e-3).mean(), (d > 2e-2).mean(), d.max())
 
 
 def test_refine_best_depth_bit_exact(case):
