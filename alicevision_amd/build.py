@@ -20,7 +20,7 @@ SOURCES = {
     "avdm_image.hip": [],
     "avdm_similarity.hip": [],                       # fast-math intrinsics + FMA contraction allowed (tolerance class)
     "avdm_sgm.hip": ["-ffp-contract=off"],           # bit-exact class
-    "avdm_maps.hip": ["-ffp-contract=off"],          # bit-exact / order-preserving class
+    "avdm_maps.hip": ["-ffp-contract=off"],          # bit-exact / order-preserving class (the colour optimisation inside it: tolerance class, AVDM_OPT_FAST)
     "avdm_fuse.hip": ["-ffp-contract=off"],          # bit-exact class (double arithmetic in the reference's order)
     "avdm_jpeg.hip": ["-ffp-contract=off"],          # bit-exact class (integers only)
     "avdm_literal.hip": ["-ffp-contract=off"],       # AVDM_SIM_LITERAL=1: the reference's similarity arithmetic as written (attribution switch)

@@ -535,10 +535,11 @@ __device__ __forceinline__ float tex_point(const float* buf, int pitch, int W, i
 
 // AVDM_OPT_FAST=1 (compile time, the default since round 4; 0 = the IEEE form of rounds 1-3 for an A/B): the colour
 // optimisation's IEEE divisions and square roots — 24 + 14 per pixel and iteration, ~10 instructions each, more than half of the kernel's 943
-// VALU instructions — as the hardware's v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp) and its four sigmoids through v_exp_f32: 559 instructions,
-// 20.7 -> 14 ms per 12 MP depth map (profiles/r04_e_ab.txt).  The two unit vectors of the smoothness angle keep the IEEE form (see
-// angleBetwABandAC).  Both forms of the stage (point map / depth map) use the same helpers, so they stay bit-identical to each other; against the
-// oracle the stage is in the tolerance class either way (acosf / expf of another library).
+// VALU instructions — as the hardware's v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp) and its four sigmoids through v_exp_f32: 440 instructions,
+// 20.7 -> 14 ms per 12 MP depth map (profiles/r04_e_ab.txt).  The two unit vectors of the smoothness angle take the fast reciprocal square
+// root too (normalize_exact; keeping them IEEE was measured and dropped: see angleBetwABandAC).  Both forms of the stage (point map / depth
+// map) use the same helpers, so they stay bit-identical to each other; against the oracle the stage is in the tolerance class either way
+// (acosf / expf of another library): |d sim| max 1.43e-2 with the fast forms (session r04_g; 1.2e-2 with the IEEE forms), asserted < 2e-2.
 #ifndef AVDM_OPT_FAST
 #define AVDM_OPT_FAST 1
 #endif
@@ -585,8 +586,8 @@ __device__ __forceinline__ f3 point_at_depth(const avdm_camera_t& cam, float px,
 }
 __device__ __forceinline__ float angleBetwABandAC(f3 A, f3 B, f3 C)
 {
-    // (measured, r04_f: IEEE unit vectors here cost 2.4 ms per 12 MP depth map and change nothing — |d sim| max 1.19e-2 against the oracle
-    // either way: for a neighbourhood 0.5 degrees from flat the last bit of the two vectors moves the energy by 8e-4 degrees, 4e-5 in the
+    // (measured, r04_f: IEEE unit vectors here — normalize_ieee — cost 2.4 ms per 12 MP depth map and do not bring |d sim| max against the
+    // oracle back under 1e-2: for a neighbourhood 0.5 degrees from flat the last bit of the two vectors moves the energy by 8e-4 degrees, 4e-5 in the
     // similarity; for a flatter one the fp32 dot product itself cannot resolve 1 - |cos| and the energy is rounding noise in ANY fp32
     // evaluation, the reference's included)
     const f3 V1 = normalize_exact(B - A);

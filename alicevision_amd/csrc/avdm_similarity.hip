@@ -80,6 +80,7 @@ constexpr unsigned kSgmChunksPerWg = AVDM_SGM_CHUNKS_PER_WG; // SGM similarity: 
 #ifndef AVDM_REFINE_CHUNKS_PER_WG
 #define AVDM_REFINE_CHUNKS_PER_WG 4
 #endif
+static_assert(4u * AVDM_SGM_CHUNKS_PER_WG <= 32u && 8u * AVDM_REFINE_CHUNKS_PER_WG <= 32u, "knifeMask: one bit per plane of a workgroup in a 32-bit word");
 constexpr unsigned kOutlierGrid = 2048; // workgroups of refine_outlier_kernel: its lanes stride over the units of the list
 constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: chunks of 8 planes per workgroup (they share one R tile, T window and pixel set-up)
 #ifndef AVDM_SIM_WAVES_PER_SIMD

@@ -19,6 +19,16 @@
 namespace avdm_host {
 
 namespace {
+// both paths exist: do they name the same file (device + inode)?
+bool sameFile(const std::string& a, const std::string& b)
+{
+    struct stat sa, sb;
+    return ::stat(a.c_str(), &sa) == 0 && ::stat(b.c_str(), &sb) == 0 && sa.st_dev == sb.st_dev && sa.st_ino == sb.st_ino;
+}
+} // namespace
+
+
+namespace {
 bool fileExists(const std::string& p)
 {
     struct stat st;
@@ -94,10 +104,12 @@ MultiViewParams::MultiViewParams(const SfMData& sfmData, const std::string& imag
                     const std::string c = _imagesFolder + std::to_string(view.viewId) + ext;
                     if(!fileExists(c))
                         continue;
-                    if(!candidate.empty())
+                    // (two spellings that name ONE file — a case-insensitive or case-folding directory — are not an ambiguity)
+                    if(!candidate.empty() && !sameFile(candidate, c))
                         throw std::runtime_error("Ambiguous case: Multiple image file found for the view '" + std::to_string(view.viewId) + "' in folder '" +
                                                  _imagesFolder + "'.");
-                    candidate = c;
+                    if(candidate.empty())
+                        candidate = c;
                 }
                 if(candidate.empty())
                     throw std::runtime_error("Cannot find image file coresponding to the view '" + std::to_string(view.viewId) + "' in folder '" +
