@@ -525,11 +525,15 @@ def main():
                 k = rec["per_kernel"][key]
                 t_launch = t_stage / T
                 out_pmc[key] = {"valu_insts_per_launch": k["SQ_INSTS_VALU"], "ms_per_launch": 1e3 * t_launch,
-                                "valu_issue_frac": k["SQ_INSTS_VALU"] * 4.0 / (simd_hz * t_launch),
-                                "valu_busy_frac_pmc": k["valu_active_per_wave"] * rec.get("waves_per_simd", 2), "lds_conflict_frac": k["lds_conflict_frac"]}
+                                "valu_issue_frac": k["SQ_INSTS_VALU"] * 4.0 / (simd_hz * t_launch), "lds_conflict_frac": k["lds_conflict_frac"],
+                                # from the counter session itself (its own launch duration and GRBM_GUI_ACTIVE): the clock the kernel ran at, the
+                                # issue fraction and the share of SIMD cycles the VALU pipe was held at THAT clock, wave cycles parked on s_waitcnt
+                                "clock_GHz_pmc": k.get("clock_GHz"), "valu_issue_frac_at_measured_clock": k.get("valu_issue_frac_at_measured_clock"),
+                                "valu_busy_frac_at_measured_clock": k.get("valu_busy_frac_at_measured_clock"), "waves_parked_frac": k.get("waves_parked_frac"),
+                                "lds_busy_frac": k.get("lds_busy_frac")}
             sim_pmc = {"valu_issue_frac": {k: v["valu_issue_frac"] for k, v in out_pmc.items()}, "per_kernel": out_pmc,
                        "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
-                       "source": f"profiles/{name}: rocprofv3 --pmc passes (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE) of "
+                       "source": f"profiles/{name}: rocprofv3 --pmc passes (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE, SQ_WAIT_ANY, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE) of "
                                  "one T-camera launch of each kernel, " + stamp + "; durations: this run"}
             break
         line = {
