@@ -402,6 +402,7 @@ def main():
     lib.avdm_debug_sgm_kernel_timing(0)
     valid = float((out[..., 0] > 0).float().mean().item())
 
+    line = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * args.steps / elapsed
@@ -590,9 +591,25 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             small = make_scene(3, 512, 384, seed=3, device="cpu")
             line["cpu_baseline"] = cpu_baseline(small, sgm, ref, Z, W * H, T)
-        print(json.dumps(line), flush=True)
+    # ONE JSON line from rank 0, and it is the LAST thing on the job's stdout: RCCL prints a version banner through C stdio, which a pipe only
+    # sees when the buffer is flushed — at process exit, i.e. AFTER a line Python printed earlier (session r05_dist).  So: every rank flushes its
+    # C stdio, the ranks meet, the group is torn down, C stdio is flushed once more, and only then rank 0 prints.
+    def flush_c_stdio():
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+
     if dist is not None:
+        flush_c_stdio()
+        dist.barrier()
         dist.destroy_process_group()
+        flush_c_stdio()
+        if rank == 0 and world > 1:
+            time.sleep(1.0)  # the other ranks' last flushes
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
