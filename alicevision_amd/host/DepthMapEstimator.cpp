@@ -363,45 +363,6 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
     DeviceCache deviceCache(nbMipmapImagesPerBatch, nbCamerasParamsPerBatch, filterModeFromEnv());
     deviceCache.setExchange(exchange, worker);
 
-    // the views of a range of tiles (R + SGM T + Refine T cameras), each once
-    auto camsOfTiles = [&tiles](int first, int last) {
-        std::vector<int> c;
-        for(int i = first; i < last; ++i)
-        {
-            const Tile& tile = tiles.at(i);
-            c.push_back(tile.rc);
-            c.insert(c.end(), tile.sgmTCams.begin(), tile.sgmTCams.end());
-            c.insert(c.end(), tile.refineTCams.begin(), tile.refineTCams.end());
-        }
-        std::sort(c.begin(), c.end());
-        c.erase(std::unique(c.begin(), c.end()), c.end());
-        return c;
-    };
-    auto decodeAll = [&ic](const std::vector<int>& camsToDecode) {
-        std::exception_ptr loadError;
-#pragma omp parallel for schedule(dynamic, 1)
-        for(int k = 0; k < (int)camsToDecode.size(); ++k)
-        {
-            try
-            {
-                ic.getImg_sync(camsToDecode[k]);
-            }
-            catch(...)
-            {
-#pragma omp critical
-                loadError = std::current_exception();
-            }
-        }
-        if(loadError)
-            std::rethrow_exception(loadError);
-    };
-    // Round 5: the FIRST batch's views are decoded on the host cores WHILE this thread sets the device up (streams, per-stream Sgm / Refine
-    // buffers, page-locked result tiles: 0.4 - 0.5 s for 24 tile slots) instead of after it — decoding touches no device state.  (With the
-    // multi-GPU exchange nothing is decoded here: own views were published by the pre-pass, the others arrive as pyramids.)
-    std::future<void> firstBatchDecode;
-    if(exchange == nullptr)
-        firstBatchDecode = std::async(std::launch::async, [&, first = camsOfTiles(0, std::min(nbTilesPerBatch, (int)tiles.size()))]() { decodeAll(first); });
-
     // build the custom patch pattern (DepthMapEstimator.cpp:272-274; library state like the reference's constant memory)
     if(_sgmParams.useCustomPatchPattern || _refineParams.useCustomPatchPattern)
     {
@@ -548,10 +509,32 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         // with the multi-GPU exchange nothing is decoded here: own views were published by the pre-pass, the others arrive as pyramids
         if(exchange == nullptr)
         {
-            if(firstBatchDecode.valid())
-                firstBatchDecode.get(); // batch 0: decoded beside the device set-up (rethrows a decoding error here)
-            else
-                decodeAll(camsOfTiles(firstTileIndex, lastTileIndex));
+            std::vector<int> camsOfBatch;
+            for(int i = firstTileIndex; i < lastTileIndex; ++i)
+            {
+                const Tile& tile = tiles.at(i);
+                camsOfBatch.push_back(tile.rc);
+                camsOfBatch.insert(camsOfBatch.end(), tile.sgmTCams.begin(), tile.sgmTCams.end());
+                camsOfBatch.insert(camsOfBatch.end(), tile.refineTCams.begin(), tile.refineTCams.end());
+            }
+            std::sort(camsOfBatch.begin(), camsOfBatch.end());
+            camsOfBatch.erase(std::unique(camsOfBatch.begin(), camsOfBatch.end()), camsOfBatch.end());
+            std::exception_ptr loadError;
+#pragma omp parallel for schedule(dynamic, 1)
+            for(int k = 0; k < (int)camsOfBatch.size(); ++k)
+            {
+                try
+                {
+                    ic.getImg_sync(camsOfBatch[k]);
+                }
+                catch(...)
+                {
+#pragma omp critical
+                    loadError = std::current_exception();
+                }
+            }
+            if(loadError)
+                std::rethrow_exception(loadError);
         }
         // load the R and T cameras of the batch in the device cache
         for(int i = firstTileIndex; i < lastTileIndex; ++i)
