@@ -205,32 +205,27 @@ __global__ void __launch_bounds__(256)
 #pragma unroll 1
     for(int s0 = -halfNbSamples; s0 <= halfNbSamples; s0 += RBD_GROUP)
     {
-        // two sub-samples per packed register: v_pk_mul_f32 + v_pk_add_f32 (this file is compiled without contraction) round each half exactly
-        // like the scalar multiply and add — the same floats in the same order — at half the instructions (round 5: 3.75 ms per 12 MP map before)
-        typedef float rbd_v2f __attribute__((ext_vector_type(2)));
-        rbd_v2f acc[RBD_GROUP / 2];
+        float acc[RBD_GROUP];
 #pragma unroll
-        for(int t = 0; t < RBD_GROUP / 2; ++t)
-            acc[t] = rbd_v2f{0.f, 0.f};
+        for(int t = 0; t < RBD_GROUP; ++t)
+            acc[t] = 0.f;
 #pragma unroll
         for(int vz = 0; vz < NZ; ++vz)
         {
             // planes past the volume: any in-range index, their simSum is 0
             const int zs = ((vz < volDimZ ? vz : 0) - halfNbDepths) * samplesPerPixSize;
             const float* g = gm.g + (s0 - zs + off);
-            const rbd_v2f sv = {simSum[vz], simSum[vz]};
 #pragma unroll
-            for(int t = 0; t < RBD_GROUP / 2; ++t)
-                acc[t] += sv * rbd_v2f{g[2 * t], g[2 * t + 1]};
+            for(int t = 0; t < RBD_GROUP; ++t)
+                acc[t] += simSum[vz] * g[t];
         }
 #pragma unroll
         for(int t = 0; t < RBD_GROUP; ++t)
         {
-            const float a = (t & 1) ? acc[t >> 1].y : acc[t >> 1].x;
-            if(s0 + t <= halfNbSamples && a < bestSampleSim)
+            if(s0 + t <= halfNbSamples && acc[t] < bestSampleSim)
             {
                 bestSampleOffsetIndex = s0 + t;
-                bestSampleSim = a;
+                bestSampleSim = acc[t];
             }
         }
     }
