@@ -32,7 +32,7 @@ def level_mismatch(a, b):
 
 
 def build_host():
-    """the C++ host programs (alicevision_amd/host), built under the checker's make lock: the suite runs in several processes (pytest-xdist)"""
+    """the C++ host programs (alicevision_amd/host), built under the checker's make lock (several test processes may want them at once)"""
     import os
     from oracle.oracle import locked_make
     locked_make(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alicevision_amd", "host"), "-j8")
