@@ -666,7 +666,7 @@ __device__ __forceinline__ Lab3x4 hlerp3x4_halfpaired(uint2 r0, unsigned r0n, ui
     return o;
 }
 
-// R side of a PLANE PAIR (ncc_accumulate_lds_fixed8_pair): the six products of one image, top and bottom texel row
+// R side of a multi-plane pass (ncc_accumulate_lds_fixed8_quad / _multi): the six products of one image, top and bottom texel row
 struct Lab3x2
 {
     Lab3 t, b;
@@ -846,8 +846,8 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
     return sim;
 }
 
-// FOUR adjacent planes of a pixel (one chunk of the SGM kernel) in one pass over the patch: ncc_accumulate_lds_fixed8_pair taken one step
-// further.  The R side of a sample — position, weights, taps, colour distance — is evaluated ONCE, from the patch of a reference plane, for
+// FOUR adjacent planes of a pixel (one chunk of the SGM kernel) in one pass over the patch (the plane-pair pass of round 2 taken one step
+// further; that pass itself was removed in round 5).  The R side of a sample — position, weights, taps, colour distance — is evaluated ONCE, from the patch of a reference plane, for
 // two packed T pairs {plane 0, plane 1}, {plane 2, plane 3}: per plane-sample (37 + 2 x 81) / 4 = 50 VALU instructions instead of 59.
 // The R taps of a plane up to two depth steps from the reference plane move by <= 2e-4 ... 2e-3 texel (the tilt of the patch's x axis; zero
 // at the principal point) — the class of the fp32 rounding of the pixel coordinates themselves.
@@ -1714,9 +1714,9 @@ __device__ __forceinline__ void init_shared(BlockShared& sh)
 // ---------------------------------------------------------------------------------------------
 // SGM similarity: best / second-best uint8 volumes, 4 planes per lane per launch-z
 // ---------------------------------------------------------------------------------------------
-// PLANES = planes per pass over the patch on the packed chunk-window path: 1, 2 (ncc_accumulate_lds_fixed8_pair) or 4 (..._multi<2>: the
-// whole chunk in one pass; chunks it cannot take — a plane range that ends inside the chunk, a wave with a lane outside the window — run
-// one plane per pass)
+// PLANES = planes per pass over the patch on the packed chunk-window path: 1, 4 (ncc_accumulate_lds_fixed8_quad: the whole chunk in one
+// pass) or 8 (..._multi<4>: two chunks of the workgroup, the default since round 5); chunks a pass cannot take — a plane range that ends
+// inside it, a wave with a lane outside the window — run four planes or one plane per pass
 // (Rounds 3-4 also carried a two-launch form of the default instantiations — a fast kernel and a fix-up kernel over the same grid,
 // AVDM_SIM_SPLIT — measured 3 % slower than the combined kernel (profiles/r03_o_split_ab.txt) and removed in round 5.)
 template <bool FIXED8, int WSH, bool PAIRED, int RP = 0, int PLANES = 1, bool REC12 = false>

@@ -704,8 +704,8 @@ def test_refine_chunk_window_equals_per_plane_windows(case):
 
 
 def test_plane_pairs_equal_single_planes(capsys):
-    """The similarity kernels run several adjacent planes per pass over the patch — the SGM kernel the four planes of a chunk
-    (ncc_accumulate_lds_fixed8_quad), the Refine kernel two (ncc_accumulate_lds_fixed8_pair): the R side of a sample is evaluated once,
+    """The similarity kernels run several adjacent planes per pass over the patch — eight by default since round 5
+    (ncc_accumulate_lds_fixed8_multi<4>), four on leftover chunks (ncc_accumulate_lds_fixed8_quad): the R side of a sample is evaluated once,
     from one plane's patch, for all of them; AVDM_SIM_PLANE_PAIRS=0 keeps one plane per pass.  The R taps of the other planes move by
     ~1e-4 ... 1e-3 texel per depth step (the tilt of the patch's x axis) and the sums are associated differently: the volumes must agree to
     the storage quantum almost everywhere — SGM: uint8 levels, Refine: fp16 sums — and the statistics are printed.  The plane spacing is
