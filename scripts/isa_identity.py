@@ -61,8 +61,9 @@ def demangle(name):
 
 
 def strip_default_tail(name):
-    # similarity_kernel<..., MODE> grew a trailing `bool DEINT = false`: ...ELi<MODE>ELb0EEEv -> ...ELi<MODE>EEEv
-    return re.sub(r"(17similarity_kernelI\w+?)ELb0EEEv", r"\1EEEv", name)
+    # hook for a template parameter appended with a default value between the two revisions (round 4: `bool DEINT = false`, removed again in
+    # round 5 together with MODE): none at present, the names compare as they are
+    return name
 
 
 def main():
