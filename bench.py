@@ -68,6 +68,18 @@ def tile_rois(W, H, n_side, buffer_w=TILE_BUFFER[0], buffer_h=TILE_BUFFER[1], pa
     return [(i * ew, min((i + 1) * ew + padding, W), j * eh, min((j + 1) * eh + padding, H)) for i in range(nx) for j in range(ny)]
 
 
+def sgm_algorithmic_bytes(vols, Z, prepared=True):
+    """Algorithmic bytes of ONE aggregation of the volumes `vols` = [(X, Y), ...] with Z planes: per voxel 4 reads of the
+    input volume, 3 reads + 4 writes of the output volume = 11 B; per pixel the adaptive P2 — 64 B of R texels read by the map kernel, and
+    one float per (path, pixel) = 16 B of P2 maps read by the four path walks.
+      timed_call   what the timed `avdm_volume_optimize_tiles_prepared` call moves: 11 B/voxel + 16 B/pixel (the maps are evaluated beside the
+                   similarity sweep since round 4); the one-call form (prepared = False) contains the map kernel: SURVEY's figure;
+      survey       SURVEY's 11 B/voxel + 64 B/pixel, to be divided by the call PLUS the map kernel's time."""
+    survey = sum(11.0 * x * y * Z + 64.0 * x * y for x, y in vols)
+    timed = sum(11.0 * x * y * Z + 16.0 * x * y for x, y in vols) if prepared else survey
+    return {"timed_call": timed, "survey": survey}
+
+
 def cpu_baseline(sc_small, sgm, ref, n_planes, full_px, full_t):
     """The CPU side of the metric on a bounded sample of the same workload (SGM + Refine of one R camera against 2 T cameras), scaled
     linearly to one full depth map.
@@ -421,12 +433,13 @@ def main():
         batched = len(vols) > 1
         n_calls = 1 if batched else len(vols)
         # SURVEY 8(d)'s figure for the whole aggregation, adaptive-P2 maps included: 11 B/voxel + 64 B/pixel of R texels
-        survey_bytes_per_volume = sum(11.0 * x * y * Z + 64.0 * x * y for x, y in vols) / n_calls
+        nbytes = sgm_algorithmic_bytes(vols, Z, prepared=os.environ.get("AVDM_SGM_PREPARE") != "0")
+        survey_bytes_per_volume = nbytes["survey"] / n_calls
         # ... of which the TIMED call (avdm_volume_optimize_tiles_prepared: the path launches alone) moves the 11 B/voxel and READS the P2 maps — one
         # float per (path, pixel) = 16 B/pixel; the 64 B/pixel of R texels belong to the map kernel, which runs beside the similarity sweep
         # (stage sgm_p2_map) since round 4.  One-call form (AVDM_SGM_PREPARE=0): the map kernel is inside the call, SURVEY's figure is the numerator.
         prepared = os.environ.get("AVDM_SGM_PREPARE") != "0"
-        alg_bytes_per_volume = (sum(11.0 * x * y * Z + 16.0 * x * y for x, y in vols) / n_calls) if prepared else survey_bytes_per_volume
+        alg_bytes_per_volume = nbytes["timed_call"] / n_calls
         alg_bytes_per_launch = alg_bytes_per_volume / n_launches
         # average duration of one path-aggregation kernel launch (HIP events around the launches alone, on their stream);
         # stages["sgm_optimize"] is the whole avdm_volume_optimize call, i.e. these launches + the adaptive-P2 map kernel

@@ -258,3 +258,23 @@ def test_whole_step_protocol_gloo_world2(stream_views):
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_roofline_numerator_is_what_the_timed_call_moves():
+    """VERDICT r4 / ADVICE r4: the headline fraction divides by the time of the path launches alone, so its numerator must not carry the 64 B /
+    pixel of R texels that only the adaptive-P2 map kernel reads (it runs beside the similarity sweep).  cfg3: 1000 x 750 x 256 voxels —
+    2.112 GB of volume traffic + 12 MB of P2 maps = 2.124 GB in the timed call (the counters say 2.121 GB, profiles/r04_sgm_pmc.json); SURVEY
+    section 8(d)'s figure with the texels: 2.160 GB, the numerator of `frac_with_p2_map`, whose denominator includes the map kernel."""
+    sys.path.insert(0, ROOT)
+    import bench
+    b = bench.sgm_algorithmic_bytes([(1000, 750)], 256)
+    assert b["timed_call"] == 11.0 * 1000 * 750 * 256 + 16.0 * 1000 * 750 == 2.124e9
+    assert b["survey"] == 11.0 * 1000 * 750 * 256 + 64.0 * 1000 * 750 == 2.16e9
+    assert bench.sgm_algorithmic_bytes([(1000, 750)], 256, prepared=False)["timed_call"] == b["survey"]
+    # configuration 5: 16 tile volumes of 416 x 288 in one call
+    b5 = bench.sgm_algorithmic_bytes([(416, 288)] * 16, 256)
+    assert b5["timed_call"] == 16 * (11.0 * 416 * 288 * 256 + 16.0 * 416 * 288)
+    # and the committed summary of the counters agrees with the timed call's bytes to 2 % (2 launches per volume)
+    import json
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_sgm_pmc.json")))
+    assert abs(2 * rec["hbm_bytes_per_launch"] / b["timed_call"] - 1.0) < 0.02
