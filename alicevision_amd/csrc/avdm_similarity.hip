@@ -41,37 +41,17 @@ constexpr int kNccUnroll = AVDM_NCC_UNROLL;
 #define AVDM_NCC_MULTI_UNROLL 3
 #endif
 constexpr int kNccMultiUnroll = AVDM_NCC_MULTI_UNROLL; // sample loop of the four-plane form (wsh != 3)
-// The eight-plane pass (ncc_accumulate_lds_fixed8_multi<4>, AVDM_SIM_PLANES8=1) — how its sample loop is scheduled, measured on the bench's SGM
-// sweep against the four-plane default at 247.1 ms (sessions r04_j, l, m; profiles/r04_planes8_ab.txt):
-//   AVDM_NCC_MULTI_PIPE 0 = the T taps of AVDM_NCC_MULTI_GROUP pairs of planes requested together, a scheduling fence between the groups
-//                           (groups of 2: 246.0 / 244.0 ms at unroll 1 / 3; all 4 pairs in flight: 260.3 ms, the taps spill),
-//                       1 = rotating: the taps of pair j + 1 are requested before pair j is consumed (236.9 ms at unroll 1, 239.7 at 3),
-//                       2 = rotating across the samples of a row too (242.4 ms),
-//                       3 = as 1, and the R taps of the next sample requested during the last pair,
-//                       4 = as 1, and the first pair's taps requested before the R side's arithmetic instead of after it.
-// The loop issues 34 VALU instructions per plane and sample instead of 43 (-20 %); the time follows by -4 % only: each wave now waits on the
-// LDS four times per sample with two waves per SIMD to cover it.  (Rotating forms of the FOUR-plane pass were A/B builds of round 4: every one
-// of them slower than the compiler's own schedule, 251.5 ... 255.3 ms.)  Session r05_a measured 3 and 4: 238.4 / 236.2 against 237.1 ... 237.7 ms.
+// The eight-plane pass (ncc_accumulate_lds_fixed8_multi<4>) — how its sample loop is scheduled, measured on the bench's SGM sweep against the
+// four-plane pass at 247.1 ms (sessions r04_j, l, m, r05_a; profiles/r04_planes8_ab.txt): the T taps of pair j + 1 are requested before pair j
+// is consumed, one sample per iteration of a rolled row loop (236.9 ms; 239.7 at unroll 3).  Tried and removed: the taps of two pairs
+// requested together with a fence between the groups (246.0 / 244.0 ms at unroll 1 / 3; all four pairs in flight: 260.3 ms, the taps spill),
+// rotating across the samples of a row too (242.4 ms), the next sample's R taps requested during the last pair (238.4 ms), the first pair's
+// taps requested before the R side's arithmetic (236.2 ms: nothing).  The loop issues 34 VALU instructions per plane and sample instead of
+// the four-plane pass's 43; over a launch that is -8.5 % instructions and -4.4 % time.
 #ifndef AVDM_NCC_OCTO_UNROLL
 #define AVDM_NCC_OCTO_UNROLL 1
 #endif
 constexpr int kNccOctoUnroll = AVDM_NCC_OCTO_UNROLL; // sample loop of the eight-plane form
-#ifndef AVDM_NCC_MULTI_PIPE
-#define AVDM_NCC_MULTI_PIPE 1
-#endif
-#ifndef AVDM_NCC_PIPE_MIN_PAIRS
-#define AVDM_NCC_PIPE_MIN_PAIRS 3
-#endif
-#ifndef AVDM_NCC_MULTI_GROUP
-#define AVDM_NCC_MULTI_GROUP 2
-#endif
-constexpr int kMultiGroup = AVDM_NCC_MULTI_GROUP;
-constexpr int kPipeMinPairs = AVDM_NCC_PIPE_MIN_PAIRS;
-constexpr int kMultiPipe = AVDM_NCC_MULTI_PIPE;
-constexpr bool kPipeRNext = kMultiPipe == 2 || kMultiPipe == 3; // the R taps of the next sample are requested during the last pair
-#ifndef AVDM_NCC_W3_MODE
-#define AVDM_NCC_W3_MODE 2 // 7-tap rows (wsh 3, the Refine default): 0 = plain `unroll 3` (spills), 1 = no unroll, 2 = 3 + 3 + 1 with fences
-#endif
 constexpr bool kLdsSplitReads = true;
 #ifndef AVDM_SGM_CHUNKS_PER_WG
 #define AVDM_SGM_CHUNKS_PER_WG 4
@@ -86,17 +66,11 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #ifndef AVDM_SIM_WAVES_PER_SIMD
 #define AVDM_SIM_WAVES_PER_SIMD 2 // occupancy the two kernels are compiled for: 3 -> 168 VGPRs, 2 -> 256 VGPRs
 #endif
-#ifndef AVDM_NCC_QUAD_W3_MODE
-#define AVDM_NCC_QUAD_W3_MODE 0 // 7-tap rows of the four-plane form: 0 = 2 + 2 + 2 + 1 with fences, 1 = one sample at a time, 2 = 3 + 3 + 1
-#endif
 #ifndef AVDM_REFINE_OCTO_PARTIAL
 #define AVDM_REFINE_OCTO_PARTIAL 1 // Refine: a chunk that only overlaps the plane range (the last 7 of the default 31 planes) through the eight-plane pass too,
 #endif                             // its planes outside as invalid planes of the pass: 267.1 against 271.6 ms per depth map (session r05_a); 0 = two four-plane passes
 #ifndef AVDM_REFINE_ANCHORED_WINDOW
 #define AVDM_REFINE_ANCHORED_WINDOW 1 // Refine with an outlier list: a workgroup whose lanes' hull is no window gets an anchored one (0: the round-4 tiers, for an A/B)
-#endif
-#ifndef AVDM_NCC_OCTO_W3_MODE
-#define AVDM_NCC_OCTO_W3_MODE 3 // 7-tap rows of the eight-plane form: as AVDM_NCC_QUAD_W3_MODE, 3 = a rolled loop (unroll AVDM_NCC_OCTO_UNROLL)
 #endif
 
 typedef float v2f_t __attribute__((ext_vector_type(2)));
@@ -115,36 +89,25 @@ typedef float v2f_t __attribute__((ext_vector_type(2)));
 #ifndef AVDM_DEV_IEEE_DIV
 #define AVDM_DEV_IEEE_DIV 0 // 1: IEEE divisions where the projections use v_rcp_f32 (matrix.cuh:117-126 evaluated like the CPU pin evaluates it)
 #endif
-// ---- forms of the four-plane pass that were A/B'd as variant builds (compile time; 0 restores the round-3 form for an A/B) ------------------
-// profiles/r04_e_ab.txt, same box, 11 steps: 563.9 ms per depth map -> 551.1 with AVDM_QUANT_MAGIC + AVDM_SUMS_NO_WGR (SGM similarity 249.7 -> 245.5,
-// Refine 287.5 -> 279.0: 541 -> 518 and 1338 -> 1284 VALU instructions per twelve / 28 plane-samples of the loop body); the knife-edge
-// evaluation costs 563.9 against 558.0 without it (AVDM_KNIFE_LITERAL=0: one more live register in the set-up blocks of the SGM kernel).
+// ---- the knife-edge evaluation's A/B (compile time) ------------------------------------------------------------------------------------------
+// profiles/r04_e_ab.txt, same box, 11 steps: the knife-edge evaluation costs 563.9 ms per depth map against 558.0 without it (one more live
+// register in the set-up blocks of the SGM kernel).
 #ifndef AVDM_KNIFE_LITERAL
 #define AVDM_KNIFE_LITERAL 1 // 0: the R-side border test on the exact pixel on the knife-edge rows too (rounds 1-3; A/B of the lit:: evaluation's cost)
 #endif
-#ifndef AVDM_QUANT_MAGIC
-#define AVDM_QUANT_MAGIC 1 // 1: the 1/256 weight quantisation floor(f * 256 + 0.5) as fma(f, 256 + 2^-14, 1.5 * 2^23) - 1.5 * 2^23: two PACKED
-                           // operations for two weights instead of a packed FMA and two v_floor_f32.  The add rounds to nearest EVEN where
-                           // floor(. + 0.5) rounds half UP, and exact halves are common — a texel coordinate near 2000 is a multiple of
-                           // 2^-13, so f * 256 is a multiple of 1/32 and one weight in 32 is a tie (r04_f: the plain magic add moved the
-                           // similarity volume of the far image corner from 94.4 % to 93.5 % identical voxels).  The 2^-14 in the
-                           // multiplier lifts every tie k + 0.5 by (k + 0.5) 2^-22 inside the ONE rounding of the FMA: round half up again;
-                           // a value is lifted across a tie wrongly only within 6e-5 below it, finer than the coordinate grid for x >= 4.
-#endif
-#ifndef AVDM_SUMS_NO_WGR
-#define AVDM_SUMS_NO_WGR 1 // 1: the R-side sums as fma(w, dLR, .) and fma(w, dLR^2, .) with dLR^2 formed once per sample for all planes
-#endif
+// The 1/256 weight quantisation floor(f * 256 + 0.5) as fma(f, 256 + 2^-14, 1.5 * 2^23) - 1.5 * 2^23: two PACKED operations for two weights
+// instead of a packed FMA and two v_floor_f32 (round 4: with the R-side sums taken as fma(w, dLR, .) / fma(w, dLR^2, .), dLR^2 formed once per
+// sample for all planes, 563.9 -> 551.1 ms per depth map; the round-3 forms are in the history).  The plain magic add rounds to nearest EVEN
+// where floor(. + 0.5) rounds half UP, and exact halves are common — a texel coordinate near 2000 is a multiple of 2^-13, so f * 256 is a
+// multiple of 1/32 and one weight in 32 is a tie (r04_f: the plain add moved the similarity volume of the far image corner from 94.4 % to
+// 93.5 % identical voxels).  The 2^-14 in the multiplier lifts every tie k + 0.5 by (k + 0.5) 2^-22 inside the ONE rounding of the FMA: round
+// half up again; a value is lifted across a tie wrongly only within 6e-5 below it, finer than the coordinate grid for x >= 4.
 __device__ __forceinline__ v2f_t quant256(v2f_t f)
 {
-#if AVDM_QUANT_MAGIC
     const float M = 12582912.0f;
     v2f_t t = f * 256.00006103515625f + M; // 256 + 2^-14 (exact in fp32)
     asm volatile("" : "+v"(t)); // keep the two roundings apart (no re-association of (x + M) - M)
     return t - M;
-#else
-    const v2f_t v = f * 256.0f + 0.5f;
-    return v2f_t{floorf(v.x), floorf(v.y)};
-#endif
 }
 __device__ __forceinline__ float proj_rcp(float x) { return AVDM_DEV_IEEE_DIV ? 1.0f / x : fast_rcp(x); }
 // the reference's weight of one image: exp(-(dC / gammaC + dP / gammaP)) (CostYKfromLab)
@@ -802,7 +765,7 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
                 sum2 = wg * dL + sum2;
                 xysum = fmaf(wg.x, dL.y, xysum);
         };
-        if(WSH == 3 && AVDM_NCC_W3_MODE == 2)
+        if(WSH == 3)
         {
             // 7 taps per row do not divide by the 3 samples in flight the register budget allows (8 LDS reads = 16 VGPRs each): any
             // `#pragma unroll k` with a remainder makes the compiler unroll the whole row and spill 20-40 VGPRs to scratch inside the
@@ -817,12 +780,6 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
             __builtin_amdgcn_sched_barrier(0);
             sample(3);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        else if(WSH == 3 && AVDM_NCC_W3_MODE == 1)
-        {
-#pragma unroll 1
-            for(int xp = -wsh; xp <= wsh; ++xp)
-                sample(xp);
         }
         else
         {
@@ -1011,9 +968,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
             const v2f qR = dRLa * dRLa;
             const float base = fmaf(__builtin_amdgcn_sqrtf(fmaf(dRb, dRb, qR.x + qR.y)), kC, -trow[xp]);
             const float dLR = dRLa.x;
-#if AVDM_SUMS_NO_WGR
             const float dLR2 = dLR * dLR;
-#endif
 #if AVDM_DEV_TWO_EXP
             const float dPl = sqrtf((float)(xp * xp + yp * yp)) * A.invGammaP;
             const float wRl = yk_weight(sqrtf(fmaf(dRb, dRb, qR.x + qR.y)) * (1.0f / 65536.0f), dPl, A.invGammaC);
@@ -1046,7 +1001,6 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
                     lit[2 * j + 1].update(VR, VT.y, w.y);
                 }
 #endif
-#if AVDM_SUMS_NO_WGR
                 const v2f wgT = w * dL;
                 wsum[j] += w;
                 s1R[j] = w * dLR + s1R[j];
@@ -1054,44 +1008,12 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
                 s2R[j] = w * dLR2 + s2R[j];
                 s2T[j] = wgT * dL + s2T[j];
                 sxy[j] = wgT * dLR + sxy[j];
-#else
-                const v2f wgR = w * dLR, wgT = w * dL;
-                wsum[j] += w;
-                s1R[j] += wgR;
-                s1T[j] += wgT;
-                s2R[j] = wgR * dLR + s2R[j];
-                s2T[j] = wgT * dL + s2T[j];
-                sxy[j] = wgR * dL + sxy[j];
-#endif
             }
         };
-        if(WSH == 3 && AVDM_NCC_QUAD_W3_MODE == 1)
+        if(WSH == 3)
         {
-            // one sample at a time
-#pragma unroll
-            for(int xp = -3; xp <= 3; ++xp)
-            {
-                sample(xp);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        else if(WSH == 3 && AVDM_NCC_QUAD_W3_MODE == 2)
-        {
-            // 7 taps per row as 3 + 3 + 1
-#pragma unroll
-            for(int xp = -3; xp < 0; ++xp)
-                sample(xp);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for(int xp = 0; xp < 3; ++xp)
-                sample(xp);
-            __builtin_amdgcn_sched_barrier(0);
-            sample(3);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        else if(WSH == 3)
-        {
-            // 7 taps per row as 2 + 2 + 2 + 1 (see ncc_accumulate_lds_fixed8: an unroll factor with a remainder unrolls the whole row)
+            // 7 taps per row as 2 + 2 + 2 + 1 with fences (see ncc_accumulate_lds_fixed8: an unroll factor with a remainder unrolls the whole
+            // row; one sample at a time and 3 + 3 + 1 were measured slower in round 3)
 #pragma unroll
             for(int g = 0; g < 3; ++g)
             {
@@ -1274,29 +1196,8 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
             }
             return t;
         };
-        // kMultiPipe == 2: the R taps and the first pair's T taps of sample xp were requested during the last pair of sample xp - 1 (rNext, tNext)
-        [[maybe_unused]] RTaps rNext;
-        [[maybe_unused]] TTaps tNext;
-        if constexpr(kPipeRNext && NPAIR >= kPipeMinPairs)
-        {
-            rNext = fetch_r(-wsh);
-            if constexpr(kMultiPipe == 2)
-                tNext = fetch_t(-wsh, 0);
-        }
         auto sample = [&](int xp) __attribute__((always_inline)) {
-            RTaps r;
-            if constexpr(kPipeRNext && NPAIR >= kPipeMinPairs)
-                r = rNext;
-            else
-                r = fetch_r(xp);
-            // kMultiPipe == 4: the first pair's T taps are requested BEFORE the R side's arithmetic (which then covers their round trip, as the
-            // first pair's address arithmetic covers the R taps'), not after it
-            [[maybe_unused]] TTaps tFirst;
-            if constexpr(kMultiPipe == 4 && NPAIR >= kPipeMinPairs)
-            {
-                tFirst = fetch_t(xp, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            const RTaps r = fetch_r(xp);
             Lab3x2 hr;
             if constexpr(WIDE)
                 hr = hlerp3x2_paired(r.r0, r.r1, r.wr);
@@ -1307,9 +1208,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
             const v2f qR = dRLa * dRLa;
             const float base = fmaf(__builtin_amdgcn_sqrtf(fmaf(dRb, dRb, qR.x + qR.y)), kC, -trow[xp]);
             const float dLR = dRLa.x;
-#if AVDM_SUMS_NO_WGR
             const float dLR2 = dLR * dLR;
-#endif
 #if AVDM_DEV_TWO_EXP
             const float dPl = sqrtf((float)(xp * xp + yp * yp)) * A.invGammaP;
             const float wRl = yk_weight(sqrtf(fmaf(dRb, dRb, qR.x + qR.y)) * (1.0f / 65536.0f), dPl, A.invGammaC);
@@ -1317,35 +1216,15 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
 #if AVDM_DEV_UNSHIFTED_SUMS
             const float VR = (hr.b.L * r.rWy - hr.t.L * r.rNy) * (1.0f / 65536.0f); // the bilinear L of R itself
 #endif
-            // the T taps of AVDM_NCC_MULTI_GROUP pairs in flight at a time (all of them for the four-plane pass; the eight-plane pass would hold
-            // 4 x 18 registers of taps per sample otherwise)
+            // rotating: the taps of pair j + 1 are requested before pair j is consumed (all four pairs' taps in flight would be 4 x 18 registers)
             TTaps t[NPAIR];
 #pragma unroll
             for(int j = 0; j < NPAIR; ++j)
             {
-                if constexpr(kMultiPipe != 0 && NPAIR >= kPipeMinPairs)
-                {
-                    // rotating: the taps of pair j + 1 are requested before pair j is consumed; kMultiPipe == 2: and those of the next sample's R side
-                    // and first pair before the last pair is (one sample past the row's end at its last sample: an LDS read nobody uses)
-                    if(j == 0)
-                        t[0] = kMultiPipe == 2 ? tNext : (kMultiPipe == 4 ? tFirst : fetch_t(xp, 0));
-                    if(j + 1 < NPAIR)
-                        t[j + 1] = fetch_t(xp, j + 1);
-                    else if(kPipeRNext)
-                    {
-                        rNext = fetch_r(xp + 1);
-                        if(kMultiPipe == 2)
-                            tNext = fetch_t(xp + 1, 0);
-                    }
-                }
-                else if(j % kMultiGroup == 0)
-                {
-                    if(j > 0)
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for(int g = j; g < j + kMultiGroup && g < NPAIR; ++g)
-                        t[g] = fetch_t(xp, g);
-                }
+                if(j == 0)
+                    t[0] = fetch_t(xp, 0);
+                if(j + 1 < NPAIR)
+                    t[j + 1] = fetch_t(xp, j + 1);
                 Lab3x4 h; // rt / rb = plane 2j top / bottom row, tt / tb = plane 2j + 1
                 if constexpr(WIDE)
                     h = hlerp3x4_paired(t[j].a0, t[j].a1, t[j].b0, t[j].b1, t[j].wtA, t[j].wtB);
@@ -1368,7 +1247,6 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
                     lit[2 * j + 1].update(VR, VT.y, w.y);
                 }
 #endif
-#if AVDM_SUMS_NO_WGR
                 const v2f wgT = w * dL;
                 wsum[j] += w;
                 s1R[j] = w * dLR + s1R[j];
@@ -1376,61 +1254,14 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
                 s2R[j] = w * dLR2 + s2R[j];
                 s2T[j] = wgT * dL + s2T[j];
                 sxy[j] = wgT * dLR + sxy[j];
-#else
-                const v2f wgR = w * dLR, wgT = w * dL;
-                wsum[j] += w;
-                s1R[j] += wgR;
-                s1T[j] += wgT;
-                s2R[j] = wgR * dLR + s2R[j];
-                s2T[j] = wgT * dL + s2T[j];
-                sxy[j] = wgR * dL + sxy[j];
-#endif
-                if constexpr(kMultiPipe != 0 && NPAIR >= kPipeMinPairs)
-                    if(j + 1 < NPAIR || kPipeRNext)
-                        __builtin_amdgcn_sched_barrier(0);
+                if(j + 1 < NPAIR)
+                    __builtin_amdgcn_sched_barrier(0);
             }
         };
-        constexpr int w3mode = NPAIR == 2 ? AVDM_NCC_QUAD_W3_MODE : AVDM_NCC_OCTO_W3_MODE; // (3 = the rolled loop below)
-        if(WSH == 3 && w3mode == 1)
+        static_assert(NPAIR >= 3, "the eight-plane pass (the four-plane pass is ncc_accumulate_lds_fixed8_quad)");
+        // a rolled loop of one sample per iteration for 7-tap rows too (the unrolled forms of the four-plane pass spill at eight planes)
         {
-            // one sample at a time
-#pragma unroll
-            for(int xp = -3; xp <= 3; ++xp)
-            {
-                sample(xp);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        else if(WSH == 3 && w3mode == 2)
-        {
-            // 7 taps per row as 3 + 3 + 1
-#pragma unroll
-            for(int xp = -3; xp < 0; ++xp)
-                sample(xp);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for(int xp = 0; xp < 3; ++xp)
-                sample(xp);
-            __builtin_amdgcn_sched_barrier(0);
-            sample(3);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        else if(WSH == 3 && w3mode == 0)
-        {
-            // 7 taps per row as 2 + 2 + 2 + 1 (see ncc_accumulate_lds_fixed8: an unroll factor with a remainder unrolls the whole row)
-#pragma unroll
-            for(int g = 0; g < 3; ++g)
-            {
-                sample(-3 + 2 * g);
-                sample(-2 + 2 * g);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            sample(3);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        else
-        {
-#pragma unroll(NPAIR == 2 ? kNccMultiUnroll : kNccOctoUnroll)
+#pragma unroll(kNccOctoUnroll)
             for(int xp = -wsh; xp <= wsh; ++xp)
                 sample(xp);
         }
