@@ -49,12 +49,13 @@ class SgmParams(C.Structure):
     """SgmParams.hpp:21-55 defaults."""
     _fields_ = [("scale", C.c_int), ("stepXY", C.c_int), ("wsh", C.c_int), ("gammaC", C.c_double), ("gammaP", C.c_double), ("p1", C.c_double),
                 ("p2Weighting", C.c_double), ("maxSimilarity", C.c_double), ("depthThicknessInflate", C.c_double), ("filteringAxes", C.c_char * 8),
-                ("useConsistentScale", C.c_int), ("strictRoiQuirk", C.c_int), ("useCustomPatchPattern", C.c_int)]
+                ("useConsistentScale", C.c_int), ("strictRoiQuirk", C.c_int), ("useCustomPatchPattern", C.c_int),
+                ("referenceArithmetic", C.c_int)]
 
     @staticmethod
     def default(**kw):
         p = SgmParams(scale=2, stepXY=2, wsh=4, gammaC=5.5, gammaP=8.0, p1=10.0, p2Weighting=100.0, maxSimilarity=1.0, depthThicknessInflate=0.0,
-                      filteringAxes=b"YX", useConsistentScale=0, strictRoiQuirk=1, useCustomPatchPattern=0)
+                      filteringAxes=b"YX", useConsistentScale=0, strictRoiQuirk=1, useCustomPatchPattern=0, referenceArithmetic=0)
         for k, v in kw.items():
             setattr(p, k, v)
         return p
@@ -64,12 +65,13 @@ class RefineParams(C.Structure):
     """RefineParams.hpp:19-45 defaults."""
     _fields_ = [("scale", C.c_int), ("stepXY", C.c_int), ("wsh", C.c_int), ("halfNbDepths", C.c_int), ("nbSubsamples", C.c_int),
                 ("optimizationNbIterations", C.c_int), ("sigma", C.c_double), ("gammaC", C.c_double), ("gammaP", C.c_double),
-                ("interpolateMiddleDepth", C.c_int), ("useConsistentScale", C.c_int), ("useCustomPatchPattern", C.c_int)]
+                ("interpolateMiddleDepth", C.c_int), ("useConsistentScale", C.c_int), ("useCustomPatchPattern", C.c_int),
+                ("referenceArithmetic", C.c_int)]
 
     @staticmethod
     def default(**kw):
         p = RefineParams(scale=1, stepXY=1, wsh=3, halfNbDepths=15, nbSubsamples=10, optimizationNbIterations=100, sigma=15.0, gammaC=15.5,
-                         gammaP=8.0, interpolateMiddleDepth=0, useConsistentScale=0, useCustomPatchPattern=0)
+                         gammaP=8.0, interpolateMiddleDepth=0, useConsistentScale=0, useCustomPatchPattern=0, referenceArithmetic=0)
         for k, v in kw.items():
             setattr(p, k, v)
         return p

@@ -17,13 +17,13 @@ LIB = os.path.join(CSRC, "libavdm.so")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-I", os.path.join(HERE, "..", "include")]
 SOURCES = {
-    "avdm_image.hip": [],
+    "avdm_image.hip": ["-ffp-contract=off"],         # bit-exact class since round 6 (the Lab pyramid: glibc's cbrtf restated, no contraction)
     "avdm_similarity.hip": [],                       # fast-math intrinsics + FMA contraction allowed (tolerance class)
     "avdm_sgm.hip": ["-ffp-contract=off"],           # bit-exact class
     "avdm_maps.hip": ["-ffp-contract=off"],          # bit-exact / order-preserving class (the colour optimisation inside it: tolerance class, AVDM_OPT_FAST)
     "avdm_fuse.hip": ["-ffp-contract=off"],          # bit-exact class (double arithmetic in the reference's order)
     "avdm_jpeg.hip": ["-ffp-contract=off"],          # bit-exact class (integers only)
-    "avdm_literal.hip": ["-ffp-contract=off"],       # AVDM_SIM_LITERAL=1: the reference's similarity arithmetic as written (attribution switch)
+    "avdm_literal.hip": ["-ffp-contract=off"],       # the reference's similarity arithmetic as written: referenceArithmetic mode + AVDM_SIM_LITERAL=1
 }
 
 
@@ -43,7 +43,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "avdm_device.h"), os.path.join(CSRC, "avdm_knife.h"), os.path.join(HERE, "..", "include", "avdm.h")]
+    headers = [os.path.join(CSRC, "avdm_device.h"), os.path.join(CSRC, "avdm_knife.h"), os.path.join(CSRC, "avdm_libm.h"),
+               os.path.join(HERE, "..", "include", "avdm.h")]
     extra_headers = {"avdm_fuse.hip": [os.path.join(HERE, "..", "include", "avdm_fuse.h")]}
     objs, jobs = [], []
     for src, extra in SOURCES.items():

@@ -3,6 +3,7 @@
 // Replaces cuda/host/DeviceCache.cpp:222-281, cuda/host/DeviceMipmapImage.cpp:28-90 and
 // cuda/imageProcessing/{deviceColorConversion,deviceGaussianFilter,deviceMipmappedArray}.cu of the reference.
 #include "avdm_device.h"
+#include "avdm_libm.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -166,8 +167,11 @@ __global__ void __launch_bounds__(256) rgba_f32_to_f16x255_kernel(uint2* out, in
     *((uint2*)((char*)out + (long long)y * out_pitch) + x) = pack_h4(make_float4(c.x * 255.0f, c.y * 255.0f, c.z * 255.0f, c.w * 255.0f));
 }
 
-// color.cuh:65-70,124-141 of the reference restated
-__device__ __forceinline__ float lab_f(float r) { return r > 216.0f / 24389.0f ? cbrtf(r) : (24389.0f / 27.0f * r + 16.0f) / 116.0f; }
+// color.cuh:65-70,124-141 of the reference restated.  The cube root is the C library's of the pinned reference build, to its bits
+// (avdm_libm.h: glibc's s_cbrtf.c restated; the device library's cbrtf is within 1 ulp of it, and that ulp moved 1-5 % of the fp16 texels of
+// every level by a quantum — rounds 1-5).  With it and without FMA contraction (this file is compiled -ffp-contract=off since round 6) the
+// Lab pyramid equals the one the reference's own code builds on the CPU texel for texel: tests/test_gpu_parity.py::test_pyramid_parity.
+__device__ __forceinline__ float lab_f(float r) { return r > 216.0f / 24389.0f ? glibc::cbrtf_pos(r) : (24389.0f / 27.0f * r + 16.0f) / 116.0f; }
 
 __global__ void __launch_bounds__(256) rgb2lab_kernel(uint2* img, int pitch, int width, int height)
 {

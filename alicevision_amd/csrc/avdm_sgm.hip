@@ -1400,6 +1400,10 @@ struct SgmKernelTimer
     bool enabled = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
     std::vector<int> pendingPath; // index of the first path a pending launch aggregates (0 / 2 for the pair kernel, 0 ... 3 otherwise)
+    std::vector<long> pendingCall; // the avdm_volume_optimize* call a pending launch belongs to
+    long callId = 0;               // incremented per call that launches path kernels
+    double spanMs = 0.0;           // per call: start of its first path kernel -> end of its last one (the launches AND the gaps between them)
+    long spans = 0;
     double ms = 0.0;
     long launches = 0;
     double msPath[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1458,6 +1462,7 @@ struct SgmKernelTimerScope
         std::lock_guard<std::mutex> lock(g_sgmTimer.m);
         g_sgmTimer.pending.push_back(ev);
         g_sgmTimer.pendingPath.push_back(path);
+        g_sgmTimer.pendingCall.push_back(g_sgmTimer.callId);
     }
 };
 
@@ -1753,6 +1758,20 @@ int avdm_debug_sgm_kernel_timing_read(double* total_ms, long* n_launches, int re
         float ms = 0.f;
         if(hipEventSynchronize(ev.second) != hipSuccess || hipEventElapsedTime(&ms, ev.first, ev.second) != hipSuccess)
             return set_error_msg(1, "avdm_debug_sgm_kernel_timing_read: reading a HIP event failed");
+        // the span of a call: from the start of its first path kernel to the end of its last one, on the device's own clock — the launches
+        // and the gaps between them, without the two command-processor hops a bracketing pair of hipEventRecord adds around the call (8-9 us)
+        if(i + 1 == g_sgmTimer.pending.size() || g_sgmTimer.pendingCall[i + 1] != g_sgmTimer.pendingCall[i])
+        {
+            size_t f = i;
+            while(f > 0 && g_sgmTimer.pendingCall[f - 1] == g_sgmTimer.pendingCall[i])
+                --f;
+            float span = 0.f;
+            if(hipEventElapsedTime(&span, g_sgmTimer.pending[f].first, ev.second) == hipSuccess)
+            {
+                g_sgmTimer.spanMs += span;
+                g_sgmTimer.spans += 1;
+            }
+        }
         g_sgmTimer.ms += ms;
         g_sgmTimer.launches += 1;
         g_sgmTimer.msPath[g_sgmTimer.pendingPath[i]] += ms;
@@ -1761,6 +1780,7 @@ int avdm_debug_sgm_kernel_timing_read(double* total_ms, long* n_launches, int re
     }
     g_sgmTimer.pending.clear();
     g_sgmTimer.pendingPath.clear();
+    g_sgmTimer.pendingCall.clear();
     if(total_ms)
         *total_ms = g_sgmTimer.ms;
     if(n_launches)
@@ -1785,6 +1805,20 @@ int avdm_debug_sgm_kernel_timing_read_paths(double ms[4], long n[4])
         g_sgmTimer.msPath[k] = 0.0;
         g_sgmTimer.launchesPath[k] = 0;
     }
+    return 0;
+}
+
+/* per avdm_volume_optimize* call: the time from the start of its first path kernel to the end of its last one (summed), and the number of calls;
+ * call it after _read, it clears the sums */
+int avdm_debug_sgm_kernel_timing_read_spans(double* span_ms, long* n_calls)
+{
+    std::lock_guard<std::mutex> lock(g_sgmTimer.m);
+    if(span_ms)
+        *span_ms = g_sgmTimer.spanMs;
+    if(n_calls)
+        *n_calls = g_sgmTimer.spans;
+    g_sgmTimer.spanMs = 0.0;
+    g_sgmTimer.spans = 0;
     return 0;
 }
 
@@ -1818,6 +1852,10 @@ static int optimize_tiles_phase(int n_tiles, const avdm_sgm_tile_t* tiles, void*
 {
     if(n_tiles <= 0)
         return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_sgmTimer.m);
+        g_sgmTimer.callId += 1;
+    }
     if(scratch == nullptr || ((uintptr_t)scratch & 3))
         return set_error_msg(1, "avdm_volume_optimize: scratch (sum of avdm_volume_optimize_scratch_bytes() over the tiles, 4-byte aligned) is required");
     std::vector<size_t> p2off(n_tiles);

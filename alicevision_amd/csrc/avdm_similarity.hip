@@ -83,6 +83,15 @@ typedef float v2f_t __attribute__((ext_vector_type(2)));
 #ifndef AVDM_DEV_UNSHIFTED_SUMS
 #define AVDM_DEV_UNSHIFTED_SUMS 0 // 1: the six NCC sums on the UNSHIFTED L values in the reference's order and form (SimStat.cuh:72-155), no FMA contraction
 #endif
+// ... per kernel (round 6, VERDICT r5 1a: "the flips are SGM's"): which of the two sweeps takes the unshifted sums when AVDM_DEV_UNSHIFTED_SUMS is set
+#ifndef AVDM_DEV_UNSHIFTED_SGM
+#define AVDM_DEV_UNSHIFTED_SGM 1
+#endif
+#ifndef AVDM_DEV_UNSHIFTED_REFINE
+#define AVDM_DEV_UNSHIFTED_REFINE 1
+#endif
+template <bool TInvert>
+constexpr bool kUnshifted = AVDM_DEV_UNSHIFTED_SUMS && (TInvert ? AVDM_DEV_UNSHIFTED_REFINE != 0 : AVDM_DEV_UNSHIFTED_SGM != 0);
 #ifndef AVDM_DEV_TWO_EXP
 #define AVDM_DEV_TWO_EXP 0 // 1: two Yoon-Kweon weights, two expf, multiplied (color.cuh:167-210)
 #endif
@@ -486,7 +495,10 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
             const float w = __builtin_amdgcn_exp2f(fmaf(dcr + dct, A.negInvGammaC_log2e, -trow[xp]));
 #endif
 #if AVDM_DEV_UNSHIFTED_SUMS
+    if constexpr(kUnshifted<TInvert>)
+    {
             lit.update(rcC.x, tcC.x, w);
+    }
 #endif
 
             // NCC statistics on L shifted by the centre values (gx = L_r(centre) - L_r(sample), same for T): variances and the
@@ -509,7 +521,10 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
     const float varXYW = (xysum - xsum * ysum * iw) * iw;
     float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
 #if AVDM_DEV_UNSHIFTED_SUMS
+    if constexpr(kUnshifted<TInvert>)
+    {
     rawSim = lit.raw_sim();
+    }
 #endif
     const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
     if(TInvert)
@@ -752,11 +767,14 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
                 const float w = __builtin_amdgcn_exp2f(fmaf(dcs, kC, -trow[xp]));
 #endif
 #if AVDM_DEV_UNSHIFTED_SUMS
+    if constexpr(kUnshifted<TInvert>)
+    {
                 {
                     // the bilinear L values themselves (x 2^16: exact horizontal products, one rounding per vertical step), then the reference's sums
                     const v2f V = v2f{rb.L, tb.L} * wb - v2f{rt.L, tt.L} * nnb;
                     lit.update(V.x * (1.0f / 65536.0f), V.y * (1.0f / 65536.0f), w);
                 }
+    }
 #endif
 
                 const v2f wg = dL * w;
@@ -795,7 +813,10 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
     const float varXYW = (xysum - sum1.x * sum1.y * iw) * iw;
     float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
 #if AVDM_DEV_UNSHIFTED_SUMS
+    if constexpr(kUnshifted<TInvert>)
+    {
     rawSim = lit.raw_sim();
+    }
 #endif
     const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
     if(TInvert)
@@ -995,11 +1016,14 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
                 const v2f w = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
 #endif
 #if AVDM_DEV_UNSHIFTED_SUMS
+    if constexpr(kUnshifted<TInvert>)
+    {
                 {
                     const v2f VT = (v2f{h.rb.L, h.tb.L} * t[j].wb - v2f{h.rt.L, h.tt.L} * t[j].nnb) * (1.0f / 65536.0f);
                     lit[2 * j].update(VR, VT.x, w.x);
                     lit[2 * j + 1].update(VR, VT.y, w.y);
                 }
+    }
 #endif
                 const v2f wgT = w * dL;
                 wsum[j] += w;
@@ -1046,6 +1070,8 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
     sim2 = finish(wsum[1].x, s1R[1].x, s1T[1].x, s2R[1].x, s2T[1].x, sxy[1].x);
     sim3 = finish(wsum[1].y, s1R[1].y, s1T[1].y, s2R[1].y, s2T[1].y, sxy[1].y);
 #if AVDM_DEV_UNSHIFTED_SUMS
+    if constexpr(kUnshifted<TInvert>)
+    {
     auto finish_lit = [&](const SimStatLit& st) __attribute__((always_inline)) -> float {
         const float rawSim = st.raw_sim();
         const float s = isfinite(rawSim) ? -rawSim : 1.0f;
@@ -1055,6 +1081,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
     sim1 = finish_lit(lit[1]);
     sim2 = finish_lit(lit[2]);
     sim3 = finish_lit(lit[3]);
+    }
 #endif
 }
 
@@ -1241,11 +1268,14 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
                 const v2f w = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
 #endif
 #if AVDM_DEV_UNSHIFTED_SUMS
+    if constexpr(kUnshifted<TInvert>)
+    {
                 {
                     const v2f VT = (v2f{h.rb.L, h.tb.L} * t[j].wb - v2f{h.rt.L, h.tt.L} * t[j].nnb) * (1.0f / 65536.0f);
                     lit[2 * j].update(VR, VT.x, w.x);
                     lit[2 * j + 1].update(VR, VT.y, w.y);
                 }
+    }
 #endif
                 const v2f wgT = w * dL;
                 wsum[j] += w;
@@ -1283,6 +1313,8 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
         sim[2 * j + 1] = finish(wsum[j].y, s1R[j].y, s1T[j].y, s2R[j].y, s2T[j].y, sxy[j].y);
     }
 #if AVDM_DEV_UNSHIFTED_SUMS
+    if constexpr(kUnshifted<TInvert>)
+    {
     auto finish_lit = [&](const SimStatLit& st) __attribute__((always_inline)) -> float {
         const float rawSim = st.raw_sim();
         const float s = isfinite(rawSim) ? -rawSim : 1.0f;
@@ -1291,6 +1323,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
 #pragma unroll
     for(int j = 0; j < 2 * NPAIR; ++j)
         sim[j] = finish_lit(lit[j]);
+    }
 #endif
 }
 
@@ -2334,6 +2367,10 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             auto list_outliers = [&](bool outl, unsigned zFirst, unsigned nPlanes) __attribute__((always_inline)) -> bool {
                 const unsigned long long m = __ballot(outl);
                 const unsigned n = (unsigned)__popcll(m);
+                // a list that is already full refuses without another atomic (every later wave with a misfit lane used to pay up to three
+                // failed global atomics per chunk before it dropped to the one-plane path — in exactly the many-outliers case that is slowest anyway)
+                if(__builtin_nontemporal_load(outliers) >= listCap) // uniform
+                    return false;
                 unsigned base = 0u;
                 if((threadIdx.x & 63u) == 0u)
                     base = atomicAdd(outliers, n);
@@ -2583,12 +2620,15 @@ __global__ void __launch_bounds__(256)
         atomicAdd(&totals[1], list[0] - count);
     }
     const uint2* const units = reinterpret_cast<const uint2*>(list) + 1;
+    // one lane per PLANE of a unit (round 6; one lane per unit until round 5: eight planes x 49 samples x 8 global taps in sequence per lane, a
+    // latency chain that made this kernel 0.3 ... 1.3 ms per launch with the machine a quarter full).  The eight lanes of a unit share its pixel
+    // (the same R taps: one cache line) and add into different halfs of the volume.
 #pragma unroll 1
-    for(unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u)
+    for(unsigned i = blockIdx.x * 256u + threadIdx.x; i < 8u * count; i += gridDim.x * 256u)
     {
-        const uint2 u = units[i];
+        const uint2 u = units[i >> 3];
         const unsigned vx = u.x & 0xffffu, vy = u.x >> 16, zFirst = u.y & 0xffffu, nPlanes = u.y >> 16;
-        if(nPlanes == 0u) // a slot of a wave that found the list full
+        if((i & 7u) >= nPlanes) // (nPlanes == 0: a slot of a wave that found the list full)
             continue;
         const float2 dps = *((const float2*)((const char*)sgmDepthPixSize + (long long)vy * map_pitch) + vx);
         if(!(dps.x > 0.0f))
@@ -2608,8 +2648,8 @@ __global__ void __launch_bounds__(256)
             continue;
         const RayConsts RK = make_ray_consts(rc, tc, C, dir, x, y);
         __half* const pv = vol + ((long long)vy * pitch_y + (long long)vx * pitch_x) / 2;
-#pragma unroll 1
-        for(unsigned vz = max(zFirst, zBegin); vz < min(zFirst + nPlanes, zEnd); ++vz)
+        const unsigned vz = zFirst + (i & 7u);
+        if(vz >= zBegin && vz < zEnd)
         {
             const int rel = (int)vz - ((volDimZ - 1) / 2);
             if(knife && !lit::refine_r_inside(rc, x, y, dps.x, dps.y, rel, dd, A.rcW1, A.rcH1))
@@ -3087,6 +3127,14 @@ static bool sim_literal_mode()
     const char* e = getenv("AVDM_SIM_LITERAL");
     return e != nullptr && e[0] == '1';
 }
+// avdm_sgm_params_t::referenceArithmetic / avdm_refine_params_t::referenceArithmetic: the reference's arithmetic as written, to the bits of the
+// pinned reference build, from LDS windows (avdm_literal.hip: strict_sgm_kernel / strict_refine_kernel) — the product's parity mode
+int strict_compute_similarity(uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, const float* depths, const avdm_camera_t* rc,
+                              const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr, const avdm_sgm_params_t* sp, avdm_range_t dr,
+                              avdm_roi_t roi, void* stream);
+int strict_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x, int dimZ, const float* sgm_depth_pixsize, int map_pitch, const float* sgm_normal,
+                             int normal_pitch, const avdm_camera_t* rc, const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
+                             const avdm_refine_params_t* rp, avdm_range_t dr, avdm_roi_t roi, void* stream);
 
 } // namespace avdm
 
@@ -3228,6 +3276,13 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
         return set_error_msg(1, "avdm_volume_compute_similarity: volume base / pitches must be multiples of 4 bytes");
     if(sim_literal_mode() && !sp->useConsistentScale && !sp->useCustomPatchPattern)
         return avdm::literal_compute_similarity(best, second, pitch_y, pitch_x, depths, rc, tc, rc_pyr, tc_pyr, sp, dr, roi, stream);
+    if(sp->referenceArithmetic)
+    {
+        if(sp->useConsistentScale || sp->useCustomPatchPattern)
+            return set_error_msg(1, "avdm_volume_compute_similarity: referenceArithmetic is built for the wsh-square patch at one level of detail "
+                                    "(not with useConsistentScale / useCustomPatchPattern)");
+        return avdm::strict_compute_similarity(best, second, pitch_y, pitch_x, depths, rc, tc, rc_pyr, tc_pyr, sp, dr, roi, stream);
+    }
     NccArgs A;
     PatchTable tab;
     const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;
@@ -3338,6 +3393,14 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
     if(sim_literal_mode() && !rp->useConsistentScale && !rp->useCustomPatchPattern)
         return avdm::literal_refine_similarity(vol_f16, pitch_y, pitch_x, dimZ, sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, rc, tc, rc_pyr, tc_pyr, rp,
                                                dr, roi, stream);
+    if(rp->referenceArithmetic)
+    {
+        if(rp->useConsistentScale || rp->useCustomPatchPattern)
+            return set_error_msg(1, "avdm_volume_refine_similarity: referenceArithmetic is built for the wsh-square patch at one level of detail "
+                                    "(not with useConsistentScale / useCustomPatchPattern)");
+        return avdm::strict_refine_similarity(vol_f16, pitch_y, pitch_x, dimZ, sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, rc, tc, rc_pyr, tc_pyr, rp,
+                                              dr, roi, stream);
+    }
     NccArgs A;
     PatchTable tab;
     const bool fixed8 = rc_pyr->filter_mode == AVDM_FILTER_CUDA_FIXED8;

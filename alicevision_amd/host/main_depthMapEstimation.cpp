@@ -135,6 +135,9 @@ int aliceVision_main(int argc, char* argv[])
     cmdline.add("sgmDepthListPerTile", &sgmParams.depthListPerTile, "Semi Global Matching: Select the list of depth planes per tile or globally to the image.");
     cmdline.add("sgmUseConsistentScale", &sgmParams.useConsistentScale, "Semi Global Matching: Compare patch with consistent scale for similarity volume computation.");
     cmdline.add("sgmUseCustomPatchPattern", &sgmParams.useCustomPatchPattern, "Semi Global Matching: Use user custom patch pattern for similarity volume computation.");
+    // (not a flag of the reference) the parity mode: the reference's similarity arithmetic as written, bit-equal volumes, ~6 x the sweep's cost
+    cmdline.add("sgmReferenceArithmetic", &sgmParams.referenceArithmetic, "Semi Global Matching: Evaluate the similarity volume in the reference implementation's arithmetic as written (bit-equal volumes; slower).");
+    cmdline.add("refineReferenceArithmetic", &refineParams.referenceArithmetic, "Refine: Evaluate the refine similarity volume in the reference implementation's arithmetic as written (bit-equal volumes; slower).");
     cmdline.add("refineScale", &refineParams.scale, "Refine: Downscale factor applied on source images for the Refine step (in addition to the global downscale).");
     cmdline.add("refineStepXY", &refineParams.stepXY, "Refine: Step is used to compute the refine volume for one pixel over N (in the XY image plane).");
     cmdline.add("refineMaxTCamsPerTile", &refineParams.maxTCamsPerTile, "Refine: Maximum number of neighbour cameras used per tile.");

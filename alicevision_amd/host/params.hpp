@@ -35,6 +35,9 @@ struct SgmParams
     bool depthListPerTile = false;
     bool useConsistentScale = false;
     bool useCustomPatchPattern = false;
+    // not a parameter of the reference: --sgmReferenceArithmetic 1 runs the similarity sweep in the reference's arithmetic as written
+    // (avdm_sgm_params_t::referenceArithmetic: volumes equal to the reference's own code compiled for the CPU bit for bit, ~6 x the sweep's cost)
+    bool referenceArithmetic = false;
     bool exportIntermediateDepthSimMaps = false;
     bool exportIntermediateNormalMaps = false;
     bool exportIntermediateVolumes = false;
@@ -60,6 +63,7 @@ struct SgmParams
         p.useConsistentScale = useConsistentScale ? 1 : 0;
         p.strictRoiQuirk = 1;
         p.useCustomPatchPattern = useCustomPatchPattern ? 1 : 0;
+        p.referenceArithmetic = referenceArithmetic ? 1 : 0;
         return p;
     }
 };
@@ -79,6 +83,7 @@ struct RefineParams
     bool interpolateMiddleDepth = false;
     bool useConsistentScale = false;
     bool useCustomPatchPattern = false;
+    bool referenceArithmetic = false; // --refineReferenceArithmetic (see SgmParams::referenceArithmetic)
     bool useRefineFuse = true;
     bool useColorOptimization = true;
     bool useSgmNormalMap = false; // const false in the reference (RefineParams.hpp:44)
@@ -98,6 +103,7 @@ struct RefineParams
         p.interpolateMiddleDepth = interpolateMiddleDepth ? 1 : 0;
         p.useConsistentScale = useConsistentScale ? 1 : 0;
         p.useCustomPatchPattern = useCustomPatchPattern ? 1 : 0;
+        p.referenceArithmetic = referenceArithmetic ? 1 : 0;
         return p;
     }
 };

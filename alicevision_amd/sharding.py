@@ -195,6 +195,21 @@ def fixed_job(n_cameras, world, step_s_of_rank):
             "how": "per-rank seconds per depth map measured in this run x the cameras round-robin deals to the rank; makespan = the slowest rank"}
 
 
+def measured_fixed_job(n_cameras, world, cams_of, step_s_of_rank, makespan_s):
+    """The fixed job as bench.py RUNS it at N > 1 (round 6): every rank stepped through exactly the cameras round-robin deals it, the step was
+    timed between barriers to the slowest rank (makespan_s = that time per pass over the job), and `value` = n_cameras / makespan_s.  Next to it
+    the same quantity priced from the per-rank seconds per depth map (what rounds 1-5 reported): the two differ by whatever the ranks cost each
+    other (shared host, power, memory)."""
+    per_rank = [len(c) for c in cams_of]
+    assert sum(per_rank) == n_cameras and sorted(c for cs in cams_of for c in cs) == list(range(n_cameras)), "every camera exactly once"
+    priced = fixed_job(n_cameras, world, step_s_of_rank)
+    return {"cameras": n_cameras, "cameras_per_rank": per_rank, "cameras_of_rank": [list(c) for c in cams_of], "measured": True,
+            "makespan_s": float(makespan_s), "depth_maps_per_s": n_cameras / makespan_s if makespan_s > 0 else None,
+            "speedup_ceiling": n_cameras / max(per_rank), "step_s_per_rank": [float(t) for t in step_s_of_rank],
+            "priced_makespan_s": priced["makespan_s"],
+            "how": "each rank computed the cameras round-robin deals it, once per step; makespan = barrier to barrier, MAX over ranks"}
+
+
 def exchange_pyramid(buf, src, dist, all_ranks=False):
     """One-shot helpers kept for callers that hold a single buffer: broadcast of `buf` from `src`, or (all_ranks) an all-gather returning
     the list of every rank's buffer."""

@@ -38,6 +38,7 @@ import torch
 
 from alicevision_amd import abi
 from alicevision_amd.pipeline import DepthMapTile, DevicePyramid, optimize_tiles_batched
+from alicevision_amd.sharding import measured_fixed_job  # noqa: E402
 from alicevision_amd.sharding import StepProtocol, ViewExchange, cameras_of_rank, fixed_job, owner_of_view
 from alicevision_amd.synthetic import make_scene, plane_depths
 
@@ -164,6 +165,8 @@ def dry_run(args, rank, world):
         done.append(rc)
 
     proto = StepProtocol(ex, cams_of, V, min(T, V - 1), build, sweep, stream_views=args.stream_views)
+    fixed = world > 1 and not args.weak and not args.stream_views  # main(): one step = the workload's cameras once, each on its rank
+    per_step = len(my_cams) if fixed else 1
     for i in range(args.warmup):
         proto.step(i)
     done.clear()
@@ -171,23 +174,31 @@ def dry_run(args, rank, world):
         dist.barrier()
     t0 = time.time()
     for i in range(args.steps):
-        proto.step(args.warmup + i)
+        for k in range(per_step):
+            proto.step((0 if fixed else args.warmup) + i * per_step + k)  # (the fixed job: every pass in the order round-robin dealt the cameras)
     proto.finish()
     if world > 1:
         dist.barrier()
     elapsed = time.time() - t0
     counts = torch.tensor([len(owned), len(my_cams), checked[0]], dtype=torch.int64)
+    done_of = [list(done)]
+    my_elapsed = elapsed
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         dist.all_reduce(counts)
+        done_of = [None] * world
+        dist.all_gather_object(done_of, list(done))  # what every rank really computed in the timed region, in order
     if rank == 0:
         # the fixed-job accounting with one second per depth map on every rank: cameras per rank, makespan, the ceiling of the speed-up
         n_job = WORKLOADS["cfg4"][0] if (args.workload or "cfg3") in ("cfg3", "cfg4") else V
         print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "views": V, "views_owned_total": int(counts[0]),
-                          "reference_cameras_total": int(counts[1]), "rank0_cameras": done, "elapsed_s": elapsed, "scaling": "weak",
-                          "stream_views": bool(args.stream_views), "exchange_collectives": ex.collectives, "tcam_pyramids_checked": int(counts[2]),
+                          "reference_cameras_total": int(counts[1]), "rank0_cameras": done, "cameras_done_of_rank": done_of, "elapsed_s": elapsed,
+                          "rank0_elapsed_s": my_elapsed, "scaling": "strong" if fixed else "weak",
+                          "value": (V if fixed else world) * args.steps / elapsed if elapsed > 0 else None,
+                          "measured_fixed_job": measured_fixed_job(V, world, cams_of, [1.0] * world, elapsed / args.steps) if fixed else None,
+                          "stream_views": bool(args.stream_views), "reference_arithmetic": args.reference_arithmetic or None, "exchange_collectives": ex.collectives, "tcam_pyramids_checked": int(counts[2]),
                           "fixed_job": fixed_job(n_job, world, [1.0] * world)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -278,6 +289,14 @@ def main():
     ap.add_argument("--stream-views", action="store_true",
                     help="the streaming job: every step's freshly rebuilt R pyramids travel to every other rank by one all-gather on a side stream "
                          "(stages pyramid_exchange / pyramid_commit).  Default: the pyramids are handed over once, before the timed region")
+    ap.add_argument("--reference-arithmetic", default="", choices=["", "sgm", "all"],
+                    help="run the similarity sweeps in the product's reference-arithmetic mode (avdm_sgm_params_t / avdm_refine_params_t::referenceArithmetic: "
+                         "the reference's operations as written, volumes equal to its own code compiled for the CPU bit for bit): sgm = the SGM sweep, "
+                         "all = both sweeps.  The parity mode's measured cost; NOT the headline configuration (the line says so in config.reference_arithmetic)")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: the weak-scaling form of rounds 1-5 (every rank times K depth maps of its own; value = N K / elapsed).  Default at "
+                         "N > 1 is the FIXED job BASELINE quotes (a step = all reference cameras of the workload dealt round-robin to the ranks, "
+                         "timed to the slowest rank; value = cameras / makespan)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only (gloo, no GPU work): what tests/test_sharding.py runs on the CPU")
     args = ap.parse_args()
@@ -305,13 +324,16 @@ def main():
     if args.workload is None:
         args.workload = "cfg3" if world == 1 else "cfg4"
     V, W, H, Z, T, n_side = WORKLOADS[args.workload]
-    sgm, ref = abi.SgmParams.default(), abi.RefineParams.default()
+    sgm = abi.SgmParams.default(referenceArithmetic=1 if args.reference_arithmetic in ("sgm", "all") else 0)
+    ref = abi.RefineParams.default(referenceArithmetic=1 if args.reference_arithmetic == "all" else 0)
 
     # ---- scene: cameras everywhere; a rank renders and converts ONLY the views it owns ----
     sc = make_scene(V, W, H, seed=3, device=dev, render=[v for v in range(V) if owner_of_view(v, world) == rank])
     images = sc.images  # {view: (H, W, 4) fp32 in HBM} for the owned views
     min_ds, max_ds = min(sgm.scale, ref.scale), max(sgm.scale, ref.scale) * 64
     # all pyramids of a rank live in the exchange arena ([row][owner rank][bytes]): a row of views travels in ONE in-place all-gather
+    if not cameras_of_rank(list(range(V)), rank, world):
+        raise SystemExit(f"rank {rank} of {world} has no reference camera of the {V}-view workload")
     exchange = ViewExchange(V, DevicePyramid.pyramid_bytes(W, H, min_ds, max_ds, abi.FILTER_CUDA_FIXED8), rank, world, dist, device=dev)
     pyr = []
     for v in range(V):
@@ -364,11 +386,17 @@ def main():
     proto = StepProtocol(exchange, cams_of, V, T, build, sweep, stream_views=args.stream_views, on_stage=tile.timers.range)
     step = proto.step
 
-    for i in range(args.warmup):
+    # N > 1 (default): the FIXED job — one step = every reference camera of the workload once, each on the rank round-robin deals it to
+    # (computeOnMultiGPUs.cpp:42-66; cfg4: 20 cameras -> 3, 3, 3, 3, 2, 2, 2, 2 at 8 ranks), timed to the slowest rank.  N = 1 (and --weak,
+    # --stream-views): one step = one depth map on every rank.
+    fixed = world > 1 and not args.weak and not args.stream_views
+    per_step = len(my_cams) if fixed else 1  # depth maps of THIS rank per step
+    for i in range(args.warmup):  # (warm-up: W depth maps per rank in either form)
         step(i)
     torch.cuda.synchronize()
     tile.reset_timers()
-    lib.avdm_debug_sgm_kernel_timing(1)  # HIP events on the launch stream around every path-aggregation kernel launch
+    kernel_events = os.environ.get("AVDM_BENCH_KERNEL_EVENTS", "1") != "0"  # 0 (diagnosis): no per-launch events inside the timed call
+    lib.avdm_debug_sgm_kernel_timing(1 if kernel_events else 0)  # HIP events on the launch stream around every path-aggregation kernel launch
     exchange.commit()
     torch.cuda.synchronize()
     exchange.events = []
@@ -379,7 +407,8 @@ def main():
     step_events[0].record()
     stats_each = []
     for i in range(args.steps):
-        out = step(args.warmup + i)
+        for k in range(per_step):
+            out = step((0 if fixed else args.warmup) + i * per_step + k)  # (the fixed job: every pass in the order round-robin dealt the cameras)
         step_events[i + 1].record()
         if os.environ.get("AVDM_SIM_STATS") == "1":  # diagnosis only (synchronises every step): tap sources of the similarity kernels per step
             torch.cuda.synchronize()
@@ -392,7 +421,7 @@ def main():
         dist.barrier()
     elapsed = time.time() - t0
     # seconds per depth map on every rank (GPU time between the step events): what the fixed-job figure is priced with
-    my_step_s = 1e-3 * step_events[0].elapsed_time(step_events[-1]) / args.steps
+    my_step_s = 1e-3 * step_events[0].elapsed_time(step_events[-1]) / (args.steps * max(per_step, 1))
     step_s_of_rank = [my_step_s]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -402,22 +431,28 @@ def main():
         dist.all_gather_into_tensor(allt, torch.tensor([my_step_s], dtype=torch.float64, device=dev))
         step_s_of_rank = [float(x) for x in allt.cpu()]
 
-    stages = tile.timers.mean_ms(per=args.steps)  # ms per step and stage (HIP events on the launch stream; summed over the tiles of a step)
+    n_maps0 = args.steps * per_step  # depth maps this rank computed in the timed region
+    stages = tile.timers.mean_ms(per=n_maps0)  # ms per DEPTH MAP and stage (HIP events on the launch stream; summed over the tiles of a step)
     if dist is not None and args.stream_views:
         # the all-gather of a step's R pyramids runs on a side stream beside the sweep: its own events, not part of the critical path
-        stages["pyramid_exchange"] = exchange.exchange_ms() / args.steps
+        stages["pyramid_exchange"] = exchange.exchange_ms() / n_maps0
     k_ms, k_n = ctypes.c_double(0.0), ctypes.c_long(0)
     abi.check(lib.avdm_debug_sgm_kernel_timing_read(ctypes.byref(k_ms), ctypes.byref(k_n), 1), "avdm_debug_sgm_kernel_timing_read")
     path_ms, path_n = (ctypes.c_double * 4)(), (ctypes.c_long * 4)()
     if hasattr(lib, "avdm_debug_sgm_kernel_timing_read_paths"):
         lib.avdm_debug_sgm_kernel_timing_read_paths(path_ms, path_n)
+    span_ms, span_n = ctypes.c_double(0.0), ctypes.c_long(0)
+    if hasattr(lib, "avdm_debug_sgm_kernel_timing_read_spans"):
+        lib.avdm_debug_sgm_kernel_timing_read_spans.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
+        lib.avdm_debug_sgm_kernel_timing_read_spans(ctypes.byref(span_ms), ctypes.byref(span_n))
     lib.avdm_debug_sgm_kernel_timing(0)
     valid = float((out[..., 0] > 0).float().mean().item())
 
     line = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.steps / elapsed
+        # fixed job: the workload's cameras per step, all ranks together, over the time of the slowest rank; otherwise one depth map per rank and step
+        value = (V if fixed else world) * args.steps / elapsed
         # roofline of the SGM path-aggregation kernel (BASELINE.json: "SGM HBM GB/s vs roofline")
         ds = sgm.scale * sgm.stepXY
         # (X, Y) the path aggregation walks for every tile of a depth map: the tile's buffer extent (= its ROI for a whole-image tile)
@@ -443,8 +478,10 @@ def main():
         alg_bytes_per_launch = alg_bytes_per_volume / n_launches
         # average duration of one path-aggregation kernel launch (HIP events around the launches alone, on their stream);
         # stages["sgm_optimize"] is the whole avdm_volume_optimize call, i.e. these launches + the adaptive-P2 map kernel
-        if k_n.value != n_launches * args.steps * n_calls:
-            raise SystemExit(f"expected {n_launches * args.steps * n_calls} path-kernel launches in the timed region, the library timed {k_n.value}")
+        if not kernel_events:
+            k_ms.value, k_n.value = float("nan"), n_launches * n_maps0 * n_calls
+        if k_n.value != n_launches * n_maps0 * n_calls:
+            raise SystemExit(f"expected {n_launches * n_maps0 * n_calls} path-kernel launches in the timed region, the library timed {k_n.value}")
         sgm_ms_per_launch = k_ms.value / k_n.value
         achieved = alg_bytes_per_launch / (sgm_ms_per_launch * 1e-3) / 1e9
         whole_call_ms = stages["sgm_optimize"] / n_calls
@@ -464,6 +501,11 @@ def main():
                 "frac_with_p2_map": survey_bytes_per_volume / ((whole_call_ms + stages.get("sgm_p2_map", 0.0) / n_calls) * 1e-3) / 1e9 / 8000.0,
                 # per launch of a volume: [first filtering axis (paths 0 + 1), second axis (paths 2 + 3)]
                 "ms_per_launch_by_axis": [path_ms[k] / path_n[k] if path_n[k] else None for k in (0, 2)]}
+        if span_n.value > 0:
+            # the call on the device's own clock: start of its first path kernel -> end of its last one (both launches and the gap between them), from
+            # the events bound to the launches — without the two command-processor hops the bracketing hipEventRecord pair adds around the call
+            roof["ms_call_span_per_volume"] = span_ms.value / span_n.value / (1 if batched else 1)
+            roof["frac_call_span"] = alg_bytes_per_volume / (roof["ms_call_span_per_volume"] * 1e-3) / 1e9 / 8000.0
         # what this box's HBM delivers to a plain device-to-device copy (1 GiB read + 1 GiB written, measured here, after the timed region):
         # the practical ceiling next to the 8 TB/s nominal peak the fraction is quoted against (profiles/README.md: box-to-box variance)
         try:
@@ -552,10 +594,14 @@ def main():
             break
         line = {
             "metric": "depth-maps/sec (12 MP, 256 depth hyp, 10 neighbours)", "value": value, "unit": "depth-maps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            # the FIXED job BASELINE quotes at N GPUs (cfg4: 20 reference cameras dealt to the ranks — the same 20 at N = 1, where cfg3 runs the same
-            # work per depth map), priced with this run's per-rank seconds per depth map — `value` above is the weak-scaling rate (K steps per rank)
-            "fixed_job": fixed_job(WORKLOADS["cfg4"][0] if args.workload in ("cfg3", "cfg4") else V, world, step_s_of_rank),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            # N > 1: the FIXED job (total work does not grow with N: "strong"); N = 1 / --weak: one depth map per rank and step
+            "scaling": "strong" if fixed else "weak",
+            "fixed_job": measured_fixed_job(V, world, cams_of, step_s_of_rank, elapsed / args.steps) if fixed else
+            # (N = 1, --weak: PRICED, not measured — this run's per-rank seconds per depth map x the cameras round-robin deals each rank)
+            fixed_job(WORKLOADS["cfg4"][0] if args.workload in ("cfg3", "cfg4") else V, world, step_s_of_rank),
+            # the weak-scaling rate next to it: depth maps per second summed over the ranks, each at its own pace
+            "weak_scaling_rate": sum(1.0 / t for t in step_s_of_rank if t > 0),
             "vs_baseline": None, "dtype": "f32 (fp16 texels, u8 cost volume)", "data": "synthetic",
             "config": {"workload": args.workload, "views": V, "width": W, "height": H, "depth_planes": Z, "t_cams": T, "tiles_per_depth_map": len(rois),
                        "sgm": "scale 2 stepXY 2 wsh 4, 4 paths", "refine": "scale 1 stepXY 1 wsh 3, 31 planes, 100 opt iters",

@@ -93,6 +93,11 @@ typedef struct avdm_sgm_params
     int useConsistentScale;
     int strictRoiQuirk;       /* 1 = replicate the begin-x/begin-y swap of deviceSimilarityVolumeKernels.cuh:688-709 */
     int useCustomPatchPattern; /* SgmParams.hpp:51: compare with the pattern of avdm_build_custom_patch_pattern instead of the wsh square */
+    int referenceArithmetic;  /* avdm_volume_compute_similarity: 1 = the reference's arithmetic AS WRITTEN (compNCCby3DptsYK, Patch.cuh:466-572;
+                                 simStat, SimStat.cuh:72-153; CostYKfromLab, color.cuh:167-210: operation for operation, IEEE division / square
+                                 root, no contraction, expf to the bits of the pinned reference build's C library) — similarity volumes equal
+                                 to the reference's own code compiled for the CPU bit for bit, at ~6 x the instructions of the default sweep;
+                                 0 (default) = the packed multi-plane kernels (tolerance class) */
 } avdm_sgm_params_t;
 
 /* subset of RefineParams used by the kernels (RefineParams.hpp:19-45) */
@@ -110,6 +115,7 @@ typedef struct avdm_refine_params
     int interpolateMiddleDepth;
     int useConsistentScale;
     int useCustomPatchPattern; /* RefineParams.hpp:42 */
+    int referenceArithmetic;   /* avdm_volume_refine_similarity: as avdm_sgm_params_t::referenceArithmetic */
 } avdm_refine_params_t;
 
 /* ---- custom patch pattern (cuda/device/DevicePatchPattern.hpp:11-54) ---- */

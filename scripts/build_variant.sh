@@ -10,7 +10,7 @@ OUT=$ROOT/scripts/ab/$NAME
 mkdir -p $OUT
 CS=$ROOT/alicevision_amd/csrc
 EXTRA=""
-case $SRC in avdm_sgm.hip|avdm_maps.hip|avdm_fuse.hip|avdm_literal.hip) EXTRA="-ffp-contract=off";; esac
+case $SRC in avdm_sgm.hip|avdm_maps.hip|avdm_fuse.hip|avdm_literal.hip|avdm_image.hip|avdm_jpeg.hip) EXTRA="-ffp-contract=off";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I $ROOT/include $EXTRA "$@" \
    -Rpass-analysis=kernel-resource-usage -c $CS/$SRC -o $OUT/${SRC%.hip}.o 2> $OUT/remarks.txt
 OBJS=""

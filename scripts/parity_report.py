@@ -71,6 +71,16 @@ def depth_stats(got, want, pix=None):
     return out
 
 
+def sim_stats(got, want):
+    """the similarity channel of the final map as the program writes it (mvsUtils/mapIO.cpp:403-540: <view>_simMap.exr is ONE HALF per pixel): share of
+    identical halfs and the distance of the rest, over the pixels valid in both maps"""
+    both = (got[..., 0] > 0) & (want[..., 0] > 0)
+    g, w = got[..., 1].astype(np.float16)[both], want[..., 1].astype(np.float16)[both]
+    d = np.abs(g.astype(np.float32) - w.astype(np.float32))
+    return {"identical_halfs": float((g.view(np.uint16) == w.view(np.uint16)).mean()), "max_abs": float(d.max()), "p99_abs": float(np.percentile(d, 99)),
+            "rmse": float(np.sqrt((d.astype(np.float64) ** 2).mean())), "frac_abs_gt_1e-2": float((d > 1e-2).mean())}
+
+
 def gpu_run(pyr, sc, sgm, ref, roi, tcs, depths, tile_buffer=None):
     """one tile through the C ABI: every intermediate the table compares"""
     import torch
@@ -93,7 +103,7 @@ def gpu_run(pyr, sc, sgm, ref, roi, tcs, depths, tile_buffer=None):
 DEVIATIONS = {"shifted_sums": 1, "merged_exp": 2, "homogeneous_v_rcp": 4, "exact_centre": 8, "shared_R": 16, "all": 31, "exact_border_r3": 32, "all_r3": 63}
 
 
-def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False, spread=False, deviations=(), modes=("well_posed", "literal")):
+def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False, spread=False, deviations=(), modes=("well_posed", "literal"), strict=()):
     """modes: the oracle evaluations to run, "literal" last (the literal run's volumes feed the later blocks); the GPU suite runs the 24 MP tile
     against the literal evaluation only (the oracle's time goes with the pixels)"""
     import torch
@@ -138,6 +148,7 @@ def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False, spread=
         pix = o.sgm_upscaled[..., 1]
         r["refined_depth"] = depth_stats(g_refined, o.refined, pix)
         r["final_depth"] = depth_stats(g_final, want, pix)
+        r["final_sim"] = sim_stats(g_final, want)
         gt = sc.gt_depth.cpu().numpy()
         if roi is not None:
             gt = gt[roi[2]:roi[3], roi[0]:roi[1]]
@@ -147,6 +158,31 @@ def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False, spread=
         r["t_oracle_s"] = time.time() - t1
         res[mode] = r
         wants[mode] = (want, o.second[..., :Z].copy())
+    # the Lab pyramids: the GPU's against the oracle's, texel for texel (round 6: glibc's cbrtf restated on the device, no contraction)
+    pdiff = []
+    for v in range(spec["n_views"]):
+        for l in range(min(pyr[v].desc.levels, o.pyr[v].desc.levels)):
+            a, b = o.pyr[v].level(l), pyr[v].level(l).cpu().numpy()
+            pdiff.append(float((a.view(np.uint16) != b.view(np.uint16)).mean()))
+    res["pyramid_texels_differing"] = {"max_over_levels": max(pdiff), "mean": float(np.mean(pdiff))}
+    # THE PRODUCT'S REFERENCE-ARITHMETIC MODE (round 6; avdm_sgm_params_t / avdm_refine_params_t::referenceArithmetic, the CLI's
+    # --sgmReferenceArithmetic / --refineReferenceArithmetic): everything on the GPU from the GPU's OWN pyramids against the literal oracle.
+    # "sgm": the SGM sweep alone in the reference's arithmetic (the default Refine kernels); "all": both sweeps.
+    for smode in strict:
+        t1 = time.time()
+        kw = dict(spec["sgm"])
+        sgm_s = abi.SgmParams.default(referenceArithmetic=1, **kw)
+        ref_s = abi.RefineParams.default(referenceArithmetic=1 if smode == "all" else 0)
+        gs = gpu_run(pyr, sc, sgm_s, ref_s, roi, tcs, depths, tb)
+        want_l, second_l = wants["literal"]
+        d = np.abs(o.refine_volume[..., :Zr].astype(np.float32) - gs["refvol"])
+        res["reference_arithmetic_" + smode + "_vs_oracle_literal"] = {
+            "similarity_volume_levels": level_hist(second_l, gs["second"]),
+            "sgm_filtered_volume_levels": level_hist(o.filtered[..., :Z], gs["filtered"]),
+            "sgm_wta_depth_differs": float((o.sgm_depth_sim[..., 0] != gs["sgm"][..., 0]).mean()),
+            "refine_volume_abs": {"identical": float((d == 0).mean()), ">2e-3": float((d > 2e-3).mean()), ">2e-2": float((d > 2e-2).mean()), "max": float(d.max())},
+            "refined_depth": depth_stats(gs["refined"], o.refined, o.sgm_upscaled[..., 1]),
+            "final_depth": depth_stats(gs["final"], want_l, o.sgm_upscaled[..., 1]), "final_sim": sim_stats(gs["final"], want_l), "t_s": time.time() - t1}
     # AVDM_SIM_LITERAL=1: the reference's similarity arithmetic as written, ON THE GPU (csrc/avdm_literal.hip), against the oracle's literal
     # mode on the oracle's own pyramids — what is left when the conditioning of the NCC sums is taken out of the comparison
     if gpu_literal:
@@ -245,13 +281,15 @@ def main():
     ap.add_argument("--literal-cases", default="cfg1,crop2,crop3", help="cases also run with AVDM_SIM_LITERAL=1 on the GPU")
     ap.add_argument("--spread-cases", default="", help="cases also run through oracle/_ref's CUDA-like evaluation (the reference's platform spread)")
     ap.add_argument("--modes", default="well_posed,literal", help="oracle evaluations to compare with (literal last)")
+    ap.add_argument("--strict", default="", help="reference-arithmetic modes of the product to run against the literal oracle: sgm, all (comma separated)")
     a = ap.parse_args()
     out = []
     for name in a.cases.split(","):
         for f in a.filters.split(","):
             mode = abi.FILTER_CUDA_FIXED8 if f == "fixed8" else abi.FILTER_EXACT
             r = run_case(name, CASES[name], mode, with_ref=name in a.ref_cases.split(","), gpu_literal=name in a.literal_cases.split(","),
-                         spread=name in a.spread_cases.split(","), modes=tuple(a.modes.split(",")))
+                         spread=name in a.spread_cases.split(","), modes=tuple(a.modes.split(",")),
+                         strict=tuple(m for m in a.strict.split(",") if m))
             out.append(r)
             print(json.dumps(r), flush=True)
     if a.out:

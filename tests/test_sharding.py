@@ -131,7 +131,8 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] and out["steps"] == 4
     assert out["views_owned_total"] == out["views"] == 3 and out["reference_cameras_total"] == 3  # every view / camera owned exactly once
-    assert len(out["rank0_cameras"]) == 4 and set(out["rank0_cameras"]) == {0, 2}  # rank 0 of 2 owns views 0 and 2
+    # rank 0 of 2 owns views 0 and 2; N > 1 runs the FIXED job: a step = every camera of the workload once, each on its rank (4 steps x 2 cameras)
+    assert len(out["rank0_cameras"]) == 8 and set(out["rank0_cameras"]) == {0, 2} and out["scaling"] == "strong"
     # and the command it becomes is the driver's own
     sys.path.insert(0, root)
     import bench
@@ -166,9 +167,24 @@ def test_fixed_job_accounting(n, per_rank, ceiling):
     assert abs(fj["speedup_ceiling"] - ceiling) < 1e-12
     V = out["views"]
     assert out["views_owned_total"] == V and out["reference_cameras_total"] == V
-    # set-up: one collective per row of N views; nothing after it (3 + 1 steps ran)
+    # set-up: one collective per row of N views; nothing after it
     assert not out["stream_views"] and out["exchange_collectives"] == (0 if n == 1 else (V + n - 1) // n)
-    assert out["tcam_pyramids_checked"] == n * 4 * 10  # every T-camera pyramid a rank swept against was whole and of the right view
+    if n == 1:
+        # one rank: a step = one depth map (the cfg3 shape of the headline), the fixed job stays a priced figure
+        assert out["scaling"] == "weak" and out["measured_fixed_job"] is None and out["tcam_pyramids_checked"] == 4 * 10
+        return
+    # N > 1 (round 6): the bench RUNS the fixed job — a step is the 20 cameras once, each on the rank round-robin deals it to,
+    # K = 3 steps timed barrier to barrier to the slowest rank; `value` = 20 K / that time
+    assert out["scaling"] == "strong"
+    for r in range(n):
+        mine = list(range(r, 20, n))
+        assert out["cameras_done_of_rank"][r] == mine * 3, (r, out["cameras_done_of_rank"][r])
+    mj = out["measured_fixed_job"]
+    assert mj["measured"] and mj["cameras_per_rank"] == per_rank and mj["cameras_of_rank"] == [list(range(r, 20, n)) for r in range(n)]
+    assert abs(mj["makespan_s"] - out["elapsed_s"] / 3) < 1e-12 and abs(out["value"] - 20 * 3 / out["elapsed_s"]) < 1e-9
+    assert abs(mj["depth_maps_per_s"] - out["value"]) < 1e-9 and out["elapsed_s"] >= out["rank0_elapsed_s"]  # MAX over ranks, not rank 0's clock
+    # every T-camera pyramid a rank swept against was whole and of the right view: (1 warm-up + 3 x its cameras) depth maps per rank, 10 T each
+    assert out["tcam_pyramids_checked"] == (n + 3 * 20) * 10
 
 
 def test_streaming_job_runs_one_collective_per_step():
