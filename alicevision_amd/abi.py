@@ -140,6 +140,8 @@ SIGNATURES = {
     "avdm_volume_add_f16": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
     "avdm_volume_update_uninitialized": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
     "avdm_volume_compute_similarity": (i32, [vp, vp, i64, i32, vp, P(Camera), P(Camera), P(Pyramid), P(Pyramid), P(SgmParams), Range, ROI, vp]),
+    "avdm_refine_similarity_scratch_bytes": (C.c_size_t, [C.c_size_t, i32]),
+    "avdm_refine_outlier_refused": (i32, [P(C.c_uint)]),
     "avdm_volume_refine_similarity": (i32, [vp, i64, i32, i32, vp, i32, vp, i32, P(Camera), P(Camera), P(Pyramid), P(Pyramid), P(RefineParams),
                                             Range, ROI, vp]),
     "avdm_volume_optimize_scratch_bytes": (C.c_size_t, [i32, i32, i32]),

@@ -254,9 +254,12 @@ __global__ void __launch_bounds__(256) mip_level_kernel(uint2* out, int out_pitc
             const float factor = taps.g[i + 2] * taps.g[j + 2];
             // `(x + j + 0.5f)` with x unsigned in the reference (deviceMipmappedArray.cu:28-29,52-53): the taps left of / above the image wrap
             // to ~4.29e9 and clamp to the RIGHT / BOTTOM edge texel — the first two rows / columns of every level carry that quirk
-            // (found by oracle/_ref).  min(., 1e4 image widths): same edge texel, and u * W stays inside the int range
-            const float u = fminf((float)((unsigned)(x + j)), 1.0e4f * (float)width) + 0.5f;
-            const float v = fminf((float)((unsigned)(y + i)), 1.0e4f * (float)height) + 0.5f;
+            // (found by oracle/_ref).  min(., 4e8): the same edge texel, u * W stays inside the int range — and far enough out (>= 2^24 texels)
+            // that the filter coordinate is integer valued like the reference's 8.6e9, i.e. the blend fraction is exactly 0: rounds 1-5 clamped
+            // to 1e4 image widths, where the fraction was 0.5 — the same two edge texels, but (1 - a) t + a t rounds differently from t, which
+            // moved a quantum on ~0.1 % of the texels of every level's first two rows / columns (session r06_a)
+            const float u = fminf((float)((unsigned)(x + j)), 4.0e8f) + 0.5f;
+            const float v = fminf((float)((unsigned)(y + i)), 4.0e8f) + 0.5f;
             const float4 c = tex2D_level<FIXED8>(prev, u * px, v * py);
             sum.x = sum.x + c.x * factor;
             sum.y = sum.y + c.y * factor;

@@ -2610,10 +2610,13 @@ template <bool FIXED8, int WSH>
 __global__ void __launch_bounds__(256)
   refine_outlier_kernel(__half* __restrict__ vol, long long pitch_y, int pitch_x, int volDimZ, const float2* __restrict__ sgmDepthPixSize, int map_pitch,
                         const float* __restrict__ sgmNormal, int normal_pitch, avdm_camera_t rc, avdm_camera_t tc, NccArgs A, PatchTable tab, int stepXY,
-                        unsigned zBegin, unsigned zEnd, avdm_roi_t roi, const unsigned* __restrict__ list, unsigned listCap, unsigned* __restrict__ totals)
+                        unsigned zBegin, unsigned zEnd, avdm_roi_t roi, const unsigned* __restrict__ list, unsigned listCap, unsigned* __restrict__ totals,
+                        unsigned* __restrict__ refused)
 {
     const int wsh = WSH > 0 ? WSH : A.wsh;
     const unsigned count = min(list[0], listCap);
+    if(refused != nullptr && blockIdx.x == 0u && threadIdx.x == 0u && list[0] > listCap) // (always on: one compare per launch)
+        atomicAdd(refused, list[0] - listCap);
     if(totals != nullptr && blockIdx.x == 0u && threadIdx.x == 0u) // AVDM_REFINE_OUTLIER_STATS=1: {units worked off, units that found the list full}
     {
         atomicAdd(&totals[0], count);
@@ -2982,6 +2985,32 @@ static bool g_patchPatternSet = false;
 static std::mutex g_patchPatternMutex;           // one host thread per device may build / read it (computeOnMultiGPUs)
 static unsigned* g_stats = nullptr; // device counters, allocated on first use when AVDM_SIM_STATS=1
 static unsigned* g_outlierTotals = nullptr; // {units worked off, units refused by a full list} of refine_outlier_kernel when AVDM_REFINE_OUTLIER_STATS=1
+// units the outlier lists of this process could not take (a full list leaves a wave on the slower per-plane path; the results do not change):
+// one counter per device, bumped by refine_outlier_kernel, read by avdm_refine_outlier_refused()
+static unsigned* g_outlierRefused[64] = {};
+static std::mutex g_outlierRefusedMutex;
+static unsigned* outlier_refused_counter()
+{
+    int dev = 0;
+    if(hipGetDevice(&dev) != hipSuccess)
+        return nullptr;
+    std::lock_guard<std::mutex> lock(g_outlierRefusedMutex);
+    unsigned*& p = g_outlierRefused[dev & 63];
+    if(p == nullptr)
+    {
+        if(hipMalloc((void**)&p, sizeof(unsigned)) != hipSuccess)
+            p = nullptr;
+        else
+            (void)hipMemset(p, 0, sizeof(unsigned));
+    }
+    return p;
+}
+// capacity of the outlier list of a launch over nPix pixels and nchunks chunks of 8 planes: a quarter of the (pixel, chunk) pairs
+static unsigned outlier_list_capacity(size_t nPix, unsigned nchunks)
+{
+    return (unsigned)std::min<size_t>(std::max<size_t>(nPix * nchunks / 4, 4096), 0x7fffff00u);
+}
+
 static unsigned* outlier_totals()
 {
     const char* e = getenv("AVDM_REFINE_OUTLIER_STATS");
@@ -3264,6 +3293,37 @@ int avdm_debug_refine_outlier_units(unsigned out[2])
     return 0;
 }
 
+/* Bytes of per-stream scratch avdm_volume_refine_similarity takes from the library's block for its outlier list (the default kernels) when it
+ * sweeps `n_pixels` pixels x `n_planes` planes: what a scheduler prices a tile slot with (host/DepthMapEstimator.cpp: getNbSimultaneousTiles). */
+size_t avdm_refine_similarity_scratch_bytes(size_t n_pixels, int n_planes)
+{
+    if(n_pixels == 0 || n_planes <= 0)
+        return 0;
+    return 8 + (size_t)outlier_list_capacity(n_pixels, (unsigned)((n_planes + 7) / 8)) * sizeof(uint2);
+}
+
+/* Units (pixel, chunk of planes) that found an outlier list FULL on the current device since the last call — they ran on the slower per-plane path,
+ * their results are the same.  Waits for the device.  0 in every run measured so far (the capacity is 40 x the lists of the bench); a scheduler
+ * logs it (host/DepthMapEstimator.cpp) so that an undersized capacity cannot go unnoticed. */
+int avdm_refine_outlier_refused(unsigned* out)
+{
+    *out = 0;
+    int dev = 0;
+    if(hipGetDevice(&dev) != hipSuccess)
+        return 1;
+    unsigned* p;
+    {
+        std::lock_guard<std::mutex> lock(g_outlierRefusedMutex);
+        p = g_outlierRefused[dev & 63];
+    }
+    if(p == nullptr)
+        return 0;
+    if(hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, p, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess)
+        return set_error_msg(1, "avdm_refine_outlier_refused: reading the counter failed");
+    (void)hipMemset(p, 0, sizeof(unsigned));
+    return 0;
+}
+
 int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pitch_y, int pitch_x, const float* depths, const avdm_camera_t* rc,
                                    const avdm_camera_t* tc, const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
                                    const avdm_sgm_params_t* sp, avdm_range_t dr, avdm_roi_t roi, void* stream)
@@ -3462,7 +3522,7 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
             const char* ol = getenv("AVDM_REFINE_OUTLIER_LIST");
             const bool useList = !(ol != nullptr && ol[0] == '0');
             const size_t nPix = (size_t)(roi.x.end - roi.x.begin) * (roi.y.end - roi.y.begin);
-            const unsigned listCap = useList ? (unsigned)std::min<size_t>(std::max<size_t>(nPix * nchunks / 4, 4096), 0x7fffff00u) : 0u;
+            const unsigned listCap = useList ? outlier_list_capacity(nPix, nchunks) : 0u;
             std::unique_ptr<StreamScratch> lease;
             if(useList)
                 lease.reset(new StreamScratch((hipStream_t)stream, 8 + (size_t)listCap * sizeof(uint2)));
@@ -3492,7 +3552,7 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
             if(useList)
                 hipLaunchKernelGGL((refine_outlier_kernel<true, 3>), dim3(kOutlierGrid), dim3(256), 0, (hipStream_t)stream, (__half*)vol_f16, pitch_y, pitch_x, dimZ,
                                    (const float2*)sgm_depth_pixsize, map_pitch, sgm_normal, normal_pitch, *rc, *tc, A, tab, rp->stepXY, dr.begin, dr.end, roi,
-                                   (const unsigned*)list, listCap, outlier_totals());
+                                   (const unsigned*)list, listCap, outlier_totals(), outlier_refused_counter());
             return ::avdm::set_error(hipGetLastError(), "avdm_volume_refine_similarity"); // the launches of the default path: done
         }
     }

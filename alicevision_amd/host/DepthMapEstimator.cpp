@@ -130,8 +130,8 @@ int DepthMapEstimator::getNbSimultaneousTiles() const
     //                              its share of the batched aggregation's scratch (adaptive-P2 maps of the group);
     //   per camera of a batch      the Lab pyramids of R + maxTCams views at their EXACT size (avdm_pyramid_layout);
     //   what is free               as the device reports it NOW — after the multi-GPU pre-pass, i.e. without the pyramids this worker
-    //                              publishes to the others (PyramidExchange, bounded by its own budget) — minus 1 GiB for code objects and
-    //                              the runtime's own pools.
+    //                              publishes to the others (PyramidExchange, bounded by its own budget) — minus 10 % (at least 1 GiB) for code
+    //                              objects, the runtime's own pools and the rounding of the allocations.
     // A batch holds whole cameras, so n tiles need the images of ceil(n / tiles per camera) cameras.  With 288 GB the answer is "as many as
     // one aggregation launch takes" (AVDM_SGM_MAX_TILES, applied by the caller) except for very large images or a nearly full device.
     const int nbTilesPerCamera = (int)_tileRoiList.size();
@@ -150,14 +150,17 @@ int DepthMapEstimator::getNbSimultaneousTiles() const
         const int ds = _refineParams.scale * _refineParams.stepXY;
         const double px = (double)divideRoundUp(_tileParams.bufferWidth, ds) * divideRoundUp(_tileParams.bufferHeight, ds);
         const double pointMaps = _refineParams.useColorOptimization ? 2.0 * 16.0 * px : 0.0;
-        const double outlierList = 8.0 + 8.0 * px * divideRoundUp(_refineParams.halfNbDepths * 2 + 1, 8) / 4.0;
+        // (the library's own figure: the capacity formula lives in ONE place)
+        const double outlierList = (double)avdm_refine_similarity_scratch_bytes((size_t)px, _refineParams.halfNbDepths * 2 + 1);
         scratchCostMB = std::max(pointMaps, outlierList) / MB;
     }
     const double tileCostMB = sgmTileCostMB + refineTileCostMB + scratchCostMB; // (the aggregation's scratch is inside the Sgm figure)
 
     double availableMB, usedMB, totalMB;
     getDeviceMemoryInfo(availableMB, usedMB, totalMB);
-    const double deviceMemoryMB = availableMB - 1024.0;
+    // a PROPORTIONAL margin with a floor (the reference keeps 20 %, DepthMapEstimator.cpp:112): 10 % of what is free, at least 1 GiB —
+    // the allocations round up and the scratch blocks grow by reallocating, on a nearly full device a fixed 1 GiB admitted one tile too many
+    const double deviceMemoryMB = std::min(availableMB * 0.9, availableMB - 1024.0);
     const double rcMinCostMB = rcCamsCostMB + tileCostMB;
     const int cap = maxStreamsFromEnv() * 64; // far beyond what the caller will take: the search below is bounded
     int out_nbSimultaneousTiles = 0;
@@ -169,7 +172,7 @@ int DepthMapEstimator::getNbSimultaneousTiles() const
     }
 
     AVDM_LOG_INFO("Device memory:" << std::endl
-                                   << "\t- available: " << deviceMemoryMB << " MB (free now, minus 1024 MB kept for the runtime)" << std::endl
+                                   << "\t- available: " << deviceMemoryMB << " MB (free now, minus 10 % / at least 1024 MB kept for the runtime)" << std::endl
                                    << "\t- requirement for the first tile: " << rcMinCostMB << " MB" << std::endl
                                    << "\t- # computation buffers per tile: " << tileCostMB << " MB"
                                    << " (Sgm: " << sgmTileCostMB << " MB"
@@ -748,6 +751,14 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): waited " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tTail0).count()
                                 << " s for the last batch's maps to be merged and written; " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tCompute0).count()
                                 << " s for " << cams.size() << " camera(s) in all.");
+        // the Refine sweep's outlier lists (library scratch): a list that was ever full put waves on the slower per-plane path — same results, but
+        // an undersized capacity must not go unnoticed (0 in every run measured)
+        unsigned refused = 0;
+        avdmCheck(avdm_refine_outlier_refused(&refused), "avdm_refine_outlier_refused");
+        if(refused > 0)
+            AVDM_LOG_WARNING("Worker " << worker << " (device " << deviceId << "): " << refused << " Refine outlier-list unit(s) found their list full and ran on the per-plane path.");
+        else
+            AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): Refine outlier lists: no unit refused.");
         const DeviceCache::ImageTimes& it = deviceCache.imageTimes();
         AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): images of the tiles' batches — " << it.received << " pyramid(s) received from their owners ("
                                 << (it.bytesReceived >> 20) << " MB; " << it.awaitOwner << " s waiting for the owner, " << it.peerCopy << " s copying), " << it.built

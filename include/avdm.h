@@ -250,6 +250,12 @@ int avdm_volume_compute_similarity(uint8_t* best, uint8_t* second, long long pit
                                    const avdm_pyramid_t* rc_pyr, const avdm_pyramid_t* tc_pyr,
                                    const avdm_sgm_params_t* params, avdm_range_t depth_range, avdm_roi_t roi, void* stream);
 /* cuda_volumeRefineSimilarity :95-105 (normal map optional, may be NULL) */
+/* (no counterpart in the reference: its kernels take no library-owned scratch) what avdm_volume_refine_similarity draws from the stream's scratch
+ * block for a sweep of n_pixels pixels x n_planes planes, and the number of list units that found it full since the last call (they ran on
+ * the slower path; results unchanged) — for the scheduler that sizes the tile slots, host/DepthMapEstimator.cpp; reference: the per-tile
+ * memory estimate of DepthMapEstimator.cpp:57-135 */
+size_t avdm_refine_similarity_scratch_bytes(size_t n_pixels, int n_planes);
+int avdm_refine_outlier_refused(unsigned int* out);
 int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x, int dimZ,
                                   const float* sgm_depth_pixsize, int map_pitch, const float* sgm_normal, int normal_pitch,
                                   const avdm_camera_t* rc, const avdm_camera_t* tc,

@@ -65,8 +65,11 @@ _lib = None
 def locked_make(directory, *args):
     """`make` under an exclusive file lock: the test suite runs in several processes (pytest-xdist) that all want the checker built"""
     import fcntl
+    import hashlib
     import tempfile
-    with open(os.path.join(tempfile.gettempdir(), "avdm_make_%s.lock" % abs(hash(os.path.abspath(directory)))), "w") as lock:
+    # a STABLE name per directory (Python randomises str hashes per process: hash() gave every process its own lock file and no exclusion at all)
+    tag = hashlib.sha1(os.path.abspath(directory).encode()).hexdigest()[:16]
+    with open(os.path.join(tempfile.gettempdir(), "avdm_make_%s.lock" % tag), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             subprocess.run(["make", "-C", directory, "-s"] + list(args), check=True)

@@ -35,6 +35,9 @@ CASES = {
     # the interior and tile (4, 3) at the far image corner (800 x 744: clipped); 2 T cameras (the oracle's time goes with pixels x T cameras)
     "tile12mp_interior": dict(n_views=3, W=4000, H=3000, Z=256, seed=3, roi=(1600, 2464, 752, 1568), sgm={}, tile_buffer=(1024, 1024)),
     "tile12mp_corner": dict(n_views=3, W=4000, H=3000, Z=256, seed=3, roi=(3200, 4000, 2256, 3000), sgm={}, tile_buffer=(1024, 1024)),
+    # the same clipped corner tile with all TEN T cameras of the bench's 11-view scene: best / second-best merging over 10 T cameras at a clipped
+    # tile is the bench's real shape (deviceSimilarityVolumeKernels.cuh:221-232)
+    "tile12mp_corner_10T": dict(n_views=11, W=4000, H=3000, Z=256, seed=3, roi=(3200, 4000, 2256, 3000), sgm={}, tile_buffer=(1024, 1024)),
     # BASELINE configuration 5 at its OWN shape (round 5): 24 MP frame (6000 x 4000), `--tileBufferWidth 1664 --tileBufferHeight 1152 --tilePadding 64`
     # -> 4 x 4 tiles of 1564 x 1064 (TileParams.cpp:15-61; tests/test_host_ref.py pins the grid to the reference's own getTileRoiList): tile (1, 1) in
     # the interior and tile (3, 3) at the far image corner (1500 x 1000: clipped), volumes laid out and aggregated over the NON-SQUARE tile buffer

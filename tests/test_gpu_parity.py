@@ -1,10 +1,10 @@
 """GPU parity tests (run with `-m gpu` on an MI355X): every HIP stage against the CPU oracle through the C ABI.
 
 Parity classes:
-  bit-exact   : SGM path aggregation, WTA depth retrieval, thickness smoothing, SGM upscale, Refine sub-sample arg-min,
-                volume init / update — compared with == on identical inputs;
-  tolerance   : image pyramid (cbrt / exp in different libms, FMA contraction), similarity volumes (fast intrinsics,
-                homogeneous patch projection), Refine volume, colour optimisation — tolerances stated in each test.
+  bit-exact   : image pyramid (round 6), SGM path aggregation, WTA depth retrieval, thickness smoothing, SGM upscale, Refine sub-sample
+                arg-min, volume init / update, and — in the product's reference-arithmetic mode — both similarity volumes: compared with ==;
+  tolerance   : the DEFAULT similarity volumes (fast intrinsics, homogeneous patch projection, shifted sums), the default Refine volume,
+                colour optimisation — tolerances stated in each test.
 """
 import ctypes as C
 import os
@@ -71,10 +71,10 @@ def test_pyramid_parity(mode):
         a = hp.level(l).astype(np.float32)
         b = dp.level(l).cpu().numpy().astype(np.float32)
         assert a.shape == b.shape
-        # fp16 storage: values < 256 have a quantum <= 0.125; allow one quantum on <= 2 % of texels (flips accumulate over levels) (libm cbrtf / FMA differences)
-        diff = np.abs(a - b)
-        assert diff.max() <= 0.13, (l, diff.max())
-        assert (diff > 0).mean() <= 5e-2, (l, (diff > 0).mean())
+        # BIT-EXACT since round 6 (rounds 1-5: one fp16 quantum on 1-5 % of the texels): the cube root of xyz2lab is the pinned build's C library
+        # restated for the device (csrc/avdm_libm.h, held to glibc on the CPU by tests/test_libm.py), avdm_image.hip is compiled without FMA
+        # contraction, and the wrapped taps of the level kernel keep a zero blend fraction like the reference's (session r06_a)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (l, float(np.abs(a - b).max()), float((a != b).mean()))
 
 
 @pytest.mark.parametrize("w,h,s", [(64, 48, 2), (67, 45, 2), (101, 77, 3), (256, 192, 4), (33, 21, 1)])
@@ -264,6 +264,65 @@ def test_similarity_volume_parity(mode):
     frac32, _ = level_mismatch(second32_in, second_h_in)
     assert floor > 0.05, floor  # the conditioning problem is real (otherwise tighten this test)
     assert frac32 <= 1.25 * floor + 0.03, (frac32, floor)
+
+
+@pytest.mark.parametrize("mode", [abi.FILTER_CUDA_FIXED8, abi.FILTER_EXACT])
+@pytest.mark.parametrize("wsh", [4, 2])
+def test_reference_arithmetic_sgm_volume_equals_the_oracle_bit_for_bit(mode, wsh):
+    """avdm_sgm_params_t::referenceArithmetic (strict_sgm_kernel, csrc/avdm_literal.hip): the reference's arithmetic as written, taps from LDS
+    windows used as a cache, expf to the bits of the pinned build's C library — the best / second-best volumes over two T cameras with ragged
+    plane ranges equal the oracle's literal evaluation (= the reference's own kernels compiled for the CPU, tests/test_oracle_ref.py) BYTE FOR BYTE,
+    both filter modes, the default patch (unrolled sample loop) and another one, and the windows change no bit (AVDM_STRICT_WINDOWS=0: every tap
+    from global memory)."""
+    torch = _torch()
+    sc, sgm, ref, depths = small_case()
+    sgm.wsh = wsh
+    Z = len(depths)
+    rng_t = [(0, 32), (3, 29)]
+    o = make_oracle(sc, sgm, ref, filter_mode=mode)
+    o.run_sgm(0, [1, 2], depths, tc_ranges=rng_t, optimize=False)
+    want_best, want_second = o.best_raw[..., :Z].copy(), o.second[..., :Z].copy()
+    sgm_s = abi.SgmParams.default(wsh=wsh, referenceArithmetic=1)
+    got = {}
+    for win in ("1", "0"):
+        os.environ["AVDM_STRICT_WINDOWS"] = win
+        try:
+            h = make_hip_from_oracle(o, sc, sgm_s, ref)
+            h.run_sgm(0, [1, 2], depths, tc_ranges=rng_t, optimize=False, keep_raw=True)
+            torch.cuda.synchronize()
+            got[win] = (h.best_raw.cpu().numpy()[..., :Z].copy(), h.second.cpu().numpy()[..., :Z].copy())
+        finally:
+            os.environ.pop("AVDM_STRICT_WINDOWS", None)
+    for win in ("1", "0"):
+        assert np.array_equal(got[win][0], want_best), (win, float((got[win][0] != want_best).mean()))
+        assert np.array_equal(got[win][1], want_second), (win, float((got[win][1] != want_second).mean()))
+    assert (want_second != 255).mean() > 0.5  # (the comparison is not one of empty volumes)
+
+
+def test_reference_arithmetic_refine_volume_equals_the_oracle_bit_for_bit(case):
+    """avdm_refine_params_t::referenceArithmetic (strict_refine_kernel): the fp16 Refine volume — the sum over two T cameras of the sigmoid-filtered
+    similarities, accumulated in the reference's order — equals the literal oracle's on the same SGM map, every half; with and without the windows"""
+    torch = _torch()
+    sc, sgm, ref, depths, o = case
+    o2 = make_oracle(sc, sgm, ref)
+    o2.sgm_depth_thickness = o.sgm_depth_thickness.copy()
+    o2.run_refine(0, [1, 2], optimize_enabled=False)
+    Zr = ref.halfNbDepths * 2 + 1
+    want = o2.refine_volume[..., :Zr]
+    ref_s = abi.RefineParams.default(referenceArithmetic=1)
+    for win in ("1", "0"):
+        os.environ["AVDM_STRICT_WINDOWS"] = win
+        try:
+            h = make_hip_from_oracle(o, sc, sgm, ref_s)
+            h._alloc(len(depths))
+            h.sgm_depth_thickness.copy_(torch.from_numpy(o.sgm_depth_thickness))
+            h.run_refine(0, [1, 2], optimize_enabled=False)
+            torch.cuda.synchronize()
+            got = h.refine_volume.cpu().numpy()[..., :Zr]
+        finally:
+            os.environ.pop("AVDM_STRICT_WINDOWS", None)
+        assert np.array_equal(got.view(np.uint16), np.ascontiguousarray(want).view(np.uint16)), (win, float((got != want).mean()), float(np.abs(got.astype(np.float32) - want.astype(np.float32)).max()))
+    assert (want != 0).mean() > 0.5
 
 
 @pytest.mark.parametrize("X,Y,Z", [(37, 29, 20), (64, 48, 33), (5, 3, 256)])
@@ -1387,6 +1446,8 @@ def test_full_size_cfg2_sweep_only_properties():
 _PARITY_CACHE = {}
 # cases that also go through the reference's CUDA-like evaluation (its platform spread) and the literal kernel's per-deviation switches
 _ATTRIBUTED = ("cfg1", "crop3")
+# cases held against the LITERAL oracle (= the reference's own code) only
+_LITERAL_ONLY = ("tile24mp_interior", "tile24mp_corner", "tile12mp_corner_10T", "crop3_corner", "crop3_far_corner")
 
 
 def _parity_case(name):
@@ -1404,9 +1465,11 @@ def _parity_case(name):
         # (the 24 MP tile: against the literal evaluation — the reference's own arithmetic — only; its 1.5 M pixels cost the oracle over a minute
         # per evaluation, and the driver's limit for this suite is 20 minutes.  scripts/parity_report.py takes both evaluations and the interior
         # tile in a session of its own: profiles/r05_*_parity_tile24mp_*.json)
+        # (round 6: the corner crops and the ten-T-camera tile too — the suite's time is the oracle's, and the well-posed evaluation of the same
+        # geometry is held by crop3 / tile12mp_*; every case also runs the product's reference-arithmetic mode, which costs no oracle time)
         _PARITY_CACHE[name] = parity_report.run_case(name, parity_report.CASES[name], abi.FILTER_CUDA_FIXED8, with_ref=False, gpu_literal=True, spread=attributed,
                                                      deviations=tuple(parity_report.DEVIATIONS) if attributed else (),
-                                                     modes=("literal",) if name.startswith("tile24mp") else ("well_posed", "literal"))
+                                                     modes=("literal",) if name in _LITERAL_ONLY else ("well_posed", "literal"), strict=("sgm", "all"))
         d = os.environ.get("AVDM_PARITY_DUMP")
         if d:
             os.makedirs(d, exist_ok=True)
@@ -1424,6 +1487,30 @@ def _assert_literal_on_gpu(gl):
     assert gl["final_depth"]["validity_differs"] < 1e-3
     lv = gl["similarity_volume_levels"]
     assert lv["0"] > 0.97 and lv["2"] + lv["3+"] < 3e-3 and lv["validity_differs"] < 1e-3, lv
+
+
+def _assert_reference_arithmetic(r, final_bar=1e-4):
+    """THE PARITY MODE OF THE PRODUCT (round 6; avdm_sgm_params_t / avdm_refine_params_t::referenceArithmetic, the CLI's --sgmReferenceArithmetic /
+    --refineReferenceArithmetic), everything on the GPU FROM THE GPU'S OWN PYRAMIDS against the literal oracle = the reference's own kernels and host
+    classes compiled for the CPU (tests/test_oracle_ref.py), NO trimming:
+      * the Lab pyramids equal the oracle's texel for texel (glibc's cbrtf restated for the device, no contraction);
+      * the SGM sweep in the reference's arithmetic (strict_sgm_kernel: every operation of compNCCby3DptsYK in its order, expf to the bits of the pinned
+        build's C library): the similarity volume, the aggregated volume and the winner-take-all depths are IDENTICAL to the reference's — every byte;
+        with the default Refine kernels the final depth map is inside BASELINE's bar (< 1e-3) on every case, the tiles of DESIGN.md section 2 included;
+      * both sweeps in the reference's arithmetic: the Refine volume and the refined map are identical too; what is left is the colour optimisation
+        (tolerance class: acosf / expf of the device library), < 1e-4 untrimmed."""
+    assert r["pyramid_texels_differing"]["max_over_levels"] == 0.0, r["pyramid_texels_differing"]
+    for key in ("reference_arithmetic_sgm_vs_oracle_literal", "reference_arithmetic_all_vs_oracle_literal"):
+        m = r[key]
+        assert m["similarity_volume_levels"]["0"] == 1.0 and m["sgm_filtered_volume_levels"]["0"] == 1.0 and m["sgm_wta_depth_differs"] == 0.0, (key, m)
+        assert m["final_depth"]["validity_differs"] == 0.0, (key, m["final_depth"])
+    sgm_only, both = r["reference_arithmetic_sgm_vs_oracle_literal"], r["reference_arithmetic_all_vs_oracle_literal"]
+    assert sgm_only["final_depth"]["rmse_untrimmed"] < 1e-3, sgm_only["final_depth"]  # BASELINE's bar, untrimmed, the default Refine kernels
+    assert both["refine_volume_abs"]["identical"] == 1.0, both["refine_volume_abs"]
+    assert both["refined_depth"]["max_abs"] == 0.0, both["refined_depth"]
+    assert both["final_depth"]["rmse_untrimmed"] < final_bar, both["final_depth"]
+    # the similarity channel as the program writes it (one half per pixel, mapIO.cpp:403-540)
+    assert both["final_sim"]["identical_halfs"] > 0.9 and both["final_sim"]["max_abs"] < 2e-2, both["final_sim"]
 
 
 def test_parity_table_cfg1():
@@ -1451,6 +1538,7 @@ def test_parity_table_cfg1():
     g = lit["median_abs_vs_ground_truth"]
     assert g["gpu"] <= 1.02 * g["oracle"] + 1e-6, g
     _assert_literal_on_gpu(r["gpu_literal_vs_oracle_literal"])
+    _assert_reference_arithmetic(r)
 
 
 @pytest.mark.parametrize("name", ["crop2", "crop3"])
@@ -1469,9 +1557,10 @@ def test_parity_table_crops_of_the_full_size_geometry(name):
     lv = wp["similarity_volume_levels"]
     assert lv["2"] + lv["3+"] < 2e-3 and lv["1"] < 0.05 and lv["validity_differs"] < 1e-3, lv
     _assert_literal_on_gpu(r["gpu_literal_vs_oracle_literal"])
+    _assert_reference_arithmetic(r)
 
 
-@pytest.mark.parametrize("name", ["crop3_corner", "crop3_far_corner", "crop3_10T"])
+@pytest.mark.parametrize("name", ["crop3_corner", "crop3_far_corner"])
 def test_parity_at_the_real_shape_of_cfg3(name):
     """BASELINE's configuration 3 at its REAL shape: the image corners of the 4000 x 3000 frame — border rejection
     (Patch.cuh:486-496) and clamp addressing inside the tile — and all TEN T cameras of the 11-view scene bench.py runs, the outer rings
@@ -1481,17 +1570,16 @@ def test_parity_at_the_real_shape_of_cfg3(name):
     reference's re-projection (literal mode) — the default kernels test the exact pixel (DESIGN.md "knife-edge rows") — so the validity masks
     may differ on those rows against the literal oracle (two of 128 SGM columns / rows), not against the well-posed one."""
     r = _parity_case(name)
-    wp, lit = r["well_posed"], r["literal"]
+    lit = r["literal"]  # (round 6: against the reference's own arithmetic only — the ten-T-camera crop of rounds 4-5 became the ten-T-camera TILE below)
     corner = "corner" in name
-    for key, m in (("well_posed", wp), ("literal", lit)):
+    for key, m in (("literal", lit),):
         assert m["final_depth"]["rmse_untrimmed"] < 1e-3, (key, m["final_depth"])
         assert m["final_depth"]["validity_differs"] < (0.03 if corner and key == "literal" else 1e-3), (key, m["final_depth"])
         g = m["median_abs_vs_ground_truth"]
         assert g["gpu"] <= 1.02 * g["oracle"] + 1e-6, (key, g)
-    lv = wp["similarity_volume_levels"]
-    assert lv["2"] + lv["3+"] < 3e-3 and lv["1"] < 0.06 and lv["validity_differs"] < 1e-3, lv
     gl = r["gpu_literal_vs_oracle_literal"]
     assert gl["final_depth"]["rmse_untrimmed"] < 1e-3, gl["final_depth"]
+    _assert_reference_arithmetic(r)
     # the knife-edge rows of the SGM stage (crop3_corner: stage column / row 3): the default kernels evaluate the reference's own border test
     # there (avdm_similarity.hip lit::) — the validity of EVERY voxel of the similarity volume equals the reference code's (1.2 % of the
     # voxels differed in rounds 1-3, when the kernels tested the exact pixel)
@@ -1511,6 +1599,8 @@ def test_parity_of_default_tiles_at_12mp(name):
         # the corner tile against the LITERAL oracle: 1.24e-3 untrimmed, 1.3e-4 over the best 99.5 %, identical validity masks, the literal
         # arithmetic on the GPU at 6.6e-5.  Located oracle against oracle on the CPU: TWO SGM pixels of 43 000 whose winner-take-all plane flips
         # between near-equal minima 30 planes apart — 36 full-size pixels carry the excess, 2.0e-4 without them
+        # (KNOWN GAP of the default mode on the corner tile, a regression guard and not the bar: BASELINE's bar is asserted for this tile in the
+        # reference-arithmetic mode below)
         bar = 2e-3 if corner and key == "literal" else 1e-3
         assert m["final_depth"]["rmse_untrimmed"] < bar, (key, m["final_depth"])
         assert m["final_depth"]["rmse_best_99.5pct"] < 3e-4, (key, m["final_depth"])
@@ -1519,27 +1609,42 @@ def test_parity_of_default_tiles_at_12mp(name):
     assert lv["2"] + lv["3+"] < 3e-3 and lv["1"] < 0.06 and lv["validity_differs"] < 1e-3, lv
     gl = r["gpu_literal_vs_oracle_literal"]
     assert gl["final_depth"]["rmse_untrimmed"] < 1e-3 and gl["final_depth"]["validity_differs"] < 1e-3, gl["final_depth"]
+    # ... and in the product's reference-arithmetic mode the corner tile is where every other is: identical volumes, 7.5e-5 / 1.9e-5 (session r06_a)
+    _assert_reference_arithmetic(r)
 
 
-def test_parity_of_a_cfg5_tile_at_24mp():
-    """BASELINE configuration 5 at its OWN shape (VERDICT r4): a 24 MP frame (6000 x 4000) cut by `--tileBufferWidth 1664 --tileBufferHeight 1152
-    --tilePadding 64` into 4 x 4 tiles of 1564 x 1064 (mvsUtils/TileParams.cpp:15-61; the grid is pinned to the reference's own getTileRoiList by
-    tests/test_host_ref.py) — here tile (3, 3), clipped at the far image corner (1500 x 1000) — laid out and aggregated over the NON-SQUARE tile
-    buffer like the reference (deviceSimilarityVolume.cu:278-283: 416 x 288 SGM columns / rows, another extent and another LDS-window regime than
-    the 1024 x 1024 buffer of the 12 MP tiles): 256 planes, 2 T cameras, everything on the GPU against the oracle's LITERAL evaluation (= the
-    reference's kernels and host classes compiled for the CPU, bit for bit), NO trimming.  (Both evaluations, the interior tile and the
-    reference's own spread of these tiles: scripts/parity_report.py in a session of its own, profiles/r05_*_parity_tile24mp_*.json.)"""
-    r = _parity_case("tile24mp_corner")
+def test_parity_of_the_ten_t_camera_corner_tile_at_12mp():
+    """The clipped corner tile of the default 12 MP tiling with all TEN T cameras of the bench's 11-view scene: best / second-best
+    merging over ten sweeps (deviceSimilarityVolumeKernels.cuh:221-232) at a clipped tile is the bench's real shape.  Against the literal oracle
+    (= the reference's own code), NO trimming: the default kernels inside BASELINE's bar, the reference-arithmetic mode identical volume for volume."""
+    r = _parity_case("tile12mp_corner_10T")
     lit = r["literal"]
-    # MEASURED (session r05_c, both evaluations, profiles/r05_c_parity_tile24mp_*.json): this tile 9.4e-4 against the literal oracle (3.8e-5
-    # against the well-posed one), the interior tile (1, 1) 1.06e-3 (2.9e-5) — AT BASELINE's bar, not under it.  At 24 MP the synthetic texture
-    # is stretched over twice the pixels: low-contrast patches, whose weighted variance the reference forms as a difference of fp32 sums of
-    # ~5e6 — its literal evaluation agrees with its own exact value on 24 % of the voxels only (37-57 % at 12 MP) and is itself 1.1e-3 from
-    # the well-posed evaluation on this tile, oracle against oracle; the reference's CUDA-like evaluation, which shares the unshifted sums,
-    # stays at 1.1e-4 from the literal one.  The literal arithmetic on the GPU (AVDM_SIM_LITERAL=1) reproduces the literal oracle to 2.9e-5.
-    # The assertion keeps a margin over the measured value; DESIGN.md section 2 reports the figures as they are.
-    assert lit["final_depth"]["rmse_untrimmed"] < 1.5e-3, lit["final_depth"]
-    assert lit["final_depth"]["rmse_untrimmed_relative"] < 3.5e-4, lit["final_depth"]  # the same without the scene's scale (depth ~ 4.5)
+    assert lit["final_depth"]["rmse_untrimmed"] < 1e-3, lit["final_depth"]
+    assert lit["final_depth"]["rmse_best_99.5pct"] < 3e-4 and lit["final_depth"]["validity_differs"] < 0.03, lit["final_depth"]
+    assert lit["similarity_volume_levels"]["validity_differs"] < 1e-3, lit["similarity_volume_levels"]
+    _assert_reference_arithmetic(r)
+
+
+@pytest.mark.parametrize("name", ["tile24mp_interior", "tile24mp_corner"])
+def test_parity_of_the_cfg5_tiles_at_24mp(name):
+    """BASELINE configuration 5 at its OWN shape (VERDICT r4, r5): a 24 MP frame (6000 x 4000) cut by `--tileBufferWidth 1664 --tileBufferHeight 1152
+    --tilePadding 64` into 4 x 4 tiles of 1564 x 1064 (mvsUtils/TileParams.cpp:15-61; the grid is pinned to the reference's own getTileRoiList by
+    tests/test_host_ref.py) — tile (1, 1) in the interior and tile (3, 3), clipped at the far image corner (1500 x 1000) — laid out and aggregated
+    over the NON-SQUARE tile buffer like the reference (deviceSimilarityVolume.cu:278-283: 416 x 288 SGM columns / rows): 256 planes, 2 T cameras,
+    everything on the GPU against the oracle's LITERAL evaluation (= the reference's kernels and host classes compiled for the CPU, bit for bit), NO
+    trimming.
+
+    BASELINE's bar (< 1e-3) is asserted in the product's REFERENCE-ARITHMETIC mode, where these tiles equal the reference volume for volume
+    (session r06_a: 4.2e-5 / 4.7e-5 with the SGM sweep alone in that mode, 8e-6 / 1.3e-5 with both sweeps).
+
+    KNOWN GAP OF THE DEFAULT (fast) MODE, stated as what it is: against the literal evaluation these two tiles measure 1.06e-3 / 9.4e-4 (rounds 5-6;
+    2.9e-5 / 3.8e-5 against the well-posed evaluation of the same formulas) — a handful of SGM pixels (0.1 %) whose winner-take-all plane flips
+    between two near-equal minima, because the reference forms its weighted variance as a difference of fp32 sums of ~5e6 and the default kernels
+    do not.  The default mode's assertion below is a regression guard at the measured value + margin, NOT the bar."""
+    r = _parity_case(name)
+    _assert_reference_arithmetic(r)
+    lit = r["literal"]
+    assert lit["final_depth"]["rmse_untrimmed"] < 1.5e-3, lit["final_depth"]            # known gap of the default mode: 1.06e-3 / 9.4e-4 measured
     assert lit["final_depth"]["rmse_best_99.5pct"] < 3e-4, lit["final_depth"]
     assert lit["final_depth"]["validity_differs"] < 0.03, lit["final_depth"]
     assert lit["similarity_volume_levels"]["validity_differs"] < 1e-3, lit["similarity_volume_levels"]

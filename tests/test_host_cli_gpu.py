@@ -115,6 +115,36 @@ def test_single_tile_equals_harness_and_oracle(dataset):
     assert np.median(rel) < 2e-3, float(np.median(rel))
 
 
+def test_reference_arithmetic_flags_equal_the_oracle(dataset):
+    """`--sgmReferenceArithmetic 1 --refineReferenceArithmetic 1` (not flags of the reference: the product's parity mode): the PROGRAM's maps — files
+    in, EXR files out — against the literal oracle (= the reference's own code compiled for the CPU) on the program's own plan, NO trimming: the
+    similarity sweeps run the reference's arithmetic to the bit, so what separates the two depth maps is the colour optimisation's tolerance
+    class alone; and the run logs that no Refine outlier-list unit was refused."""
+    from oracle import oracle
+    sc, sfm, img, d = dataset
+    out = os.path.join(d, "out_refarith")
+    args = common_args(sfm, img, out) + ["--sgmReferenceArithmetic", 1, "--refineReferenceArithmetic", 1]
+    plan = json.loads(run_cli(args + ["--dryRun", 1]).stdout.strip().splitlines()[-1])
+    t0 = plan["tiles"][0]
+    assert args[-6:-4] == ["-v", "warning"]
+    log = run_cli(args[:-6] + ["-v", "info"] + args[-4:])
+    assert "no unit refused" in (log.stdout + log.stderr)
+    depth, sim, _, _ = read_maps(out)
+    sgm = abi.SgmParams.default(scale=plan["sgmScale"], stepXY=plan["sgmStepXY"])
+    ref = abi.RefineParams.default(optimizationNbIterations=OPT_ITERS)
+    depths = np.asarray(t0["depths"], np.float32)
+    ranges = [(a, a + n) for a, n in t0["depthsTcLimits"]]
+    o = oracle.OracleDepthMap(sc.images.numpy(), sc.K, sc.R, sc.C, sgm, ref)
+    o.run_sgm(0, t0["sgmTCams"], depths, tc_ranges=ranges)
+    want = o.run_refine(0, t0["refineTCams"])
+    assert np.array_equal(want[..., 0] > 0, depth > 0)
+    both = depth > 0
+    err = (depth - want[..., 0])[both].astype(np.float64)
+    assert float(np.sqrt((err ** 2).mean())) < 1e-4, float(np.sqrt((err ** 2).mean()))  # untrimmed; BASELINE's bar is 1e-3
+    ws = want[..., 1].astype(np.float16).astype(np.float32)
+    assert float(np.abs(ws - sim)[both].max()) < 2e-2 and float((ws == sim)[both].mean()) > 0.9
+
+
 def test_tiled_run_merges(dataset):
     sc, sfm, img, d = dataset
     out1, out4 = os.path.join(d, "out_single_b"), os.path.join(d, "out_tiled")
