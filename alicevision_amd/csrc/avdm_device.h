@@ -185,6 +185,10 @@ __device__ __forceinline__ float4 unpack_h4(uint2 t)
 }
 __device__ __forceinline__ uint2 pack_h4(float4 c)
 {
+    // The four values are fp32 RESULTS, rounded as such, before they are rounded to fp16 — like the reference's `__float2half(x * k)`.  Without
+    // the fence the compiler folds a producing multiplication into the conversion (v_fma_mixlo_f16: ONE rounding of the exact product), which
+    // moved the last bit of ~0.1 % of the texels of the Lab pyramid against the reference's (found in session r06_b by the ISA of rgb2lab_kernel).
+    asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
     const __half2 lo = __floats2half2_rn(c.x, c.y);
     const __half2 hi = __floats2half2_rn(c.z, c.w);
     uint2 r;

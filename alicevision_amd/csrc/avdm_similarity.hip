@@ -69,6 +69,9 @@ constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: ch
 #ifndef AVDM_REFINE_OCTO_PARTIAL
 #define AVDM_REFINE_OCTO_PARTIAL 1 // Refine: a chunk that only overlaps the plane range (the last 7 of the default 31 planes) through the eight-plane pass too,
 #endif                             // its planes outside as invalid planes of the pass: 267.1 against 271.6 ms per depth map (session r05_a); 0 = two four-plane passes
+#ifndef AVDM_OUTLIER_UNROLL
+#define AVDM_OUTLIER_UNROLL 4 // refine_outlier_kernel: samples of a patch row whose global-memory taps are in flight together (session r06_c, Refine sweep over the 11 cameras: 1 -> 240.6 ms with the library sigmoid, 7 -> 237.2, 4 -> 236.6 ms with the fast one)
+#endif
 #ifndef AVDM_REFINE_ANCHORED_WINDOW
 #define AVDM_REFINE_ANCHORED_WINDOW 1 // Refine with an outlier list: a workgroup whose lanes' hull is no window gets an anchored one (0: the round-4 tiers, for an A/B)
 #endif
@@ -121,6 +124,19 @@ __device__ __forceinline__ v2f_t quant256(v2f_t f)
 __device__ __forceinline__ float proj_rcp(float x) { return AVDM_DEV_IEEE_DIV ? 1.0f / x : fast_rcp(x); }
 // the reference's weight of one image: exp(-(dC / gammaC + dP / gammaP)) (CostYKfromLab)
 __device__ __forceinline__ float yk_weight(float dC, float dP, float invGammaC) { return expf(-(dC * invGammaC + dP)); }
+// sigmoid(0, 1, 0.7, -0.7, x) = 1 / (1 + exp(10 (x + 0.7) / 0.7)) of the Refine sweep (kernels.cuh:374) on the hardware's exp2 / rcp (1 ulp each:
+// 2e-7 relative, the fp16 volume's quantum is 1e-3) — 4 instructions where the library expf and two IEEE divisions were ~35 per plane (round 6)
+#ifndef AVDM_FAST_SIGMOID
+#define AVDM_FAST_SIGMOID 1
+#endif
+__device__ __forceinline__ float refine_sigmoid(float x)
+{
+#if AVDM_FAST_SIGMOID
+    return fast_rcp(1.0f + __builtin_amdgcn_exp2f(fmaf(x, 20.609929155556620f, 14.426950408889634f))); // 10 / 0.7 * log2(e), 10 * log2(e)
+#else
+    return sigmoid(0.0f, 1.0f, 0.7f, -0.7f, x);
+#endif
+}
 // SimStat::update(gx, gy, w) and computeWSim as written (no contraction: the pinned CPU build of the reference has none)
 struct SimStatLit
 {
@@ -458,7 +474,9 @@ __device__ __forceinline__ void row_of(const PatchProj& Q, float fy, f3& hrRow, 
 }
 
 // weighted NCC over the (2*wsh+1)^2 patch; TInvert: sigmoid-filtered positive similarity (Refine) else raw NCC in [-1, 1]
-template <bool FIXED8, int WSH, bool TInvert, class RTap, class TTap>
+// UNR: samples of a row in flight (1 inside the sweep kernels, see below; the outlier kernel — every tap a global-memory round trip, one lane per
+// plane, registers to spare — takes a whole 7-tap row)
+template <bool FIXED8, int WSH, bool TInvert, class RTap, class TTap, int UNR = 1>
 __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArgs& A, const PatchTable& tab, const RTap& rt, const TTap& tt,
                                                 float4 rcCenter, float4 tcCenter)
 {
@@ -475,7 +493,7 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
         const float* trow = tab.c + (yp + wsh) * n + wsh;
 // (the generic paths run on ~5 % of the plane-workgroups: no unrolling here — unrolled, their taps raise the register demand of the whole
         // kernel and the compiler spills values that are live across the packed path's loop)
-#pragma unroll 1
+#pragma unroll UNR
         for(int xp = -wsh; xp <= wsh; ++xp)
         {
             float rX, rY, tX, tY;
@@ -528,7 +546,7 @@ __device__ __forceinline__ float ncc_accumulate(const PatchProj& Q, const NccArg
 #endif
     const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
     if(TInvert)
-        return sigmoid(0.0f, 1.0f, 0.7f, -0.7f, sim);
+        return refine_sigmoid(sim);
     return sim;
 }
 
@@ -820,7 +838,7 @@ __device__ __forceinline__ float ncc_accumulate_lds_fixed8(const PatchProj& Q, c
 #endif
     const float sim = isfinite(rawSim) ? -rawSim : 1.0f;
     if(TInvert)
-        return sigmoid(0.0f, 1.0f, 0.7f, -0.7f, sim);
+        return refine_sigmoid(sim);
     return sim;
 }
 
@@ -1063,7 +1081,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
         const float varXYW = (xy - x1 * y1 * iw) * iw;
         const float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
         const float s = isfinite(rawSim) ? -rawSim : 1.0f;
-        return TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, s) : s;
+        return TInvert ? refine_sigmoid(s) : s;
     };
     sim0 = finish(wsum[0].x, s1R[0].x, s1T[0].x, s2R[0].x, s2T[0].x, sxy[0].x);
     sim1 = finish(wsum[0].y, s1R[0].y, s1T[0].y, s2R[0].y, s2T[0].y, sxy[0].y);
@@ -1075,7 +1093,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_quad(f3 rax, f3 ray, f
     auto finish_lit = [&](const SimStatLit& st) __attribute__((always_inline)) -> float {
         const float rawSim = st.raw_sim();
         const float s = isfinite(rawSim) ? -rawSim : 1.0f;
-        return TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, s) : s;
+        return TInvert ? refine_sigmoid(s) : s;
     };
     sim0 = finish_lit(lit[0]);
     sim1 = finish_lit(lit[1]);
@@ -1304,7 +1322,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
         const float varXYW = (xy - x1 * y1 * iw) * iw;
         const float rawSim = varXYW * __builtin_amdgcn_rsqf(varXW * varYW);
         const float s = isfinite(rawSim) ? -rawSim : 1.0f;
-        return TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, s) : s;
+        return TInvert ? refine_sigmoid(s) : s;
     };
 #pragma unroll
     for(int j = 0; j < NPAIR; ++j)
@@ -1318,7 +1336,7 @@ __device__ __forceinline__ void ncc_accumulate_lds_fixed8_multi(f3 rax, f3 ray, 
     auto finish_lit = [&](const SimStatLit& st) __attribute__((always_inline)) -> float {
         const float rawSim = st.raw_sim();
         const float s = isfinite(rawSim) ? -rawSim : 1.0f;
-        return TInvert ? sigmoid(0.0f, 1.0f, 0.7f, -0.7f, s) : s;
+        return TInvert ? refine_sigmoid(s) : s;
     };
 #pragma unroll
     for(int j = 0; j < 2 * NPAIR; ++j)
@@ -1810,7 +1828,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 const f3 nn = normalize((v1 + v2) * 0.5f);
                 const f3 axd = normalize(cross(ay, nn)) * (RK.pixK * kk);
                 q.tax = M3x3mulV3(tc.P, axd);
-                raxOut = M3x3mulV3(rc.P, axd);
+                raxOut = axd; // (projected into R only for the ONE plane that provides the R side of the pass: M3x3mulV3(rc.P, .) at the call)
                 const f3 ht0 = fma3(kk, RK.htB, RK.htA);
                 const float it0 = proj_rcp(ht0.z);
                 const float tpx = ht0.x * it0, tpy = ht0.y * it0;
@@ -1882,7 +1900,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                                 qq[k] = selP8(vv[k], q[k], qf);
                             const float tw = qf.t * RK.hrW;
                             ncc_accumulate_lds_fixed8_multi<WSH, false, PAIRED, RP, REC12, 4>(
-                              raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, qq, Bt, RK.htB, RK.htA, A, tab,
+                              M3x3mulV3(rc.P, raf), Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, qq, Bt, RK.htB, RK.htA, A, tab,
                               make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter, sim);
                         }
                         auto commit2 = [&](unsigned& wbx, unsigned& wsx, int k, float fsim) __attribute__((always_inline)) {
@@ -1938,7 +1956,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                     const QuadPlane qf = selP(v1b, q1, selP(v2b, q2, selP(v0, q0, q3)));
                     const f3 raf = sel3(v1b, ra1, sel3(v2b, ra2, sel3(v0, ra0, ra3)));
                     const float tw = qf.t * RK.hrW;
-                    ncc_accumulate_lds_fixed8_quad<WSH, false, PAIRED, RP, REC12>(raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
+                    ncc_accumulate_lds_fixed8_quad<WSH, false, PAIRED, RP, REC12>(M3x3mulV3(rc.P, raf), Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
                                                                     selP(v0, q0, qf), selP(v1b, q1, qf), selP(v2b, q2, qf), selP(v3, q3, qf), Bt, RK.htB, RK.htA, A, tab,
                                                                     make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : (REC12 ? 12 : 8)), rcCenter,
                                                                     s0, s1, s2, s3);
@@ -2338,7 +2356,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                     nn = normalize((v1 + v2) * 0.5f);
                 const f3 axd = normalize(cross(ay, nn)) * (RK.pixK * t);
                 q.tax = M3x3mulV3(tc.P, axd);
-                raxOut = M3x3mulV3(rc.P, axd);
+                raxOut = axd; // (projected into R only for the ONE plane that provides the R side of the pass: M3x3mulV3(rc.P, .) at the call)
                 const f3 ht0 = fma3(t, RK.htB, RK.htA);
                 const float it0 = proj_rcp(ht0.z);
                 const float tpx = ht0.x * it0, tpy = ht0.y * it0;
@@ -2445,7 +2463,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                             float sim[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                             const float tw = qf.t * RK.hrW;
                             ncc_accumulate_lds_fixed8_multi<WSH, true, PAIRED, RP, false, 4>(
-                              raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, qq, Bt, RK.htB, RK.htA, A, tab,
+                              M3x3mulV3(rc.P, raf), Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z}, qq, Bt, RK.htB, RK.htA, A, tab,
                               make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8), rcCenter, sim);
                             if(vv[0]) commit(0, sim[0]);
                             if(vv[1]) commit(1, sim[1]);
@@ -2499,7 +2517,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                     const QuadPlane qf = selP(v1b, q1, selP(v2b, q2, selP(v0, q0, q3)));
                     const f3 raf = sel3(v1b, ra1, sel3(v2b, ra2, sel3(v0, ra0, ra3)));
                     const float tw = qf.t * RK.hrW;
-                    ncc_accumulate_lds_fixed8_quad<WSH, true, PAIRED, RP>(raf, Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
+                    ncc_accumulate_lds_fixed8_quad<WSH, true, PAIRED, RP>(M3x3mulV3(rc.P, raf), Br * qf.t, f3{fmaf(tw, x, RK.hrA.x), fmaf(tw, y, RK.hrA.y), tw + RK.hrA.z},
                                                                           selP(v0, q0, qf), selP(v1b, q1, qf), selP(v2b, q2, qf), selP(v3, q3, qf), Bt, RK.htB, RK.htA, A,
                                                                           tab, make_windows(smem, A.rcap, R.pitch, R.x0, R.y0, Wc.pitch, Wc.x0, Wc.y0, PAIRED ? 16 : 8),
                                                                           rcCenter, s0, s1, s2, s3);
@@ -2685,7 +2703,7 @@ __global__ void __launch_bounds__(256)
             const float4 tcCenter = tex_bilinear_px<FIXED8>(A.tcL, fmaf(tpx, A.tcSx, A.tcOx), fmaf(tpy, A.tcSy, A.tcOy));
             if(tcCenter.w < (255.f * 0.4f))
                 continue;
-            const float sim = ncc_accumulate<FIXED8, WSH, true>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
+            const float sim = ncc_accumulate<FIXED8, WSH, true, GlobalTap, GlobalTap, AVDM_OUTLIER_UNROLL>(Q, A, tab, GlobalTap{A.rcL}, GlobalTap{A.tcL}, rcCenter, tcCenter);
             pv[vz] = __float2half(__half2float(pv[vz]) + sim);
         }
     }

@@ -297,6 +297,9 @@ def main():
                     help="N > 1: the weak-scaling form of rounds 1-5 (every rank times K depth maps of its own; value = N K / elapsed).  Default at "
                          "N > 1 is the FIXED job BASELINE quotes (a step = all reference cameras of the workload dealt round-robin to the ranks, "
                          "timed to the slowest rank; value = cameras / makespan)")
+    ap.add_argument("--no-parity-mode-cost", action="store_true",
+                    help="skip the leg after the timed region that measures what the product's reference-arithmetic mode costs (N = 1: two depth maps with "
+                         "the SGM sweep in that mode, ~4 s)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only (gloo, no GPU work): what tests/test_sharding.py runs on the CPU")
     args = ap.parse_args()
@@ -666,6 +669,33 @@ def main():
                 e2e["tiles_s_over_kernel_only_s"] = e2e["split"]["tiles_s"] / pred
                 e2e["bench_voxelT_per_depth_map"] = {"sgm": px_sgm * Z * T, "refine": px_ref * nz_ref * T}
             line["cli_end_to_end"] = e2e
+        if world == 1 and len(tiles) == 1 and not args.reference_arithmetic and not args.no_parity_mode_cost:
+            # THE PARITY MODE'S COST, measured here ("with its measured cost in the bench line"): the same depth map with the SGM sweep in
+            # the reference's arithmetic (avdm_sgm_params_t::referenceArithmetic — the mode in which every parity case meets BASELINE's bar, volumes
+            # identical to the reference's own code), the default Refine kernels; one warm-up + two timed depth maps
+            sgm_p = abi.SgmParams.default(referenceArithmetic=1)
+            tile_p = DepthMapTile(pyr, sc.K, sc.R, sc.C, sgm_p, ref, roi=rois[0], device=dev, tile_buffer=tile_buffer)
+            tile_p.enable_timers(True)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            for j in range(3):
+                rc = my_cams[j % len(my_cams)]
+                if j == 1:
+                    tile_p.reset_timers()
+                if j >= 1:
+                    ev[j - 1].record()
+                tile_p.run_sgm(rc, proto.tcams_of(rc), depths)
+                tile_p.run_refine(rc, proto.tcams_of(rc))
+            ev[2].record()
+            torch.cuda.synchronize()
+            ms_p = ev[0].elapsed_time(ev[2]) / 2.0
+            st_p = tile_p.timers.mean_ms(per=2)
+            line["reference_arithmetic"] = {"mode": "sgm sweep (avdm_sgm_params_t::referenceArithmetic = 1), default Refine kernels",
+                                            "value": 1e3 / ms_p, "unit": "depth-maps/s", "ms_per_step": ms_p, "steps": 2,
+                                            "sgm_similarity_ms": st_p.get("sgm_similarity"), "refine_similarity_ms": st_p.get("refine_similarity"),
+                                            "slowdown_vs_default": ms_p / ms_per_step,
+                                            "parity": "similarity / aggregated volumes and WTA depths identical to the reference's own code compiled for the CPU; "
+                                                      "final depth RMSE < 1e-3 untrimmed on every parity case (tests/test_gpu_parity.py::_assert_reference_arithmetic)"}
+            del tile_p
         if world == 1 and not args.no_cpu_baseline:
             small = make_scene(3, 512, 384, seed=3, device="cpu")
             line["cpu_baseline"] = cpu_baseline(small, sgm, ref, Z, W * H, T)

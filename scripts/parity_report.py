@@ -150,6 +150,7 @@ def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False, spread=
         r["refine_volume_abs"] = {">2e-3": float((d > 2e-3).mean()), ">2e-2": float((d > 2e-2).mean()), "max": float(d.max())}
         pix = o.sgm_upscaled[..., 1]
         r["refined_depth"] = depth_stats(g_refined, o.refined, pix)
+        r["refined_sim"] = sim_stats(g_refined, o.refined)  # the Refine stage's similarity, BEFORE the colour optimisation re-draws it (see final_sim)
         r["final_depth"] = depth_stats(g_final, want, pix)
         r["final_sim"] = sim_stats(g_final, want)
         gt = sc.gt_depth.cpu().numpy()
@@ -184,7 +185,7 @@ def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False, spread=
             "sgm_filtered_volume_levels": level_hist(o.filtered[..., :Z], gs["filtered"]),
             "sgm_wta_depth_differs": float((o.sgm_depth_sim[..., 0] != gs["sgm"][..., 0]).mean()),
             "refine_volume_abs": {"identical": float((d == 0).mean()), ">2e-3": float((d > 2e-3).mean()), ">2e-2": float((d > 2e-2).mean()), "max": float(d.max())},
-            "refined_depth": depth_stats(gs["refined"], o.refined, o.sgm_upscaled[..., 1]),
+            "refined_depth": depth_stats(gs["refined"], o.refined, o.sgm_upscaled[..., 1]), "refined_sim": sim_stats(gs["refined"], o.refined),
             "final_depth": depth_stats(gs["final"], want_l, o.sgm_upscaled[..., 1]), "final_sim": sim_stats(gs["final"], want_l), "t_s": time.time() - t1}
     # AVDM_SIM_LITERAL=1: the reference's similarity arithmetic as written, ON THE GPU (csrc/avdm_literal.hip), against the oracle's literal
     # mode on the oracle's own pyramids — what is left when the conditioning of the NCC sums is taken out of the comparison
@@ -251,7 +252,10 @@ def run_case(name, spec, filter_mode, with_ref=False, gpu_literal=False, spread=
             rc_.run_sgm(0, tcs, depths)
             want_cuda = rc_.run_refine(0, tcs).copy()
             res["platform_spread"] = {
-                "cuda_vs_literal": {"final_depth": depth_stats(want_cuda, wants["literal"][0], pix), "similarity_volume_levels": level_hist(wants["literal"][1], rc_.second[..., :Z])},
+                "cuda_vs_literal": {"final_depth": depth_stats(want_cuda, wants["literal"][0], pix), "similarity_volume_levels": level_hist(wants["literal"][1], rc_.second[..., :Z]),
+                                    # the similarity channel of the reference against itself: after the colour optimisation it is an energy term that ANY
+                                    # perturbation of the depths re-draws (cfg1: 1.5 % identical halfs, p99 |d| 7.0) — the yardstick of final_sim
+                                    "final_sim": sim_stats(want_cuda, wants["literal"][0]), "refined_sim": sim_stats(rc_.refined, o.refined)},
                 "cuda_vs_well_posed": {"final_depth": depth_stats(want_cuda, wants["well_posed"][0], pix)},
                 "well_posed_vs_literal": {"final_depth": depth_stats(wants["well_posed"][0], wants["literal"][0], pix),
                                           "similarity_volume_levels": level_hist(wants["literal"][1], wants["well_posed"][1])},

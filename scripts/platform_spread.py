@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 from alicevision_amd import abi  # noqa: E402
 from alicevision_amd.synthetic import make_scene, plane_depths  # noqa: E402
-from scripts.parity_report import CASES, depth_stats, level_hist  # noqa: E402
+from scripts.parity_report import CASES, depth_stats, level_hist, sim_stats  # noqa: E402
 
 ALL_CASES = dict(CASES)
 # the scene of __graft_entry__.smoke() in rounds 1-3 (3 views 320 x 240, 48 planes, default parameters)
@@ -49,12 +49,15 @@ def run_variant(variant, images, sc, sgm, ref, roi, tcs, depths, filter_mode, ti
 
 def compare(a, b, pix=None):
     if "refvol" not in a:  # tile cases: maps only
-        return {"sgm_wta_depth_differs": float((a["sgm"][..., 0] != b["sgm"][..., 0]).mean()), "final_depth": depth_stats(b["final"], a["final"], pix)}
+        return {"sgm_wta_depth_differs": float((a["sgm"][..., 0] != b["sgm"][..., 0]).mean()), "final_depth": depth_stats(b["final"], a["final"], pix),
+                "final_sim": sim_stats(b["final"], a["final"])}
     d = np.abs(a["refvol"] - b["refvol"])
     return {"similarity_volume_levels": level_hist(a["second"], b["second"]), "sgm_filtered_volume_levels": level_hist(a["filtered"], b["filtered"]),
             "sgm_wta_depth_differs": float((a["sgm"][..., 0] != b["sgm"][..., 0]).mean()),
             "refine_volume_abs": {">2e-3": float((d > 2e-3).mean()), ">2e-2": float((d > 2e-2).mean()), "max": float(d.max())},
-            "refined_depth": depth_stats(b["refined"], a["refined"], a["pix"]), "final_depth": depth_stats(b["final"], a["final"], a["pix"])}
+            "refined_depth": depth_stats(b["refined"], a["refined"], a["pix"]), "final_depth": depth_stats(b["final"], a["final"], a["pix"]),
+            # the similarity channel as the program writes it (one half per pixel): the reference against itself (VERDICT r5 #5's yardstick)
+            "refined_sim": sim_stats(b["refined"], a["refined"]), "final_sim": sim_stats(b["final"], a["final"])}
 
 
 def run_case(name, variants, filter_mode=abi.FILTER_CUDA_FIXED8):

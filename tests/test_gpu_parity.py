@@ -1509,8 +1509,15 @@ def _assert_reference_arithmetic(r, final_bar=1e-4):
     assert both["refine_volume_abs"]["identical"] == 1.0, both["refine_volume_abs"]
     assert both["refined_depth"]["max_abs"] == 0.0, both["refined_depth"]
     assert both["final_depth"]["rmse_untrimmed"] < final_bar, both["final_depth"]
-    # the similarity channel as the program writes it (one half per pixel, mapIO.cpp:403-540)
-    assert both["final_sim"]["identical_halfs"] > 0.9 and both["final_sim"]["max_abs"] < 2e-2, both["final_sim"]
+    # The similarity channel as the program writes it (one half per pixel, mapIO.cpp:403-540).  The Refine stage's similarity is IDENTICAL in the
+    # parity mode.  AFTER the colour optimisation the channel is (1 - closeToRough) (w sim + (1 - w) depthEnergy / 20) (mapKernels.cuh:604) with
+    # depthEnergy the smoothness ANGLE in degrees between neighbouring depths: on a smooth surface that angle is made of the last bits of the
+    # depths, so ANY two evaluations — the reference's own two included (profiles/r06_platform_spread_sim_cfg1.json: 1.5 % identical halfs, p99
+    # |d| 7.0) — draw it afresh; the parity mode, whose optimisation starts from identical maps and differs by its tolerance class only, must
+    # be at least as close to the reference as the default mode is (test_deviation_attribution holds the default to the reference's own spread)
+    assert both["refined_sim"]["identical_halfs"] == 1.0, both["refined_sim"]
+    if "final_sim" in r["literal"]:
+        assert both["final_sim"]["rmse"] <= r["literal"]["final_sim"]["rmse"], (both["final_sim"], r["literal"]["final_sim"])
 
 
 def test_parity_table_cfg1():
@@ -1713,6 +1720,15 @@ def test_deviation_attribution(name):
     # the sums alone are what makes the VOLUMES differ: with shifted sums the literal kernel's volume is the well-posed oracle's
     assert dev["shifted_sums"]["vs_well_posed"]["similarity_volume_levels"]["0"] > 0.98
     assert dev["shifted_sums"]["vs_literal"]["similarity_volume_levels"]["0"] < 0.65
+    # THE SIMILARITY MAP END TO END (BASELINE: "depth / sim maps"), as the program writes it — one half per pixel, mapIO.cpp:403-540.
+    # Its yardstick is the reference against itself as well: after the colour optimisation the channel carries the smoothness angle between
+    # neighbouring depths (mapKernels.cuh:604), which any two evaluations draw afresh (see _assert_reference_arithmetic).  The default kernels are
+    # no further from the reference's arithmetic than its two evaluations are from each other; BEFORE the optimisation (the Refine stage's own
+    # similarity) both distances are small and are printed for DESIGN.md's table.
+    Xs, ds = sp["cuda_vs_literal"]["final_sim"], r["literal"]["final_sim"]
+    print(name, "final_sim: reference vs itself", Xs, "default vs literal", ds, "| refined_sim: reference vs itself", sp["cuda_vs_literal"]["refined_sim"],
+          "default vs literal", r["literal"]["refined_sim"])
+    assert ds["rmse"] <= 1.15 * Xs["rmse"] and ds["p99_abs"] <= 1.15 * Xs["p99_abs"] + 1e-2, (ds, Xs)
 
 
 def test_full_size_cfg2_sweep_against_the_oracle():
