@@ -924,6 +924,28 @@ def test_refine_outlier_list_equals_the_wave_fallback(capsys):
     # (the inlier lanes of a wave with an outlier used to run one plane per pass with fp32 taps from global memory, now the packed eight-plane
     # pass from the window: the Refine volume's tolerance class)
     assert (d > 2e-3).mean() <= 2e-3 and (d > 2e-2).mean() <= 1e-4 and d.max() <= 0.15, ((d > 2e-3).mean(), (d > 2e-2).mean(), d.max())
+    # ... AND AGAINST THE ORACLE on the same map with the wrong depths (the list path had only been compared HIP with HIP): the
+    # pyramids are the oracle's texel for texel since round 6, so its Refine volume of THIS map is the reference for the listed pixels too —
+    # the well-posed evaluation in the Refine volume's tolerance class, over the whole volume and over the pixels with a wrong depth alone
+    from oracle import oracle
+    o = make_oracle(sc, sgm, ref)
+    o.sgm_depth_thickness = bad.cpu().numpy().copy()
+    with oracle.well_posed():
+        o.run_refine(0, [1, 2], optimize_enabled=False)
+    Zr = ref.halfNbDepths * 2 + 1
+    want = o.refine_volume[..., :Zr].astype(np.float32)
+    got = out["1"][..., :Zr]
+    assert got.shape == want.shape, (got.shape, want.shape)
+    do = np.abs(got - want)
+    step = got.shape[0] // wrong.shape[0]
+    wrong_full = np.kron(wrong.cpu().numpy().astype(np.uint8), np.ones((step, step), np.uint8)).astype(bool)[: got.shape[0], : got.shape[1]]
+    dw = do[wrong_full]
+    with capsys.disabled():
+        print("outlier list vs the ORACLE on the same map: %.5f of all entries differ by > 2e-3, %.6f by > 2e-2; on the %d pixels with a wrong depth: %.5f / %.6f, max %.3e"
+              % ((do > 2e-3).mean(), (do > 2e-2).mean(), int(wrong_full.sum()), (dw > 2e-3).mean(), (dw > 2e-2).mean(), float(dw.max()) if dw.size else 0.0))
+    assert wrong_full.sum() > 500 and (want[wrong_full] != 0).mean() > 0.05
+    assert (do > 2e-3).mean() <= 3e-3 and (do > 2e-2).mean() <= 2e-4, ((do > 2e-3).mean(), (do > 2e-2).mean())
+    assert (dw > 2e-3).mean() <= 2e-2 and (dw > 2e-2).mean() <= 2e-3, ((dw > 2e-3).mean(), (dw > 2e-2).mean())
 
 
 def test_refine_best_depth_bit_exact(case):
