@@ -1469,7 +1469,7 @@ _PARITY_CACHE = {}
 # cases that also go through the reference's CUDA-like evaluation (its platform spread) and the literal kernel's per-deviation switches
 _ATTRIBUTED = ("cfg1", "crop3")
 # cases held against the LITERAL oracle (= the reference's own code) only
-_LITERAL_ONLY = ("tile24mp_interior", "tile24mp_corner", "tile12mp_corner_10T", "crop3_corner", "crop3_far_corner")
+_LITERAL_ONLY = ("tile24mp_interior", "tile24mp_corner", "tile12mp_corner_10T", "tile12mp_corner", "crop3_corner", "crop3_far_corner")
 
 
 def _parity_case(name):
@@ -1622,9 +1622,9 @@ def test_parity_of_default_tiles_at_12mp(name):
     (OracleDepthMap(tile_buffer=...) is pinned to the reference's own Sgm.cpp / Refine.cpp, tests/test_oracle_ref.py): 256 planes, 2 T
     cameras, everything on the GPU against everything in the oracle, NO trimming."""
     r = _parity_case(name)
-    wp, lit = r["well_posed"], r["literal"]
     corner = "corner" in name
-    for key, m in (("well_posed", wp), ("literal", lit)):
+    # (the corner tile: against the reference's own arithmetic only since round 6 — its well-posed figure, 9.1e-5, is profiles/r06_d_parity_tile12mp_corner.json)
+    for key, m in [(k, r[k]) for k in ("well_posed", "literal") if k in r]:
         # the corner tile against the LITERAL oracle: 1.24e-3 untrimmed, 1.3e-4 over the best 99.5 %, identical validity masks, the literal
         # arithmetic on the GPU at 6.6e-5.  Located oracle against oracle on the CPU: TWO SGM pixels of 43 000 whose winner-take-all plane flips
         # between near-equal minima 30 planes apart — 36 full-size pixels carry the excess, 2.0e-4 without them (DESIGN.md section 2)
@@ -1634,8 +1634,9 @@ def test_parity_of_default_tiles_at_12mp(name):
         assert m["final_depth"]["rmse_untrimmed"] < bar, (key, m["final_depth"])
         assert m["final_depth"]["rmse_best_99.5pct"] < 3e-4, (key, m["final_depth"])
         assert m["final_depth"]["validity_differs"] < (0.03 if corner and key == "literal" else 1e-3), (key, m["final_depth"])
-    lv = wp["similarity_volume_levels"]
-    assert lv["2"] + lv["3+"] < 3e-3 and lv["1"] < 0.06 and lv["validity_differs"] < 1e-3, lv
+    if "well_posed" in r:
+        lv = r["well_posed"]["similarity_volume_levels"]
+        assert lv["2"] + lv["3+"] < 3e-3 and lv["1"] < 0.06 and lv["validity_differs"] < 1e-3, lv
     gl = r["gpu_literal_vs_oracle_literal"]
     assert gl["final_depth"]["rmse_untrimmed"] < 1e-3 and gl["final_depth"]["validity_differs"] < 1e-3, gl["final_depth"]
     # ... and in the product's reference-arithmetic mode the corner tile is where every other is: identical volumes, 7.5e-5 / 1.9e-5 (session r06_a)
