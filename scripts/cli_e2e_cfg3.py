@@ -38,6 +38,8 @@ args += os.environ.get("AVDM_E2E_ARGS", "").split()  # e.g. "--tileBufferWidth 4
 t0 = time.time()
 r = subprocess.run(args, capture_output=True, text=True)
 wall = time.time() - t0
+if os.environ.get("AVDM_E2E_LOG"):  # the program's whole log (timestamped lines): where the seconds outside the tiles go
+    open(os.environ["AVDM_E2E_LOG"], "w").write(r.stdout + "\n---- stderr ----\n" + r.stderr)
 print("exit", r.returncode, "wall %.2f s for %d camera(s) -> %.3f depth-maps/s (including image decode, upload, EXR output)" % (wall, ncam, ncam / wall))
 for l in r.stdout.splitlines():
     if any(k in l for k in ("Task done", "simultaneous", "tiles per image", "Optimizing volume of", "Batch ", "Found ", "Device memory (")):
