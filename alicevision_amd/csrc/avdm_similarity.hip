@@ -3023,10 +3023,15 @@ static unsigned* outlier_refused_counter()
     }
     return p;
 }
-// capacity of the outlier list of a launch over nPix pixels and nchunks chunks of 8 planes: a quarter of the (pixel, chunk) pairs
+// Capacity of the outlier list of a launch over nPix pixels and nchunks chunks of 8 planes: EVERY unit the sweep can append — one per (pixel,
+// chunk) from the eight-plane pass, two from the four-plane form (a unit per quad) — so that a full list cannot happen (8 B per unit: 64 MB
+// for a 1024 x 1024 tile, 768 MB for an undivided 12 MP frame, of 288 GB).  Rounds 5-6a sized it at a quarter of the pairs ("40 x the bench's
+// lists"); the program's run on the wide-baseline scene of scripts/cli_e2e_cfg3.py then logged 348 670 refused units (session r06_g) — a
+// refused wave takes the one-plane path, which is slower AND makes WHICH waves do so depend on the order of the atomics, i.e. the volume's
+// last fp16 bit on the schedule.  With room for every unit the sweep's result is a function of its inputs again.
 static unsigned outlier_list_capacity(size_t nPix, unsigned nchunks)
 {
-    return (unsigned)std::min<size_t>(std::max<size_t>(nPix * nchunks / 4, 4096), 0x7fffff00u);
+    return (unsigned)std::min<size_t>(std::max<size_t>(2 * nPix * nchunks, 4096), 0x7fffff00u);
 }
 
 static unsigned* outlier_totals()
@@ -3320,9 +3325,9 @@ size_t avdm_refine_similarity_scratch_bytes(size_t n_pixels, int n_planes)
     return 8 + (size_t)outlier_list_capacity(n_pixels, (unsigned)((n_planes + 7) / 8)) * sizeof(uint2);
 }
 
-/* Units (pixel, chunk of planes) that found an outlier list FULL on the current device since the last call — they ran on the slower per-plane path,
- * their results are the same.  Waits for the device.  0 in every run measured so far (the capacity is 40 x the lists of the bench); a scheduler
- * logs it (host/DepthMapEstimator.cpp) so that an undersized capacity cannot go unnoticed. */
+/* Units (pixel, chunk of planes) that found an outlier list FULL on the current device since the last call (they ran on the slower per-plane
+ * path).  Waits for the device.  Cannot happen since the capacity holds every unit a sweep can append (outlier_list_capacity) unless the
+ * sweep exceeds 2^31 units; a scheduler logs it (host/DepthMapEstimator.cpp) so that it cannot go unnoticed if it ever does. */
 int avdm_refine_outlier_refused(unsigned* out)
 {
     *out = 0;
@@ -3536,7 +3541,7 @@ int avdm_volume_refine_similarity(void* vol_f16, long long pitch_y, int pitch_x,
             const char* p8 = getenv("AVDM_REFINE_PLANES8");
             // The outlier list (AVDM_REFINE_OUTLIER_LIST, default on; refine_similarity_kernel): lanes whose taps leave their workgroup's T window are
             // appended to a list in the stream's scratch block and worked off by refine_outlier_kernel right after the sweep — {count, pad,
-            // (pixel, planes) units}; capacity = a quarter of the launch's (pixel, chunk) pairs, a full list leaves the remaining waves on the old path
+            // (pixel, planes) units}; capacity = every unit the launch can append (outlier_list_capacity): the list cannot be full
             const char* ol = getenv("AVDM_REFINE_OUTLIER_LIST");
             const bool useList = !(ol != nullptr && ol[0] == '0');
             const size_t nPix = (size_t)(roi.x.end - roi.x.begin) * (roi.y.end - roi.y.begin);

@@ -168,12 +168,13 @@ def test_counter_summaries_describe_the_kernels_that_ship():
 
 def test_refine_scratch_bytes_is_the_library_s_own_capacity_formula():
     """avdm_refine_similarity_scratch_bytes (what the scheduler prices a tile slot with, host/DepthMapEstimator.cpp::getNbSimultaneousTiles): the
-    outlier list of a Refine sweep = a header + 8 bytes per unit, a quarter of the (pixel, 8-plane chunk) pairs, at least 4096 units — a host
+    outlier list of a Refine sweep = a header + 8 bytes per unit, room for EVERY unit the sweep can append (two per (pixel, 8-plane chunk) pair:
+    a full list cannot happen), at least 4096 units — a host
     function, callable without a GPU (one formula, in the library)"""
     lib = abi.load()
     f = lib.avdm_refine_similarity_scratch_bytes
     assert f(0, 31) == 0 and f(1000, 0) == 0
-    assert f(1024 * 1024, 31) == 8 + (1024 * 1024 * 4 // 4) * 8      # a 1024 x 1024 tile, 31 planes = 4 chunks: 8 MB
-    assert f(4000 * 3000, 31) == 8 + (4000 * 3000 * 4 // 4) * 8      # an undivided 12 MP frame: 96 MB
+    assert f(1024 * 1024, 31) == 8 + (1024 * 1024 * 4 * 2) * 8       # a 1024 x 1024 tile, 31 planes = 4 chunks, every unit the sweep can append: 64 MB
+    assert f(4000 * 3000, 31) == 8 + (4000 * 3000 * 4 * 2) * 8       # an undivided 12 MP frame: 768 MB
     assert f(100, 31) == 8 + 4096 * 8                                # the floor
     assert f(1024 * 1024, 32) == f(1024 * 1024, 31) < f(1024 * 1024, 33)
