@@ -130,6 +130,7 @@ SIGNATURES = {
     "avdm_pyramid_build_levels": (i32, [P(Pyramid), vp]),
     "avdm_image_resize": (i32, [vp, i32, i32, i32, vp, i32, i32, i32, vp]),
     "avdm_image_decode_integer": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "avdm_image_decode_exr_lines": (i32, [vp, i32, vp, i64, i32, i32, vp, vp, vp]),
     "avdm_image_decode_jpeg_scratch_bytes": (C.c_size_t, [P(JpegComponent), i32]),
     "avdm_image_decode_jpeg": (i32, [vp, i32, i32, i32, P(JpegComponent), i32, i32, i32, i32, vp, vp]),
     "avdm_image_undistort": (i32, [vp, i32, vp, i32, P(Intrinsic), P(C.c_float * 4), vp]),

@@ -1039,6 +1039,44 @@ __global__ void __launch_bounds__(256) decode_integer_kernel(float4* dst, int ds
     *((float4*)((char*)dst + (long long)roiY * dst_pitch) + roiX) = o;
 }
 
+// avdm_image_decode_exr_lines: one lane per pixel; per channel the lanes of a wave read consecutive samples of one line (coalesced), the four
+// values leave as one 16-byte store.  HALF -> float is exact, UINT -> float is OpenEXR's / OpenImageIO's conversion ((float)u).
+struct ExrLineLayout
+{
+    long long lineStride;
+    long long off[4];
+    int type[4]; // 0 UINT, 1 HALF, 2 FLOAT; off < 0: absent
+};
+// ALIGNED = false: OpenEXR aligns nothing (the header has any length, a line of HALF channels of odd width any parity): bytes one by one then
+template <bool ALIGNED>
+__device__ __forceinline__ float exr_sample(const unsigned char* line, long long off, int type, unsigned x)
+{
+    if(type == 1)
+    {
+        const unsigned char* p = line + off + 2ll * x;
+        const unsigned short h = ALIGNED ? *(const unsigned short*)p : (unsigned short)(p[0] | (p[1] << 8));
+        return __half2float(__ushort_as_half(h));
+    }
+    const unsigned char* p = line + off + 4ll * x;
+    const unsigned u = ALIGNED ? *(const unsigned*)p : ((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) | ((unsigned)p[3] << 24));
+    return type == 2 ? __uint_as_float(u) : (float)u;
+}
+template <bool ALIGNED>
+__global__ void __launch_bounds__(256) decode_exr_lines_kernel(float4* dst, int dst_pitch, const unsigned char* __restrict__ lines, ExrLineLayout L, int width,
+                                                               int height)
+{
+    MAP_XY();
+    if(roiX >= (unsigned)width || roiY >= (unsigned)height)
+        return;
+    const unsigned char* line = lines + (long long)roiY * L.lineStride;
+    float4 o;
+    o.x = exr_sample<ALIGNED>(line, L.off[0], L.type[0], roiX);
+    o.y = exr_sample<ALIGNED>(line, L.off[1], L.type[1], roiX);
+    o.z = exr_sample<ALIGNED>(line, L.off[2], L.type[2], roiX);
+    o.w = L.off[3] >= 0 ? exr_sample<ALIGNED>(line, L.off[3], L.type[3], roiX) : 1.0f;
+    *((float4*)((char*)dst + (long long)roiY * dst_pitch) + roiX) = o;
+}
+
 static inline dim3 map_grid(unsigned w, unsigned h) { return dim3(divUp(w, 64), divUp(h, 4)); }
 static inline int stream_blocks(long long total)
 {
@@ -1235,6 +1273,44 @@ int avdm_image_decode_integer(float* dst_rgba, int dst_pitch, const void* src, i
         hipLaunchKernelGGL(decode_integer_kernel<uint16_t>, map_grid((unsigned)width, (unsigned)height), dim3(256), 0, st, (float4*)dst_rgba, dst_pitch,
                            (const uint16_t*)src, src_pitch, width, height, channels, dlut, inv);
     AVDM_LAUNCH_CHECK("avdm_image_decode_integer");
+}
+
+int avdm_image_decode_exr_lines(float* dst_rgba, int dst_pitch, const void* lines, long long line_stride, int width, int height,
+                                const long long chan_offset[4], const int chan_type[4], void* stream)
+{
+    if(width <= 0 || height <= 0)
+        return set_error_msg(1, "avdm_image_decode_exr_lines: empty image");
+    if(dst_rgba == nullptr || lines == nullptr || chan_offset == nullptr || chan_type == nullptr)
+        return set_error_msg(1, "avdm_image_decode_exr_lines: null argument");
+    ExrLineLayout L;
+    L.lineStride = line_stride;
+    bool aligned = true;
+    for(int k = 0; k < 4; ++k)
+    {
+        L.off[k] = chan_offset[k];
+        L.type[k] = chan_type[k];
+        if(k < 3 && chan_offset[k] < 0)
+            return set_error_msg(1, "avdm_image_decode_exr_lines: the R, G and B offsets are required (a Y-only image passes Y three times)");
+        if(chan_offset[k] >= 0)
+        {
+            if(chan_type[k] < 0 || chan_type[k] > 2)
+                return set_error_msg(1, "avdm_image_decode_exr_lines: pixel type must be 0 (UINT), 1 (HALF) or 2 (FLOAT)");
+            const long long size = chan_type[k] == 1 ? 2 : 4;
+            if(chan_offset[k] + size * width > (line_stride < 0 ? -line_stride : line_stride))
+                return set_error_msg(1, "avdm_image_decode_exr_lines: a channel does not fit the line stride");
+            if((((uintptr_t)lines + (uintptr_t)chan_offset[k]) % (uintptr_t)size) || (line_stride % size))
+                aligned = false;
+        }
+    }
+    if((dst_pitch & 15) || ((uintptr_t)dst_rgba & 15))
+        return set_error_msg(1, "avdm_image_decode_exr_lines: destination base / pitch must be multiples of 16 bytes");
+    if(aligned)
+        hipLaunchKernelGGL(decode_exr_lines_kernel<true>, map_grid((unsigned)width, (unsigned)height), dim3(256), 0, (hipStream_t)stream, (float4*)dst_rgba,
+                           dst_pitch, (const unsigned char*)lines, L, width, height);
+    else
+        hipLaunchKernelGGL(decode_exr_lines_kernel<false>, map_grid((unsigned)width, (unsigned)height), dim3(256), 0, (hipStream_t)stream, (float4*)dst_rgba,
+                           dst_pitch, (const unsigned char*)lines, L, width, height);
+    AVDM_LAUNCH_CHECK("avdm_image_decode_exr_lines");
 }
 
 int avdm_image_undistort(float* dst_rgba, int dst_pitch, const float* src_rgba, int src_pitch, const avdm_intrinsic_t* cam, const float fill_rgba[4],

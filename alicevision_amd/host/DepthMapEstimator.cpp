@@ -355,7 +355,6 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         return;
 
     const int nbStreams = std::min({getNbSimultaneousTiles(), static_cast<int>(tiles.size()), maxStreamsFromEnv()});
-    DeviceStreamManager deviceStreamManager(nbStreams);
 
     const int nbTilesPerCamera = static_cast<int>(_tileRoiList.size());
     const int nbRcPerBatch = divideRoundUp(nbStreams, nbTilesPerCamera);
@@ -363,8 +362,113 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
     const int nbMipmapImagesPerBatch = nbRcPerBatch * (1 + _depthMapParams.maxTCams);
     const int nbCamerasParamsPerBatch = nbMipmapImagesPerBatch * 3;
 
+    struct PinnedRegistrations
+    {
+        std::vector<void*> ptrs;
+        void add(void* p, size_t bytes)
+        {
+            if(hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) // unpinned tiles still work (synchronous copies)
+                ptrs.push_back(p);
+            else
+                (void)hipGetLastError();
+        }
+        void releaseAll()
+        {
+            for(void* p : ptrs)
+                (void)hipHostUnregister(p);
+            ptrs.clear();
+        }
+        ~PinnedRegistrations() { releaseAll(); }
+    };
+    // final depth/similarity map tiles in host memory, per camera of a batch (the map size of the last stage: Refine.cpp:17-18 / Sgm.cpp:22-23)
+    const int finalDownscale = _depthMapParams.useRefine ? _refineParams.scale * _refineParams.stepXY : _sgmParams.scale * _sgmParams.stepXY;
+    const int finalMapW = divideRoundUp(_tileParams.bufferWidth, finalDownscale), finalMapH = divideRoundUp(_tileParams.bufferHeight, finalDownscale);
+    // two sets: while the tiles of batch b are merged and written by a background task, batch b + 1 computes into the other set
+    // (the reference merges and writes between the batches, DepthMapEstimator.cpp:446-466, with the device idle)
+    const int nbHostSets = 2;
+    std::vector<std::vector<Float2Tile>> depthSimMapTileSets[nbHostSets];
+    PinnedRegistrations pinned; // declared after the tile sets: unregistered before the vectors are freed
+    std::vector<std::vector<std::pair<float, float>>> depthMinMaxTileSets[nbHostSets];
+    // allocated (huge pages, depthMapUtils.hpp) and page-locked by a background task that starts HERE, beside the rest of the set-up and the first
+    // batch's images; set 0 first — the first batch waits for it alone, set 1 is ready long before the second batch asks
+    std::promise<void> hostSetPromise[nbHostSets];
+    std::future<void> hostSetReady[nbHostSets];
+    for(int s = 0; s < nbHostSets; ++s)
+        hostSetReady[s] = hostSetPromise[s].get_future();
+    std::future<void> hostTilesTask = std::async(std::launch::async, [&]() {
+        int s = 0;
+        try
+        {
+            AVDM_HIP_CHECK(hipSetDevice(deviceId));
+            for(; s < nbHostSets; ++s)
+            {
+                depthSimMapTileSets[s].resize(nbRcPerBatch);
+                depthMinMaxTileSets[s].resize(nbRcPerBatch);
+                for(int i = 0; i < nbRcPerBatch; ++i)
+                {
+                    depthSimMapTileSets[s][i].resize(nbTilesPerCamera);
+                    depthMinMaxTileSets[s][i].resize(nbTilesPerCamera);
+                    for(int j = 0; j < nbTilesPerCamera; ++j)
+                    {
+                        depthSimMapTileSets[s][i][j].allocate(finalMapW, finalMapH);
+                        // page-lock the result tiles (CudaHostMemoryHeap is pinned memory in the reference): the device-to-host copies of a
+                        // group then run asynchronously on the tile streams instead of blocking the host thread that feeds them
+                        auto& v = depthSimMapTileSets[s][i][j].data;
+                        pinned.add(v.data(), v.size() * sizeof(float));
+                    }
+                }
+                hostSetPromise[s].set_value();
+            }
+        }
+        catch(...)
+        {
+            for(; s < nbHostSets; ++s)
+                hostSetPromise[s].set_exception(std::current_exception());
+        }
+    });
+
     DeviceCache deviceCache(nbMipmapImagesPerBatch, nbCamerasParamsPerBatch, filterModeFromEnv());
     deviceCache.setExchange(exchange, worker);
+
+    // the views of batch b, in the order its tiles first use them
+    auto viewsOfBatch = [&](int b) {
+        std::vector<int> views;
+        auto want = [&](int c) {
+            if(std::find(views.begin(), views.end(), c) == views.end())
+                views.push_back(c);
+        };
+        const int i1 = std::min((b + 1) * nbTilesPerBatch, static_cast<int>(tiles.size()));
+        for(int i = b * nbTilesPerBatch; i < i1; ++i)
+        {
+            const Tile& tile = tiles.at(i);
+            if(tile.roi.isEmpty())
+                continue;
+            want(tile.rc);
+            for(const int tc : tile.sgmTCams)
+                want(tc);
+            if(_depthMapParams.useRefine)
+                for(const int tc : tile.refineTCams)
+                    want(tc);
+        }
+        return views;
+    };
+    // AVDM_HOST_INGEST=serial: rounds 1-5's form (parallel decode, then one view after the other uploaded and converted by this thread)
+    const bool teamIngest = [] {
+        const char* e = getenv("AVDM_HOST_INGEST");
+        return !(e != nullptr && std::string(e) == "serial");
+    }();
+    // the first batch's views are decoded, uploaded and converted (DeviceCache::addMipmapImages: a team of host threads, one view each on a
+    // stream of its own) BESIDE the rest of the set-up — streams, the tile slots' device buffers, the page-locked result tiles
+    std::future<void> firstIngest;
+    const auto tIngest0 = std::chrono::steady_clock::now();
+    if(exchange == nullptr && teamIngest)
+        firstIngest = std::async(std::launch::async, [&]() {
+            AVDM_HIP_CHECK(hipSetDevice(deviceId));
+            deviceCache.addMipmapImages(viewsOfBatch(0), minMipmapDownscale, maxMipmapDownscale, ic, _mp);
+        });
+
+    // (after the two background tasks have been started: creating 24 streams — a hardware queue each — takes ~0.1 s)
+    DeviceStreamManager deviceStreamManager(nbStreams);
 
     // build the custom patch pattern (DepthMapEstimator.cpp:272-274; library state like the reference's constant memory)
     if(_sgmParams.useCustomPatchPattern || _refineParams.useCustomPatchPattern)
@@ -380,9 +484,28 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
                   "Cannot build custom patch pattern");
     }
 
+    // ONE device allocation for the fixed-size buffers of all tile slots (DeviceArena, device.hpp): ~12 buffers per slot used to be ~500 hipMalloc
+    // calls at set-up and ~500 hipFree calls — each a device-wide wait — at the end (AVDM_HOST_ARENA=0: the A/B).  Declared before its users.
+    const auto tSetup0 = std::chrono::steady_clock::now();
+    size_t arenaBytes = 0;
+    {
+        const char* e = getenv("AVDM_HOST_ARENA");
+        if(!(e != nullptr && e[0] == '0'))
+        {
+            const double MB = 1024.0 * 1024.0;
+            const double perSlotMB = Sgm::deviceMemoryConsumption(_tileParams, _sgmParams, !_depthMapParams.useRefine, _refineParams.useSgmNormalMap) +
+                                     (_depthMapParams.useRefine ? Refine::deviceMemoryConsumption(_tileParams, _refineParams) : 0.0);
+            // + a guard page and the 4 KiB rounding per buffer, and the group's aggregation scratch (bounded by one more slot's Sgm figure)
+            arenaBytes = (size_t)((double)nbStreams * (perSlotMB * MB * 1.02 + 32.0 * 8192.0) +
+                                  Sgm::deviceMemoryConsumption(_tileParams, _sgmParams, false, false) * MB * (double)nbStreams * 0.25 + 16.0 * MB);
+        }
+    }
+    DeviceArena arena(arenaBytes);
     std::vector<std::unique_ptr<Sgm>> sgmPerStream;
     std::vector<std::unique_ptr<Refine>> refinePerStream;
+    DeviceBuffer groupScratch;
     {
+        const DeviceArena::Scope arenaScope(&arena);
         const bool sgmComputeDepthSimMap = !_depthMapParams.useRefine;
         const bool sgmComputeNormalMap = _refineParams.useSgmNormalMap;
         for(int i = 0; i < nbStreams; ++i)
@@ -391,12 +514,12 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         if(_depthMapParams.useRefine)
             for(int i = 0; i < nbStreams; ++i)
                 refinePerStream.push_back(std::make_unique<Refine>(_mp, _tileParams, _refineParams, deviceCache, deviceStreamManager.getStream(i)));
+        // scratch of the batched aggregation: the sum over a group is bounded by nbStreams maximum-size tiles
+        if(_sgmParams.doSgmOptimizeVolume)
+            groupScratch.allocate((size_t)nbStreams * avdm_volume_optimize_scratch_bytes(sgmPerStream.front()->getMapWidth(), sgmPerStream.front()->getMapHeight(),
+                                                                                         std::max(_sgmParams.maxDepths, 1)));
     }
-    // scratch of the batched aggregation: the sum over a group is bounded by nbStreams maximum-size tiles
-    DeviceBuffer groupScratch;
-    if(_sgmParams.doSgmOptimizeVolume)
-        groupScratch.allocate((size_t)nbStreams * avdm_volume_optimize_scratch_bytes(sgmPerStream.front()->getMapWidth(), sgmPerStream.front()->getMapHeight(),
-                                                                                     std::max(_sgmParams.maxDepths, 1)));
+    const double secondsDeviceBuffers = std::chrono::duration<double>(std::chrono::steady_clock::now() - tSetup0).count();
     // one event per stream (group fan-in) + one for the aggregation (fan-out); RAII holders: an exception anywhere below (a tile that does
     // not fit, a decoding error, a failed launch) must not leak events or free page-locked vectors while they are still registered
     struct EventSet
@@ -420,53 +543,10 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         EventSet(const EventSet&) = delete;
         EventSet& operator=(const EventSet&) = delete;
     };
-    struct PinnedRegistrations
-    {
-        std::vector<void*> ptrs;
-        void add(void* p, size_t bytes)
-        {
-            if(hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) // unpinned tiles still work (synchronous copies)
-                ptrs.push_back(p);
-            else
-                (void)hipGetLastError();
-        }
-        ~PinnedRegistrations()
-        {
-            for(void* p : ptrs)
-                (void)hipHostUnregister(p);
-        }
-    };
     EventSet events((size_t)nbStreams + 1);
     std::vector<hipEvent_t> volumeDone(events.ev.begin(), events.ev.begin() + nbStreams);
     const hipEvent_t aggregationDone = events.ev.back();
 
-    // final depth/similarity map tiles in host memory, per camera of a batch
-    const int finalMapW = _depthMapParams.useRefine ? refinePerStream.front()->getMapWidth() : sgmPerStream.front()->getMapWidth();
-    const int finalMapH = _depthMapParams.useRefine ? refinePerStream.front()->getMapHeight() : sgmPerStream.front()->getMapHeight();
-    // two sets: while the tiles of batch b are merged and written by a background task, batch b + 1 computes into the other set
-    // (the reference merges and writes between the batches, DepthMapEstimator.cpp:446-466, with the device idle)
-    const int nbHostSets = 2;
-    std::vector<std::vector<Float2Tile>> depthSimMapTileSets[nbHostSets];
-    PinnedRegistrations pinned; // declared after the tile sets: unregistered before the vectors are freed
-    std::vector<std::vector<std::pair<float, float>>> depthMinMaxTileSets[nbHostSets];
-    for(int s = 0; s < nbHostSets; ++s)
-    {
-        depthSimMapTileSets[s].resize(nbRcPerBatch);
-        depthMinMaxTileSets[s].resize(nbRcPerBatch);
-        for(int i = 0; i < nbRcPerBatch; ++i)
-        {
-            depthSimMapTileSets[s][i].resize(nbTilesPerCamera);
-            depthMinMaxTileSets[s][i].resize(nbTilesPerCamera);
-            for(int j = 0; j < nbTilesPerCamera; ++j)
-            {
-                depthSimMapTileSets[s][i][j].allocate(finalMapW, finalMapH);
-                // page-lock the result tiles (CudaHostMemoryHeap is pinned memory in the reference): the device-to-host copies of a
-                // group then run asynchronously on the tile streams instead of blocking the host thread that feeds them
-                std::vector<float>& v = depthSimMapTileSets[s][i][j].data;
-                pinned.add(v.data(), v.size() * sizeof(float));
-            }
-        }
-    }
     std::future<void> pendingWrite;
     // the background writer reads the host tile sets: on unwinding it must have finished before they go away (its own exception, if any, is
     // dropped then — the one in flight is reported)
@@ -488,8 +568,12 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         }
     } writerGuard{pendingWrite};
     logDeviceMemoryInfo();
-    AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): set-up (streams, per-stream device buffers, page-locked result tiles) in "
-                            << std::chrono::duration<double>(std::chrono::steady_clock::now() - tCompute0).count() << " s.");
+    AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): set-up (streams, per-stream device buffers; the result tiles are page-locked and the first batch's images "
+                            << "uploaded beside it) in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tCompute0).count() << " s ("
+                            << secondsDeviceBuffers << " s for the device buffers of " << nbStreams << " tile slot(s): "
+                            << (arena.bytes() ? "one arena of " + std::to_string(arena.bytes() >> 20) + " MB, " + std::to_string(arena.used() >> 20) + " MB used"
+                                              : std::string("one allocation per buffer"))
+                            << ").");
 
     const int nbBatches = divideRoundUp(static_cast<int>(tiles.size()), nbTilesPerBatch);
     double tilesSeconds = 0.0; // from "the batch's images are on the device" to "its tiles are computed", summed over the batches
@@ -508,36 +592,36 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
 
         const auto tBatch0 = std::chrono::steady_clock::now();
         auto secondsSince = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
-        // decode the images of the batch on the host cores first (the reference reads them one by one inside addMipmapImage);
+        // the views of the batch: decoded, uploaded and converted to pyramids by a team of host threads, one view each on its own stream
+        // (DeviceCache::addMipmapImages; the first batch's team has been at it since before the set-up) — the reference reads and converts them
+        // one by one inside addMipmapImage (DepthMapEstimator.cpp:224-232), and so did rounds 1-5 after a parallel decode;
         // with the multi-GPU exchange nothing is decoded here: own views were published by the pre-pass, the others arrive as pyramids
         if(exchange == nullptr)
         {
-            std::vector<int> camsOfBatch;
-            for(int i = firstTileIndex; i < lastTileIndex; ++i)
+            if(firstIngest.valid())
+                firstIngest.get(); // (rethrows)
+            else if(teamIngest)
+                deviceCache.addMipmapImages(viewsOfBatch(b), minMipmapDownscale, maxMipmapDownscale, ic, _mp);
+            else
             {
-                const Tile& tile = tiles.at(i);
-                camsOfBatch.push_back(tile.rc);
-                camsOfBatch.insert(camsOfBatch.end(), tile.sgmTCams.begin(), tile.sgmTCams.end());
-                camsOfBatch.insert(camsOfBatch.end(), tile.refineTCams.begin(), tile.refineTCams.end());
-            }
-            std::sort(camsOfBatch.begin(), camsOfBatch.end());
-            camsOfBatch.erase(std::unique(camsOfBatch.begin(), camsOfBatch.end()), camsOfBatch.end());
-            std::exception_ptr loadError;
+                const std::vector<int> camsOfBatch = viewsOfBatch(b);
+                std::exception_ptr loadError;
 #pragma omp parallel for schedule(dynamic, 1)
-            for(int k = 0; k < (int)camsOfBatch.size(); ++k)
-            {
-                try
+                for(int k = 0; k < (int)camsOfBatch.size(); ++k)
                 {
-                    ic.getImg_sync(camsOfBatch[k]);
-                }
-                catch(...)
-                {
+                    try
+                    {
+                        ic.getImg_sync(camsOfBatch[k]);
+                    }
+                    catch(...)
+                    {
 #pragma omp critical
-                    loadError = std::current_exception();
+                        loadError = std::current_exception();
+                    }
                 }
+                if(loadError)
+                    std::rethrow_exception(loadError);
             }
-            if(loadError)
-                std::rethrow_exception(loadError);
         }
         // load the R and T cameras of the batch in the device cache
         for(int i = firstTileIndex; i < lastTileIndex; ++i)
@@ -563,7 +647,16 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
             deviceCache.addCameraParams(tile.rc, 1, _mp); // retrieveBestDepth always asks for downscale 1 (Sgm.cpp:316)
         }
         AVDM_HIP_CHECK(hipDeviceSynchronize());
-        AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": images decoded, uploaded and converted to pyramids in " << secondsSince(tBatch0) << " s.");
+        AVDM_LOG_INFO("Batch " << (b + 1) << "/" << nbBatches << ": images decoded, uploaded and converted to pyramids in " << secondsSince(tBatch0) << " s"
+                               << (b == 0 && teamIngest && exchange == nullptr ? " after the set-up (" + std::to_string(secondsSince(tIngest0)) + " s since its team started, beside the set-up)" : std::string())
+                               << ".");
+        if(hostSetReady[b % nbHostSets].valid())
+        {
+            const auto th0 = std::chrono::steady_clock::now();
+            hostSetReady[b % nbHostSets].get(); // (rethrows the task's failure)
+            AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): waited " << secondsSince(th0) << " s more for the page-locked result tiles of set "
+                                    << (b % nbHostSets) << ".");
+        }
         const auto tTiles0 = std::chrono::steady_clock::now();
 
         // what the batch actually sweeps, in the kernels' work unit (voxel x T camera): the depth lists are capped per tile and every T camera has
@@ -746,6 +839,21 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
     }
     {
         const auto tTail0 = std::chrono::steady_clock::now();
+        // While the background task merges and writes the last batch's maps (it reads host memory only), this thread gives the device side back:
+        // the tile slots' buffers, the page-locks of the result tiles (unpinning leaves the host bytes where they are), the pyramids, the streams
+        // with the library's scratch blocks — ~0.4 s of hipFree / hipHostUnregister calls that used to follow the wait.
+        {
+            refinePerStream.clear();
+            sgmPerStream.clear();
+            groupScratch.release();
+            hostTilesTask.wait();
+            arena.release();
+            pinned.releaseAll();
+            deviceCache.releaseImages();
+            deviceStreamManager.destroy();
+            AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): device buffers, pyramids, streams and page-locks released in "
+                                    << std::chrono::duration<double>(std::chrono::steady_clock::now() - tTail0).count() << " s, beside the last batch's merge + write.");
+        }
         if(pendingWrite.valid())
             pendingWrite.get();
         AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): waited " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tTail0).count()
@@ -764,6 +872,17 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
                                 << (it.bytesReceived >> 20) << " MB; " << it.awaitOwner << " s waiting for the owner, " << it.peerCopy << " s copying), " << it.built
                                 << " built here (" << it.localBuild << " s: decode unless cached, upload, pyramid); tiles: " << tilesSeconds << " s in " << nbBatches
                                 << " batch(es).");
+    }
+
+    {
+        const auto tFree0 = std::chrono::steady_clock::now();
+        for(int s = 0; s < nbHostSets; ++s)
+        {
+            depthSimMapTileSets[s].clear();
+            depthSimMapTileSets[s].shrink_to_fit();
+        }
+        AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): host result tiles freed in "
+                                << std::chrono::duration<double>(std::chrono::steady_clock::now() - tFree0).count() << " s.");
     }
 
     // merge intermediate result tiles (:470-505)

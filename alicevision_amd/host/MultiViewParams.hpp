@@ -143,6 +143,9 @@ struct HostImage
     // a JPEG file: the entropy-decoded coefficients (host/jpeg.cpp); the inverse DCT, up-sampling, colour conversion and the sRGB decoding run
     // on the device (avdm_image_decode_jpeg + avdm_image_decode_integer).  `rgba` and `raw` are empty then.
     std::shared_ptr<const JpegImage> jpeg;
+    // an OpenEXR file: its scan lines as stored (exr.hpp ExrLines: mapped when uncompressed, inflated otherwise); the de-interleave to float
+    // RGBA runs on the device (avdm_image_decode_exr_lines).  `rgba` is empty then.  AVDM_HOST_EXR=host: rounds 1-5's form (`rgba` filled here).
+    std::shared_ptr<const ExrLines> exrLines;
 };
 // mvsUtils/fileIO.cpp:389-443 loadImage + mvsUtils/ImagesCache.hpp: a small thread-safe RAM cache keyed by camera index
 class ImagesCache

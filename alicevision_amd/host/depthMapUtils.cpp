@@ -8,11 +8,14 @@
 #include "exr.hpp"
 #include "log.hpp"
 
+#include <sys/mman.h>
+
 #include <dirent.h>
 #include <sys/stat.h>
 
 #include <algorithm>
 #include <fstream>
+#include <future>
 #include <sstream>
 #include <cstdio>
 #include <fstream>
@@ -20,6 +23,25 @@
 #include <regex>
 
 namespace avdm_host {
+
+void* hugePageAlloc(size_t bytes)
+{
+    const size_t huge = (size_t)2 << 20;
+    void* p = nullptr;
+    if(bytes >= huge)
+    {
+        const size_t rounded = (bytes + huge - 1) & ~(huge - 1);
+        if(posix_memalign(&p, huge, rounded) != 0)
+            throw std::bad_alloc();
+        (void)madvise(p, rounded, MADV_HUGEPAGE); // (advice: a kernel without transparent huge pages serves 4 KiB pages)
+        return p;
+    }
+    p = std::malloc(bytes ? bytes : 1);
+    if(p == nullptr)
+        throw std::bad_alloc();
+    return p;
+}
+void hugePageFree(void* p) { std::free(p); }
 
 void resetDepthSimMap(Float2Tile& inout, float depth, float sim)
 {
@@ -615,46 +637,52 @@ void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileP
     const int scaleStep = scale * step;
     const int width = divideRoundUp(mp.getWidth(rc), scaleStep);
     const int height = divideRoundUp(mp.getHeight(rc), scaleStep);
-    FloatMap depthMap(width, height, 0.0f), simMap(width, height, 0.0f);
-    // the two tile maps are allocated once (largest tile) and reshaped per tile: allocating and freeing multi-megabyte vectors per
-    // tile means mmap / munmap each time, and every munmap interrupts all the cores the OpenMP team runs on
-    FloatMap tileDepthMap, tileSimMap;
-    {
-        size_t maxPixels = 0;
-        for(const ROI& t : tileRoiList)
-        {
-            const ROI r = downscaleROI(intersect(t, imageRoi), (float)scaleStep);
-            maxPixels = std::max(maxPixels, (size_t)r.width() * r.height());
-        }
-        tileDepthMap.data.reserve(maxPixels);
-        tileSimMap.data.reserve(maxPixels);
-    }
-
-    for(size_t i = 0; i < tileRoiList.size(); ++i)
-    {
-        const ROI roi = intersect(tileRoiList.at(i), imageRoi);
-        if(roi.isEmpty())
-            continue;
-        const ROI r = downscaleROI(roi, (float)scaleStep);
-        const int w = (int)r.width(), h = (int)r.height();
-        const Float2Tile& t = in_depthSimMapTiles.at(i);
-        tileDepthMap.reshape(w, h);
-        tileSimMap.reshape(w, h);
-#pragma omp parallel for schedule(static) num_threads(8)
-        for(int y = 0; y < h; ++y)
-            for(int x = 0; x < w; ++x)
-            {
-                tileDepthMap(y, x) = t.data[((size_t)y * t.width + x) * 2];
-                tileSimMap(y, x) = t.data[((size_t)y * t.width + x) * 2 + 1];
-            }
-        addTileMapWeighted(rc, mp, tileParams, roi, scaleStep, tileDepthMap, depthMap);
-        addTileMapWeighted(rc, mp, tileParams, roi, scaleStep, tileSimMap, simMap);
-    }
-    // the merged maps are written with DEFAULT tile parameters and the full-size ROI (mapIO.hpp:118-130)
-    const TileParams defaultTileParams;
+    // the two channels are independent from the tile buffers to the files: merged and written by two threads (the last batch of a job has
+    // nothing to hide behind — its merge + write is on the critical path)
+    const TileParams defaultTileParams; // the merged maps are written with DEFAULT tile parameters and the full-size ROI (mapIO.hpp:118-130)
     const ROI fullRoi(0, mp.getWidth(rc), 0, mp.getHeight(rc));
-    writeMap(rc, mp, EFileType::depthMap, defaultTileParams, fullRoi, depthMap, scale, step, customSuffix);
-    writeMap(rc, mp, EFileType::simMap, defaultTileParams, fullRoi, simMap, scale, step, customSuffix);
+    auto channel = [&](int c, EFileType fileType) {
+        FloatMap map(width, height, 0.0f);
+        // the tile map is allocated once (largest tile) and reshaped per tile: allocating and freeing multi-megabyte vectors per
+        // tile means mmap / munmap each time, and every munmap interrupts all the cores the OpenMP team runs on
+        FloatMap tileMap;
+        {
+            size_t maxPixels = 0;
+            for(const ROI& t : tileRoiList)
+            {
+                const ROI r = downscaleROI(intersect(t, imageRoi), (float)scaleStep);
+                maxPixels = std::max(maxPixels, (size_t)r.width() * r.height());
+            }
+            tileMap.data.reserve(maxPixels);
+        }
+        for(size_t i = 0; i < tileRoiList.size(); ++i)
+        {
+            const ROI roi = intersect(tileRoiList.at(i), imageRoi);
+            if(roi.isEmpty())
+                continue;
+            const ROI r = downscaleROI(roi, (float)scaleStep);
+            const int w = (int)r.width(), h = (int)r.height();
+            const Float2Tile& t = in_depthSimMapTiles.at(i);
+            tileMap.reshape(w, h);
+#pragma omp parallel for schedule(static) num_threads(8)
+            for(int y = 0; y < h; ++y)
+                for(int x = 0; x < w; ++x)
+                    tileMap(y, x) = t.data[((size_t)y * t.width + x) * 2 + c];
+            addTileMapWeighted(rc, mp, tileParams, roi, scaleStep, tileMap, map);
+        }
+        writeMap(rc, mp, fileType, defaultTileParams, fullRoi, map, scale, step, customSuffix);
+    };
+    std::future<void> sim = std::async(std::launch::async, channel, 1, EFileType::simMap);
+    try
+    {
+        channel(0, EFileType::depthMap);
+    }
+    catch(...)
+    {
+        sim.wait();
+        throw;
+    }
+    sim.get();
 }
 
 namespace {

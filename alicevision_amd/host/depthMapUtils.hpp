@@ -32,10 +32,34 @@ struct FloatMap
 };
 
 // host copy of a tile's float2 map: interleaved (x, y) pairs, row-major, `width` pairs per row (CudaHostMemoryHeap<float2, 2>)
+// Storage of a result tile: 2 MiB-aligned and marked for transparent huge pages (madvise).  A tile is several MB that is zero-filled, page-
+// locked (hipHostRegister) and written by the device: with 4 KiB pages that is ~1 400 page faults and as many pages to pin per tile — the
+// page-locking of a 12 MP job's 80 tiles took 0.25 s; with 2 MiB pages it is three of each.
+template <typename T>
+struct HugePageAllocator
+{
+    using value_type = T;
+    HugePageAllocator() = default;
+    template <typename U>
+    HugePageAllocator(const HugePageAllocator<U>&) {}
+    T* allocate(size_t n);
+    void deallocate(T* p, size_t) noexcept;
+    template <typename U>
+    bool operator==(const HugePageAllocator<U>&) const { return true; }
+    template <typename U>
+    bool operator!=(const HugePageAllocator<U>&) const { return false; }
+};
+void* hugePageAlloc(size_t bytes);
+void hugePageFree(void* p);
+template <typename T>
+T* HugePageAllocator<T>::allocate(size_t n) { return static_cast<T*>(hugePageAlloc(n * sizeof(T))); }
+template <typename T>
+void HugePageAllocator<T>::deallocate(T* p, size_t) noexcept { hugePageFree(p); }
+
 struct Float2Tile
 {
     int width = 0, height = 0;
-    std::vector<float> data;
+    std::vector<float, HugePageAllocator<float>> data;
     void allocate(int w, int h)
     {
         width = w, height = h;

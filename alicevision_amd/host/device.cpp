@@ -1,7 +1,11 @@
 // device.cpp — see device.hpp.
 #include "device.hpp"
 
+#include <algorithm>
+#include <cstdlib>
 #include <chrono>
+
+#include <omp.h>
 
 #include "jpeg.hpp"
 #include "log.hpp"
@@ -16,13 +20,15 @@ DeviceStreamManager::DeviceStreamManager(int nbStreams)
     for(auto& s : _streams)
         AVDM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
 }
-DeviceStreamManager::~DeviceStreamManager()
+DeviceStreamManager::~DeviceStreamManager() { destroy(); }
+void DeviceStreamManager::destroy()
 {
     for(auto& s : _streams)
     {
         (void)avdm_stream_release(s); // the library's per-stream block (optimisation point maps, resize tap tables) goes with the stream
         (void)hipStreamDestroy(s);
     }
+    _streams.clear();
 }
 
 void decodeJpegToLinearRgba(const JpegImage& jpeg, float* rgba_d, hipStream_t stream)
@@ -51,7 +57,7 @@ void decodeJpegToLinearRgba(const JpegImage& jpeg, float* rgba_d, hipStream_t st
     AVDM_HIP_CHECK(hipStreamSynchronize(stream));
 }
 
-void DeviceMipmapImage::fill(const HostImage& img, int minDownscale, int maxDownscale, int filterMode, hipStream_t stream)
+void DeviceMipmapImage::fill(const HostImage& img, int minDownscale, int maxDownscale, int filterMode, hipStream_t stream, DeviceBuffer* staging)
 {
     avdm_pyramid_t p;
     avdmCheck(avdm_pyramid_layout(&p, img.width, img.height, minDownscale, maxDownscale, filterMode), "avdm_pyramid_layout");
@@ -61,11 +67,25 @@ void DeviceMipmapImage::fill(const HostImage& img, int minDownscale, int maxDown
     _pyr = p;
     const int srcW = img.srcWidth > 0 ? img.srcWidth : img.width, srcH = img.srcHeight > 0 ? img.srcHeight : img.height;
     const size_t srcBytes = (size_t)srcW * srcH * 16, imgBytes = (size_t)img.width * img.height * 16;
-    DeviceBuffer rgba(srcBytes), resized, scratch, samples;
+    DeviceBuffer rgbaOwn, resized, scratch, samples;
+    if(staging == nullptr)
+        rgbaOwn.allocate(srcBytes);
+    else if(staging->bytes() < srcBytes)
+        staging->allocate(srcBytes);
+    const DeviceBuffer& rgba = staging != nullptr ? *staging : rgbaOwn;
     if(minDownscale > 1)
         scratch.allocate((size_t)img.width * img.height * 8);
     if(img.jpeg)
         decodeJpegToLinearRgba(*img.jpeg, rgba.as<float>(), stream);
+    else if(img.exrLines)
+    {
+        // an OpenEXR file: its scan lines as stored (mapped file or inflated blocks) go up as they are; float RGBA is made on the device
+        const ExrLines& x = *img.exrLines;
+        samples.allocate(x.bytes);
+        AVDM_HIP_CHECK(hipMemcpyAsync(samples.ptr(), x.lines, x.bytes, hipMemcpyHostToDevice, stream));
+        avdmCheck(avdm_image_decode_exr_lines(rgba.as<float>(), srcW * 16, samples.ptr(), x.lineStride, srcW, srcH, x.chanOffset, x.chanType, stream),
+                  "avdm_image_decode_exr_lines");
+    }
     else if(!img.raw.empty())
     {
         // an integer file (PNG): upload the decoder's samples, make the linear float RGBA image on the device
@@ -241,6 +261,100 @@ void DeviceCache::addMipmapImage(int camId, int minDownscale, int maxDownscale, 
     ++_times.built;
 }
 
+void DeviceCache::addMipmapImages(const std::vector<int>& camIds, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp)
+{
+    struct Job
+    {
+        int camId, slot;
+    };
+    std::vector<Job> jobs;
+    if(_exchange != nullptr || camIds.size() > _mipmaps.size())
+    { // (more views than slots: a later view would evict an earlier one of the same list)
+        hipStream_t s = nullptr;
+        AVDM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        try
+        {
+            for(const int c : camIds)
+                addMipmapImage(c, minDownscale, maxDownscale, imageCache, mp, s);
+        }
+        catch(...)
+        {
+            (void)avdm_stream_release(s);
+            (void)hipStreamDestroy(s);
+            throw;
+        }
+        (void)avdm_stream_release(s);
+        (void)hipStreamDestroy(s);
+        return;
+    }
+    for(const int c : camIds)
+    {
+        int slot;
+        if(_mipmapCache.insert(c, &slot))
+            jobs.push_back({c, slot});
+    }
+    if(jobs.empty())
+        return;
+    const auto tL = std::chrono::steady_clock::now();
+    int dev = 0;
+    AVDM_HIP_CHECK(hipGetDevice(&dev));
+    // (measured, session r06_j/k: an uncompressed EXR is mapped and uploaded as it lies — 13 ms per 12 MP view from ONE thread; a team of 11
+    // was slower than that thread alone: the uploads share one staging path and the page faults of the mappings one address space)
+    int teamSize = 2;
+    if(const char* e = getenv("AVDM_HOST_INGEST_THREADS"))
+        teamSize = std::max(1, atoi(e));
+    const int nbThreads = (int)std::min<size_t>(jobs.size(), (size_t)teamSize);
+    while((int)_staging.size() < nbThreads)
+        _staging.push_back(std::make_unique<DeviceBuffer>());
+    std::exception_ptr error;
+#pragma omp parallel num_threads(nbThreads)
+    {
+        const int tid = omp_get_thread_num();
+        hipStream_t s = nullptr;
+        bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+        if(!ok)
+        {
+#pragma omp critical
+            error = std::make_exception_ptr(std::runtime_error("addMipmapImages: cannot create a stream on the device"));
+        }
+#pragma omp for schedule(dynamic, 1)
+        for(int k = 0; k < (int)jobs.size(); ++k)
+        {
+            if(!ok)
+                continue;
+            try
+            {
+                const Job& j = jobs[(size_t)k];
+                AVDM_LOG_TRACE("Add mipmap image on device cache (id: " << j.camId << ", view id: " << mp.getViewId(j.camId) << ").");
+                const std::shared_ptr<const HostImage> img = imageCache.getImg_sync(j.camId);
+                // the pyramid the slot held is reused when nobody else holds it (same image size: no allocation at all)
+                std::shared_ptr<DeviceMipmapImage> own;
+                if(_mipmaps.at((size_t)j.slot) && _mipmaps.at((size_t)j.slot).use_count() == 1)
+                    own = std::const_pointer_cast<DeviceMipmapImage>(_mipmaps.at((size_t)j.slot));
+                else
+                    own = std::make_shared<DeviceMipmapImage>();
+                _mipmaps.at((size_t)j.slot).reset();
+                own->fill(*img, minDownscale, maxDownscale, _filterMode, s, _staging.at((size_t)tid).get());
+                _mipmaps.at((size_t)j.slot) = own; // (every job has a slot of its own)
+            }
+            catch(...)
+            {
+#pragma omp critical
+                error = std::current_exception();
+            }
+        }
+        if(s != nullptr)
+        {
+            (void)avdm_stream_release(s);
+            (void)hipStreamDestroy(s);
+        }
+    }
+    if(error)
+        std::rethrow_exception(error);
+    _times.localBuild += std::chrono::duration<double>(std::chrono::steady_clock::now() - tL).count();
+    _times.built += (int)jobs.size();
+}
+
 void DeviceCache::buildOwnedView(int camId, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp, hipStream_t stream)
 {
     if(_exchange == nullptr || _exchange->find(camId) || _exchange->isDeclined(camId))
@@ -258,6 +372,14 @@ void DeviceCache::buildOwnedView(int camId, int minDownscale, int maxDownscale, 
     auto own = std::make_shared<DeviceMipmapImage>();
     own->fill(*img, minDownscale, maxDownscale, _filterMode, stream);
     (void)_exchange->publish(camId, own);
+}
+
+void DeviceCache::releaseImages()
+{
+    _mipmapCache = LRUCache<int>((int)_mipmaps.size());
+    for(auto& m : _mipmaps)
+        m.reset();
+    _staging.clear();
 }
 
 void DeviceCache::addCameraParams(int camId, int downscale, const MultiViewParams& mp)

@@ -47,6 +47,62 @@ struct JpegImage;
 // sRGB decoding (image::readImage(path, img, LINEAR) for an 8-bit file).  Synchronises `stream` (its temporaries die on return).
 void decodeJpegToLinearRgba(const JpegImage& jpeg, float* rgba_d, hipStream_t stream);
 
+// One hipMalloc for the many fixed-size buffers of a worker (no counterpart in the reference, which allocates every CudaDeviceMemoryPitched
+// by itself, memory.hpp:326-548).  A worker's set-up creates ~12 device buffers per tile slot — ~500 hipMalloc calls for the default tiling of a
+// 12 MP camera, and as many hipFree calls (each a device-wide wait) at the end: measured 0.3 s + 0.4 s of a 6.4 s job.  While
+// a DeviceArena::Scope is alive on a thread, DeviceBuffer::allocate on THAT thread takes its bytes from the arena (4 KiB-aligned, one guard
+// page between neighbours); a request the arena cannot serve falls back to hipMalloc.  The arena must outlive the buffers carved from it.
+class DeviceArena
+{
+  public:
+    DeviceArena() = default;
+    explicit DeviceArena(size_t bytes)
+    {
+        if(bytes && hipMalloc(&_base, bytes) == hipSuccess)
+            _bytes = bytes;
+        else
+            (void)hipGetLastError(); // no arena: every buffer allocates for itself
+    }
+    DeviceArena(const DeviceArena&) = delete;
+    DeviceArena& operator=(const DeviceArena&) = delete;
+    ~DeviceArena() { release(); }
+    // (every buffer carved from it must be gone)
+    void release()
+    {
+        if(_base)
+            (void)hipFree(_base);
+        _base = nullptr, _bytes = _used = 0;
+    }
+    void* take(size_t bytes)
+    {
+        const size_t need = ((bytes + 4095) & ~(size_t)4095) + 4096;
+        if(_base == nullptr || _used + need > _bytes)
+            return nullptr;
+        void* p = static_cast<char*>(_base) + _used;
+        _used += need;
+        return p;
+    }
+    size_t bytes() const { return _bytes; }
+    size_t used() const { return _used; }
+    static DeviceArena*& current()
+    {
+        static thread_local DeviceArena* a = nullptr;
+        return a;
+    }
+    struct Scope
+    {
+        DeviceArena* prev;
+        explicit Scope(DeviceArena* a) : prev(current()) { current() = a; }
+        ~Scope() { current() = prev; }
+        Scope(const Scope&) = delete;
+        Scope& operator=(const Scope&) = delete;
+    };
+
+  private:
+    void* _base = nullptr;
+    size_t _bytes = 0, _used = 0;
+};
+
 class DeviceBuffer
 {
   public:
@@ -54,13 +110,13 @@ class DeviceBuffer
     explicit DeviceBuffer(size_t bytes) { allocate(bytes); }
     DeviceBuffer(const DeviceBuffer&) = delete;
     DeviceBuffer& operator=(const DeviceBuffer&) = delete;
-    DeviceBuffer(DeviceBuffer&& o) noexcept : _p(o._p), _bytes(o._bytes) { o._p = nullptr, o._bytes = 0; }
+    DeviceBuffer(DeviceBuffer&& o) noexcept : _p(o._p), _bytes(o._bytes), _owned(o._owned) { o._p = nullptr, o._bytes = 0; }
     DeviceBuffer& operator=(DeviceBuffer&& o) noexcept
     {
         if(this != &o)
         {
             release();
-            _p = o._p, _bytes = o._bytes;
+            _p = o._p, _bytes = o._bytes, _owned = o._owned;
             o._p = nullptr, o._bytes = 0;
         }
         return *this;
@@ -70,14 +126,20 @@ class DeviceBuffer
     {
         release();
         if(bytes)
-            AVDM_HIP_CHECK(hipMalloc(&_p, bytes));
+        {
+            DeviceArena* const arena = DeviceArena::current();
+            _p = arena != nullptr ? arena->take(bytes) : nullptr;
+            _owned = _p == nullptr;
+            if(_owned)
+                AVDM_HIP_CHECK(hipMalloc(&_p, bytes));
+        }
         _bytes = bytes;
     }
     void release()
     {
-        if(_p)
+        if(_p && _owned)
             (void)hipFree(_p);
-        _p = nullptr, _bytes = 0;
+        _p = nullptr, _bytes = 0, _owned = true;
     }
     void* ptr() const { return _p; }
     template <typename T>
@@ -87,6 +149,7 @@ class DeviceBuffer
   private:
     void* _p = nullptr;
     size_t _bytes = 0;
+    bool _owned = true; // false: carved from a DeviceArena
 };
 
 // pinned, unpadded host buffer (CudaHostMemoryHeap)
@@ -128,6 +191,8 @@ class DeviceStreamManager
   public:
     explicit DeviceStreamManager(int nbStreams);
     ~DeviceStreamManager();
+    // give the streams (and the library's per-stream scratch blocks) back before the object dies; getStream() must not be called afterwards
+    void destroy();
     hipStream_t getStream(int i) const { return _streams.at(i % _streams.size()); }
     int getNbStreams() const { return (int)_streams.size(); }
     void waitStream(int i) const { AVDM_HIP_CHECK(hipStreamSynchronize(getStream(i))); }
@@ -141,7 +206,9 @@ class DeviceMipmapImage
 {
   public:
     // DeviceMipmapImage.cpp:28-90 via avdm_pyramid_layout + avdm_pyramid_fill (x255 -> fp16 -> Gaussian downscale -> Lab -> levels)
-    void fill(const HostImage& img, int minDownscale, int maxDownscale, int filterMode, hipStream_t stream);
+    // staging: a device buffer kept by the caller for the uploaded float RGBA image (grown when too small) — without it every call allocates
+    // and frees one (a hipFree is a device-wide wait: with several views in flight on several streams each would wait for all the others)
+    void fill(const HostImage& img, int minDownscale, int maxDownscale, int filterMode, hipStream_t stream, DeviceBuffer* staging = nullptr);
     // a copy of a pyramid that lives on another device (or on this one): hipMemcpyPeerAsync over xGMI, same bytes, own descriptor
     void copyFromPeer(const DeviceMipmapImage& src, int srcDevice, int dstDevice, hipStream_t stream);
     const avdm_pyramid_t& pyramid() const { return _pyr; }
@@ -256,6 +323,10 @@ class DeviceCache
     void buildOwnedView(int camId, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp, hipStream_t stream);
     // DeviceCache.cpp:222-281
     void addMipmapImage(int camId, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp, hipStream_t stream);
+    // the same for a list of views at once: LRU slots taken in list order on the calling thread, then one host thread per NEW view decodes it,
+    // uploads it and converts it on a stream of its own (pyramid buffers of evicted slots and the upload staging buffers are reused).  Without
+    // the exchange only (the multi-GPU path publishes its views in the pre-pass).
+    void addMipmapImages(const std::vector<int>& camIds, int minDownscale, int maxDownscale, ImagesCache& imageCache, const MultiViewParams& mp);
     // DeviceCache.cpp:283-323 (+ fillHostCameraParameters :41-134 through avdm_camera_fill)
     void addCameraParams(int camId, int downscale, const MultiViewParams& mp);
     // DeviceCache.cpp:325-365: throw when absent
@@ -272,6 +343,8 @@ class DeviceCache
         long long bytesReceived = 0;
     };
     const ImageTimes& imageTimes() const { return _times; }
+    // free the pyramids of the slots and the upload buffers now (the cache stays usable: empty)
+    void releaseImages();
 
   private:
     ImageTimes _times;
@@ -280,6 +353,7 @@ class DeviceCache
     LRUCache<std::pair<int, int>> _cameraParamCache;
     std::vector<std::shared_ptr<const DeviceMipmapImage>> _mipmaps; // a slot owns its pyramid, or aliases one this worker published
     std::vector<avdm_camera_t> _cameraParams;
+    std::vector<std::unique_ptr<DeviceBuffer>> _staging; // upload buffers of addMipmapImages, one per team thread
     PyramidExchange* _exchange = nullptr;
     int _worker = 0;
 };

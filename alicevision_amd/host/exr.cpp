@@ -4,6 +4,11 @@
 
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstring>
 #include <fstream>
@@ -406,6 +411,186 @@ void readExr(const std::string& path, ExrImage& out, bool headerOnly)
     }
     if(!err.empty())
         throw std::runtime_error(err + " ('" + path + "')");
+}
+
+ExrLines::~ExrLines()
+{
+    if(mapBase != nullptr)
+        (void)munmap(mapBase, mapBytes);
+}
+
+bool readExrLines(const std::string& path, ExrLines& out)
+{
+    const int fd = open(path.c_str(), O_RDONLY);
+    if(fd < 0)
+        throw std::runtime_error("cannot open image '" + path + "'");
+    struct stat st;
+    if(fstat(fd, &st) != 0 || st.st_size < 16)
+    {
+        close(fd);
+        throw std::runtime_error("cannot read image '" + path + "'");
+    }
+    const size_t fileSize = (size_t)st.st_size;
+    void* const base = mmap(nullptr, fileSize, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if(base == MAP_FAILED)
+        return false;
+    out.mapBase = base, out.mapBytes = fileSize; // (unmapped by the destructor on every path below)
+    const uint8_t* const file = static_cast<const uint8_t*>(base);
+    Cursor c{file, file + fileSize};
+    if(c.i32() != 20000630)
+        throw std::runtime_error("'" + path + "' is not an OpenEXR file");
+    const int32_t version = c.i32();
+    if((version & 0xff) != 2 || (version & 0x200) || (version & 0x1000) || (version & 0x800))
+        throw std::runtime_error("EXR '" + path + "': only single-part scan-line files are supported");
+    std::vector<Chan> chans;
+    int compression = -1;
+    int dw[4] = {0, 0, -1, -1};
+    for(;;)
+    {
+        c.need(1);
+        if(*c.p == 0)
+        {
+            ++c.p;
+            break;
+        }
+        const std::string name = c.cstr(), type = c.cstr();
+        const int32_t size = c.i32();
+        if(size < 0)
+            throw std::runtime_error("EXR: bad attribute size");
+        c.need((size_t)size);
+        const uint8_t* d = c.p;
+        c.p += size;
+        if(name == "channels")
+        {
+            Cursor cc{d, d + size};
+            while(cc.p < cc.e && *cc.p)
+            {
+                Chan ch;
+                ch.name = cc.cstr();
+                ch.type = cc.i32();
+                cc.need(4);
+                cc.p += 4;
+                const int xs = cc.i32(), ys = cc.i32();
+                if(xs != 1 || ys != 1)
+                    return false;
+                chans.push_back(ch);
+            }
+        }
+        else if(name == "compression")
+            compression = d[0];
+        else if(name == "dataWindow")
+            std::memcpy(dw, d, 16);
+    }
+    if(chans.empty() || dw[2] < dw[0] || dw[3] < dw[1])
+        throw std::runtime_error("EXR '" + path + "': missing channels or data window");
+    if(compression != C_NONE && compression != C_ZIPS && compression != C_ZIP)
+        throw std::runtime_error("EXR '" + path + "': compression " + std::to_string(compression) + " is not supported (use none, zips or zip)");
+    const int W = dw[2] - dw[0] + 1, H = dw[3] - dw[1] + 1;
+    out.width = W, out.height = H;
+    size_t bytesPerLine = 0;
+    std::vector<long long> offsetOf(chans.size());
+    for(size_t i = 0; i < chans.size(); ++i)
+    {
+        if(chans[i].type != PT_UINT && chans[i].type != PT_HALF && chans[i].type != PT_FLOAT)
+            return false;
+        offsetOf[i] = (long long)bytesPerLine;
+        bytesPerLine += (size_t)W * (chans[i].type == PT_HALF ? 2 : 4);
+    }
+    auto indexOf = [&](const char* n) {
+        for(size_t i = 0; i < chans.size(); ++i)
+            if(chans[i].name == n)
+                return (int)i;
+        return -1;
+    };
+    const int iR = indexOf("R"), iG = indexOf("G"), iB = indexOf("B"), iA = indexOf("A"), iY = indexOf("Y");
+    if(!((iR >= 0 && iG >= 0 && iB >= 0) || iY >= 0))
+        throw std::runtime_error("image '" + path + "' has neither R,G,B nor Y channels");
+    const int pick[4] = {iR >= 0 ? iR : iY, iG >= 0 ? iG : iY, iB >= 0 ? iB : iY, iA};
+    for(int k = 0; k < 4; ++k)
+        if(pick[k] >= 0)
+            out.chanOffset[k] = offsetOf[(size_t)pick[k]], out.chanType[k] = chans[(size_t)pick[k]].type;
+
+    const int linesPerBlock = compression == C_ZIP ? 16 : 1;
+    const int nBlocks = (H + linesPerBlock - 1) / linesPerBlock;
+    const size_t tableOff = (size_t)(c.p - file);
+    if(fileSize < tableOff + (size_t)nBlocks * 8)
+        throw std::runtime_error("EXR: truncated offset table");
+    std::vector<uint64_t> offsets((size_t)nBlocks);
+    std::memcpy(offsets.data(), file + tableOff, (size_t)nBlocks * 8);
+    auto chunkHead = [&](int b, int32_t& y, int32_t& sz) {
+        const uint64_t off = offsets[(size_t)b];
+        if(off + 8 > fileSize)
+            throw std::runtime_error("EXR: chunk offset out of range ('" + path + "')");
+        std::memcpy(&y, file + off, 4);
+        std::memcpy(&sz, file + off + 4, 4);
+        if(sz < 0 || off + 8 + (uint64_t)sz > fileSize)
+            throw std::runtime_error("EXR: bad chunk ('" + path + "')");
+    };
+    if(compression == C_NONE)
+    {
+        // lines where they lie in the mapping: chunk b must be line b, its size one line, the chunks one stride apart
+        const uint64_t stride = bytesPerLine + 8;
+        for(int b = 0; b < nBlocks; ++b)
+        {
+            int32_t y, sz;
+            chunkHead(b, y, sz);
+            if(y != dw[1] + b || (size_t)sz != bytesPerLine || offsets[(size_t)b] != offsets[0] + (uint64_t)b * stride)
+                return false;
+        }
+        out.lines = file + offsets[0] + 8;
+        out.lineStride = (long long)stride;
+        out.bytes = (size_t)(H - 1) * stride + bytesPerLine;
+        (void)madvise(base, fileSize, MADV_SEQUENTIAL);
+        return true;
+    }
+    // ZIP / ZIPS: inflate the blocks (host cores) into one buffer of lines
+    out.inflated.reset(new uint8_t[(size_t)H * bytesPerLine]);
+    std::string err;
+#pragma omp parallel
+    {
+        std::vector<uint8_t> buf, tmp;
+#pragma omp for schedule(dynamic, 4)
+        for(int b = 0; b < nBlocks; ++b)
+        {
+            try
+            {
+                int32_t y, sz;
+                chunkHead(b, y, sz);
+                const int line0 = y - dw[1];
+                const int nLines = std::min(linesPerBlock, H - line0);
+                if(line0 < 0 || nLines <= 0 || line0 % linesPerBlock != 0)
+                    throw std::runtime_error("EXR: bad chunk ('" + path + "')");
+                const size_t rawSize = bytesPerLine * (size_t)nLines;
+                uint8_t* const dst = out.inflated.get() + (size_t)line0 * bytesPerLine;
+                const uint8_t* const src = file + offsets[(size_t)b] + 8;
+                if((size_t)sz == rawSize)
+                    std::memcpy(dst, src, rawSize);
+                else
+                {
+                    buf.resize(rawSize);
+                    uLongf n = (uLongf)rawSize;
+                    if(uncompress(buf.data(), &n, src, (uLong)sz) != Z_OK || n != rawSize)
+                        throw std::runtime_error("EXR: zlib inflate failed ('" + path + "')");
+                    zipUndo(buf, tmp);
+                    std::memcpy(dst, buf.data(), rawSize);
+                }
+            }
+            catch(const std::exception& e)
+            {
+#pragma omp critical
+                err = e.what();
+            }
+        }
+    }
+    if(!err.empty())
+        throw std::runtime_error(err);
+    (void)munmap(out.mapBase, out.mapBytes);
+    out.mapBase = nullptr, out.mapBytes = 0;
+    out.lines = out.inflated.get();
+    out.lineStride = (long long)bytesPerLine;
+    out.bytes = (size_t)H * bytesPerLine;
+    return true;
 }
 
 void writeExr(const std::string& path, int width, int height, const std::vector<ExrChannelIn>& channelsIn, bool storeHalf, const ExrAttributes& attributes,

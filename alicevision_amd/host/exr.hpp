@@ -6,6 +6,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -46,6 +47,33 @@ struct ExrImage
 
 // throws std::runtime_error; headerOnly skips the pixel data (readImageMetadata / readImageSize)
 void readExr(const std::string& path, ExrImage& out, bool headerOnly = false);
+
+// The scan lines of a file as OpenEXR stores them — per line the channels one after the other (alphabetical), each `width` samples of its
+// pixel type — WITHOUT being de-interleaved on the host: the bytes go to the device as they are and become linear float RGBA there
+// (avdm_image_decode_exr_lines).  An uncompressed file is mapped, not read: `lines` then points into the mapping and consecutive lines are
+// `lineStride` = bytes per line + the 8-byte chunk header apart; ZIP / ZIPS blocks are inflated (host cores) into one buffer, lineStride =
+// bytes per line.  What image::readImage does for an .exr through OpenImageIO (image/io.cpp, called by mvsUtils/fileIO.cpp:389-443), split
+// between host (container) and device (samples).
+struct ExrLines
+{
+    int width = 0, height = 0;
+    const uint8_t* lines = nullptr; // first sample of line 0
+    size_t bytes = 0;               // from `lines` to the end of the last line
+    long long lineStride = 0;
+    long long chanOffset[4] = {-1, -1, -1, -1}; // byte offset inside a line of R, G, B, A (-1: absent; a Y-only file gives Y as R, G and B)
+    int chanType[4] = {2, 2, 2, 2};             // OpenEXR pixel type: 0 UINT, 1 HALF, 2 FLOAT
+    ExrLines() = default;
+    ExrLines(const ExrLines&) = delete;
+    ExrLines& operator=(const ExrLines&) = delete;
+    ~ExrLines();
+    // (owners of `lines`)
+    void* mapBase = nullptr;
+    size_t mapBytes = 0;
+    std::unique_ptr<uint8_t[]> inflated;
+};
+// false: a layout this form does not take (line chunks not in increasing-y order at a uniform stride, no R,G,B or Y channel, sub-sampling):
+// the caller falls back to readExr.  Throws like readExr on a broken file.
+bool readExrLines(const std::string& path, ExrLines& out);
 
 struct ExrChannelIn
 {

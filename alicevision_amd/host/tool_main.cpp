@@ -144,6 +144,25 @@ int main(int argc, char** argv)
             writeExr(argv[3], img.width, img.height, ch, std::atoi(argv[4]) != 0, img.attributes, img.dataX0, img.dataY0, img.displayW, img.displayH);
             return 0;
         }
+        if(cmd == "exr-lines-dump" && argc == 4)
+        { // the scan lines as readExrLines hands them to the device: "<w> <h> <stride> <bytes> <mapped> <offR> <offG> <offB> <offA> <types...>" to stdout,
+          // the line bytes to a raw file ("refused" when the layout is not taken)
+            ExrLines x;
+            if(!readExrLines(argv[2], x))
+            {
+                std::cout << "refused" << std::endl;
+                return 0;
+            }
+            std::ofstream f(argv[3], std::ios::binary);
+            f.write((const char*)x.lines, (std::streamsize)x.bytes);
+            std::cout << x.width << " " << x.height << " " << x.lineStride << " " << x.bytes << " " << (x.mapBase != nullptr ? 1 : 0);
+            for(int k = 0; k < 4; ++k)
+                std::cout << " " << x.chanOffset[k];
+            for(int k = 0; k < 4; ++k)
+                std::cout << " " << x.chanType[k];
+            std::cout << std::endl;
+            return 0;
+        }
         if(cmd == "png-dump" && argc == 4)
         { // decode a PNG, write "<w> <h> <channels> <bits>" to stdout and the samples (host byte order) to a raw file
             PngImage img;

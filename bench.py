@@ -260,7 +260,7 @@ def cli_end_to_end(sc, V, W, H, Z, T, n_cams):
     if dec and set(dec) == set(comp):
         # per batch: decode + upload + pyramids, then the tiles (every stage of every tile, results copied back), then merge + EXR output — the
         # output of a batch runs in the background beside the next batch's tiles, so only its tail after the last tile is on the critical path
-        setup = [float(x) for x in re.findall(r"set-up \(streams, per-stream device buffers, page-locked result tiles\) in " + num + " s", log)]
+        setup = [float(x) for x in re.findall(r"set-up \(streams, per-stream device buffers[^)]*\) in " + num + " s", log)]
         tail = [float(x) for x in re.findall(r"waited " + num + " s for the last batch's maps to be merged and written", log)]
         stalls = [float(x) for x in re.findall(r"waited " + num + " s for the previous batch's maps to be written", log)]
         split = {"batches": len(dec), "decode_upload_pyramids_s": sum(dec.values()), "tiles_s": sum(comp[b] - dec[b] for b in dec),

@@ -195,6 +195,12 @@ int avdm_image_resize(float* dst_rgba, int dst_pitch, int dst_w, int dst_h, cons
  * host-evaluated table (C library powf): the device result is a look-up, bit-identical to the oracle's. */
 int avdm_image_decode_integer(float* dst_rgba, int dst_pitch, const void* src, int src_pitch, int width, int height, int channels, int bits,
                               int srgb_to_linear, void* stream);
+/* OpenEXR scan lines -> linear float RGBA on the device: image::readImage(path, img, LINEAR) as mvsUtils/fileIO.cpp:386-446
+ * calls it for an .exr.  `lines` = the scan lines as stored (per line the channels one after the other, `width` samples each), line y at
+ * lines + y * line_stride.  chan_offset[k] / chan_type[k]: byte offset in a line and pixel type (0 UINT, 1 HALF, 2 FLOAT) of R, G, B, A
+ * (A offset -1: absent -> 1; Y-only: Y three times).  Unaligned samples are read byte by byte.  Bit-identical to host/exr.cpp readExr. */
+int avdm_image_decode_exr_lines(float* dst_rgba, int dst_pitch, const void* lines, long long line_stride, int width, int height,
+                                const long long chan_offset[4], const int chan_type[4], void* stream);
 /* one component of a JPEG frame as the host's entropy decoder leaves it (avdm_image_decode_jpeg below) */
 typedef struct avdm_jpeg_component
 {

@@ -282,3 +282,22 @@ class OracleDepthMap:
             opt = refined.copy()
         self.optimized = opt
         return opt
+
+
+def exr_lines_to_rgba(lines, line_stride, width, height, chan_offset, chan_type):
+    """numpy restatement of avdm_image_decode_exr_lines (and of what image::readImage hands mvsUtils::loadImage for an .exr,
+    mvsUtils/fileIO.cpp:386-446, through OpenImageIO): `lines` = bytes of the scan lines as OpenEXR stores them (per line the channels one after
+    the other, `width` samples each; "OpenEXR File Layout", openexr.com), line y at y * line_stride; chan_offset / chan_type of R, G, B, A
+    (type 0 UINT -> float(u), 1 HALF -> exact, 2 FLOAT; A offset -1 -> 1).  Test infrastructure."""
+    buf = np.frombuffer(bytes(lines), np.uint8)
+    out = np.ones((height, width, 4), np.float32)
+    dt = {0: "<u4", 1: "<f2", 2: "<f4"}
+    for k in range(4):
+        if chan_offset[k] < 0:
+            continue
+        size = 2 if chan_type[k] == 1 else 4
+        for y in range(height):
+            o = y * line_stride + chan_offset[k]
+            out[y, :, k] = np.frombuffer(buf[o:o + size * width].tobytes(), dt[chan_type[k]]).astype(np.float32)
+    return out
+

@@ -136,6 +136,66 @@ def test_image_decode_integer_bit_exact(bits, ch):
     assert lib.avdm_image_decode_integer(_ptr(tdst), (W + 3) * 16, _ptr(tsrc), W * bpp + pad, W, H, 5, bits, 1, _st()) != 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["rgba_f32_headers", "rgb_f16_odd", "y_u32", "mixed_unaligned"])
+def test_image_decode_exr_lines_bit_exact(layout):
+    """avdm_image_decode_exr_lines (OpenEXR scan lines as stored -> linear float RGBA on the device: what image::readImage hands
+    mvsUtils::loadImage for an .exr, mvsUtils/fileIO.cpp:386-446) against the oracle's restatement: FLOAT lines with the 8-byte chunk headers of
+    an uncompressed file, HALF lines of odd width (alternate lines not 4-aligned), a UINT Y-only image, mixed types at odd offsets (the
+    byte-by-byte path) — identical bits (FLOAT NaN payloads, subnormals, infinities included); the padding of the destination rows untouched"""
+    import ctypes as C
+    torch = _torch()
+    from oracle import oracle
+    lib = abi.load()
+    rng = np.random.default_rng(11)
+    H, W = 19, 131
+    lead = 0
+    if layout == "rgba_f32_headers":
+        names, types = "ABGR", [2, 2, 2, 2]
+        stride_extra = 8
+    elif layout == "rgb_f16_odd":
+        names, types = "BGR", [1, 1, 1]
+        stride_extra = 0
+    elif layout == "y_u32":
+        names, types = "Y", [0]
+        stride_extra = 8
+    else:
+        names, types = "ABGR", [1, 2, 0, 1]
+        stride_extra, lead = 3, 1
+    size = {0: 4, 1: 2, 2: 4}
+    offs, o = {}, 0
+    for n, t in zip(names, types):
+        offs[n] = (o, t)
+        o += W * size[t]
+    bpl = o
+    stride = bpl + stride_extra
+    raw = rng.integers(0, 256, size=lead + H * stride, dtype=np.uint8)  # every bit pattern: NaNs, infinities, subnormals
+    for n, (o, t) in offs.items():  # HALF NaNs become infinities (a signalling NaN is quieted by the hardware conversion, not by numpy's)
+        if t == 1:
+            for y in range(H):
+                b0 = lead + y * stride + o
+                hi = raw[b0 + 1:b0 + 2 * W:2]
+                lo = raw[b0:b0 + 2 * W:2]
+                nan = ((hi & 0x7c) == 0x7c) & (((hi & 0x03) != 0) | (lo != 0))
+                hi[nan] &= 0xfc
+                lo[nan] = 0
+    pick = (lambda n: offs[n] if n in offs else offs["Y"])
+    off = [pick("R")[0], pick("G")[0], pick("B")[0], offs["A"][0] if "A" in offs else -1]
+    typ = [pick("R")[1], pick("G")[1], pick("B")[1], offs["A"][1] if "A" in offs else 2]
+    want = oracle.exr_lines_to_rgba(raw[lead:].tobytes(), stride, W, H, off, typ)
+    tsrc = torch.from_numpy(raw).cuda()
+    tdst = torch.full((H, W + 3, 4), -1.0, dtype=torch.float32, device="cuda")
+    coff, ctyp = (C.c_longlong * 4)(*off), (C.c_int * 4)(*typ)
+    abi.check(lib.avdm_image_decode_exr_lines(_ptr(tdst), (W + 3) * 16, tsrc.data_ptr() + lead, stride, W, H, coff, ctyp, _st()))
+    torch.cuda.synchronize()
+    got = tdst.cpu().numpy()
+    assert np.array_equal(got[:, :W].view(np.uint32), want.view(np.uint32))
+    assert np.all(got[:, W:] == -1.0)
+    bad = (C.c_int * 4)(3, 2, 2, 2)
+    assert lib.avdm_image_decode_exr_lines(_ptr(tdst), (W + 3) * 16, tsrc.data_ptr() + lead, stride, W, H, coff, bad, _st()) != 0
+    assert lib.avdm_image_decode_exr_lines(_ptr(tdst), (W + 3) * 16, tsrc.data_ptr() + lead, bpl - 4, W, H, coff, ctyp, _st()) != 0
+
+
 def _jpeg_device_and_oracle(path):
     import ctypes as C
     torch = _torch()

@@ -176,6 +176,34 @@ def test_exr_cpp_reads_python_writes_and_back(tmp_path, compression, half):
     assert "channels A B G R" in lines and "attr AliceVision:P m44d 128" in lines
 
 
+@pytest.mark.parametrize("compression", [0, 2, 3])
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("names", ["RGBA", "RGB", "Y"])
+def test_exr_scan_lines_for_the_device(tmp_path, compression, half, names):
+    """host/exr.cpp readExrLines: the container taken apart on the host (an uncompressed file mapped where it lies, ZIP / ZIPS blocks inflated), the
+    scan lines handed over AS STORED with the channel offsets — de-interleaved by the oracle's restatement of avdm_image_decode_exr_lines they
+    equal what the Python codec reads"""
+    from oracle import oracle
+    rng = np.random.RandomState(5 + compression)
+    h, w = 37, 53  # (odd width: HALF lines end on a 2-byte boundary, the samples of the next line are not 4-aligned)
+    chans = {n: (rng.rand(h, w) * (300.0 if n == "G" else 1.0)).astype(np.float32) for n in names}
+    a, raw = str(tmp_path / "a.exr"), str(tmp_path / "a.raw")
+    exr_io.write_exr(a, chans, half=half, compression=compression, data_origin=(3, 2), display_size=(80, 60))
+    f = run([TOOL, "exr-lines-dump", a, raw]).stdout.split()
+    assert f[0] != "refused"
+    W, H, stride, nbytes, mapped = (int(v) for v in f[:5])
+    off, typ = [int(v) for v in f[5:9]], [int(v) for v in f[9:13]]
+    assert (W, H) == (w, h) and mapped == (1 if compression == 0 else 0)
+    bpl = len(names) * w * (2 if half else 4)
+    assert stride == bpl + (8 if compression == 0 else 0) and nbytes == (h - 1) * stride + bpl
+    assert all(t == (1 if half else 2) for t, o in zip(typ, off) if o >= 0) and (off[3] >= 0) == ("A" in names)
+    got = oracle.exr_lines_to_rgba(open(raw, "rb").read(), stride, W, H, off, typ)
+    want, _ = exr_io.read_exr(a)
+    for k, n in enumerate("RGBA"):
+        src = want[n] if n in want else (want["Y"] if n != "A" else np.ones((h, w), np.float32))
+        assert np.array_equal(got[..., k], src), n
+
+
 def test_half_conversion_matches_numpy(tmp_path):
     """the C++ float -> half rounding (round to nearest even, subnormals, overflow) against numpy's"""
     vals = np.concatenate([np.linspace(-70000, 70000, 4001), np.logspace(-9, 5, 3000), -np.logspace(-9, 5, 500), [0.0, 65504.0, 65519.9, 65520.0, 5.96e-8,
