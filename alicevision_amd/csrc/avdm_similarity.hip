@@ -62,6 +62,37 @@ constexpr unsigned kSgmChunksPerWg = AVDM_SGM_CHUNKS_PER_WG; // SGM similarity: 
 #endif
 static_assert(4u * AVDM_SGM_CHUNKS_PER_WG <= 32u && 8u * AVDM_REFINE_CHUNKS_PER_WG <= 32u, "knifeMask: one bit per plane of a workgroup in a 32-bit word");
 constexpr unsigned kOutlierGrid = 2048; // workgroups of refine_outlier_kernel: its lanes stride over the units of the list
+// -DAVDM_LEAN_STATS=1 (a variant build, scripts/build_variant.sh; never the shipped library): which pass the waves of the DEFAULT instantiations take —
+// [0..6] SGM sweep {eight-plane passes, four-plane passes, one-plane passes from LDS, one-plane passes from global memory, workgroups without a
+// chunk window, workgroups, workgroups that retried without outliers}, [8..14] Refine sweep {eight, four, one LDS, one global, workgroups with an
+// anchored window, workgroups, workgroups without a chunk window}, [16..19] / [20..23] the outcome of the FIRST chunk-window search of a workgroup of
+// the SGM / Refine sweep {window staged, R tile unusable or nobody valid, hull leaves the T image, hull exceeds the LDS budget}; read and cleared by
+// avdm_debug_lean_stats
+// 0 (variant build): the hull of a workgroup's T taps must lie inside the T image to become a window (rounds 1-6a), the A/B of the clamped windows
+#ifndef AVDM_WINDOWS_OUTSIDE
+#define AVDM_WINDOWS_OUTSIDE 1
+#endif
+#ifndef AVDM_LEAN_STATS
+#define AVDM_LEAN_STATS 0
+#endif
+#if AVDM_LEAN_STATS
+__device__ unsigned g_leanStats[32];
+#define LEANSTAT(i)                                                                                                                                       \
+    do                                                                                                                                                    \
+    {                                                                                                                                                     \
+        if((threadIdx.x & 63u) == 0u)                                                                                                                     \
+            atomicAdd(&g_leanStats[i], 1u);                                                                                                               \
+    } while(0)
+#define LEANSTAT_WG(i)                                                                                                                                    \
+    do                                                                                                                                                    \
+    {                                                                                                                                                     \
+        if(threadIdx.x == 0u)                                                                                                                             \
+            atomicAdd(&g_leanStats[i], 1u);                                                                                                               \
+    } while(0)
+#else
+#define LEANSTAT(i) ((void)0)
+#define LEANSTAT_WG(i) ((void)0)
+#endif
 constexpr unsigned kRefineChunksPerWg = AVDM_REFINE_CHUNKS_PER_WG; // Refine: chunks of 8 planes per workgroup (they share one R tile, T window and pixel set-up)
 #ifndef AVDM_SIM_WAVES_PER_SIMD
 #define AVDM_SIM_WAVES_PER_SIMD 2 // occupancy the two kernels are compiled for: 3 -> 168 VGPRs, 2 -> 256 VGPRs
@@ -279,18 +310,22 @@ __device__ __forceinline__ void stage_window(uint2* dst, int pitch, const TexLev
 // row tap is ONE ds_read_b128 instead of two ds_read_b64.  Costs twice the LDS per texel: used where the windows are small enough.
 #define AVDM_PERM_LO 0x05040100u // {lo16(src1), lo16(src0)}
 #define AVDM_PERM_HI 0x07060302u // {hi16(src1), hi16(src0)}
+// The window may reach OUTSIDE the image (round 6): a position outside holds the nearest texel of the image — clamp addressing, what the texture
+// unit (tex_bilinear_px: texel_clamped per tap) gives a tap there — so that the patches of a workgroup at the image border take their taps from
+// LDS like everybody else.  Until then a hull that left the T image was no window: 2-3.5 % of the SGM sweep's workgroups ran one plane per pass,
+// a third of those passes from global memory — 1.2 M one-plane wave passes per depth map beside 3.4 M eight-plane ones (session r06_o).
 __device__ __forceinline__ void stage_window_paired(uint4* dst, int pitch, const TexLevel& L, int x0, int y0, int w, int h)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for(int r = wave; r < h; r += 4)
     {
-        const uint2* src = L.base + (long long)(y0 + r) * L.pitch8 + x0;
+        const uint2* src = L.base + (long long)min(max(y0 + r, 0), L.H - 1) * L.pitch8;
         uint4* d = dst + r * pitch;
         // 63 records per pass: every lane loads one texel, the right neighbour comes from the next lane (wave_shl:1); lane 63 only lends its texel
         for(int c0 = 0; c0 < w; c0 += 63)
         {
             const int c = c0 + lane;
-            const uint2 t0 = src[min(c, w - 1)]; // the last column is never the left tap of a lerp: its record pairs it with itself
+            const uint2 t0 = src[min(max(x0 + min(c, w - 1), 0), L.W - 1)]; // the last column is never the left tap of a lerp: its record pairs it with itself
             uint2 t1;
             t1.x = (unsigned)__builtin_amdgcn_update_dpp((int)t0.x, (int)t0.x, 0x130, 0xf, 0xf, false);
             t1.y = (unsigned)__builtin_amdgcn_update_dpp((int)t0.y, (int)t0.y, 0x130, 0xf, 0xf, false);
@@ -324,12 +359,12 @@ __device__ __forceinline__ void stage_window_rec12(Rec12* dst, int pitch, const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for(int r = wave; r < h; r += 4)
     {
-        const uint2* src = L.base + (long long)(y0 + r) * L.pitch8 + x0;
+        const uint2* src = L.base + (long long)min(max(y0 + r, 0), L.H - 1) * L.pitch8; // (a window may reach outside the image: stage_window_paired)
         Rec12* d = dst + r * pitch;
         for(int c0 = 0; c0 < w; c0 += 63)
         {
             const int c = c0 + lane;
-            const uint2 t0 = src[min(c, w - 1)]; // the last column is never the left tap of a lerp: its record pairs it with itself
+            const uint2 t0 = src[min(max(x0 + min(c, w - 1), 0), L.W - 1)]; // the last column is never the left tap of a lerp: its record pairs it with itself
             uint2 t1;
             t1.x = (unsigned)__builtin_amdgcn_update_dpp((int)t0.x, (int)t0.x, 0x130, 0xf, 0xf, false);
             t1.y = (unsigned)__builtin_amdgcn_update_dpp((int)t0.y, (int)t0.y, 0x130, 0xf, 0xf, false);
@@ -1545,7 +1580,7 @@ struct TWindow
 
 // second half (after the barrier): decide — uniformly for the workgroup — whether plane k runs from LDS, and stage the T window
 __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& sh, int k, const NccArgs& A, bool rTileOk, bool paired, bool halfPaired,
-                                                  bool lean = false, bool rec12 = false)
+                                                  bool lean = false, bool rec12 = false, int leanStatBase = -1)
 {
     TWindow Wd;
     const int mnx = sh.box[k][0], mny = sh.box[k][1], mxx = sh.box[k][2], mxy = sh.box[k][3];
@@ -1555,12 +1590,15 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
     int reason = 1; // 0 = LDS path, 1 = R tile unusable / nothing valid, 2 = T taps leave the image, 3 = T window exceeds the LDS budget
     if(rTileOk && !sh.bad[k] && mnx != INT_MAX && mxx != INT_MIN)
     {
-        // the taps (texels floor(x), floor(x) + 1) must be inside the T image; the window adds one texel of slack on each side
-        // (see corner_boxes), clipped at the image edge
-        const bool inImage = mnx >= 0 && mny >= 0 && mxx + 1 <= A.tcL.W - 1 && mxy + 1 <= A.tcL.H - 1;
-        Wd.x0 = max(mnx - 1, 0);
-        Wd.y0 = max(mny - 1, 0);
-        const int x1 = min(mxx + 2, A.tcL.W - 1), y1 = min(mxy + 2, A.tcL.H - 1);
+        // the taps (texels floor(x), floor(x) + 1) of the packed layouts may lie up to kOutside texels outside the T image (their windows hold
+        // the clamped texels there: stage_window_paired); the other layouts need them inside.  The window adds one texel of slack on each side
+        // (see corner_boxes), clipped at the image edge where the layout cannot leave it
+        const bool mayLeave = AVDM_WINDOWS_OUTSIDE && (paired || rec12);
+        const int kOutside = mayLeave ? 24 : 0;
+        const bool inImage = mnx >= -kOutside && mny >= -kOutside && mxx + 1 <= A.tcL.W - 1 + kOutside && mxy + 1 <= A.tcL.H - 1 + kOutside;
+        Wd.x0 = mayLeave ? mnx - 1 : max(mnx - 1, 0);
+        Wd.y0 = mayLeave ? mny - 1 : max(mny - 1, 0);
+        const int x1 = mayLeave ? mxx + 2 : min(mxx + 2, A.tcL.W - 1), y1 = mayLeave ? mxy + 2 : min(mxy + 2, A.tcL.H - 1);
         Wd.w = x1 - Wd.x0 + 1;
         Wd.h = y1 - Wd.y0 + 1;
         Wd.pitch = lds_pitch_for(Wd.w);
@@ -1582,6 +1620,10 @@ __device__ __forceinline__ TWindow stage_t_window(uint2* sT, const BlockShared& 
     }
     if(!lean && A.stats != nullptr && threadIdx.x == 0)
         atomicAdd(A.stats + reason, 1u);
+#if AVDM_LEAN_STATS
+    if(leanStatBase >= 0 && threadIdx.x == 0)
+        atomicAdd(&g_leanStats[leanStatBase + reason], 1u);
+#endif
     return Wd;
 }
 
@@ -1748,10 +1790,12 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             }
             publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
             __syncthreads();
-            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12);
+            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, rec12, LEAN ? 16 : -1);
             __syncthreads();
             if(Wc.tooLarge) // uniform
             {
+                if(LEAN)
+                    LEANSTAT_WG(6);
                 // the hull of ALL lanes does not fit: once more without the outliers (wave_inlier) — their waves then take the global-memory
                 // taps on the planes they are valid on, the rest of the workgroup keeps the LDS path
                 if(threadIdx.x < 4)
@@ -1766,6 +1810,12 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             chunkWin = Wc.ok;
             lanePart = part;
         }
+    }
+    if(LEAN)
+    {
+        LEANSTAT_WG(5);
+        if(!chunkWin)
+            LEANSTAT_WG(4);
     }
 
 #pragma unroll 1
@@ -1875,6 +1925,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                             wsB = *reinterpret_cast<const unsigned*>(psB);
                         }
                         float sim[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        LEANSTAT(0);
                         if(anyValid)
                         {
                             auto selP8 = [](bool cnd, const QuadPlane& a, const QuadPlane& b) __attribute__((always_inline)) -> QuadPlane {
@@ -1942,6 +1993,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             if(l0 && l1 && l2 && l3) // wave-uniform
             {
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                LEANSTAT(1);
                 if(v0 || v1b || v2b || v3)
                 {
                     // a lane's invalid planes run a copy of one of its valid planes (their results are not committed); the R side comes
@@ -2021,6 +2073,13 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
         }
 
         float fsim = 255.0f;
+        if(LEAN && __any(valid))
+        {
+            if(Wd.ok && laneLds)
+                LEANSTAT(2);
+            else
+                LEANSTAT(3);
+        }
         if(valid)
         {
             float s;
@@ -2217,7 +2276,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             }
             publish_box(sh, AVDM_CHUNK_BOX, part, bx0 - 1.0f, by0 - 1.0f, bx1 + 1.0f, by1 + 1.0f, rIn);
             __syncthreads();
-            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN);
+            Wc = stage_t_window(sT, sh, AVDM_CHUNK_BOX, A, R.ok, paired, halfPaired, LEAN, false, LEAN ? 20 : -1);
             __syncthreads();
             if(AVDM_REFINE_ANCHORED_WINDOW && listing && !Wc.ok && R.ok) // uniform
             {
@@ -2259,6 +2318,8 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 }
                 init_shared(sh);
                 __syncthreads();
+                if(LEAN)
+                    LEANSTAT_WG(12);
                 if(nn > 0.0f) // uniform
                 {
                     if(threadIdx.x == 0)
@@ -2296,6 +2357,12 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             chunkWin = Wc.ok;
             lanePart = part;
         }
+    }
+    if(LEAN)
+    {
+        LEANSTAT_WG(13);
+        if(!chunkWin)
+            LEANSTAT_WG(14);
     }
 
 #pragma unroll 1
@@ -2445,6 +2512,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                         anyValid = anyValid || vv[k];
                     if(allLds) // wave-uniform
                     {
+                        LEANSTAT(8);
                         if(anyValid)
                         {
                             QuadPlane qf = q[7];
@@ -2509,6 +2577,7 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
                 }
                 if(!quadLds) // wave-uniform: this wave runs the quad one plane per pass
                     continue;
+                LEANSTAT(9);
                 if(v0 || v1b || v2b || v3)
                 {
                     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -2597,6 +2666,13 @@ __global__ void __launch_bounds__(256, AVDM_SIM_WAVES_PER_SIMD)
             __syncthreads();
         }
 
+        if(LEAN && __any(valid))
+        {
+            if(Wd.ok && laneLds)
+                LEANSTAT(10);
+            else
+                LEANSTAT(11);
+        }
         if(valid)
         {
             float s;
@@ -3301,6 +3377,20 @@ int avdm_debug_similarity_stats(unsigned out[4])
     (void)hipMemset(g_stats, 0, sizeof(h));
     for(int i = 0; i < 4; ++i)
         out[i] = h[i];
+    return 0;
+}
+
+/* debugging aid (not part of avdm.h): the pass counters of a -DAVDM_LEAN_STATS=1 variant build (zeros in the shipped library), read and cleared */
+int avdm_debug_lean_stats(unsigned out[32])
+{
+    for(int i = 0; i < 32; ++i)
+        out[i] = 0;
+#if AVDM_LEAN_STATS
+    if(hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(g_leanStats), 32 * sizeof(unsigned)) != hipSuccess)
+        return 1;
+    const unsigned zero[32] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_leanStats), zero, sizeof(zero));
+#endif
     return 0;
 }
 

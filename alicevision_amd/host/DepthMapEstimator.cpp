@@ -402,6 +402,7 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
             AVDM_HIP_CHECK(hipSetDevice(deviceId));
             for(; s < nbHostSets; ++s)
             {
+                const auto tSet0 = std::chrono::steady_clock::now();
                 depthSimMapTileSets[s].resize(nbRcPerBatch);
                 depthMinMaxTileSets[s].resize(nbRcPerBatch);
                 for(int i = 0; i < nbRcPerBatch; ++i)
@@ -418,6 +419,9 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
                     }
                 }
                 hostSetPromise[s].set_value();
+                AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): result tiles of set " << s << " (" << nbRcPerBatch * nbTilesPerCamera << " x "
+                                        << ((size_t)finalMapW * finalMapH * 8 >> 10) << " KiB) allocated and page-locked in "
+                                        << std::chrono::duration<double>(std::chrono::steady_clock::now() - tSet0).count() << " s (background).");
             }
         }
         catch(...)
@@ -843,16 +847,32 @@ void DepthMapEstimator::computeImpl(int deviceId, const std::vector<int>& cams, 
         // the tile slots' buffers, the page-locks of the result tiles (unpinning leaves the host bytes where they are), the pyramids, the streams
         // with the library's scratch blocks — ~0.4 s of hipFree / hipHostUnregister calls that used to follow the wait.
         {
+            auto lap = [last = tTail0]() mutable {
+                const auto now = std::chrono::steady_clock::now();
+                const double d = std::chrono::duration<double>(now - last).count();
+                last = now;
+                return d;
+            };
             refinePerStream.clear();
             sgmPerStream.clear();
             groupScratch.release();
             hostTilesTask.wait();
             arena.release();
-            pinned.releaseAll();
+            const double tBuffers = lap();
+            // (the page-locks on a second thread: 80 hipHostUnregister calls beside the frees of this one)
+            std::future<void> unpin = std::async(std::launch::async, [&]() {
+                (void)hipSetDevice(deviceId);
+                pinned.releaseAll();
+            });
             deviceCache.releaseImages();
+            const double tImages = lap();
             deviceStreamManager.destroy();
+            const double tStreams = lap();
+            unpin.wait();
+            const double tUnpin = lap();
             AVDM_LOG_INFO("Worker " << worker << " (device " << deviceId << "): device buffers, pyramids, streams and page-locks released in "
-                                    << std::chrono::duration<double>(std::chrono::steady_clock::now() - tTail0).count() << " s, beside the last batch's merge + write.");
+                                    << std::chrono::duration<double>(std::chrono::steady_clock::now() - tTail0).count() << " s, beside the last batch's merge + write (tile slots "
+                                    << tBuffers << ", pyramids " << tImages << ", streams + scratch blocks " << tStreams << ", waiting for the page-locks " << tUnpin << " s).");
         }
         if(pendingWrite.valid())
             pendingWrite.get();

@@ -14,6 +14,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <chrono>
 #include <fstream>
 #include <future>
 #include <sstream>
@@ -238,16 +239,24 @@ void writeMap(int rc, const MultiViewParams& mp, EFileType fileType, const TileP
     if(fileType == EFileType::depthMap || fileType == EFileType::depthMapFiltered)
     {
         // mapIO.cpp:493-511
-        const int nbDepthValues = (int)std::count_if(in_map.data.begin(), in_map.data.end(), [](float v) { return v > 0.0f; });
+        // (one pass, a team of 8: a count and two order-independent extrema — the same values as the reference's three sequential passes)
+        long long nbDepthValuesL = 0;
         float maxDepth = -1.0f;
         float minDepth = std::numeric_limits<float>::max();
-        for(const float depth : in_map.data)
+        const float* const dv = in_map.data.data();
+        const long long nv = (long long)in_map.data.size();
+#pragma omp parallel for schedule(static) num_threads(8) reduction(+ : nbDepthValuesL) reduction(max : maxDepth) reduction(min : minDepth)
+        for(long long i = 0; i < nv; ++i)
         {
+            const float depth = dv[i];
+            if(depth > 0.0f)
+                ++nbDepthValuesL;
             if(depth <= -1.0f)
                 continue;
             maxDepth = std::max(maxDepth, depth);
             minDepth = std::min(minDepth, depth);
         }
+        const int nbDepthValues = (int)nbDepthValuesL;
         f.metadata.setInt("AliceVision:nbDepthValues", nbDepthValues);
         f.metadata.setFloat("AliceVision:minDepth", minDepth);
         f.metadata.setFloat("AliceVision:maxDepth", maxDepth);
@@ -642,6 +651,7 @@ void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileP
     const TileParams defaultTileParams; // the merged maps are written with DEFAULT tile parameters and the full-size ROI (mapIO.hpp:118-130)
     const ROI fullRoi(0, mp.getWidth(rc), 0, mp.getHeight(rc));
     auto channel = [&](int c, EFileType fileType) {
+        const auto tC0 = std::chrono::steady_clock::now();
         FloatMap map(width, height, 0.0f);
         // the tile map is allocated once (largest tile) and reshaped per tile: allocating and freeing multi-megabyte vectors per
         // tile means mmap / munmap each time, and every munmap interrupts all the cores the OpenMP team runs on
@@ -670,7 +680,10 @@ void writeDepthSimMapFromTileList(int rc, const MultiViewParams& mp, const TileP
                     tileMap(y, x) = t.data[((size_t)y * t.width + x) * 2 + c];
             addTileMapWeighted(rc, mp, tileParams, roi, scaleStep, tileMap, map);
         }
+        const auto tW0 = std::chrono::steady_clock::now();
         writeMap(rc, mp, fileType, defaultTileParams, fullRoi, map, scale, step, customSuffix);
+        AVDM_LOG_DEBUG("Map of rc " << rc << " (channel " << c << "): tiles merged in " << std::chrono::duration<double>(tW0 - tC0).count() << " s, written in "
+                                    << std::chrono::duration<double>(std::chrono::steady_clock::now() - tW0).count() << " s.");
     };
     std::future<void> sim = std::async(std::launch::async, channel, 1, EFileType::simMap);
     try

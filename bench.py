@@ -409,6 +409,7 @@ def main():
     step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     step_events[0].record()
     stats_each = []
+    lean_each = []
     # The two figures of the SGM aggregation perturb each other (session r06_a: the start / stop events bound to the two launches of a call cost the
     # call ~17 us — 0.443 ms with them, 0.424 without, the sum of the kernels' own durations being 0.424): they are taken on ALTERNATING depth maps
     # of the timed region — even ones with the per-launch events (kernel durations, rocprofv3's figure), odd ones without (the whole call).
@@ -426,6 +427,10 @@ def main():
             st = (ctypes.c_uint * 4)()
             lib.avdm_debug_similarity_stats(st)
             stats_each.append([int(v) for v in st])
+        if os.environ.get("AVDM_LEAN_STATS") == "1" and hasattr(lib, "avdm_debug_lean_stats"):  # diagnosis only, with a -DAVDM_LEAN_STATS=1 variant (AVDM_LIB)
+            st16 = (ctypes.c_uint * 32)()
+            lib.avdm_debug_lean_stats(st16)
+            lean_each.append([int(v) for v in st16])
     proto.finish()  # (streaming job: the last round's pyramids are part of it)
     torch.cuda.synchronize()
     if dist is not None:
@@ -643,6 +648,10 @@ def main():
             "similarity_ms_each": {k: [round(a.elapsed_time(b), 2) for a, b in tile.timers.events.get(k, [])] for k in ("sgm_similarity", "refine_similarity")}
             if len(tiles) == 1 else None,
         }
+        if lean_each:
+            # per step (diagnosis, variant build): SGM sweep {8-plane, 4-plane, 1-plane LDS, 1-plane global passes of a wave; workgroups without a chunk
+            # window, workgroups, retried without outliers, -}, Refine sweep {8, 4, 1 LDS, 1 global; anchored windows, workgroups, without window, -}
+            line["lean_pass_counters_each"] = lean_each
         if os.environ.get("AVDM_SIM_STATS") == "1":
             # [LDS path, generic: R tile unusable / nothing valid, generic: T taps leave the image, generic: T window exceeds the LDS budget] per step
             line["similarity_plane_workgroups_each"] = stats_each
