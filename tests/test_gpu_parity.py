@@ -954,8 +954,12 @@ def test_refine_outlier_list_equals_the_wave_fallback(capsys):
     h.run_sgm(0, [1, 2], depths)
     bad = h.sgm_depth_thickness.clone()
     g = torch.Generator().manual_seed(5)
-    wrong = (torch.rand(bad.shape[:2], generator=g) < 0.02).to(bad.device) & (bad[..., 0] > 0)
-    bad[..., 0] = torch.where(wrong, bad[..., 0] * 0.35, bad[..., 0])  # much too near: the patch lands tens of texels away in T
+    density, factor = float(os.environ.get("AVDM_TEST_OUTLIER_DENSITY", "0.02")), float(os.environ.get("AVDM_TEST_OUTLIER_FACTOR", "0.2"))  # (probing aid)
+    wrong = (torch.rand(bad.shape[:2], generator=g) < density).to(bad.device) & (bad[..., 0] > 0)
+    # much too near: the patch lands ~ 80 texels from its neighbours' in T — farther than a window of the workgroup's hull holds, which is what sends
+    # a lane to the list.  (Until the chunk windows could reach outside the T image — session r06_p — a factor of 0.35, ~ 40 texels, was enough: the list's
+    # units then came from the border workgroups' anchored windows; sessions r06_s / r06_t: 13 units at 0.35, 6 427 at 0.2.)
+    bad[..., 0] = torch.where(wrong, bad[..., 0] * factor, bad[..., 0])
     lib = abi.load()
     lib.avdm_debug_refine_outlier_units.argtypes = [ctypes.POINTER(ctypes.c_uint)]
     out, units = {}, {}
@@ -978,7 +982,7 @@ def test_refine_outlier_list_equals_the_wave_fallback(capsys):
     with capsys.disabled():
         print("\noutlier list: %d units worked off, %d refused; vs the wave fall-back: %.4f of the entries differ, %.5f by more than one fp16 quantum (2e-3), max %.2e"
               % (units["1"] + ((d > 0).mean(), (d > 2e-3).mean(), d.max())))
-    assert units["0"] == (0, 0) and units["1"][0] > 50 and units["1"][1] == 0, units
+    assert units["0"] == (0, 0) and units["1"][0] > 1000 and units["1"][1] == 0, units
     assert (out["0"] != 0).mean() > 0.3
     assert ((out["0"] == 0) != (out["1"] == 0)).mean() <= 1e-4
     # (the inlier lanes of a wave with an outlier used to run one plane per pass with fp32 taps from global memory, now the packed eight-plane
